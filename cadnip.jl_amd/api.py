@@ -1,0 +1,353 @@
+"""Reference-shaped user API on top of the GPU hot path.
+
+Mirrors the surface a Cadnip.jl user touches on this path -- same names, argument meaning and
+result layout -- so that tests read like the reference's own:
+
+    MNASpec, MNACircuit, alter                       /root/reference/src/mna/solve.jl:57-70, 1585-1597, 1719-1732
+    dc(circuit) / tran(circuit, tspan)               /root/reference/src/sweeps.jl:450-455, 588-665   (dc! / tran!)
+    Sweep, ProductSweep, TandemSweep, SerialSweep    /root/reference/src/sweeps.jl:150-330
+    CircuitSweep, SweepResult, dc(cs), tran(cs)      /root/reference/src/sweeps.jl:387-424, 477-532, 692-707
+    solution layout [V | I | q*1e12 | v_lim], sol[name]   /root/reference/src/mna/build.jl:39-51, 421-457
+
+Differences forced by the target: a ``MNACircuit`` wraps a flattened device table instead of a
+generated Julia builder; ``tran``/``dc`` over a ``CircuitSweep`` integrate all sweep points as
+one resident batch on the GPU instead of the reference's serial loop (sweeps.jl:696-703);
+temperature is a per-point axis (``temp`` key), which the reference can only reach through an
+outer loop over ``MNASpec``.
+"""
+import itertools
+from dataclasses import dataclass, field, replace
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+
+from .circuit import Circuit
+from .structure import Structure, discover, expand_breakpoints, pack_params
+
+
+@dataclass(frozen=True)
+class MNASpec:
+    temp: float = 27.0
+    mode: str = "tran"
+    time: float = 0.0
+    gmin: float = 1e-12
+    gshunt: float = 0.0
+    srcFact: float = 1.0
+    tnom: float = 27.0
+    abstol: float = 1e-12
+    reltol: float = 1e-3
+    vntol: float = 1e-6
+    iabstol: float = 1e-12
+
+
+def with_mode(spec, mode):
+    return replace(spec, mode=mode)
+
+
+def with_temp(spec, temp):
+    return replace(spec, temp=float(temp))
+
+
+@dataclass(frozen=True)
+class MNACircuit:
+    circuit: Circuit
+    params: Dict[str, float] = field(default_factory=dict)
+    spec: MNASpec = MNASpec()
+
+
+def alter(c: MNACircuit, spec: Optional[MNASpec] = None, **params) -> MNACircuit:
+    """solve.jl:1719-1732: new circuit with some parameters (or the spec) replaced."""
+    p = dict(c.params)
+    for k, v in params.items():
+        if k not in p:
+            raise KeyError("unknown circuit parameter %r" % k)
+        p[k] = v
+    return MNACircuit(c.circuit, p, spec if spec is not None else c.spec)
+
+
+# ------------------------------------------------------------------------------------------------
+# sweeps (sweeps.jl:150-330)
+# ------------------------------------------------------------------------------------------------
+class Sweep:
+    def __init__(self, **axes):
+        if len(axes) != 1:
+            raise ValueError("Sweep takes exactly one name=values axis; combine with ProductSweep/TandemSweep")
+        (self.name, vals), = axes.items()
+        self.values = list(vals)
+
+    def __iter__(self):
+        return ({self.name: v} for v in self.values)
+
+    def __len__(self):
+        return len(self.values)
+
+
+class ProductSweep:
+    """Cartesian product, first axis fastest (Base.Iterators.product, sweeps.jl:272)."""
+
+    def __init__(self, *sweeps, **axes):
+        self.sweeps = list(sweeps) + [Sweep(**{k: v}) for k, v in axes.items()]
+
+    def __iter__(self):
+        lists = [list(s) for s in self.sweeps]
+        for combo in itertools.product(*reversed(lists)):
+            d = {}
+            for part in reversed(combo):
+                d.update(part)
+            yield d
+
+    def __len__(self):
+        return int(np.prod([len(s) for s in self.sweeps]))
+
+
+class TandemSweep:
+    def __init__(self, *sweeps, **axes):
+        self.sweeps = list(sweeps) + [Sweep(**{k: v}) for k, v in axes.items()]
+        if len({len(s) for s in self.sweeps}) > 1:
+            raise ValueError("TandemSweep axes must have equal lengths")
+
+    def __iter__(self):
+        for parts in zip(*self.sweeps):
+            d = {}
+            for p in parts:
+                d.update(p)
+            yield d
+
+    def __len__(self):
+        return len(self.sweeps[0]) if self.sweeps else 0
+
+
+class SerialSweep:
+    def __init__(self, *sweeps):
+        self.sweeps = list(sweeps)
+
+    def __iter__(self):
+        return itertools.chain(*self.sweeps)
+
+    def __len__(self):
+        return sum(len(s) for s in self.sweeps)
+
+
+class CircuitSweep:
+    """sweeps.jl:387-424.  Sweep keys name circuit parameters; the extra key ``temp`` sweeps
+    MNASpec.temp."""
+
+    def __init__(self, circuit: MNACircuit, iterator):
+        self.circuit = circuit
+        self.iterator = iterator
+        for pt in iterator:
+            for k in pt:
+                if k != "temp" and k not in circuit.params:
+                    raise KeyError("sweep variable %r is not a circuit parameter" % k)
+
+    def points(self):
+        return list(self.iterator)
+
+    def __len__(self):
+        return len(self.iterator)
+
+
+class SweepResult:
+    """sweeps.jl:477-487: iterates (params, solution) pairs."""
+
+    def __init__(self, points, solutions):
+        self.points = points
+        self.solutions = solutions
+
+    def __iter__(self):
+        return iter(zip(self.points, self.solutions))
+
+    def __len__(self):
+        return len(self.points)
+
+    def __getitem__(self, i):
+        return self.solutions[i]
+
+
+# ------------------------------------------------------------------------------------------------
+# solutions
+# ------------------------------------------------------------------------------------------------
+class DCSolution:
+    """solve.jl:156-166."""
+
+    def __init__(self, st: Structure, x, converged):
+        self.st = st
+        self.x = np.asarray(x)
+        self.converged = bool(converged)
+        self.node_names = st.node_names
+        self.current_names = st.current_names
+        self.charge_names = st.charge_names
+        self.limit_names = st.limit_names
+        self.n_nodes = st.n_nodes
+
+    def __getitem__(self, name):
+        return float(self.x[self.st.index_of(name)])
+
+
+class TranSolution:
+    """What the path hands back: states at the requested ``saveat`` times plus solver statistics
+    (sol.t, sol[name], sol(t), sol.stats.nnonliniter as in benchmarks/vacask/ring/cedarsim/runme.jl:74-76)."""
+
+    def __init__(self, st, t, u, stats, retcode):
+        self.st = st
+        self.t = np.asarray(t)
+        self.u = np.asarray(u)          # [n_save, n]
+        self.stats = stats
+        self.retcode = retcode
+
+    def __getitem__(self, name):
+        return self.u[:, self.st.index_of(name)]
+
+    def __call__(self, t, name=None):
+        cols = self.u if name is None else self.u[:, self.st.index_of(name)]
+        if cols.ndim == 1:
+            return float(np.interp(t, self.t, cols))
+        return np.array([np.interp(t, self.t, cols[:, j]) for j in range(cols.shape[1])])
+
+
+def nameat(sol, name, t):
+    """solve.jl:347-353"""
+    return sol(t, name)
+
+
+# ------------------------------------------------------------------------------------------------
+# batched simulator
+# ------------------------------------------------------------------------------------------------
+class BatchSimulator:
+    """One structure, B resident sweep instances on one GPU."""
+
+    def __init__(self, mc: MNACircuit, points: Optional[List[Dict[str, Any]]] = None, device: int = 0):
+        from . import hip
+        self.mc = mc
+        points = points if points else [{}]
+        self.points = points
+        B = len(points)
+        self.B = B
+        params = {k: np.full(B, float(v)) for k, v in mc.params.items()}
+        temps = np.full(B, mc.spec.temp)
+        for i, pt in enumerate(points):
+            for k, v in pt.items():
+                if k == "temp":
+                    temps[i] = float(v)
+                else:
+                    params[k][i] = float(v)
+        self.params, self.temps = params, temps
+        p0 = {k: float(v[0]) for k, v in params.items()}
+        self.st = discover(mc.circuit, p0)
+        self.h = hip.Handle(self.st, B, device)
+        self.h.set_params(pack_params(self.st, mc.circuit, params, temps, B, gmin=mc.spec.gmin, tnom_c=mc.spec.tnom))
+        self.h.set_spec(mode=mc.spec.mode if mc.spec.mode in ("dcop", "tran", "tranop") else "tran",
+                        gmin=mc.spec.gmin, gshunt=mc.spec.gshunt, srcFact=mc.spec.srcFact)
+        self._analyzed = False
+
+    def close(self):
+        self.h.close()
+
+    def vscale(self):
+        v = [abs(float(np.max(np.abs(self.params[k])))) for k in self.params] + [1.0]
+        for d in self.mc.circuit.devices:
+            if d.type == "V":
+                dc = d.params.get("dc", 0.0)
+                if not hasattr(dc, "name"):
+                    v.append(abs(float(dc)))
+                if d.wave is not None and d.wave[0] == "pwl":
+                    v.append(max(abs(float(y)) for y in d.wave[2]))
+        return max(v)
+
+    def analyze(self, gamma=1e9, n_samples=6, seed=1234):
+        """Symbolic LU phase on the element-wise max |G + gamma*C| over several operating points
+        (cold start with initjct, zero, and random points), so the static pivot order suits all."""
+        rng = np.random.default_rng(seed)
+        st, h = self.st, self.h
+        vs = self.vscale()
+        acc = np.zeros(st.nnz)
+        for k in range(n_samples):
+            if k == 0:
+                u = np.zeros(st.n)
+                u[st.n - st.n_limits:] = st.limit_init
+                h.set_initjct(True)
+            elif k == 1:
+                u = np.zeros(st.n)
+            else:
+                u = (rng.random(st.n) * 1.2 - 0.1) * vs
+                u[st.n_nodes:st.n_nodes + st.n_currents] = 0.0
+            h.rebuild(u, 0.0)
+            h.set_initjct(False)
+            J = h.jacobian(gamma)
+            acc = np.maximum(acc, np.max(np.abs(np.nan_to_num(J, nan=0.0, posinf=0.0, neginf=0.0)), axis=0))
+        h.analyze_values(acc)
+        self._analyzed = True
+
+    def dc(self, u0=None, abstol=1e-10, maxiters=100, mode="dcop"):
+        self.h.set_spec(mode=mode)
+        if not self._analyzed:
+            self.analyze()
+        return self.h.dc_run(u0, abstol=abstol, maxiters=maxiters, use_pcnr=True, cold_start=u0 is None)
+
+    def tran(self, tspan, abstol, reltol, saveat, **kw):
+        st = self.st
+        if not self._analyzed:
+            self.analyze()
+        # CedarTranOp: DC solve in :tranop mode at t0 (dcop.jl:160-212), abstol 1e-9
+        u0, conv, dcs = self.dc(abstol=1e-9, mode="tranop")
+        if not np.all(conv):
+            raise RuntimeError("transient initialisation (CedarTranOp) failed for %d instance(s)" % int((~conv).sum()))
+        breaks = expand_breakpoints(st.breakpoints, tspan)
+        self.h.set_spec(mode="tran")
+        out, per, stats = self.h.tran_run(tspan[0], tspan[1], abstol, reltol, breaks=breaks, save_t=saveat, **kw)
+        stats["dc_newton_iters"] = dcs["newton_iters"]
+        return out, per, stats
+
+
+def _resolve_abstol(abstol, st):
+    """_resolve_abstol (sweeps.jl:626): per-class NamedTuple -> vector via state_abstol."""
+    if isinstance(abstol, dict):
+        return st.state_abstol(**abstol)
+    return np.broadcast_to(np.asarray(abstol, dtype=float), (st.n,)).copy()
+
+
+def dc(target, u0=None, device=0):
+    """dc!(circuit) / dc!(cs::CircuitSweep) -- sweeps.jl:450-455, 511-532.  Goes through with_mode(:dcop),
+    which keeps only temp+mode of the spec (solve.jl:1976-1989)."""
+    if isinstance(target, CircuitSweep):
+        mc = target.circuit
+        mc = MNACircuit(mc.circuit, mc.params, MNASpec(temp=mc.spec.temp, mode="dcop"))
+        sim = BatchSimulator(mc, target.points(), device)
+        try:
+            u, conv, _ = sim.dc()
+            return SweepResult(target.points(), [DCSolution(sim.st, u[i], conv[i]) for i in range(sim.B)])
+        finally:
+            sim.close()
+    mc = MNACircuit(target.circuit, target.params, MNASpec(temp=target.spec.temp, mode="dcop"))
+    sim = BatchSimulator(mc, None, device)
+    try:
+        u, conv, _ = sim.dc(u0=u0)
+        return DCSolution(sim.st, u[0], conv[0])
+    finally:
+        sim.close()
+
+
+def tran(target, tspan, abstol=1e-10, reltol=1e-8, saveat=None, device=0, **kw):
+    """tran!(circuit, tspan) / tran!(cs::CircuitSweep, tspan) -- sweeps.jl:588-665, 692-707."""
+    tspan = (float(tspan[0]), float(tspan[1]))
+    if saveat is None:
+        saveat = np.linspace(tspan[0], tspan[1], 501)
+    saveat = np.asarray(saveat, dtype=float)
+    if isinstance(target, CircuitSweep):
+        sim = BatchSimulator(target.circuit, target.points(), device)
+    else:
+        sim = BatchSimulator(target, None, device)
+    try:
+        out, per, stats = sim.tran(tspan, _resolve_abstol(abstol, sim.st), reltol, saveat, **kw)
+        sols = []
+        for i in range(sim.B):
+            s = {"nnonliniter": int(per[i, 0]), "naccept": int(per[i, 1]), "nreject": int(per[i, 2])}
+            sols.append(TranSolution(sim.st, saveat, out[i], s, "Success" if per[i, 3] == 1 else "Failure"))
+        if isinstance(target, CircuitSweep):
+            res = SweepResult(target.points(), sols)
+            res.stats = stats
+            return res
+        sols[0].run_stats = stats
+        return sols[0]
+    finally:
+        sim.close()

@@ -1,0 +1,360 @@
+// api.hip -- the C ABI of include/cadnip_hip.h (everything except the two host drivers).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "internal.hpp"
+
+using namespace cadnip;
+
+namespace {
+template <class T>
+int dev_alloc(T** p, size_t count) {
+  if (count == 0) count = 1;
+  HIP_TRY(hipMalloc((void**)p, count * sizeof(T)));
+  HIP_TRY(hipMemset(*p, 0, count * sizeof(T)));
+  return CADNIP_OK;
+}
+template <class T>
+int dev_upload(T** p, const T* src, size_t count) {
+  int rc = dev_alloc(p, count);
+  if (rc) return rc;
+  if (count) HIP_TRY(hipMemcpy(*p, src, count * sizeof(T), hipMemcpyHostToDevice));
+  return CADNIP_OK;
+}
+template <class T>
+int dev_upload(T** p, const std::vector<T>& v) { return dev_upload(p, v.data(), v.size()); }
+#define TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+}  // namespace
+
+extern "C" {
+
+const char* cadnip_version(void) { return "cadnip_hip 0.1.0 (gfx950)"; }
+
+int cadnip_create(const CadnipStructure* s, int32_t n_instances, int32_t device, CadnipHandle** out) {
+  if (!s || !out || n_instances <= 0 || s->n <= 0) return CADNIP_BADARG;
+  HIP_TRY(hipSetDevice(device));
+  CadnipHandle* h = new CadnipHandle();
+  h->device = device;
+  h->B = n_instances;
+  h->n = s->n; h->n_nodes = s->n_nodes; h->n_currents = s->n_currents; h->n_charges = s->n_charges; h->n_limits = s->n_limits;
+  h->nnz = s->nnz;
+  h->ns_g = s->ns_g; h->ns_c = s->ns_c; h->ns_b = s->ns_b; h->ns = s->ns_g + s->ns_c + s->ns_b;
+  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&h->ev0));
+  HIP_TRY(hipEventCreate(&h->ev1));
+  HIP_TRY(hipHostMalloc((void**)&h->h_pinned, 64 * sizeof(int), hipHostMallocDefault));
+  h->h_rowptr.assign(s->rowptr, s->rowptr + s->n + 1);
+  h->h_colidx.assign(s->colidx, s->colidx + s->nnz);
+  h->h_to_ref.assign(s->to_ref_nz, s->to_ref_nz + s->nnz);
+  h->h_limit_init.assign(s->limit_init, s->limit_init + s->n_limits);
+  // host-side shape checks: every index a kernel will dereference is validated here
+  for (int i = 0; i < s->n; ++i) if (s->rowptr[i] > s->rowptr[i + 1]) { delete h; return CADNIP_BADARG; }
+  if (s->rowptr[s->n] != s->nnz) { delete h; return CADNIP_BADARG; }
+  for (int k = 0; k < s->nnz; ++k) if (s->colidx[k] < 0 || s->colidx[k] >= s->n || s->to_ref_nz[k] < 0 || s->to_ref_nz[k] >= s->nnz) { delete h; return CADNIP_BADARG; }
+  for (int k = 0; k < s->g_ptr[s->nnz]; ++k) if (s->g_slots[k] < 0 || s->g_slots[k] >= s->ns_g) { delete h; return CADNIP_BADARG; }
+  for (int k = 0; k < s->c_ptr[s->nnz]; ++k) if (s->c_slots[k] < 0 || s->c_slots[k] >= s->ns_c) { delete h; return CADNIP_BADARG; }
+  for (int k = 0; k < s->b_ptr[s->n]; ++k) if (s->b_slots[k] < 0 || s->b_slots[k] >= s->ns_b) { delete h; return CADNIP_BADARG; }
+  TRY(dev_upload(&h->d_rowptr, s->rowptr, (size_t)s->n + 1));
+  TRY(dev_upload(&h->d_colidx, s->colidx, (size_t)s->nnz));
+  TRY(dev_upload(&h->d_to_ref, s->to_ref_nz, (size_t)s->nnz));
+  TRY(dev_upload(&h->d_g_ptr, s->g_ptr, (size_t)s->nnz + 1));
+  TRY(dev_upload(&h->d_g_slots, s->g_slots, (size_t)s->g_ptr[s->nnz]));
+  TRY(dev_upload(&h->d_c_ptr, s->c_ptr, (size_t)s->nnz + 1));
+  TRY(dev_upload(&h->d_c_slots, s->c_slots, (size_t)s->c_ptr[s->nnz]));
+  TRY(dev_upload(&h->d_b_ptr, s->b_ptr, (size_t)s->n + 1));
+  TRY(dev_upload(&h->d_b_slots, s->b_slots, (size_t)s->b_ptr[s->n]));
+  std::vector<unsigned char> dflag(s->nnz, 0);
+  for (int i = 0; i < s->n_nodes; ++i) { int p = s->diag_nz[i]; if (p >= 0 && p < s->nnz) dflag[p] = 1; }
+  TRY(dev_upload(&h->d_diag_flag, dflag.data(), dflag.size()));
+  TRY(dev_upload(&h->d_wave, s->wave_data, (size_t)s->n_wave_data));
+  TRY(dev_upload(&h->d_limit_init, s->limit_init, (size_t)s->n_limits));
+  for (int bi = 0; bi < s->n_blocks; ++bi) {
+    const CadnipDeviceBlock& sb = s->blocks[bi];
+    DeviceBlock b;
+    b.type = sb.type; b.count = sb.count; b.n_nodes = sb.n_nodes; b.n_ipar = sb.n_ipar; b.n_par = sb.n_par;
+    b.g_base = sb.g_base; b.c_base = sb.c_base; b.b_base = sb.b_base; b.n_g = sb.n_g; b.n_c = sb.n_c; b.n_b = sb.n_b;
+    if (b.type < 0 || b.type >= CADNIP_DEV_NTYPES || b.count < 0) { cadnip_destroy(h); return CADNIP_BADARG; }
+    if (b.g_base + b.n_g * b.count > s->ns_g || b.c_base + b.n_c * b.count > s->ns_c || b.b_base + b.n_b * b.count > s->ns_b) { cadnip_destroy(h); return CADNIP_BADARG; }
+    for (int k = 0; k < b.n_nodes * b.count; ++k) if (sb.nodes[k] < -1 || sb.nodes[k] >= s->n) { cadnip_destroy(h); return CADNIP_BADARG; }
+    if ((b.type == CADNIP_DEV_VSOURCE || b.type == CADNIP_DEV_ISOURCE)) {
+      if (b.n_ipar < 3) { cadnip_destroy(h); return CADNIP_BADARG; }
+      for (int d = 0; d < b.count; ++d) {
+        int kind = sb.ipar[d], off = sb.ipar[b.count + d], len = sb.ipar[2 * b.count + d];
+        int need = kind == CADNIP_WAVE_PWL ? 2 * len : (kind == CADNIP_WAVE_DC ? 0 : len);
+        if (kind < 0 || kind > 3 || off < 0 || off + need > s->n_wave_data || (kind == CADNIP_WAVE_PWL && len < 1)) { cadnip_destroy(h); return CADNIP_BADARG; }
+      }
+    }
+    if (b.type == CADNIP_DEV_MOS1 && (b.n_par != CADNIP_MOS1_NPAR || b.n_nodes != 14)) { cadnip_destroy(h); return CADNIP_BADARG; }
+    TRY(dev_upload(&b.d_nodes, sb.nodes, (size_t)b.n_nodes * b.count));
+    TRY(dev_upload(&b.d_ipar, sb.ipar, (size_t)(b.n_ipar > 0 ? b.n_ipar : 1) * b.count));
+    TRY(dev_alloc(&b.d_par, (size_t)h->B * b.n_par * b.count));
+    h->blocks.push_back(b);
+  }
+  size_t B = h->B, n = h->n, nnz = h->nnz;
+  TRY(dev_alloc(&h->d_u, B * n)); TRY(dev_alloc(&h->d_du, B * n)); TRY(dev_alloc(&h->d_t, B)); TRY(dev_alloc(&h->d_gamma, B));
+  TRY(dev_alloc(&h->d_S, B * h->ns)); TRY(dev_alloc(&h->d_G, B * nnz)); TRY(dev_alloc(&h->d_C, B * nnz)); TRY(dev_alloc(&h->d_b, B * n));
+  TRY(dev_alloc(&h->d_J, B * nnz)); TRY(dev_alloc(&h->d_resid, B * n)); TRY(dev_alloc(&h->d_delta, B * n));
+  TRY(dev_alloc(&h->d_limit_w, B * n)); TRY(dev_alloc(&h->d_tmp, B * n));
+  TRY(dev_alloc(&h->d_flags, B)); TRY(dev_alloc(&h->d_active, B));
+  std::vector<int> ones(B, 1);
+  HIP_TRY(hipMemcpy(h->d_active, ones.data(), B * sizeof(int), hipMemcpyHostToDevice));
+  *out = h;
+  return CADNIP_OK;
+}
+
+void cadnip_driver_free(CadnipHandle* h);   // driver.hip
+
+void cadnip_destroy(CadnipHandle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  cadnip_driver_free(h);
+  void* ptrs[] = {h->d_rowptr, h->d_colidx, h->d_to_ref, h->d_g_ptr, h->d_g_slots, h->d_c_ptr, h->d_c_slots, h->d_b_ptr, h->d_b_slots,
+                  h->d_diag_flag, h->d_wave, h->d_limit_init, h->d_u, h->d_du, h->d_t, h->d_gamma, h->d_S, h->d_G, h->d_C, h->d_b, h->d_J,
+                  h->d_resid, h->d_delta, h->d_limit_w, h->d_LU, h->d_tmp, h->d_flags, h->d_active, h->d_load_src, h->d_load_dst, h->d_ent_pos,
+                  h->d_ent_diag, h->d_ent_ptr, h->d_term_a, h->d_term_b, h->d_lev_ptr, h->d_lu_rowptr, h->d_lu_col, h->d_lu_diag, h->d_rperm,
+                  h->d_cperm, h->d_fwd_rows, h->d_fwd_lev_ptr, h->d_bwd_rows, h->d_bwd_lev_ptr};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (auto& b : h->blocks) { if (b.d_nodes) (void)hipFree(b.d_nodes); if (b.d_ipar) (void)hipFree(b.d_ipar); if (b.d_par) (void)hipFree(b.d_par); }
+  if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int cadnip_set_params(CadnipHandle* h, int32_t block, const double* par_host) {
+  if (!h || block < 0 || block >= (int)h->blocks.size() || !par_host) return CADNIP_BADARG;
+  auto& b = h->blocks[block];
+  HIP_TRY(hipMemcpyAsync(b.d_par, par_host, (size_t)h->B * b.n_par * b.count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CADNIP_OK;
+}
+
+int cadnip_set_spec(CadnipHandle* h, const CadnipSpec* spec) {
+  if (!h || !spec || spec->mode < 0 || spec->mode > 2) return CADNIP_BADARG;
+  h->spec = *spec;
+  return CADNIP_OK;
+}
+
+int cadnip_set_initjct(CadnipHandle* h, int32_t on) { if (!h) return CADNIP_BADARG; h->initjct = on ? 1 : 0; return CADNIP_OK; }
+
+static int upload_state(CadnipHandle* h, const double* u_host, const double* t_host) {
+  size_t B = h->B, n = h->n;
+  if (u_host) HIP_TRY(hipMemcpyAsync(h->d_u, u_host, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (t_host) HIP_TRY(hipMemcpyAsync(h->d_t, t_host, B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  return CADNIP_OK;
+}
+
+static int check_nonfinite(CadnipHandle* h) { return CADNIP_OK; }
+
+int cadnip_rebuild(CadnipHandle* h, const double* u_host, const double* t_host) {
+  if (!h) return CADNIP_BADARG;
+  TRY(upload_state(h, u_host, t_host));
+  TRY(launch_rebuild(h));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return check_nonfinite(h);
+}
+
+int cadnip_residual(CadnipHandle* h, const double* du_host, const double* u_host, double* resid_host) {
+  if (!h || !du_host || !resid_host) return CADNIP_BADARG;
+  size_t B = h->B, n = h->n;
+  TRY(upload_state(h, u_host, nullptr));
+  HIP_TRY(hipMemcpyAsync(h->d_du, du_host, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  TRY(launch_residual(h, h->d_du));
+  HIP_TRY(hipMemcpyAsync(resid_host, h->d_resid, B * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (size_t k = 0; k < B * n; ++k) if (!(resid_host[k] == resid_host[k]) || resid_host[k] - resid_host[k] != 0.0) return CADNIP_NONFINITE;
+  return CADNIP_OK;
+}
+
+static int readback_ref_order(CadnipHandle* h, const double* d_src, double* host_out) {
+  size_t B = h->B, nnz = h->nnz;
+  std::vector<double> tmp(B * nnz);
+  HIP_TRY(hipMemcpyAsync(tmp.data(), d_src, B * nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (size_t i = 0; i < B; ++i)
+    for (size_t k = 0; k < nnz; ++k) host_out[i * nnz + h->h_to_ref[k]] = tmp[i * nnz + k];
+  return CADNIP_OK;
+}
+
+int cadnip_jacobian(CadnipHandle* h, const double* gamma_host, double* J_ref_nz_host) {
+  if (!h || !gamma_host) return CADNIP_BADARG;
+  HIP_TRY(hipMemcpyAsync(h->d_gamma, gamma_host, (size_t)h->B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  TRY(launch_jacobian(h));
+  if (J_ref_nz_host) TRY(readback_ref_order(h, h->d_J, J_ref_nz_host));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CADNIP_OK;
+}
+
+int cadnip_get_GCb(CadnipHandle* h, double* G_ref_nz, double* C_ref_nz, double* b, double* limit_w) {
+  if (!h) return CADNIP_BADARG;
+  size_t B = h->B, n = h->n;
+  if (G_ref_nz) TRY(readback_ref_order(h, h->d_G, G_ref_nz));
+  if (C_ref_nz) TRY(readback_ref_order(h, h->d_C, C_ref_nz));
+  if (b) HIP_TRY(hipMemcpyAsync(b, h->d_b, B * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (limit_w) {
+    std::vector<double> tmp(B * n);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), h->d_limit_w, B * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    size_t L = h->n_limits, l0 = n - L;
+    for (size_t i = 0; i < B; ++i) for (size_t k = 0; k < L; ++k) limit_w[i * L + k] = tmp[i * n + l0 + k];
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CADNIP_OK;
+}
+
+int cadnip_analyze(CadnipHandle* h, int32_t sample_instance) {
+  if (!h || sample_instance < 0 || sample_instance >= h->B) return CADNIP_BADARG;
+  std::vector<double> vals(h->nnz);
+  HIP_TRY(hipMemcpyAsync(vals.data(), h->d_J + (size_t)sample_instance * h->nnz, (size_t)h->nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::string err;
+  int rc = lu_analyze(h->n, h->h_rowptr, h->h_colidx, vals, 1e-3, h->lu, err);
+  if (rc) { fprintf(stderr, "[cadnip_hip] analyze: %s\n", err.c_str()); return rc; }
+  return upload_lu(h);
+}
+
+int cadnip_analyze_values(CadnipHandle* h, const double* J_csr_host) {
+  if (!h || !J_csr_host) return CADNIP_BADARG;
+  std::vector<double> vals(J_csr_host, J_csr_host + h->nnz);
+  std::string err;
+  int rc = lu_analyze(h->n, h->h_rowptr, h->h_colidx, vals, 1e-3, h->lu, err);
+  if (rc) { fprintf(stderr, "[cadnip_hip] analyze: %s\n", err.c_str()); return rc; }
+  return upload_lu(h);
+}
+
+struct CadnipHostLU { cadnip::LUProgram p; };
+static const std::vector<int>* host_lu_array(const CadnipHostLU* lu, int which) {
+  const cadnip::LUProgram& P = lu->p;
+  switch (which) {
+    case CADNIP_LU_RPERM: return &P.rperm; case CADNIP_LU_CPERM: return &P.cperm; case CADNIP_LU_ROWPTR: return &P.lu_rowptr;
+    case CADNIP_LU_COL: return &P.lu_col; case CADNIP_LU_DIAG: return &P.lu_diag; case CADNIP_LU_LOAD_SRC: return &P.load_src;
+    case CADNIP_LU_LOAD_DST: return &P.load_dst; case CADNIP_LU_ENT_POS: return &P.ent_pos; case CADNIP_LU_ENT_DIAG: return &P.ent_diag;
+    case CADNIP_LU_ENT_PTR: return &P.ent_ptr; case CADNIP_LU_TERM_A: return &P.term_a; case CADNIP_LU_TERM_B: return &P.term_b;
+    case CADNIP_LU_LEV_PTR: return &P.lev_ptr; case CADNIP_LU_FWD_ROWS: return &P.fwd_rows; case CADNIP_LU_FWD_LEV_PTR: return &P.fwd_lev_ptr;
+    case CADNIP_LU_BWD_ROWS: return &P.bwd_rows; case CADNIP_LU_BWD_LEV_PTR: return &P.bwd_lev_ptr;
+  }
+  return nullptr;
+}
+int cadnip_host_lu_analyze(int32_t n, const int32_t* rowptr, const int32_t* colidx, const double* vals, double pivot_tol, CadnipHostLU** out) {
+  if (n <= 0 || !rowptr || !colidx || !vals || !out) return CADNIP_BADARG;
+  CadnipHostLU* lu = new CadnipHostLU();
+  std::vector<int> rp(rowptr, rowptr + n + 1), ci(colidx, colidx + rowptr[n]);
+  std::vector<double> v(vals, vals + rowptr[n]);
+  std::string err;
+  int rc = lu_analyze(n, rp, ci, v, pivot_tol, lu->p, err);
+  if (rc) { delete lu; return rc; }
+  *out = lu;
+  return CADNIP_OK;
+}
+int32_t cadnip_host_lu_size(const CadnipHostLU* lu, int32_t which) { auto* v = lu ? host_lu_array(lu, which) : nullptr; return v ? (int32_t)v->size() : -1; }
+int cadnip_host_lu_get(const CadnipHostLU* lu, int32_t which, int32_t* dst) {
+  auto* v = lu ? host_lu_array(lu, which) : nullptr;
+  if (!v || !dst) return CADNIP_BADARG;
+  memcpy(dst, v->data(), v->size() * sizeof(int));
+  return CADNIP_OK;
+}
+void cadnip_host_lu_free(CadnipHostLU* lu) { delete lu; }
+
+int cadnip_factor(CadnipHandle* h) {
+  if (!h) return CADNIP_BADARG;
+  HIP_TRY(hipMemsetAsync(h->d_flags, 0, (size_t)h->B * sizeof(int), h->stream));
+  TRY(launch_factor(h, false));
+  std::vector<int> fl(h->B);
+  HIP_TRY(hipMemcpyAsync(fl.data(), h->d_flags, (size_t)h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int f : fl) if (f & 1) return CADNIP_SINGULAR;
+  return CADNIP_OK;
+}
+
+int cadnip_solve(CadnipHandle* h, const double* rhs_host, double* x_host) {
+  if (!h || !rhs_host || !x_host) return CADNIP_BADARG;
+  size_t B = h->B, n = h->n;
+  HIP_TRY(hipMemcpyAsync(h->d_resid, rhs_host, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  TRY(launch_solve(h, h->d_resid, h->d_delta));
+  HIP_TRY(hipMemcpyAsync(x_host, h->d_delta, B * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CADNIP_OK;
+}
+
+int cadnip_lu_stats(CadnipHandle* h, int32_t* nnz_lu, int32_t* n_terms, int32_t* n_levels, int32_t* n_fwd, int32_t* n_bwd) {
+  if (!h || !h->analyzed) return CADNIP_NOTREADY;
+  if (nnz_lu) *nnz_lu = h->lu.nnz_lu;
+  if (n_terms) *n_terms = (int)h->lu.term_a.size();
+  if (n_levels) *n_levels = (int)h->lu.lev_ptr.size() - 1;
+  if (n_fwd) *n_fwd = (int)h->lu.fwd_lev_ptr.size() - 1;
+  if (n_bwd) *n_bwd = (int)h->lu.bwd_lev_ptr.size() - 1;
+  return CADNIP_OK;
+}
+
+void* cadnip_dev_ptr(CadnipHandle* h, int32_t which) {
+  if (!h) return nullptr;
+  switch (which) {
+    case CADNIP_BUF_U: return h->d_u; case CADNIP_BUF_G: return h->d_G; case CADNIP_BUF_C: return h->d_C; case CADNIP_BUF_B: return h->d_b;
+    case CADNIP_BUF_J: return h->d_J; case CADNIP_BUF_RESID: return h->d_resid; case CADNIP_BUF_SLOTS: return h->d_S; case CADNIP_BUF_LU: return h->d_LU;
+    case CADNIP_BUF_FLAGS: return h->d_flags;
+  }
+  return nullptr;
+}
+void* cadnip_stream(CadnipHandle* h) { return h ? (void*)h->stream : nullptr; }
+
+int cadnip_set_u(CadnipHandle* h, const double* u_host) {
+  if (!h || !u_host) return CADNIP_BADARG;
+  HIP_TRY(hipMemcpyAsync(h->d_u, u_host, (size_t)h->B * h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CADNIP_OK;
+}
+int cadnip_get_u(CadnipHandle* h, double* u_host) {
+  if (!h || !u_host) return CADNIP_BADARG;
+  HIP_TRY(hipMemcpyAsync(u_host, h->d_u, (size_t)h->B * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CADNIP_OK;
+}
+int cadnip_get_flags(CadnipHandle* h, int32_t* flags_host) {
+  if (!h || !flags_host) return CADNIP_BADARG;
+  HIP_TRY(hipMemcpyAsync(flags_host, h->d_flags, (size_t)h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CADNIP_OK;
+}
+int cadnip_sync(CadnipHandle* h) { if (!h) return CADNIP_BADARG; HIP_TRY(hipStreamSynchronize(h->stream)); return CADNIP_OK; }
+
+int cadnip_profile_enable(CadnipHandle* h, int32_t on) {
+  if (!h) return CADNIP_BADARG;
+  h->prof_on = on != 0;
+  h->prof.clear();
+  return CADNIP_OK;
+}
+int cadnip_profile_read(CadnipHandle* h, int32_t max_entries, const char** names, double* ms, int64_t* calls) {
+  if (!h) return 0;
+  int k = 0;
+  for (auto& e : h->prof) { if (k >= max_entries) break; names[k] = e.name; ms[k] = e.ms; calls[k] = e.calls; ++k; }
+  return k;
+}
+
+}  // extern "C"
+
+namespace cadnip {
+int upload_lu(CadnipHandle* h) {
+  LUProgram& P = h->lu;
+  int** olds[] = {&h->d_load_src, &h->d_load_dst, &h->d_ent_pos, &h->d_ent_diag, &h->d_ent_ptr, &h->d_term_a, &h->d_term_b, &h->d_lev_ptr,
+                  &h->d_lu_rowptr, &h->d_lu_col, &h->d_lu_diag, &h->d_rperm, &h->d_cperm, &h->d_fwd_rows, &h->d_fwd_lev_ptr, &h->d_bwd_rows, &h->d_bwd_lev_ptr};
+  for (int** p : olds) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (h->d_LU) { (void)hipFree(h->d_LU); h->d_LU = nullptr; }
+  // load_dst indexed by csr position (load_src is 0..nnz-1 in order)
+  std::vector<int> dst(h->nnz, 0);
+  for (size_t k = 0; k < P.load_src.size(); ++k) dst[P.load_src[k]] = P.load_dst[k];
+  TRY(dev_upload(&h->d_load_dst, dst));
+  TRY(dev_upload(&h->d_ent_pos, P.ent_pos)); TRY(dev_upload(&h->d_ent_diag, P.ent_diag)); TRY(dev_upload(&h->d_ent_ptr, P.ent_ptr));
+  TRY(dev_upload(&h->d_term_a, P.term_a)); TRY(dev_upload(&h->d_term_b, P.term_b)); TRY(dev_upload(&h->d_lev_ptr, P.lev_ptr));
+  TRY(dev_upload(&h->d_lu_rowptr, P.lu_rowptr)); TRY(dev_upload(&h->d_lu_col, P.lu_col)); TRY(dev_upload(&h->d_lu_diag, P.lu_diag));
+  TRY(dev_upload(&h->d_rperm, P.rperm)); TRY(dev_upload(&h->d_cperm, P.cperm));
+  TRY(dev_upload(&h->d_fwd_rows, P.fwd_rows)); TRY(dev_upload(&h->d_fwd_lev_ptr, P.fwd_lev_ptr));
+  TRY(dev_upload(&h->d_bwd_rows, P.bwd_rows)); TRY(dev_upload(&h->d_bwd_lev_ptr, P.bwd_lev_ptr));
+  TRY(dev_alloc(&h->d_LU, (size_t)h->B * P.nnz_lu));
+  h->analyzed = true;
+  return CADNIP_OK;
+}
+}  // namespace cadnip

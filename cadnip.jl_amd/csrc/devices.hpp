@@ -1,0 +1,520 @@
+// devices.hpp -- per-device-type stamp functions for gfx950 (device code only).
+//
+// One function per reference `stamp!` method; each is called by one GPU kernel per device
+// type (kernels.hip: k_stamp<T>) and by the fused per-instance Newton kernel.  A stamp
+// function reads the unknowns it needs from `u` (one sweep instance's solution vector),
+// its parameters from the SoA parameter block, and writes the values of its fixed G / C / b
+// slots; slot (k, dev) lives at S[base + k*count + dev] so that consecutive device lanes
+// write consecutive addresses.  No branch changes which slots are written: the stamp
+// sequence of the reference is branch-independent by construction
+// (/root/reference/src/mna/value_only.jl:395-421, src/vasim.jl:1984-2134).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace cadnip {
+
+#define CADNIP_CHARGE_SCALE 1e12   // /root/reference/src/mna/contrib.jl:39
+
+struct DevCtx {
+  const int* __restrict__ nodes;   // [n_nodes][count]
+  const int* __restrict__ ipar;    // [n_ipar][count]
+  const double* __restrict__ par;  // this instance: [n_par][count]
+  const double* __restrict__ wave; // shared wave tables
+  int count;
+  int dev;
+  double t;
+  int mode;                        // 0 dcop, 1 tran, 2 tranop
+  int initjct;
+};
+
+// slot writers: S points at this instance's slot buffer; bases are per block
+struct SlotOut {
+  double* __restrict__ g;  // S + g_base
+  double* __restrict__ c;  // S + ns_g + c_base
+  double* __restrict__ b;  // S + ns_g + ns_c + b_base
+  int count, dev;
+  __device__ __forceinline__ void G(int k, double v) const { g[k * count + dev] = v; }
+  __device__ __forceinline__ void C(int k, double v) const { c[k * count + dev] = v; }
+  __device__ __forceinline__ void B(int k, double v) const { b[k * count + dev] = v; }
+};
+
+__device__ __forceinline__ int node_of(const DevCtx& d, int k) { return d.nodes[k * d.count + d.dev]; }
+__device__ __forceinline__ double par_of(const DevCtx& d, int k) { return d.par[k * d.count + d.dev]; }
+__device__ __forceinline__ double volt(const double* u, int node) { return node < 0 ? 0.0 : u[node]; }
+
+// ------------------------------------------------------------------------------------------
+// source waves (devices.jl:30-103, 155-203)
+// ------------------------------------------------------------------------------------------
+__device__ inline double pwl_at_time(const double* ts, const double* ys, int n, double t) {
+  // find_t_in_ts: searchsortedfirst, +1 on an exact hit (devices.jl:30-36); i is 1-based
+  int lo = 0, hi = n;
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (ts[mid] < t) lo = mid + 1; else hi = mid; }
+  int i = lo + 1;
+  if (i <= n && ts[i - 1] == t) i += 1;
+  if (i <= 1) return ys[0];
+  if (i > n) return ys[n - 1];
+  if (ys[i - 2] == ys[i - 1]) return ys[i - 1];
+  if (ts[i - 1] == ts[i - 2]) return (ys[i - 2] + ys[i - 1]) / 2;
+  double slope = (ys[i - 1] - ys[i - 2]) / (ts[i - 1] - ts[i - 2]);
+  return ys[i - 2] + (t - ts[i - 2]) * slope;
+}
+
+__device__ inline double pulse_at_time(double v1, double v2, double td, double tr, double tf, double pw, double per, double t) {
+  if (t < td) return v1;
+  double phase;
+  if (per > 0) { phase = fmod(t - td, per); if (phase < 0) phase += per; } else phase = t - td;
+  if (phase < tr) return tr > 0 ? v1 + (v2 - v1) * (phase / tr) : v2;
+  else if (phase < tr + pw) return v2;
+  else if (phase < tr + pw + tf) return tf > 0 ? v2 + (v1 - v2) * ((phase - tr - pw) / tf) : v1;
+  return v1;
+}
+
+__device__ inline double sind_deg(double deg) {
+  double r = fmod(deg, 360.0);
+  if (r == 0.0 || r == 180.0 || r == -180.0) return 0.0;
+  if (r == 90.0 || r == -270.0) return 1.0;
+  if (r == -90.0 || r == 270.0) return -1.0;
+  return sin(r * (3.14159265358979323846 / 180.0));
+}
+
+// get_source_value (devices.jl:352-360): :dcop -> dc, otherwise tran(t)
+__device__ inline double source_value(const DevCtx& d, double dc, double scale) {
+  int kind = d.ipar[0 * d.count + d.dev];
+  if (kind == 0 || d.mode == 0) return dc;
+  int off = d.ipar[1 * d.count + d.dev];
+  int len = d.ipar[2 * d.count + d.dev];
+  const double* w = d.wave + off;
+  double v;
+  if (kind == 1) v = pwl_at_time(w, w + len, len, d.t);
+  else if (kind == 2) v = pulse_at_time(w[0], w[1], w[2], w[3], w[4], w[5], w[6], d.t);
+  else {
+    double vo = w[0], va = w[1], freq = w[2], td = w[3], theta = w[4], phase = w[5];
+    if (d.t < td) v = vo + va * sind_deg(phase);
+    else v = vo + va * exp(-theta * (d.t - td)) * sind_deg(360 * freq * (d.t - td) + phase);
+  }
+  return scale * v;
+}
+
+// ------------------------------------------------------------------------------------------
+// linear devices
+// ------------------------------------------------------------------------------------------
+__device__ inline void conductance4(const SlotOut& s, int k0, double g) { s.G(k0, g); s.G(k0 + 1, -g); s.G(k0 + 2, -g); s.G(k0 + 3, g); }
+__device__ inline void capacitance4(const SlotOut& s, int k0, double c) { s.C(k0, c); s.C(k0 + 1, -c); s.C(k0 + 2, -c); s.C(k0 + 3, c); }
+__device__ inline void branch4(const SlotOut& s) { s.G(0, 1.0); s.G(1, -1.0); s.G(2, 1.0); s.G(3, -1.0); }
+
+__device__ inline void stamp_resistor(const DevCtx& d, const double*, const SlotOut& s, double*) { conductance4(s, 0, par_of(d, 0)); }
+__device__ inline void stamp_capacitor(const DevCtx& d, const double*, const SlotOut& s, double*) { capacitance4(s, 0, par_of(d, 0)); }
+__device__ inline void stamp_inductor(const DevCtx& d, const double*, const SlotOut& s, double*) { branch4(s); s.C(0, -par_of(d, 0)); }
+__device__ inline void stamp_vsource(const DevCtx& d, const double*, const SlotOut& s, double*) {
+  branch4(s);
+  s.B(0, source_value(d, par_of(d, 0), par_of(d, 1)));
+}
+__device__ inline void stamp_isource(const DevCtx& d, const double*, const SlotOut& s, double*) {
+  double i = source_value(d, par_of(d, 0), par_of(d, 1));
+  s.B(0, i); s.B(1, -i);
+}
+__device__ inline void stamp_vcvs(const DevCtx& d, const double*, const SlotOut& s, double*) {
+  double a = par_of(d, 0);
+  s.G(0, 1.0); s.G(1, -1.0); s.G(2, 1.0); s.G(3, -1.0); s.G(4, -a); s.G(5, a);
+}
+__device__ inline void stamp_vccs(const DevCtx& d, const double*, const SlotOut& s, double*) {
+  double gm = par_of(d, 0);
+  s.G(0, -gm); s.G(1, gm); s.G(2, gm); s.G(3, -gm);
+}
+__device__ inline void stamp_ccvs(const DevCtx& d, const double*, const SlotOut& s, double*) {
+  s.G(0, 1.0); s.G(1, -1.0); s.G(2, 1.0); s.G(3, -1.0);
+  s.G(4, 1.0); s.G(5, -1.0); s.G(6, 1.0); s.G(7, -1.0); s.G(8, -par_of(d, 0));
+}
+__device__ inline void stamp_cccs(const DevCtx& d, const double*, const SlotOut& s, double*) {
+  double a = par_of(d, 0);
+  s.G(0, 1.0); s.G(1, -1.0); s.G(2, 1.0); s.G(3, -1.0); s.G(4, -a); s.G(5, a);
+}
+
+// ------------------------------------------------------------------------------------------
+// diode (devices.jl:1169-1189 pnjlim, :1209-1234 limit!, :1333-1345 _diode_iv, :1370-1428)
+// ------------------------------------------------------------------------------------------
+__device__ inline double pnjlim(double vnew, double vold, double vt, double vcrit) {
+  if (vnew > vcrit && fabs(vnew - vold) > vt + vt) {
+    if (vold > 0.0) {
+      double arg = (vnew - vold) / vt;
+      if (arg > 0.0) return vold + vt * (2.0 + log(arg - 2.0));
+      return vold - vt * (2.0 + log(2.0 - arg));
+    }
+    return vt * log(vnew / vt);
+  } else if (vnew < 0.0) {
+    double arg = vold > 0.0 ? -vold - 1.0 : 2.0 * vold - 1.0;
+    if (vnew < arg) return arg;
+  }
+  return vnew;
+}
+
+__device__ inline void stamp_diode(const DevCtx& d, const double* u, const SlotOut& s, double* limit_w_base) {
+  int p = node_of(d, 0), n = node_of(d, 1), l = node_of(d, 2);
+  double Is = par_of(d, 0), nVt = par_of(d, 1), vcrit = par_of(d, 2);
+  double V0 = volt(u, p) - volt(u, n);
+  double I0, Gd, Ieq;
+  if (d.ipar[d.dev]) {
+    double vold = u[l];
+    double w = d.initjct ? vcrit : pnjlim(V0, vold, nVt, vcrit);
+    limit_w_base[l] = w;                       // record_limit_w! (value_only.jl:384)
+    s.G(0, 1.0); s.G(1, -1.0); s.G(2, 1.0);    // g_lim row (devices.jl:1228-1231)
+    double xarg = w / nVt;
+    if (xarg > 80.0) { double e80 = exp(80.0); I0 = Is * (e80 * (1.0 + (xarg - 80.0)) - 1.0); Gd = Is / nVt * e80; }
+    else { double e = exp(xarg); I0 = Is * (e - 1.0); Gd = Is / nVt * e; }
+    Ieq = I0 - Gd * w;                         // anchored at w (devices.jl:1251-1258)
+  } else {
+    s.G(0, 0.0); s.G(1, 0.0); s.G(2, 0.0);
+    double e = exp(V0 / nVt);
+    I0 = Is * (e - 1.0); Gd = Is / nVt * e;
+    Ieq = I0 - Gd * V0;
+  }
+  conductance4(s, 3, Gd);
+  s.B(0, -Ieq); s.B(1, Ieq);
+}
+
+__device__ inline void stamp_diodecap(const DevCtx& d, const double* u, const SlotOut& s, double*) {
+  int p = node_of(d, 0), n = node_of(d, 1);
+  double Is = par_of(d, 0), nVt = par_of(d, 1), Cj0 = par_of(d, 2), Vj = par_of(d, 3), m = par_of(d, 4);
+  double V0 = volt(u, p) - volt(u, n);
+  double e = exp(V0 / nVt);
+  double I0 = Is * (e - 1.0), G = Is / nVt * e, Ieq = I0 - G * V0;
+  conductance4(s, 0, G);
+  s.B(0, -Ieq); s.B(1, Ieq);
+  double Vmax = 0.9 * Vj, C;              // diode_junction_cap devices.jl:1505-1516
+  if (V0 < Vmax) C = Cj0 / pow(1 - V0 / Vj, m);
+  else { double Ca = Cj0 / pow(1 - Vmax / Vj, m); double dC = Cj0 * m / Vj / pow(1 - Vmax / Vj, m + 1); C = Ca + dC * (V0 - Vmax); }
+  capacitance4(s, 0, C);
+}
+
+// SimpleMOSFET (devices.jl:1667-1749)
+__device__ inline void stamp_simplemos(const DevCtx& d, const double* u, const SlotOut& s, double*) {
+  double Vd = volt(u, node_of(d, 0)), Vg = volt(u, node_of(d, 1)), Vs = volt(u, node_of(d, 2));
+  double Vth = par_of(d, 0), K = par_of(d, 1), lam = par_of(d, 2), Cgd = par_of(d, 3), Cgs = par_of(d, 4);
+  double Vgs = Vg - Vs, Vds = Vd - Vs, Ids, gm, gds;
+  if (Vgs <= Vth) { Ids = 0; gm = 0; gds = 0; }
+  else if (Vds <= Vgs - Vth) { Ids = K * ((Vgs - Vth) * Vds - Vds * Vds / 2); gm = K * Vds; gds = K * (Vgs - Vth - Vds); }
+  else { double vov = Vgs - Vth; Ids = K / 2 * (vov * vov) * (1 + lam * Vds); gm = K * vov * (1 + lam * Vds); gds = K / 2 * (vov * vov) * lam; }
+  double Ieq = Ids - gm * Vgs - gds * Vds;
+  s.G(0, gds); s.G(1, gm); s.G(2, -(gds + gm)); s.G(3, -gds); s.G(4, -gm); s.G(5, gds + gm);
+  s.B(0, -Ieq); s.B(1, Ieq);
+  capacitance4(s, 0, Cgs);
+  capacitance4(s, 4, Cgd);
+}
+
+// ------------------------------------------------------------------------------------------
+// forward-mode dual numbers (the JacobianTag dual of contrib.jl:54-101, restricted to the N
+// independent voltages a model actually depends on)
+// ------------------------------------------------------------------------------------------
+template <int N>
+struct Dual {
+  double v;
+  double p[N];
+  __device__ __forceinline__ Dual() {}
+  __device__ __forceinline__ Dual(double x) : v(x) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = 0.0;
+  }
+  __device__ __forceinline__ static Dual seed(double x, int k) { Dual r(x); r.p[k] = 1.0; return r; }
+};
+#define DUAL_BIN(op, vexpr, pexpr)                                                        \
+  template <int N> __device__ __forceinline__ Dual<N> operator op(const Dual<N>& a, const Dual<N>& b) { \
+    Dual<N> r; r.v = vexpr;                                                                \
+    _Pragma("unroll") for (int i = 0; i < N; ++i) r.p[i] = pexpr;                          \
+    return r; }
+DUAL_BIN(+, a.v + b.v, a.p[i] + b.p[i])
+DUAL_BIN(-, a.v - b.v, a.p[i] - b.p[i])
+DUAL_BIN(*, a.v * b.v, a.p[i] * b.v + b.p[i] * a.v)
+template <int N> __device__ __forceinline__ Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) {
+  Dual<N> r; double q = a.v / b.v; r.v = q;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.p[i] = (a.p[i] - q * b.p[i]) / b.v;
+  return r;
+}
+template <int N> __device__ __forceinline__ Dual<N> operator+(const Dual<N>& a, double b) { Dual<N> r = a; r.v += b; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator+(double b, const Dual<N>& a) { return a + b; }
+template <int N> __device__ __forceinline__ Dual<N> operator-(const Dual<N>& a, double b) { Dual<N> r = a; r.v -= b; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator-(double b, const Dual<N>& a) {
+  Dual<N> r; r.v = b - a.v;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.p[i] = -a.p[i];
+  return r;
+}
+template <int N> __device__ __forceinline__ Dual<N> operator-(const Dual<N>& a) { return 0.0 - a; }
+template <int N> __device__ __forceinline__ Dual<N> operator*(const Dual<N>& a, double b) {
+  Dual<N> r; r.v = a.v * b;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.p[i] = a.p[i] * b;
+  return r;
+}
+template <int N> __device__ __forceinline__ Dual<N> operator*(double b, const Dual<N>& a) { return a * b; }
+template <int N> __device__ __forceinline__ Dual<N> operator/(const Dual<N>& a, double b) {
+  Dual<N> r; r.v = a.v / b;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.p[i] = a.p[i] / b;
+  return r;
+}
+template <int N> __device__ __forceinline__ Dual<N> operator/(double b, const Dual<N>& a) {
+  Dual<N> r; double q = b / a.v; r.v = q;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.p[i] = (-q / a.v) * a.p[i];
+  return r;
+}
+template <int N> __device__ __forceinline__ Dual<N> dsqrt(const Dual<N>& a) {
+  Dual<N> r; double s = sqrt(a.v); r.v = s; double f = 0.5 / s;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.p[i] = a.p[i] * f;
+  return r;
+}
+template <int N> __device__ __forceinline__ Dual<N> dexp(const Dual<N>& a) {
+  Dual<N> r; double e = exp(a.v); r.v = e;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.p[i] = a.p[i] * e;
+  return r;
+}
+template <int N> __device__ __forceinline__ Dual<N> dlog(const Dual<N>& a) {
+  Dual<N> r; r.v = log(a.v);
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.p[i] = a.p[i] / a.v;
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// sp_mos1 (models/VADistillerModels.jl/va/mos1.va) as Cadnip stamps it (vasim.jl:3319-3521)
+//
+// Every node-voltage dependence of the load section enters through the three limited,
+// type-adjusted branch voltages vgs, vds, vbs returned by the `$limit ... DEVlimitNewSet`
+// sites (mos1.va:976-980); their duals are pass-through (vasim.jl:1319-1330: value = w,
+// d/dV_p = +1, d/dV_n = -1, unit partial in the site's own slot), and every partial produced
+// by the limiter functions themselves is discarded there.  So a Dual<3> over (vgs, vds, vbs)
+// carries exactly the information of the reference's width-14 JacobianTag dual:
+//   d/dV_g = type*da, d/dV_dint = type*db, d/dV_b = type*dc, d/dV_sint = -type*(da+db+dc),
+//   d/dW(site vgs,vds,vbs) = type*(da,db,dc)  ->  lim_rhs terms (vasim.jl:2957-2966).
+// ------------------------------------------------------------------------------------------
+enum { M1_TYPE = 0, M1_VT, M1_TPHI, M1_TVBI, M1_TVTO, M1_GAMMA, M1_LAMBDA, M1_BETA, M1_OXCAP, M1_SSATCUR, M1_DSATCUR,
+       M1_SVCRIT, M1_DVCRIT, M1_CBS, M1_CBSSW, M1_CBD, M1_CBDSW, M1_TBULKPOT, M1_TDEPCAP, M1_F2S, M1_F3S, M1_F4S,
+       M1_F2D, M1_F3D, M1_F4D, M1_MJ, M1_MJSW, M1_CGSOV, M1_CGDOV, M1_CGBOV, M1_GD, M1_GS, M1_MFACTOR, M1_GMIN };
+
+__device__ inline double m1_fetlim(double vnew, double vold, double vto) {   // DEVfetlim mos1.va:542-605
+  double vlimited = vnew;
+  double vtsthi = fabs(2 * (vold - vto)) + 2;
+  double vtstlo = fabs(vold - vto) + 1;
+  double vtox = vto + 3.5;
+  double delv = vnew - vold;
+  if (vold >= vto) {
+    if (vold >= vtox) {
+      if (delv <= 0) {
+        if (vlimited >= vtox) { if (-delv > vtstlo) vlimited = vold - vtstlo; }
+        else vlimited = fmax(vnew, vto + 2);
+      } else { if (delv >= vtsthi) vlimited = vold + vtsthi; }
+    } else {
+      if (delv <= 0) vlimited = fmax(vnew, vto - 0.5);
+      else vlimited = fmin(vnew, vto + 4);
+    }
+  } else {
+    if (delv <= 0) { if (-delv > vtsthi) vlimited = vold - vtsthi; }
+    else {
+      double vtemp = vto + 0.5;
+      if (vnew <= vtemp) { if (delv > vtstlo) vlimited = vold + vtstlo; }
+      else vlimited = vtemp;
+    }
+  }
+  return vlimited;
+}
+__device__ inline double m1_limvds(double vnew, double vold) {               // DEVlimvds mos1.va:607-635
+  if (vold >= 3.5) {
+    if (vnew > vold) return fmin(vnew, (3 * vold) + 2);
+    if (vnew < 3.5) return fmax(vnew, 2.0);
+    return vnew;
+  }
+  if (vnew > vold) return fmin(vnew, 4.0);
+  return fmax(vnew, -0.5);
+}
+__device__ inline double m1_pnjlim(double vnew, double vold, double vt, double vcrit) {   // DEVpnjlim mos1.va:503-540
+  double limited = vnew;
+  if ((vnew > vcrit) && (fabs(vnew - vold) > (vt + vt))) {
+    if (vold > 0) {
+      double arg = (vnew - vold) / vt;
+      if (arg > 0) limited = vold + vt * log(1 + arg);
+      else limited = vold - vt * log(1 - arg);
+    } else limited = vt * log(vnew / vt);
+  } else if (vnew < 0) {
+    double arg = vold > 0 ? -1 * vold - 1 : 2 * vold - 1;
+    if (vnew < arg) limited = arg;
+  }
+  return limited;
+}
+
+typedef Dual<3> D3;
+
+// DEVqmeyer (mos1.va:401-465): Meyer capacitances, evaluated on duals
+__device__ inline void m1_qmeyer(const D3& vgs, const D3& vgd, const D3& von, const D3& vdsat_in, double phi, double cox,
+                                 D3& capgs, D3& capgd, D3& capgb) {
+  D3 vdsat = vdsat_in;
+  D3 vgst = vgs - von;
+  if (!(vdsat.v > 0.025)) vdsat = D3(0.025);
+  if (vgst.v <= -phi) { capgb = D3(cox / 2); capgs = D3(0.0); capgd = D3(0.0); }
+  else if (vgst.v <= -phi / 2) { capgb = -1.0 * vgst * cox / (2 * phi); capgs = D3(0.0); capgd = D3(0.0); }
+  else if (vgst.v <= 0) {
+    capgb = -1.0 * vgst * cox / (2 * phi);
+    capgs = vgst * cox / (1.5 * phi) + cox / 3;
+    D3 vds = vgs - vgd;
+    if (vds.v >= vdsat.v) capgd = D3(0.0);
+    else {
+      D3 vddif = 2.0 * vdsat - vds, vddif1 = vdsat - vds, vddif2 = vddif * vddif;
+      capgd = capgs * (1.0 - vdsat * vdsat / vddif2);
+      capgs = capgs * (1.0 - vddif1 * vddif1 / vddif2);
+    }
+  } else {
+    D3 vds = vgs - vgd;
+    if (vdsat.v <= vds.v) { capgs = D3(cox / 3); capgd = D3(0.0); capgb = D3(0.0); }
+    else {
+      D3 vddif = 2.0 * vdsat - vds, vddif1 = vdsat - vds, vddif2 = vddif * vddif;
+      capgd = cox * (1.0 - vdsat * vdsat / vddif2) / 3;
+      capgs = cox * (1.0 - vddif1 * vddif1 / vddif2) / 3;
+      capgb = D3(0.0);
+    }
+  }
+}
+
+// depletion charge (mos1.va:1049-1109)
+__device__ inline D3 m1_qdep(const D3& v, double Cb, double Cbsw, double tBulkPot, double tDepCap, double mj, double mjsw,
+                             double f2, double f3, double f4) {
+  if (Cb != 0 || Cbsw != 0) {
+    if (v.v < tDepCap) {
+      D3 arg = 1.0 - v / tBulkPot;
+      D3 sarg = (mj == 0.5) ? 1.0 / dsqrt(arg) : dexp(-mj * dlog(arg));
+      D3 sargsw = (mjsw == mj) ? sarg : ((mjsw == 0.5) ? 1.0 / dsqrt(arg) : dexp(-mjsw * dlog(arg)));
+      return tBulkPot * (Cb * (1.0 - arg * sarg) / (1 - mj) + Cbsw * (1.0 - arg * sargsw) / (1 - mjsw));
+    }
+    return f4 + v * (f2 + v * (f3 / 2));
+  }
+  return D3(0.0);
+}
+
+__device__ inline void stamp_mos1(const DevCtx& d, const double* u, const SlotOut& s, double* limit_w_base) {
+  const double CS = CADNIP_CHARGE_SCALE;
+  int nd = node_of(d, 0), ng = node_of(d, 1), ns = node_of(d, 2), nb = node_of(d, 3), ndi = node_of(d, 4), nsi = node_of(d, 5);
+  int l0 = node_of(d, 6), l1 = node_of(d, 7), l2 = node_of(d, 8), l3 = node_of(d, 9);
+  double Vd = volt(u, nd), Vg = volt(u, ng), Vs = volt(u, ns), Vb = volt(u, nb), Vdi = volt(u, ndi), Vsi = volt(u, nsi);
+  double type = par_of(d, M1_TYPE), vt = par_of(d, M1_VT), tPhi = par_of(d, M1_TPHI), tVbi = par_of(d, M1_TVBI);
+  double gamma = par_of(d, M1_GAMMA), lambda = par_of(d, M1_LAMBDA), Beta = par_of(d, M1_BETA), OxideCap = par_of(d, M1_OXCAP);
+  double mf = par_of(d, M1_MFACTOR), gmin_m = par_of(d, M1_GMIN) / mf;
+  // ---- limiting (mos1.va:919-980), on values
+  double o_vgs = type * u[l0], o_vds = type * u[l1], o_vbs = type * u[l2], o_vbd = type * u[l3];
+  int omode = o_vds >= 0 ? 1 : -1;
+  double osel = omode == 1 ? o_vbs : o_vbd, osarg;
+  if (osel <= 0) osarg = sqrt(tPhi - osel);
+  else { osarg = sqrt(tPhi); osarg = osarg - o_vbs / (osarg + osarg); osarg = fmax(0.0, osarg); }   // mos1.va:940 (sic: always vbs)
+  double o_von = (tVbi * type) + gamma * osarg;
+  double vbs = type * (Vb - Vsi), vgs = type * (Vg - Vsi), vds = type * (Vdi - Vsi);
+  double vbd = vbs - vds, vgd = vgs - vds, vgdo = o_vgs - o_vds, von = type * o_von;
+  if (o_vds >= 0) {
+    vgs = m1_fetlim(vgs, o_vgs, von);
+    vds = vgs - vgd;
+    vds = m1_limvds(vds, o_vds);
+    vgd = vgs - vds;
+  } else {
+    vgd = m1_fetlim(vgd, vgdo, von);
+    vds = vgs - vgd;
+    vds = -m1_limvds(-vds, -o_vds);
+    vgs = vgd + vds;
+  }
+  if (vds >= 0) { vbs = m1_pnjlim(vbs, o_vbs, vt, par_of(d, M1_SVCRIT)); vbd = vbs - vds; }
+  else { vbd = m1_pnjlim(vbd, o_vbd, vt, par_of(d, M1_DVCRIT)); vbs = vbd + vds; }
+  if (d.initjct) { vbs = -1; vgs = type * par_of(d, M1_TVTO); vds = 0; vbd = vbs - vds; }   // mos1.va:969-974
+  double w_gs = type * vgs, w_ds = type * vds, w_bs = type * vbs, w_bd = type * vbd;
+  limit_w_base[l0] = w_gs; limit_w_base[l1] = w_ds; limit_w_base[l2] = w_bs; limit_w_base[l3] = w_bd;
+  // g_lim rows (vasim.jl:3134-3136)
+#pragma unroll
+  for (int lb = 0; lb < 4; ++lb) { s.G(3 * lb, 1.0); s.G(3 * lb + 1, -1.0); s.G(3 * lb + 2, 1.0); }
+  // ---- evaluation on pass-through duals anchored at w
+  D3 a = D3::seed(type * w_gs, 0), b = D3::seed(type * w_ds, 1), c = D3::seed(type * w_bs, 2);   // load_vgs, load_vds, load_vbs
+  D3 dvbd = c - b, dvgd = a - b, dvgb = a - c;
+  D3 cbs, cbd;                                           // junction currents mos1.va:983-998
+  if (c.v <= -3 * vt) cbs = gmin_m * c - par_of(d, M1_SSATCUR);
+  else { D3 x = c / vt; D3 e = dexp(709.0 < x.v ? D3(709.0) : x); cbs = par_of(d, M1_SSATCUR) * (e - 1.0) + gmin_m * c; }
+  if (dvbd.v <= -3 * vt) cbd = gmin_m * dvbd - par_of(d, M1_DSATCUR);
+  else { D3 x = dvbd / vt; D3 e = dexp(709.0 < x.v ? D3(709.0) : x); cbd = par_of(d, M1_DSATCUR) * (e - 1.0) + gmin_m * dvbd; }
+  int mode = b.v >= 0 ? 1 : -1;
+  D3 sel = mode == 1 ? c : dvbd, sarg;
+  if (sel.v <= 0) sarg = dsqrt(tPhi - sel);
+  else { double s0 = sqrt(tPhi); sarg = s0 - sel / (s0 + s0); if (0 > sarg.v) sarg = D3(0.0); }
+  D3 dvon = tVbi * type + gamma * sarg;
+  D3 vgst = (mode == 1 ? a : dvgd) - dvon;
+  D3 vdsat = vgst.v > 0 ? vgst : D3(0.0);
+  D3 cdrain;
+  if (vgst.v <= 0) cdrain = D3(0.0);
+  else {
+    D3 vdsm = b * (double)mode;
+    D3 betap = Beta * (1.0 + lambda * vdsm);
+    if (vgst.v <= vdsm.v) cdrain = betap * vgst * vgst * 0.5;
+    else cdrain = betap * vdsm * (vgst - 0.5 * vdsm);
+  }
+  double ms = OxideCap == 0 ? 0.0 : OxideCap, mu = OxideCap == 0 ? 1.0 : OxideCap;   // meyer_scale / meyer_unscale mos1.va:1042-1048
+  D3 qbs = m1_qdep(c, par_of(d, M1_CBS), par_of(d, M1_CBSSW), par_of(d, M1_TBULKPOT), par_of(d, M1_TDEPCAP), par_of(d, M1_MJ),
+                   par_of(d, M1_MJSW), par_of(d, M1_F2S), par_of(d, M1_F3S), par_of(d, M1_F4S));
+  D3 qbd = m1_qdep(dvbd, par_of(d, M1_CBD), par_of(d, M1_CBDSW), par_of(d, M1_TBULKPOT), par_of(d, M1_TDEPCAP), par_of(d, M1_MJ),
+                   par_of(d, M1_MJSW), par_of(d, M1_F2D), par_of(d, M1_F3D), par_of(d, M1_F4D));
+  D3 mcgs, mcgd, mcgb;
+  if (mode > 0) m1_qmeyer(a, dvgd, dvon, vdsat, tPhi, OxideCap, mcgs, mcgd, mcgb);
+  else m1_qmeyer(dvgd, a, dvon, vdsat, tPhi, OxideCap, mcgd, mcgs, mcgb);
+  D3 capgs = mcgs + mcgs + par_of(d, M1_CGSOV), capgd = mcgd + mcgd + par_of(d, M1_CGDOV), capgb = mcgb + mcgb + par_of(d, M1_CGBOV);
+  D3 qgs = capgs * ((ms * a) / mu), qgd = capgd * ((ms * dvgd) / mu), qgb = capgb * ((ms * dvgb) / mu);   // reactive part of ceqg* mos1.va:1140-1147
+  D3 cdreq = (mode >= 0 ? type : -type) * cdrain;
+  // branch contributions (mos1.va:1164-1169), split into resistive (Ir) and reactive (q) parts; I(d), I(s) are linear
+  double gd = par_of(d, M1_GD), gs = par_of(d, M1_GS);
+  D3 Ir[6], q[4];
+  Ir[0] = D3(0.0); Ir[1] = D3(0.0); Ir[2] = D3(0.0);
+  Ir[3] = type * cbs + type * cbd;
+  Ir[4] = -1.0 * (type * cbd - cdreq);
+  Ir[5] = -1.0 * (cdreq + type * cbs);
+  q[0] = type * (qgs + qgb + qgd);
+  q[1] = (type * qbs + type * qbd) - type * qgb;
+  q[2] = -1.0 * (type * qbd + type * qgd);
+  q[3] = -1.0 * (type * qbs + type * qgs);
+  double dW_gs = (Vg - Vsi) - w_gs, dW_ds = (Vdi - Vsi) - w_ds, dW_bs = (Vb - Vsi) - w_bs;   // lim_rhs deltas
+  const double Vk[6] = {Vd, Vg, Vs, Vb, Vdi, Vsi};
+  // linear conductance terms of I(d), I(s), I(d_int), I(s_int) in node space: value and d/dV_k
+  double Iv[6], dI[6][6];
+#pragma unroll
+  for (int br = 0; br < 6; ++br) {
+    double fa = type * Ir[br].p[0], fb = type * Ir[br].p[1], fc = type * Ir[br].p[2];
+    dI[br][0] = 0.0; dI[br][1] = fa; dI[br][2] = 0.0; dI[br][3] = fc; dI[br][4] = fb; dI[br][5] = -(fa + fb + fc);
+    Iv[br] = Ir[br].v;
+  }
+  Iv[0] += gd * (Vd - Vdi); dI[0][0] += gd; dI[0][4] -= gd;
+  Iv[2] += gs * (Vs - Vsi); dI[2][2] += gs; dI[2][5] -= gs;
+  Iv[4] += gd * (Vdi - Vd); dI[4][4] += gd; dI[4][0] -= gd;
+  Iv[5] += gs * (Vsi - Vs); dI[5][5] += gs; dI[5][2] -= gs;
+#pragma unroll
+  for (int br = 0; br < 6; ++br) {
+    double Ieq = mf * Iv[br];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { double g = mf * dI[br][k]; s.G(12 + 6 * br + k, g); Ieq = Ieq + (-g * Vk[k]); }
+    Ieq = Ieq + (mf * type * Ir[br].p[0]) * dW_gs;
+    Ieq = Ieq + (mf * type * Ir[br].p[1]) * dW_ds;
+    Ieq = Ieq + (mf * type * Ir[br].p[2]) * dW_bs;
+    s.B(br, -Ieq);
+  }
+  int vdep = d.ipar[d.dev];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double fa = mf * type * q[r].p[0], fb = mf * type * q[r].p[1], fc = mf * type * q[r].p[2];
+    double dq[6] = {0.0, fa, 0.0, fc, fb, -(fa + fb + fc)};
+    // charge-state formulation (vasim.jl:3433-3472)
+    s.C(r, 1.0 / CS);
+    s.G(48 + 7 * r, 1.0);
+    double bc = mf * q[r].v;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { s.G(48 + 7 * r + 1 + k, -CS * dq[k]); bc -= dq[k] * Vk[k]; }
+    bc += fa * dW_gs; bc += fb * dW_ds; bc += fc * dW_bs;
+    s.B(6 + r, CS * bc);
+    // linear form (vasim.jl:3474-3482), used when the branch was not flagged voltage dependent
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s.C(4 + 6 * r + k, dq[k]);
+  }
+  (void)vdep;
+}
+
+}  // namespace cadnip

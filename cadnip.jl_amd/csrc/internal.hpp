@@ -1,0 +1,108 @@
+// internal.hpp -- handle layout shared by the kernel, symbolic and driver translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/cadnip_hip.h"
+
+#define HIP_TRY(expr)                                                     \
+  do {                                                                    \
+    hipError_t _e = (expr);                                               \
+    if (_e != hipSuccess) {                                               \
+      cadnip::set_last_error(#expr, _e);                                  \
+      return CADNIP_HIPERROR;                                             \
+    }                                                                     \
+  } while (0)
+
+namespace cadnip {
+
+void set_last_error(const char* what, hipError_t e);
+
+// host-side result of the symbolic phase (symbolic.cpp)
+struct LUProgram {
+  int n = 0;
+  std::vector<int> rperm, cperm;       // pivot k uses original row rperm[k], column cperm[k]
+  int nnz_lu = 0;
+  // LU stored row-major in permuted indices; row i occupies [lu_rowptr[i], lu_rowptr[i+1]) with sorted columns
+  std::vector<int> lu_rowptr, lu_col, lu_diag;   // lu_diag[i] = position of U(i,i)
+  std::vector<int> load_src, load_dst;           // J csr position -> LU position
+  // entry-wise left-looking factorisation program, entries sorted by dependency level
+  std::vector<int> ent_pos, ent_diag, ent_ptr;   // ent_diag = -1 for U entries, else position of the pivot
+  std::vector<int> term_a, term_b;               // LU positions: acc -= lu[a]*lu[b]
+  std::vector<int> lev_ptr;                      // factor levels -> ranges of entries
+  // triangular solves, row-wise gather, rows sorted by level
+  std::vector<int> fwd_rows, fwd_lev_ptr, bwd_rows, bwd_lev_ptr;
+};
+
+struct DeviceBlock {
+  int type, count, n_nodes, n_ipar, n_par;
+  int g_base, c_base, b_base, n_g, n_c, n_b;
+  int* d_nodes = nullptr;
+  int* d_ipar = nullptr;
+  double* d_par = nullptr;   // [B][n_par][count]
+};
+
+struct ProfEntry { const char* name; double ms = 0; int64_t calls = 0; };
+
+}  // namespace cadnip
+
+struct CadnipHandle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int B = 0;
+  // structure (host copies kept for the symbolic phase)
+  int n = 0, n_nodes = 0, n_currents = 0, n_charges = 0, n_limits = 0, nnz = 0;
+  std::vector<int> h_rowptr, h_colidx, h_to_ref;
+  int ns_g = 0, ns_c = 0, ns_b = 0, ns = 0;
+  std::vector<cadnip::DeviceBlock> blocks;
+  std::vector<double> h_limit_init;
+  CadnipSpec spec{1, 1e-12, 0.0, 1.0};
+  int initjct = 0;
+  // device: structure
+  int *d_rowptr = nullptr, *d_colidx = nullptr, *d_to_ref = nullptr;
+  int *d_g_ptr = nullptr, *d_g_slots = nullptr, *d_c_ptr = nullptr, *d_c_slots = nullptr, *d_b_ptr = nullptr, *d_b_slots = nullptr;
+  unsigned char* d_diag_flag = nullptr;   // [nnz] 1 where the entry is G[i,i] of a voltage node
+  double* d_wave = nullptr;
+  double* d_limit_init = nullptr;
+  // device: per-instance state [B][..]
+  double *d_u = nullptr, *d_du = nullptr, *d_t = nullptr, *d_gamma = nullptr;
+  double *d_S = nullptr, *d_G = nullptr, *d_C = nullptr, *d_b = nullptr, *d_J = nullptr, *d_resid = nullptr, *d_delta = nullptr;
+  double *d_limit_w = nullptr, *d_LU = nullptr, *d_tmp = nullptr;
+  int* d_flags = nullptr;        // [B] per-instance status bits (1 = singular pivot, 2 = non-finite)
+  int* d_active = nullptr;       // [B] 1 = instance takes part in the next launches
+  // LU
+  bool analyzed = false;
+  cadnip::LUProgram lu;
+  int *d_load_src = nullptr, *d_load_dst = nullptr, *d_ent_pos = nullptr, *d_ent_diag = nullptr, *d_ent_ptr = nullptr;
+  int *d_term_a = nullptr, *d_term_b = nullptr, *d_lev_ptr = nullptr;
+  int *d_lu_rowptr = nullptr, *d_lu_col = nullptr, *d_lu_diag = nullptr, *d_rperm = nullptr, *d_cperm = nullptr;
+  int *d_fwd_rows = nullptr, *d_fwd_lev_ptr = nullptr, *d_bwd_rows = nullptr, *d_bwd_lev_ptr = nullptr;
+  // driver state (allocated lazily)
+  struct Driver* drv = nullptr;
+  // profiling
+  bool prof_on = false;
+  std::vector<cadnip::ProfEntry> prof;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // pinned scratch
+  int* h_pinned = nullptr;
+};
+
+namespace cadnip {
+// symbolic.cpp
+int lu_analyze(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, const std::vector<double>& vals,
+               double pivot_tol, LUProgram& out, std::string& err);
+// kernels.hip launchers (all asynchronous on h->stream)
+int launch_rebuild(CadnipHandle* h);                       // stamps + assemble at (d_u, d_t)
+int launch_residual(CadnipHandle* h, const double* d_du);  // d_resid = C du + G u - b
+int launch_jacobian(CadnipHandle* h);                      // d_J = G + gamma C
+int launch_factor(CadnipHandle* h, bool fuse_jacobian);    // LU of J (or of G + gamma C)
+int launch_solve(CadnipHandle* h, const double* d_rhs, double* d_x);
+int launch_factor_solve(CadnipHandle* h, bool fuse_jacobian, const double* d_rhs, double* d_x);
+int upload_lu(CadnipHandle* h);
+struct ProfScope {
+  CadnipHandle* h; int idx;
+  ProfScope(CadnipHandle* h, const char* name);
+  ~ProfScope();
+};
+}  // namespace cadnip

@@ -1,0 +1,210 @@
+// symbolic.cpp -- host-side symbolic phase of the GPU sparse LU (run once per structure).
+//
+// Stands in for KLU's analyse + first factor (SuiteSparse, third-party, reached in the
+// reference through Sundials IDA `linear_solver=:KLU`, /root/reference/src/sweeps.jl:600, and
+// LinearSolve's KLUFactorization with the symbolic factorisation reused,
+// /root/reference/src/mna/solve.jl:612-613,667-670).  Like klu_refactor, every later numeric
+// factorisation on the GPU reuses the pivot sequence chosen here.
+//
+// MNA matrices have structurally zero diagonals (V-source / inductor rows,
+// /root/reference/src/mna/devices.jl:619-633), so the order is chosen numerically on a sample
+// Jacobian: Markowitz cost (r-1)(c-1) among entries passing a relative threshold test,
+// diagonal entries preferred on ties (node diagonals are sums of conductances and stay
+// dominant across operating points, which is what a static order needs).
+//
+// Output: permuted row-major L+U pattern with fill, the J -> LU load map, an entry-wise
+// left-looking program  lu[e] = (lu[e] - sum_k lu[a_k]*lu[b_k]) [/ pivot]  whose entries are
+// grouped into dependency levels (each LU entry is written exactly once, by one lane, no
+// atomics), and level schedules for the two triangular solves.
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <set>
+#include <unordered_map>
+#include "internal.hpp"
+
+namespace cadnip {
+
+int lu_analyze(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, const std::vector<double>& vals,
+               double pivot_tol, LUProgram& out, std::string& err) {
+  out = LUProgram();
+  out.n = n;
+  std::vector<std::map<int, double>> rows(n);
+  std::vector<std::set<int>> cols(n);
+  for (int i = 0; i < n; ++i)
+    for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+      rows[i][colidx[p]] = vals[p];
+      cols[colidx[p]].insert(i);
+    }
+  std::vector<char> rdone(n, 0);
+  std::vector<std::vector<int>> Urow(n), Lcol(n);
+  out.rperm.assign(n, -1);
+  out.cperm.assign(n, -1);
+  std::vector<double> colmax(n);
+  std::vector<int> colmax_stamp(n, -1);
+  for (int k = 0; k < n; ++k) {
+    long best_cost = -1;
+    int bi = -1, bj = -1;
+    bool bdiag = false;
+    double brel = 0;
+    for (int i = 0; i < n; ++i) {
+      if (rdone[i]) continue;
+      long r = (long)rows[i].size();
+      for (auto& kv : rows[i]) {
+        int j = kv.first;
+        double av = std::fabs(kv.second);
+        if (!(av > 0.0) || !std::isfinite(av)) continue;
+        long c = (long)cols[j].size();
+        long cost = (r - 1) * (c - 1);
+        if (best_cost >= 0 && cost > best_cost) continue;
+        if (colmax_stamp[j] != k) {
+          double m = 0;
+          for (int ii : cols[j]) m = std::max(m, std::fabs(rows[ii][j]));
+          colmax[j] = m;
+          colmax_stamp[j] = k;
+        }
+        if (av < pivot_tol * colmax[j]) continue;
+        double rel = av / colmax[j];
+        bool diag = (i == j);
+        bool better = false;
+        if (best_cost < 0 || cost < best_cost) better = true;
+        else if (diag != bdiag) better = diag;
+        else if (rel > brel * (1 + 1e-12)) better = true;
+        if (better) { best_cost = cost; bi = i; bj = j; bdiag = diag; brel = rel; }
+      }
+    }
+    if (bi < 0) { err = "matrix is singular at pivot step " + std::to_string(k); return CADNIP_SINGULAR; }
+    out.rperm[k] = bi;
+    out.cperm[k] = bj;
+    double piv = rows[bi][bj];
+    std::vector<int> lrows;
+    for (int i : cols[bj]) if (i != bi) lrows.push_back(i);
+    for (auto& kv : rows[bi]) Urow[k].push_back(kv.first);
+    Lcol[k] = lrows;
+    for (int i : lrows) {
+      double f = rows[i][bj] / piv;
+      for (auto& kv : rows[bi]) {
+        int j = kv.first;
+        if (j == bj) continue;
+        auto it = rows[i].find(j);
+        if (it == rows[i].end()) { rows[i][j] = -f * kv.second; cols[j].insert(i); }
+        else it->second -= f * kv.second;
+      }
+      rows[i].erase(bj);
+    }
+    for (auto& kv : rows[bi]) cols[kv.first].erase(bi);
+    cols[bj].clear();
+    rdone[bi] = 1;
+  }
+  std::vector<int> pinv(n), qinv(n);
+  for (int k = 0; k < n; ++k) { pinv[out.rperm[k]] = k; qinv[out.cperm[k]] = k; }
+  // permuted row-major L+U pattern
+  std::vector<std::vector<int>> prow(n);
+  for (int k = 0; k < n; ++k) {
+    for (int j : Urow[k]) prow[k].push_back(qinv[j]);
+    for (int i : Lcol[k]) prow[pinv[i]].push_back(k);
+  }
+  out.lu_rowptr.assign(n + 1, 0);
+  out.lu_diag.assign(n, -1);
+  for (int i = 0; i < n; ++i) {
+    std::sort(prow[i].begin(), prow[i].end());
+    prow[i].erase(std::unique(prow[i].begin(), prow[i].end()), prow[i].end());
+    out.lu_rowptr[i + 1] = out.lu_rowptr[i] + (int)prow[i].size();
+  }
+  out.nnz_lu = out.lu_rowptr[n];
+  out.lu_col.resize(out.nnz_lu);
+  std::unordered_map<long long, int> posmap;
+  posmap.reserve((size_t)out.nnz_lu * 2);
+  for (int i = 0; i < n; ++i)
+    for (size_t t = 0; t < prow[i].size(); ++t) {
+      int p = out.lu_rowptr[i] + (int)t;
+      out.lu_col[p] = prow[i][t];
+      posmap[(long long)i * n + prow[i][t]] = p;
+      if (prow[i][t] == i) out.lu_diag[i] = p;
+    }
+  for (int i = 0; i < n; ++i)
+    if (out.lu_diag[i] < 0) { err = "internal: missing diagonal in LU pattern"; return CADNIP_SINGULAR; }
+  // load map
+  for (int i = 0; i < n; ++i)
+    for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+      auto it = posmap.find((long long)pinv[i] * n + qinv[colidx[p]]);
+      if (it == posmap.end()) { err = "internal: J entry outside LU pattern"; return CADNIP_BADARG; }
+      out.load_src.push_back(p);
+      out.load_dst.push_back(it->second);
+    }
+  // entry-wise program + levels
+  std::vector<int> level(out.nnz_lu, 0);
+  struct Ent { int pos, diag, lvl; std::vector<int> a, b; };
+  std::vector<Ent> ents;
+  for (int i = 0; i < n; ++i) {
+    int r0 = out.lu_rowptr[i], r1 = out.lu_rowptr[i + 1], dp = out.lu_diag[i];
+    for (int p = r0; p < r1; ++p) {
+      int j = out.lu_col[p];
+      Ent e;
+      e.pos = p;
+      e.diag = (j < i) ? out.lu_diag[j] : -1;
+      int lvl = 0;
+      for (int pl = r0; pl < dp; ++pl) {       // L(i,k), k ascending
+        int kk = out.lu_col[pl];
+        if (kk >= j) break;
+        auto it = posmap.find((long long)kk * n + j);
+        if (it == posmap.end()) continue;
+        e.a.push_back(pl);
+        e.b.push_back(it->second);
+        lvl = std::max(lvl, std::max(level[pl], level[it->second]) + 1);
+      }
+      if (e.diag >= 0) lvl = std::max(lvl, level[e.diag] + 1);
+      level[p] = lvl;
+      e.lvl = lvl;
+      if (!e.a.empty() || e.diag >= 0) ents.push_back(std::move(e));
+    }
+  }
+  std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.lvl < y.lvl; });
+  int nlev = 0;
+  for (auto& e : ents) nlev = std::max(nlev, e.lvl + 1);
+  out.lev_ptr.assign(1, 0);
+  out.ent_ptr.assign(1, 0);
+  {
+    int cur = ents.empty() ? 0 : ents[0].lvl;
+    // levels start at the first level that has work
+    for (size_t t = 0; t < ents.size(); ++t) {
+      if (ents[t].lvl != cur) { out.lev_ptr.push_back((int)t); cur = ents[t].lvl; }
+      out.ent_pos.push_back(ents[t].pos);
+      out.ent_diag.push_back(ents[t].diag);
+      out.term_a.insert(out.term_a.end(), ents[t].a.begin(), ents[t].a.end());
+      out.term_b.insert(out.term_b.end(), ents[t].b.begin(), ents[t].b.end());
+      out.ent_ptr.push_back((int)out.term_a.size());
+    }
+    out.lev_ptr.push_back((int)ents.size());
+  }
+  // triangular solve schedules
+  std::vector<int> fl(n, 0), bl(n, 0);
+  std::vector<std::pair<int, int>> fr, br;
+  for (int i = 0; i < n; ++i) {
+    int lv = 0;
+    bool any = false;
+    for (int p = out.lu_rowptr[i]; p < out.lu_diag[i]; ++p) { lv = std::max(lv, fl[out.lu_col[p]] + 1); any = true; }
+    fl[i] = lv;
+    if (any) fr.push_back({lv, i});
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    int lv = 0;
+    for (int p = out.lu_diag[i] + 1; p < out.lu_rowptr[i + 1]; ++p) lv = std::max(lv, bl[out.lu_col[p]] + 1);
+    bl[i] = lv;
+    br.push_back({lv, i});
+  }
+  auto pack = [](std::vector<std::pair<int, int>>& v, std::vector<int>& rws, std::vector<int>& ptr) {
+    std::stable_sort(v.begin(), v.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first < y.first; });
+    ptr.assign(1, 0);
+    for (size_t t = 0; t < v.size(); ++t) {
+      if (t > 0 && v[t].first != v[t - 1].first) ptr.push_back((int)t);
+      rws.push_back(v[t].second);
+    }
+    ptr.push_back((int)v.size());
+  };
+  pack(fr, out.fwd_rows, out.fwd_lev_ptr);
+  pack(br, out.bwd_rows, out.bwd_lev_ptr);
+  return CADNIP_OK;
+}
+
+}  // namespace cadnip

@@ -1,0 +1,335 @@
+"""ctypes binding of libcadnip_hip.so (include/cadnip_hip.h).
+
+The library is the product; this module only marshals numpy arrays across the C ABI.  There
+is no CPU fallback: if the extension is missing or no GPU is present, the calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .structure import Structure, TYPE_ID
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcadnip_hip.so")
+
+OK, BADARG, SINGULAR, NONFINITE, HIPERROR, NOTREADY, NOCONV = range(7)
+STATUS_NAMES = {0: "CADNIP_OK", 1: "CADNIP_BADARG", 2: "CADNIP_SINGULAR", 3: "CADNIP_NONFINITE",
+                4: "CADNIP_HIPERROR", 5: "CADNIP_NOTREADY", 6: "CADNIP_NOCONV"}
+
+# every symbol declared in include/cadnip_hip.h
+EXPORTS = [
+    "cadnip_create", "cadnip_destroy", "cadnip_set_params", "cadnip_set_spec", "cadnip_set_initjct",
+    "cadnip_rebuild", "cadnip_residual", "cadnip_jacobian", "cadnip_get_GCb", "cadnip_analyze",
+    "cadnip_analyze_values", "cadnip_factor", "cadnip_solve", "cadnip_lu_stats", "cadnip_dc_run",
+    "cadnip_tran_run", "cadnip_dev_ptr", "cadnip_stream", "cadnip_set_u", "cadnip_get_u", "cadnip_get_flags",
+    "cadnip_sync", "cadnip_profile_enable", "cadnip_profile_read", "cadnip_version",
+    "cadnip_host_lu_analyze", "cadnip_host_lu_size", "cadnip_host_lu_get", "cadnip_host_lu_free",
+]
+
+
+class CadnipError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        super().__init__("%s returned %s" % (where, STATUS_NAMES.get(code, code)))
+
+
+class SingularException(CadnipError):
+    """Maps CADNIP_SINGULAR like the Julia shim maps it to LinearAlgebra.SingularException."""
+
+
+class DeviceBlockC(C.Structure):
+    _fields_ = [("type", C.c_int32), ("count", C.c_int32),
+                ("n_nodes", C.c_int32), ("nodes", C.POINTER(C.c_int32)),
+                ("n_ipar", C.c_int32), ("ipar", C.POINTER(C.c_int32)),
+                ("n_par", C.c_int32),
+                ("g_base", C.c_int32), ("c_base", C.c_int32), ("b_base", C.c_int32),
+                ("n_g", C.c_int32), ("n_c", C.c_int32), ("n_b", C.c_int32)]
+
+
+_I = C.POINTER(C.c_int32)
+_D = C.POINTER(C.c_double)
+
+
+class StructureC(C.Structure):
+    _fields_ = [("n", C.c_int32), ("n_nodes", C.c_int32), ("n_currents", C.c_int32), ("n_charges", C.c_int32),
+                ("n_limits", C.c_int32), ("nnz", C.c_int32), ("rowptr", _I), ("colidx", _I), ("to_ref_nz", _I),
+                ("n_blocks", C.c_int32), ("blocks", C.POINTER(DeviceBlockC)),
+                ("n_wave_data", C.c_int32), ("wave_data", _D),
+                ("ns_g", C.c_int32), ("ns_c", C.c_int32), ("ns_b", C.c_int32),
+                ("g_ptr", _I), ("g_slots", _I), ("c_ptr", _I), ("c_slots", _I), ("b_ptr", _I), ("b_slots", _I),
+                ("diag_nz", _I), ("limit_init", _D)]
+
+
+class SpecC(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("gmin", C.c_double), ("gshunt", C.c_double), ("srcFact", C.c_double)]
+
+
+class DCOptsC(C.Structure):
+    _fields_ = [("abstol", C.c_double), ("maxiters", C.c_int32), ("use_pcnr", C.c_int32), ("cold_start", C.c_int32),
+                ("use_stepping", C.c_int32)]
+
+
+class TranOptsC(C.Structure):
+    _fields_ = [("t0", C.c_double), ("t1", C.c_double), ("reltol", C.c_double), ("abstol", _D), ("h0", C.c_double),
+                ("hmin", C.c_double), ("hmax", C.c_double), ("max_newton", C.c_int32), ("max_order", C.c_int32),
+                ("use_pcnr", C.c_int32), ("newton_tol", C.c_double), ("n_break", C.c_int32), ("breaks", _D),
+                ("n_save", C.c_int32), ("save_t", _D), ("n_obs", C.c_int32), ("obs", _I),
+                ("max_iterations", C.c_int64), ("fused", C.c_int32)]
+
+
+class RunStatsC(C.Structure):
+    _fields_ = [("newton_iters", C.c_int64), ("steps_accepted", C.c_int64), ("steps_rejected", C.c_int64),
+                ("newton_failures", C.c_int64), ("launches", C.c_int64), ("n_failed", C.c_int32),
+                ("wall_seconds", C.c_double)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree extension; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.cadnip_version.restype = C.c_char_p
+    lib.cadnip_dev_ptr.restype = C.c_void_p
+    lib.cadnip_stream.restype = C.c_void_p
+    lib.cadnip_destroy.restype = None
+    lib.cadnip_host_lu_free.restype = None
+    lib.cadnip_host_lu_size.restype = C.c_int32
+    lib.cadnip_dev_ptr.argtypes = [C.c_void_p, C.c_int32]
+    lib.cadnip_stream.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _ip(a):
+    return a.ctypes.data_as(_I)
+
+
+def _dp(a):
+    return a.ctypes.data_as(_D)
+
+
+def _check(code, where):
+    if code == OK:
+        return
+    if code == SINGULAR:
+        raise SingularException(code, where)
+    raise CadnipError(code, where)
+
+
+MODE = {"dcop": 0, "tran": 1, "tranop": 2}
+
+MODE_NAMES = ("dcop", "tran", "tranop")
+
+
+class Handle:
+    """One (structure, GPU) handle with ``B`` resident sweep instances."""
+
+    def __init__(self, st: Structure, B: int = 1, device: int = 0):
+        self.lib = load_library()
+        self.st = st
+        self.B = int(B)
+        self._keep = []
+        blocks = (DeviceBlockC * max(1, len(st.blocks)))()
+        for k, blk in enumerate(st.blocks):
+            nodes = np.ascontiguousarray(blk.nodes, dtype=np.int32)
+            ipar = np.ascontiguousarray(blk.ipar, dtype=np.int32)
+            self._keep += [nodes, ipar]
+            b = blocks[k]
+            b.type, b.count = TYPE_ID[blk.type], blk.count
+            b.n_nodes, b.nodes = nodes.shape[0], _ip(nodes)
+            b.n_ipar, b.ipar = ipar.shape[0], _ip(ipar)
+            b.n_par = blk.n_par
+            b.g_base, b.c_base, b.b_base = blk.g_base, blk.c_base, blk.b_base
+            b.n_g, b.n_c, b.n_b = blk.n_g, blk.n_c, blk.n_b
+        s = StructureC()
+        s.n, s.n_nodes, s.n_currents, s.n_charges, s.n_limits = st.n, st.n_nodes, st.n_currents, st.n_charges, st.n_limits
+        s.nnz = st.nnz
+        arrs = {}
+        for nm in ("rowptr", "colidx", "to_ref_nz", "g_ptr", "g_slots", "c_ptr", "c_slots", "b_ptr", "b_slots", "diag_nz"):
+            a = np.ascontiguousarray(getattr(st, nm), dtype=np.int32)
+            if a.size == 0:
+                a = np.zeros(1, dtype=np.int32)
+            arrs[nm] = a
+            setattr(s, nm, _ip(a))
+        wd = np.ascontiguousarray(st.wave_data, dtype=np.float64)
+        wdp = wd if wd.size else np.zeros(1)
+        li = np.ascontiguousarray(st.limit_init, dtype=np.float64)
+        lip = li if li.size else np.zeros(1)
+        self._keep += [arrs, wdp, lip, blocks]
+        s.n_blocks, s.blocks = len(st.blocks), blocks
+        s.n_wave_data, s.wave_data = wd.size, _dp(wdp)
+        s.ns_g, s.ns_c, s.ns_b = st.ns_g, st.ns_c, st.ns_b
+        s.limit_init = _dp(lip)
+        self.h = C.c_void_p()
+        _check(self.lib.cadnip_create(C.byref(s), C.c_int32(self.B), C.c_int32(device), C.byref(self.h)), "cadnip_create")
+        self.spec = dict(mode="tran", gmin=1e-12, gshunt=0.0, srcFact=1.0)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.cadnip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- parameters / spec --------------------------------------------------------------
+    def set_params(self, packed):
+        for k, arr in enumerate(packed):
+            a = np.ascontiguousarray(arr, dtype=np.float64)
+            assert a.shape == (self.B, self.st.blocks[k].n_par, self.st.blocks[k].count), a.shape
+            _check(self.lib.cadnip_set_params(self.h, C.c_int32(k), _dp(a)), "cadnip_set_params")
+
+    def set_spec(self, mode=None, gmin=None, gshunt=None, srcFact=None):
+        for k, v in (("mode", mode), ("gmin", gmin), ("gshunt", gshunt), ("srcFact", srcFact)):
+            if v is not None:
+                self.spec[k] = v
+        sp = SpecC(MODE[self.spec["mode"]], self.spec["gmin"], self.spec["gshunt"], self.spec["srcFact"])
+        _check(self.lib.cadnip_set_spec(self.h, C.byref(sp)), "cadnip_set_spec")
+
+    def set_initjct(self, on):
+        _check(self.lib.cadnip_set_initjct(self.h, C.c_int32(1 if on else 0)), "cadnip_set_initjct")
+
+    # -- the three callbacks --------------------------------------------------------------
+    def _bn(self, x):
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float64), (self.B, self.st.n)))
+        return a
+
+    def _b(self, x):
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float64), (self.B,)))
+
+    def rebuild(self, u, t=0.0):
+        """fast_rebuild!(ws, u, t)"""
+        ua, ta = self._bn(u), self._b(t)
+        _check(self.lib.cadnip_rebuild(self.h, _dp(ua), _dp(ta)), "cadnip_rebuild")
+
+    def residual(self, du, u):
+        """fast_residual! minus the restamp: resid = C*du + G*u - b at the last rebuild."""
+        dua, ua = self._bn(du), self._bn(u)
+        r = np.empty((self.B, self.st.n))
+        _check(self.lib.cadnip_residual(self.h, _dp(dua), _dp(ua), _dp(r)), "cadnip_residual")
+        return r
+
+    def jacobian(self, gamma, readback=True):
+        """fast_jacobian! minus the restamp: J = G + gamma*C; returned in the reference's CSC nz order."""
+        g = self._b(gamma)
+        J = np.empty((self.B, self.st.nnz)) if readback else None
+        _check(self.lib.cadnip_jacobian(self.h, _dp(g), _dp(J) if readback else None), "cadnip_jacobian")
+        return J
+
+    def get_GCb(self):
+        B, st = self.B, self.st
+        G, Cm, b = np.empty((B, st.nnz)), np.empty((B, st.nnz)), np.empty((B, st.n))
+        lw = np.empty((B, max(st.n_limits, 1)))
+        _check(self.lib.cadnip_get_GCb(self.h, _dp(G), _dp(Cm), _dp(b), _dp(lw)), "cadnip_get_GCb")
+        return G, Cm, b, lw[:, :st.n_limits]
+
+    # -- LU ----------------------------------------------------------------------------------
+    def analyze(self, sample_instance=0):
+        _check(self.lib.cadnip_analyze(self.h, C.c_int32(sample_instance)), "cadnip_analyze")
+
+    def analyze_values(self, J_ref_nz):
+        """``J_ref_nz``: sample values in the reference's CSC nz order."""
+        csr = np.ascontiguousarray(np.asarray(J_ref_nz, dtype=np.float64)[self.st.to_ref_nz])
+        _check(self.lib.cadnip_analyze_values(self.h, _dp(csr)), "cadnip_analyze_values")
+
+    def factor(self):
+        _check(self.lib.cadnip_factor(self.h), "cadnip_factor")
+
+    def solve(self, rhs):
+        r = self._bn(rhs)
+        x = np.empty_like(r)
+        _check(self.lib.cadnip_solve(self.h, _dp(r), _dp(x)), "cadnip_solve")
+        return x
+
+    def lu_stats(self):
+        v = [C.c_int32() for _ in range(5)]
+        _check(self.lib.cadnip_lu_stats(self.h, *[C.byref(x) for x in v]), "cadnip_lu_stats")
+        return dict(zip(("nnz_lu", "n_terms", "n_levels", "n_fwd_levels", "n_bwd_levels"), [x.value for x in v]))
+
+    # -- drivers -------------------------------------------------------------------------------
+    def dc_run(self, u0=None, abstol=1e-10, maxiters=100, use_pcnr=True, cold_start=True, use_stepping=True,
+               raise_on_fail=False):
+        u = self._bn(0.0 if u0 is None else u0).copy()
+        conv = np.zeros(self.B, dtype=np.int32)
+        st = RunStatsC()
+        o = DCOptsC(abstol, maxiters, int(use_pcnr), int(cold_start), int(use_stepping))
+        rc = self.lib.cadnip_dc_run(self.h, C.byref(o), _dp(u), _ip(conv), C.byref(st))
+        if rc not in (OK, NOCONV) or (rc == NOCONV and raise_on_fail):
+            _check(rc, "cadnip_dc_run")
+        return u, conv.astype(bool), _stats(st)
+
+    def tran_run(self, t0, t1, abstol, reltol=1e-4, breaks=(), save_t=(), obs=None, h0=0.0, hmin=0.0, hmax=0.0,
+                 max_newton=10, max_order=2, use_pcnr=True, newton_tol=1e-3, max_iterations=0, fused=False):
+        at = np.ascontiguousarray(np.broadcast_to(np.asarray(abstol, dtype=np.float64), (self.st.n,)))
+        br = np.ascontiguousarray(np.asarray(breaks, dtype=np.float64))
+        sv = np.ascontiguousarray(np.asarray(save_t, dtype=np.float64))
+        ob = np.ascontiguousarray(np.asarray(obs if obs is not None else [], dtype=np.int32))
+        n_obs = ob.size if ob.size else self.st.n
+        out = np.zeros((self.B, sv.size, n_obs))
+        per = np.zeros((self.B, 4), dtype=np.int64)
+        st = RunStatsC()
+        o = TranOptsC(t0, t1, reltol, _dp(at), h0, hmin, hmax, max_newton, max_order, int(use_pcnr), newton_tol,
+                      br.size, _dp(br) if br.size else None, sv.size, _dp(sv) if sv.size else None,
+                      ob.size, _ip(ob) if ob.size else None, max_iterations, int(fused))
+        rc = self.lib.cadnip_tran_run(self.h, C.byref(o), _dp(out), per.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(st))
+        if rc not in (OK, NOCONV):
+            _check(rc, "cadnip_tran_run")
+        return out, per, _stats(st)
+
+    # -- misc ------------------------------------------------------------------------------------
+    def set_u(self, u):
+        _check(self.lib.cadnip_set_u(self.h, _dp(self._bn(u))), "cadnip_set_u")
+
+    def get_u(self):
+        u = np.empty((self.B, self.st.n))
+        _check(self.lib.cadnip_get_u(self.h, _dp(u)), "cadnip_get_u")
+        return u
+
+    def profile(self, on=True):
+        _check(self.lib.cadnip_profile_enable(self.h, C.c_int32(1 if on else 0)), "cadnip_profile_enable")
+
+    def profile_read(self):
+        names = (C.c_char_p * 64)()
+        ms = (C.c_double * 64)()
+        calls = (C.c_int64 * 64)()
+        k = self.lib.cadnip_profile_read(self.h, C.c_int32(64), names, ms, calls)
+        return {names[i].decode(): (ms[i], calls[i]) for i in range(k)}
+
+
+def _stats(st):
+    return {f: getattr(st, f) for f, _ in RunStatsC._fields_}
+
+
+LU_ARRAYS = ("rperm", "cperm", "rowptr", "col", "diag", "load_src", "load_dst", "ent_pos", "ent_diag", "ent_ptr",
+             "term_a", "term_b", "lev_ptr", "fwd_rows", "fwd_lev_ptr", "bwd_rows", "bwd_lev_ptr")
+
+
+def host_lu_analyze(n, rowptr, colidx, vals, pivot_tol=1e-3):
+    """Host-only symbolic phase (no GPU needed): returns the LU program as a dict of int32 arrays."""
+    lib = load_library()
+    rp = np.ascontiguousarray(rowptr, dtype=np.int32)
+    ci = np.ascontiguousarray(colidx, dtype=np.int32)
+    v = np.ascontiguousarray(vals, dtype=np.float64)
+    p = C.c_void_p()
+    _check(lib.cadnip_host_lu_analyze(C.c_int32(n), _ip(rp), _ip(ci), _dp(v), C.c_double(pivot_tol), C.byref(p)),
+           "cadnip_host_lu_analyze")
+    out = {}
+    try:
+        for k, nm in enumerate(LU_ARRAYS):
+            sz = lib.cadnip_host_lu_size(p, C.c_int32(k))
+            a = np.zeros(max(sz, 1), dtype=np.int32)
+            _check(lib.cadnip_host_lu_get(p, C.c_int32(k), _ip(a)), "cadnip_host_lu_get")
+            out[nm] = a[:sz]
+    finally:
+        lib.cadnip_host_lu_free(p)
+    return out

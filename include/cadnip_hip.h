@@ -1,0 +1,229 @@
+/*
+ * cadnip_hip.h -- C ABI of libcadnip_hip.so, the MI355X (gfx950) replacement for the
+ * CPU hot path of Cadnip.jl's transient analysis (reference: /root/reference/src/mna).
+ *
+ * Every entry point names the reference interface it replaces (file:line relative to
+ * /root/reference).  The reference-side binding (Julia `ccall`) is shown in
+ * INTEGRATION.md and shipped as source in cadnip.jl_amd/julia/CadnipHIP.jl.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types; all indices are 0-based int32;
+ *     all values are IEEE fp64.
+ *   - every function returns a CadnipStatus (0 = ok); nothing throws across the ABI.
+ *     The Julia shim maps CADNIP_SINGULAR -> LinearAlgebra.SingularException and
+ *     CADNIP_NONFINITE -> DomainError so `_dc_solve_with_fallbacks`
+ *     (src/mna/solve.jl:887-897) keeps working.
+ *   - a handle owns all device memory; the caller owns every host array it passes.
+ *     `*_host` arguments are host pointers (copied over PCIe inside the call);
+ *     `cadnip_dev_ptr` exposes the handle's device buffers for zero-copy callers.
+ *   - one handle = one (structure, GPU, HIP stream); handles are independent.
+ *   - `n_instances` > 1 batches sweep points / Monte-Carlo instances that share one
+ *     structure (CircuitSweep, src/sweeps.jl:387-424); all per-instance arrays are laid
+ *     out instance-major: x[inst * n + i].
+ */
+#ifndef CADNIP_HIP_H
+#define CADNIP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  CADNIP_OK = 0,
+  CADNIP_BADARG = 1,
+  CADNIP_SINGULAR = 2,   /* zero / non-finite pivot in some instance (KLU: SingularException) */
+  CADNIP_NONFINITE = 3,  /* non-finite stamp value (reference: DomainError from device math) */
+  CADNIP_HIPERROR = 4,
+  CADNIP_NOTREADY = 5,   /* e.g. factor before analyze */
+  CADNIP_NOCONV = 6      /* driver: some instance did not converge / step size underflow */
+} CadnipStatus;
+
+/* Device types: one stamping kernel per type (src/mna/devices.jl `stamp!` methods and the
+ * Verilog-A stamp pattern src/vasim.jl:3319-3521). */
+typedef enum {
+  CADNIP_DEV_RESISTOR = 0,   /* devices.jl:498-510   nodes p,n        par: g=1/r                */
+  CADNIP_DEV_CAPACITOR = 1,  /* devices.jl:531-534   nodes p,n        par: c                    */
+  CADNIP_DEV_INDUCTOR = 2,   /* devices.jl:569-586   nodes p,n,I      par: l                    */
+  CADNIP_DEV_VSOURCE = 3,    /* devices.jl:619-663   nodes p,n,I      par: dc,scale  ipar: wave */
+  CADNIP_DEV_ISOURCE = 4,    /* devices.jl:698-737   nodes p,n        par: dc,scale  ipar: wave */
+  CADNIP_DEV_VCVS = 5,       /* devices.jl:760-775   nodes op,on,ip,in,I          par: gain     */
+  CADNIP_DEV_VCCS = 6,       /* devices.jl:797-808   nodes op,on,ip,in            par: gm       */
+  CADNIP_DEV_CCVS = 7,       /* devices.jl:824-849   nodes op,on,ip,in,Iin,Iout   par: rm       */
+  CADNIP_DEV_CCCS = 8,       /* devices.jl:865-881   nodes op,on,ip,in,Iin        par: gain     */
+  CADNIP_DEV_DIODE = 9,      /* devices.jl:1370-1428 nodes p,n,lim    par: Is,nVt,vcrit  ipar: limit flag */
+  CADNIP_DEV_DIODECAP = 10,  /* devices.jl:1558-1602 nodes p,n        par: Is,nVt,Cj0,Vj,m      */
+  CADNIP_DEV_SIMPLEMOS = 11, /* devices.jl:1667-1749 nodes d,g,s      par: Vth,K,lambda,Cgd,Cgs */
+  CADNIP_DEV_MOS1 = 12,      /* models/VADistillerModels.jl/va/mos1.va via vasim.jl:3319-3521;
+                                nodes d,g,s,b,d_int,s_int,lim[4],q[4]; par: CADNIP_MOS1_NPAR derived
+                                (setup+temp hoisted, mos1.va:695-897) values; ipar: flags       */
+  CADNIP_DEV_NTYPES = 13
+} CadnipDeviceType;
+
+#define CADNIP_MOS1_NPAR 36
+
+typedef enum { CADNIP_WAVE_DC = 0, CADNIP_WAVE_PWL = 1, CADNIP_WAVE_PULSE = 2, CADNIP_WAVE_SIN = 3 } CadnipWaveKind;
+
+/* One block per device type.  Node / ipar arrays are shared by all instances (structure);
+ * parameters are per instance and set with cadnip_set_params.
+ *   nodes[k * count + d]  : unknown index (0-based) read/written by device d's k-th node
+ *                           slot, -1 = ground
+ *   ipar[k * count + d]   : integer parameters (wave kind, offset/length into wave_data, flags)
+ *   slot ids              : device d's k-th G stamp owns slot  g_base + k*count + d  of the
+ *                           per-instance slot buffer (likewise C, b); limit_w index
+ *                           lim_base + k*count + d is written by limiting devices. */
+typedef struct {
+  int32_t type;      /* CadnipDeviceType */
+  int32_t count;
+  int32_t n_nodes;   const int32_t* nodes;
+  int32_t n_ipar;    const int32_t* ipar;
+  int32_t n_par;     /* doubles per device per instance */
+  int32_t g_base, c_base, b_base; /* first slot of this block in the G / C / b slot ranges */
+  int32_t n_g, n_c, n_b;          /* slots per device */
+} CadnipDeviceBlock;
+
+/* Fixed structure of one circuit == the reference's CompiledStructure
+ * (src/mna/precompile.jl:75-124), in CSR and with slot->nz gather lists instead of the
+ * positional COO->nz maps (value_only.jl:395-478). */
+typedef struct {
+  int32_t n, n_nodes, n_currents, n_charges, n_limits;
+  /* unified G u C pattern (precompile.jl:413-421), CSR, column indices sorted */
+  int32_t nnz;
+  const int32_t* rowptr;    /* [n+1] */
+  const int32_t* colidx;    /* [nnz] */
+  const int32_t* to_ref_nz; /* [nnz] position of CSR entry k in the reference's CSC nzval order */
+  /* device blocks */
+  int32_t n_blocks;
+  const CadnipDeviceBlock* blocks;
+  int32_t n_wave_data; const double* wave_data; /* PWL (t,y) tables etc. */
+  /* slot -> nz gather lists, each list in the reference's COO (stamp) order so that the
+   * floating-point summation order equals `nzval[map[pos]] += v` (value_only.jl:414-418) */
+  int32_t ns_g, ns_c, ns_b;
+  const int32_t* g_ptr; const int32_t* g_slots; /* [nnz+1], [..] */
+  const int32_t* c_ptr; const int32_t* c_slots;
+  const int32_t* b_ptr; const int32_t* b_slots; /* [n+1],  [..]  deferred b (precompile.jl:508-515) */
+  const int32_t* diag_nz;   /* [n_nodes] CSR position of G[i,i] or -1 (precompile.jl:451-467) */
+  const double*  limit_init;/* [n_limits] (precompile.jl:119-123) */
+} CadnipStructure;
+
+/* MNASpec scalars (src/mna/solve.jl:57-70).  temp is per instance (corner sweeps); the
+ * temperature dependence of device parameters is hoisted into the per-instance parameter
+ * blocks, so only mode / gmin / gshunt / srcFact reach the kernels. */
+typedef struct {
+  int32_t mode;      /* 0 = :dcop, 1 = :tran, 2 = :tranop */
+  double gmin, gshunt, srcFact;
+} CadnipSpec;
+
+typedef struct CadnipHandle CadnipHandle;
+
+/* ---- lifetime -------------------------------------------------------------------------
+ * replaces compile_structure + create_workspace (precompile.jl:312-443, 193-222) */
+int cadnip_create(const CadnipStructure* s, int32_t n_instances, int32_t device, CadnipHandle** out);
+void cadnip_destroy(CadnipHandle* h);
+int cadnip_set_params(CadnipHandle* h, int32_t block, const double* par_host /* [B][n_par][count] */);
+int cadnip_set_spec(CadnipHandle* h, const CadnipSpec* spec);
+int cadnip_set_initjct(CadnipHandle* h, int32_t on);            /* DirectStampContext.initjct, value_only.jl:93-95 */
+
+/* ---- the three hot-path callbacks ------------------------------------------------------
+ * cadnip_rebuild   == fast_rebuild!(ws, u, t)                  precompile.jl:493-537
+ * cadnip_residual  == fast_residual!(resid, du, u, ws, t)      precompile.jl:546-557
+ * cadnip_jacobian  == fast_jacobian!(J, du, u, ws, gamma, t)   precompile.jl:568-585
+ * Unlike the reference, residual and jacobian do NOT restamp: they reuse the stamps of the
+ * last cadnip_rebuild (the reference restamps the whole circuit in each, precompile.jl:548,572).
+ * u_host/du_host: [B][n]; t_host: [B] (instances may sit at different times); gamma_host: [B]. */
+int cadnip_rebuild(CadnipHandle* h, const double* u_host, const double* t_host);
+int cadnip_residual(CadnipHandle* h, const double* du_host, const double* u_host, double* resid_host);
+int cadnip_jacobian(CadnipHandle* h, const double* gamma_host, double* J_ref_nz_host /* may be NULL */);
+/* parity / debug read-back in the reference's CSC nzval order (any pointer may be NULL) */
+int cadnip_get_GCb(CadnipHandle* h, double* G_ref_nz, double* C_ref_nz, double* b, double* limit_w);
+
+/* ---- sparse LU == KLU at src/sweeps.jl:600 (IDA linear_solver=:KLU) and
+ * src/mna/solve.jl:612-613,667-670 (LinearSolve KLUFactorization, symbolic reused) ----------
+ * cadnip_analyze: host symbolic phase, once: threshold-Markowitz pivot order chosen on the
+ *   current J of instance `sample_instance`, symbolic fill, level schedules.
+ * cadnip_factor : numeric refactor of J for every instance on the GPU with the static pivot
+ *   order; returns CADNIP_SINGULAR if any instance hit a bad pivot (flags via cadnip_get_flags).
+ * cadnip_solve  : x = J^-1 rhs per instance. */
+int cadnip_analyze(CadnipHandle* h, int32_t sample_instance);
+/* same, on caller-supplied sample values (CSR order of CadnipStructure.colidx), e.g. the element-wise
+ * max |J| over several operating points so that the static pivot order suits all of them */
+int cadnip_analyze_values(CadnipHandle* h, const double* J_csr_host);
+int cadnip_factor(CadnipHandle* h);
+int cadnip_solve(CadnipHandle* h, const double* rhs_host, double* x_host);
+int cadnip_lu_stats(CadnipHandle* h, int32_t* nnz_lu, int32_t* n_terms, int32_t* n_levels, int32_t* n_fwd_levels, int32_t* n_bwd_levels);
+
+/* ---- host drivers (Newton loop + step controller; stand-in for IDA / _dc_pcnr_newton) ----
+ * The loops run on the host and launch the kernels above on the handle's stream; the
+ * per-instance convergence / step decisions are evaluated on the device (one lane-group
+ * per instance) so that B desynchronised instances need no per-iteration PCIe traffic. */
+typedef struct {
+  double abstol;          /* ||G u - b||_2 < abstol      solve.jl:640 (1e-10 dc!, 1e-9 CedarTranOp) */
+  int32_t maxiters;       /* solve.jl:600 */
+  int32_t use_pcnr;       /* PCNR corrector u[lim] = limit_w  solve.jl:682-688 */
+  int32_t cold_start;     /* seed limit vars + initjct       solve.jl:615-625 */
+  int32_t use_stepping;   /* gshunt / source stepping fallbacks solve.jl:909-925 */
+} CadnipDCOpts;
+
+typedef struct {
+  double t0, t1;
+  double reltol;
+  const double* abstol;     /* [n] per-unknown absolute tolerance (state_abstol, build.jl:276-283) */
+  double h0;                /* initial step (<=0: automatic) */
+  double hmin, hmax;        /* hmax <= 0: (t1-t0)/50 */
+  int32_t max_newton;       /* IDA max_nonlinear_iters = 10, sweeps.jl:600 */
+  int32_t max_order;        /* 1 = backward Euler only, 2 = variable-step BDF2 */
+  int32_t use_pcnr;         /* apply the PCNR corrector inside transient Newton */
+  double newton_tol;        /* weighted-RMS norm of the Newton update that counts as converged */
+  int32_t n_break; const double* breaks; /* sorted tstops from source breakpoints (solve.jl:1847-1960) */
+  int32_t n_save;  const double* save_t; /* sorted output times (saveat) */
+  int32_t n_obs;   const int32_t* obs;   /* unknown indices to record; n_obs = 0 -> all n */
+  int64_t max_iterations;   /* safety bound on lock-step Newton launches */
+  int32_t fused;            /* 1 = fused per-instance Newton kernel, 0 = one kernel per op */
+} CadnipTranOpts;
+
+typedef struct {
+  int64_t newton_iters;     /* == sol.stats.nnonliniter summed over instances */
+  int64_t steps_accepted, steps_rejected, newton_failures;
+  int64_t launches;         /* lock-step Newton launches */
+  int32_t n_failed;         /* instances that did not reach t1 / did not converge */
+  double  wall_seconds;     /* host wall clock of the driver loop (device-synchronised) */
+} CadnipRunStats;
+
+/* u_host [B][n]: in = initial guess (zeros = cold start), out = solution; converged_host [B] */
+int cadnip_dc_run(CadnipHandle* h, const CadnipDCOpts* o, double* u_host, int32_t* converged_host, CadnipRunStats* st);
+/* starts from the handle's current state u (e.g. left by cadnip_dc_run in :tranop mode);
+ * out_host [B][n_save][n_obs]; per_inst_host [B][4] = {newton_iters, accepted, rejected, status} */
+int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, int64_t* per_inst_host, CadnipRunStats* st);
+
+/* ---- misc -------------------------------------------------------------------------------- */
+typedef enum { CADNIP_BUF_U = 0, CADNIP_BUF_G = 1, CADNIP_BUF_C = 2, CADNIP_BUF_B = 3, CADNIP_BUF_J = 4,
+               CADNIP_BUF_RESID = 5, CADNIP_BUF_SLOTS = 6, CADNIP_BUF_LU = 7, CADNIP_BUF_FLAGS = 8 } CadnipBuffer;
+void* cadnip_dev_ptr(CadnipHandle* h, int32_t which);  /* device pointer of a handle-owned buffer */
+void* cadnip_stream(CadnipHandle* h);                  /* hipStream_t the handle launches on */
+int cadnip_set_u(CadnipHandle* h, const double* u_host);
+int cadnip_get_u(CadnipHandle* h, double* u_host);
+int cadnip_get_flags(CadnipHandle* h, int32_t* flags_host /* [B] */);
+int cadnip_sync(CadnipHandle* h);
+/* timing of the kernels launched since the last reset, measured with hipEvents on the handle's
+ * stream: names[i] (static strings), ms[i] total, calls[i]; returns number of entries */
+int cadnip_profile_enable(CadnipHandle* h, int32_t on);
+int cadnip_profile_read(CadnipHandle* h, int32_t max_entries, const char** names, double* ms, int64_t* calls);
+const char* cadnip_version(void);
+
+/* ---- host-only helpers (no GPU needed): run the symbolic phase on any CSR matrix and read the
+ * resulting program back; used by the CPU test-suite to validate the LU program --------------- */
+typedef struct CadnipHostLU CadnipHostLU;
+typedef enum { CADNIP_LU_RPERM = 0, CADNIP_LU_CPERM, CADNIP_LU_ROWPTR, CADNIP_LU_COL, CADNIP_LU_DIAG, CADNIP_LU_LOAD_SRC,
+               CADNIP_LU_LOAD_DST, CADNIP_LU_ENT_POS, CADNIP_LU_ENT_DIAG, CADNIP_LU_ENT_PTR, CADNIP_LU_TERM_A, CADNIP_LU_TERM_B,
+               CADNIP_LU_LEV_PTR, CADNIP_LU_FWD_ROWS, CADNIP_LU_FWD_LEV_PTR, CADNIP_LU_BWD_ROWS, CADNIP_LU_BWD_LEV_PTR,
+               CADNIP_LU_NARRAYS } CadnipLUArray;
+int cadnip_host_lu_analyze(int32_t n, const int32_t* rowptr, const int32_t* colidx, const double* vals, double pivot_tol, CadnipHostLU** out);
+int32_t cadnip_host_lu_size(const CadnipHostLU* lu, int32_t which);
+int cadnip_host_lu_get(const CadnipHostLU* lu, int32_t which, int32_t* dst);
+void cadnip_host_lu_free(CadnipHostLU* lu);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CADNIP_HIP_H */

@@ -1,0 +1,97 @@
+"""TEST INFRASTRUCTURE (oracle) -- builder functions from a neutral device list.
+
+The reference turns a netlist into a Julia ``builder(params, spec, t; x, ctx)`` that
+calls ``stamp!`` once per instance in netlist order
+(/root/reference/src/spc/codegen.jl:3437-3518).  ``make_builder`` does the same from
+a list of plain dicts::
+
+    {"type": "R", "name": "r1", "nodes": ["a", "b"], "r": 1e3}
+
+Numeric fields may be a number or the name of a key of ``params`` (sweepable).
+Wave fields: ``wave = ("pwl", ts, ys) | ("pulse", v1, v2, td, tr, tf, pw, per) |
+("sin", vo, va, freq, td, theta, phase)``; ``scale`` multiplies the transient value.
+"""
+from . import devices_ref as D
+from .mna_ref import MNAContext, ZERO_VECTOR
+from .va_mos1_ref import Mos1Model, stamp_mos1
+
+
+def _num(v, params):
+    if isinstance(v, str):
+        return float(params[v])
+    return v
+
+
+class _Scaled:
+    def __init__(self, wave, scale):
+        self.wave = wave
+        self.scale = scale
+
+    def __call__(self, t):
+        return self.scale * self.wave(t)
+
+    def breakpoints(self):
+        return self.wave.breakpoints()
+
+
+def make_wave(spec, scale=1.0):
+    if spec is None:
+        return None
+    kind = spec[0]
+    if kind == "pwl":
+        w = D.PWLWave(spec[1], spec[2])
+    elif kind == "pulse":
+        w = D.PulseWave(*spec[1:])
+    elif kind == "sin":
+        w = D.SinWave(*spec[1:])
+    else:
+        raise ValueError(kind)
+    return w if scale == 1.0 else _Scaled(w, scale)
+
+
+def make_builder(devices):
+    def builder(params, spec, t, x=ZERO_VECTOR, ctx=None):
+        if ctx is None:
+            ctx = MNAContext()
+        for dev in devices:
+            ty = dev["type"]
+            nodes = [ctx.get_node(nm) for nm in dev["nodes"]]
+            g = lambda k, default=None: _num(dev.get(k, default), params)
+            name = dev.get("name", ty)
+            if ty == "R":
+                D.stamp_resistor(ctx, nodes[0], nodes[1], g("r"))
+            elif ty == "C":
+                D.stamp_capacitor(ctx, nodes[0], nodes[1], g("c"))
+            elif ty == "L":
+                D.stamp_inductor(ctx, nodes[0], nodes[1], g("l"), name)
+            elif ty == "V":
+                w = make_wave(dev.get("wave"), g("scale", 1.0))
+                D.stamp_vsource(ctx, nodes[0], nodes[1], g("dc", 0.0), w, t, spec.mode, name)
+            elif ty == "I":
+                w = make_wave(dev.get("wave"), g("scale", 1.0))
+                D.stamp_isource(ctx, nodes[0], nodes[1], g("dc", 0.0), w, t, spec.mode, name)
+            elif ty == "E":
+                D.stamp_vcvs(ctx, nodes[0], nodes[1], nodes[2], nodes[3], g("gain"), name)
+            elif ty == "G":
+                D.stamp_vccs(ctx, nodes[0], nodes[1], nodes[2], nodes[3], g("gm"))
+            elif ty == "H":
+                D.stamp_ccvs(ctx, nodes[0], nodes[1], nodes[2], nodes[3], g("rm"), name)
+            elif ty == "F":
+                D.stamp_cccs(ctx, nodes[0], nodes[1], nodes[2], nodes[3], g("gain"), name)
+            elif ty == "D":
+                D.stamp_diode(ctx, nodes[0], nodes[1], x, g("Is", 1e-14), g("Vt", 0.026), g("n", 1.0),
+                              bool(dev.get("limit", True)), name)
+            elif ty == "DCAP":
+                D.stamp_diode_with_cap(ctx, nodes[0], nodes[1], x, g("Is", 1e-14), g("Vt", 0.026), g("n", 1.0),
+                                       g("Cj0", 1e-12), g("Vj", 0.7), g("m", 0.5))
+            elif ty == "SMOS":
+                D.stamp_simple_mosfet(ctx, nodes[0], nodes[1], nodes[2], x, g("Vth", 0.5), g("K", 1e-3),
+                                      g("lambda", 0.0), g("Cgd", 1e-15), g("Cgs", 1e-15))
+            elif ty == "MOS1":
+                mp = {k: _num(v, params) for k, v in dev["model"].items()}
+                stamp_mos1(ctx, Mos1Model(**mp), nodes[0], nodes[1], nodes[2], nodes[3], x, spec, name,
+                           mfactor=g("m", 1.0))
+            else:
+                raise ValueError("unknown device type %r" % ty)
+        return ctx
+    return builder

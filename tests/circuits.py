@@ -1,0 +1,112 @@
+"""Test circuits shared by the CPU (oracle) and GPU (parity) suites."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cadnip_jl_amd as cj
+from cadnip_jl_amd import benchmarks as bm
+
+NM = dict(bm.NFET_06V0)
+PM = dict(bm.PFET_06V0)
+
+
+def divider(v=5.0, r1=1e3, r2=1e3):
+    c = cj.Circuit()
+    c.V("v1", "vcc", "0", dc=v)
+    c.R("r1", "vcc", "out", r1)
+    c.R("r2", "out", "0", r2)
+    return c
+
+
+def linear_zoo():
+    """Every linear builtin once (R C L V I VCVS VCCS CCVS CCCS) with PWL / PULSE / SIN sources."""
+    c = cj.Circuit()
+    c.V("v1", "a", "0", dc=1.5, wave=("pwl", [0.0, 1e-3, 2e-3, 2e-3, 5e-3], [0.0, 1.0, 1.0, 3.0, -1.0]))
+    c.V("v2", "b", "0", dc=0.3, wave=("pulse", 0.0, 2.0, 1e-4, 2e-4, 3e-4, 5e-4, 2e-3))
+    c.I("i1", "c", "0", dc=1e-3, wave=("sin", 0.1e-3, 1e-3, 1e3, 2e-4, 50.0, 30.0))
+    c.R("r1", "a", "c", 1e3)
+    c.R("r2", "b", "c", 2.2e3)
+    c.C("c1", "c", "0", 1e-6)
+    c.L("l1", "c", "d", 1e-3)
+    c.R("r3", "d", "0", 50.0)
+    c.E("e1", "e", "0", "c", "d", 2.0)
+    c.R("r4", "e", "f", 1e3)
+    c.G("g1", "f", "0", "a", "b", 1e-3)
+    c.R("r5", "f", "0", 3e3)
+    c.H("h1", "g", "0", "f", "h", 100.0)
+    c.R("r6", "h", "0", 1e3)
+    c.R("r7", "g", "0", 1e3)
+    c.F("f1", "k", "0", "g", "m", 3.0)
+    c.R("r8", "m", "0", 500.0)
+    c.R("r9", "k", "0", 1e3)
+    return c
+
+
+def diode_rectifier(limit=True):
+    c = cj.Circuit()
+    c.V("v1", "vin", "0", dc=5.0)
+    c.R("r1", "vin", "out", 1e3)
+    c.D("d1", "out", "0", Is=1e-14, limit=limit)
+    return c
+
+
+def diode_chain():
+    """3-diode 50 V chain of test/mna/pcnr.jl:330-350."""
+    c = cj.Circuit()
+    c.V("v1", "n0", "0", dc=50.0)
+    c.R("r1", "n0", "n1", 1e3)
+    c.D("d1", "n1", "n2", Is=1e-14)
+    c.D("d2", "n2", "n3", Is=1e-14)
+    c.D("d3", "n3", "0", Is=1e-14)
+    return c
+
+
+def nonlinear_zoo():
+    c = cj.Circuit()
+    c.V("v1", "vdd", "0", dc=3.0)
+    c.V("v2", "in", "0", dc=1.2, wave=("pwl", [0.0, 1e-6], [0.0, 3.0]))
+    c.R("r1", "vdd", "out", 10e3)
+    c.SMOS("m1", "out", "in", "0", Vth=0.5, K=1e-3, lambda_=0.02)
+    c.DCAP("d1", "out", "x", Is=1e-14, Cj0=2e-12)
+    c.R("r2", "x", "0", 1e4)
+    c.D("d2", "in", "y", limit=False)
+    c.R("r3", "y", "0", 1e5)
+    return c
+
+
+def rc_charge(v=5.0, r=1e3, c_=1e-6):
+    c = cj.Circuit()
+    c.V("v1", "vin", "0", dc=v)
+    c.R("r1", "vin", "out", r)
+    c.C("c1", "out", "0", c_)
+    return c
+
+
+def inverter_dc(vin=2.5):
+    c = cj.Circuit()
+    c.V("vdd", "vdd", "0", dc=5.0)
+    c.V("vin", "in", "0", dc=vin)
+    c.MOS1("mn", "out", "in", "0", "0", NM, l=0.6e-6, w=0.36e-6)
+    c.MOS1("mp", "out", "in", "vdd", "vdd", PM, l=0.5e-6, w=0.495e-6)
+    c.C("cl", "out", "0", 1e-15)
+    return c
+
+
+def mos1_rd():
+    """sp_mos1 with rd/rs given -> genuine internal nodes d_int, s_int; nsub/tox-derived card."""
+    c = cj.Circuit()
+    card = dict(type=1, tox=2e-8, nsub=1e16, u0=500.0, rd=20.0, rs=15.0, cj=2e-4, cjsw=1e-10, mj=0.4, mjsw=0.3, js=1e-6,
+                cgso=2e-10, cgdo=2e-10, cgbo=1e-10, ld=5e-8)
+    card["lambda"] = 0.05
+    c.V("vd", "d", "0", dc=2.0)
+    c.V("vg", "g", "0", dc=1.5)
+    c.R("rs", "s", "0", 100.0)
+    c.V("vb", "b", "0", dc=-0.5)
+    c.MOS1("m1", "d", "g", "s", "b", card, l=1e-6, w=10e-6, ad=1e-11, pd=2e-5, ps=2e-5, m=2.0, **{"as": 1e-11})
+    return c
+
+
+ALL_STAMP = {
+    "divider": (divider, {}), "linear_zoo": (linear_zoo, {}), "diode": (diode_rectifier, {}),
+    "diode_nolimit": (lambda: diode_rectifier(False), {}), "diode_chain": (diode_chain, {}),
+    "nonlinear_zoo": (nonlinear_zoo, {}), "inverter": (inverter_dc, {}), "mos1_rd": (mos1_rd, {}),
+    "dff": (bm.dff_circuit, {"vdd": 5.0}),
+}

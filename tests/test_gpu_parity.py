@@ -1,0 +1,146 @@
+"""GPU parity: HIP path (through the C ABI) vs the oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+import cadnip_jl_amd as cj
+from cadnip_jl_amd import hip
+from oracle import mna_ref as M
+from oracle.netlist_ref import make_builder
+from tests.circuits import ALL_STAMP
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12    # fp64 parity tolerance on stamped values (relative to the entry scale)
+
+
+def _oracle(circ, params, mode, temp=27.0):
+    b = make_builder(circ.to_dicts(params))
+    spec = M.MNASpec(mode=mode, temp=temp)
+    ctx = M.build_with_detection(b, {}, spec)
+    cs = M.compile_structure(b, {}, spec, ctx=ctx)
+    ws = M.create_workspace(cs, ctx=ctx)
+    return cs, ws
+
+
+def _handle(circ, params, B=1, temps=27.0, mode="tran"):
+    st = cj.discover(circ, params)
+    h = hip.Handle(st, B)
+    pp = {k: np.full(B, float(v)) for k, v in params.items()}
+    h.set_params(cj.pack_params(st, circ, pp, np.full(B, temps) if np.isscalar(temps) else temps, B))
+    h.set_spec(mode=mode)
+    return st, h
+
+
+def _close(a, b, scale=None):
+    scale = max(np.max(np.abs(b)), 1e-300) if scale is None else scale
+    return np.max(np.abs(a - b)) <= RTOL * scale + 1e-300
+
+
+@pytest.mark.parametrize("name", list(ALL_STAMP))
+@pytest.mark.parametrize("mode,t", [("tran", 0.0), ("tran", 1.3e-3), ("dcop", 0.0)])
+def test_rebuild_matches_oracle(name, mode, t):
+    mk, params = ALL_STAMP[name]
+    circ = mk()
+    if name == "dff" and t > 0:
+        t = 2.005e-7
+    cs, ws = _oracle(circ, params, mode)
+    st, h = _handle(circ, params, mode=mode)
+    assert st.n == cs.n and st.nnz == cs.G.nnz
+    rng = np.random.default_rng(42)
+    for trial in range(3):
+        u = (rng.random(st.n) * 2 - 0.5) * (1.0 if trial else 0.0)
+        if name in ("dff", "inverter") and trial == 2:
+            u = rng.random(st.n) * 5.0
+        M.fast_rebuild(ws, u, t)
+        h.rebuild(u, t)
+        G, C, b, lw = h.get_GCb()
+        for got, ref in ((G[0], cs.G.data), (C[0], cs.C.data), (b[0], ws.dctx.b)):
+            # entries are sums of stamps: compare relative to the largest stamp magnitude in the array
+            assert _close(got, ref), (name, trial, np.max(np.abs(got - ref)), np.max(np.abs(ref)))
+        if st.n_limits:
+            assert _close(lw[0], ws.dctx.limit_w, scale=max(1.0, np.max(np.abs(ws.dctx.limit_w))))
+        du = rng.random(st.n)
+        r = h.residual(du, u)[0]
+        rr = cs.C @ du + cs.G @ u - ws.dctx.b
+        assert _close(r, rr, scale=max(np.max(np.abs(cs.G.data)) * max(1.0, np.max(np.abs(u))), np.max(np.abs(rr)), 1e-30))
+        J = h.jacobian(1e7)[0]
+        assert _close(J, cs.G.data + 1e7 * cs.C.data)
+    h.close()
+
+
+def test_initjct_stamp_matches_oracle():
+    mk, params = ALL_STAMP["dff"]
+    circ = mk()
+    cs, ws = _oracle(circ, params, "tranop")
+    st, h = _handle(circ, params, mode="tranop")
+    u = np.zeros(st.n)
+    ws.dctx.initjct = True
+    M.fast_rebuild(ws, u, 0.0)
+    ws.dctx.initjct = False
+    h.set_initjct(True)
+    h.rebuild(u, 0.0)
+    h.set_initjct(False)
+    G, C, b, lw = h.get_GCb()
+    assert _close(G[0], cs.G.data) and _close(C[0], cs.C.data) and _close(b[0], ws.dctx.b)
+    assert _close(lw[0], ws.dctx.limit_w, scale=5.0)
+    h.close()
+
+
+def test_batched_instances_are_independent():
+    """B instances with different Vdd / temperature == B single-instance runs."""
+    mk, _ = ALL_STAMP["dff"]
+    circ = mk()
+    vdds = np.array([4.5, 5.0, 5.5, 5.2])
+    temps = np.array([-40.0, 27.0, 125.0, 85.0])
+    st = cj.discover(circ, {"vdd": 5.0})
+    h = hip.Handle(st, 4)
+    h.set_params(cj.pack_params(st, circ, {"vdd": vdds}, temps, 4))
+    h.set_spec(mode="tran")
+    rng = np.random.default_rng(7)
+    u = rng.random((4, st.n)) * 5
+    tt = np.array([0.0, 5.1e-8, 2.005e-7, 6e-7])
+    h.rebuild(u, tt)
+    G, C, b, lw = h.get_GCb()
+    for i in range(4):
+        cs, ws = _oracle(circ, {"vdd": vdds[i]}, "tran", temp=temps[i])
+        M.fast_rebuild(ws, u[i], tt[i])
+        assert _close(G[i], cs.G.data) and _close(C[i], cs.C.data) and _close(b[i], ws.dctx.b)
+    h.close()
+
+
+@pytest.mark.parametrize("name", ["linear_zoo", "inverter", "dff", "mos1_rd"])
+def test_lu_factor_solve(name):
+    mk, params = ALL_STAMP[name]
+    circ = mk()
+    st, h = _handle(circ, params, B=3)
+    rng = np.random.default_rng(3)
+    u = rng.random((3, st.n)) * 3
+    h.rebuild(u, 1e-7)
+    gam = np.array([1e6, 1e8, 1e10])
+    J = h.jacobian(gam)
+    h.analyze_values(np.max(np.abs(J), axis=0))
+    h.factor()
+    rhs = rng.random((3, st.n))
+    x = h.solve(rhs)
+    for i in range(3):
+        A = sp.csc_matrix((J[i], st.ref_rowval, st.ref_colptr), shape=(st.n, st.n))
+        xr = spla.splu(A).solve(rhs[i])
+        assert np.max(np.abs(x[i] - xr)) <= 1e-8 * max(1.0, np.max(np.abs(xr))), (name, i)
+        assert np.max(np.abs(A @ x[i] - rhs[i])) <= 1e-9 * max(1.0, np.max(np.abs(rhs[i])))
+    print(name, h.lu_stats())
+    h.close()
+
+
+def test_singular_matrix_reports_status():
+    c = cj.Circuit()
+    c.I("i1", "a", "0", dc=1e-3)
+    c.C("c1", "a", "0", 1e-9)    # no DC path: G is structurally singular in DC
+    c.R("r1", "b", "0", 1.0)
+    st, h = _handle(c, {})
+    h.rebuild(np.zeros(st.n), 0.0)
+    h.jacobian(0.0)
+    with pytest.raises(hip.CadnipError):
+        h.analyze()
+    h.close()
