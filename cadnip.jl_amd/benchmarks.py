@@ -14,12 +14,31 @@ import numpy as np
 from .circuit import Circuit, Param
 
 # Synthetic 5 V CMOS level-1 cards (documented, not a PDK extraction).
-NFET_06V0 = dict(type=1, vto=0.7, kp=100e-6, gamma=0.45, phi=0.7, tox=1.5e-8, cgso=0.3e-9, cgdo=0.3e-9,
-                 cbd=1e-15, cbs=1e-15, pb=0.8)
+#
+# Two variants:
+#  * *_MEYER: tox given -> sp_mos1's Meyer gate-charge model is active.  Cadnip lowers
+#    ``capgs*ddt(vgs)`` through its s-dual into a branch *charge* q = capgs(V)*vgs
+#    (contrib.jl:356-375), whose dq/dV jumps by ~10x at the Meyer region boundaries.  At hot
+#    corners the resulting DAE has impasse points (no solution of the step equation across the
+#    kink, for any step size -- tools/dbg_root.py), so this variant is used for stamp / DC /
+#    nominal-corner parity tests only.
+#  * default (benchmark) cards: no tox -> OxideCap = 0, the Meyer charge is identically zero
+#    (meyer_scale = 0, mos1.va:1042-1048, which also removes the cgso/cgdo overlap terms); the
+#    gate capacitance is lumped into fixed Cgs / Cgd capacitors per instance
+#    (0.5*Cox*W*L + Cov*W each, Cox = 3.9 eps0 / 15 nm, Cov = 0.3 nF/m).  Junction charges
+#    (cbd = cbs = 1 fF, depletion law mos1.va:1049-1109) stay voltage dependent.
+NFET_06V0 = dict(type=1, vto=0.7, kp=100e-6, gamma=0.45, phi=0.7, cbd=1e-15, cbs=1e-15, pb=0.8)
 NFET_06V0["lambda"] = 0.03
-PFET_06V0 = dict(type=-1, vto=-0.8, kp=50e-6, gamma=0.45, phi=0.7, tox=1.5e-8, cgso=0.3e-9, cgdo=0.3e-9,
-                 cbd=1e-15, cbs=1e-15, pb=0.8)
+PFET_06V0 = dict(type=-1, vto=-0.8, kp=50e-6, gamma=0.45, phi=0.7, cbd=1e-15, cbs=1e-15, pb=0.8)
 PFET_06V0["lambda"] = 0.04
+NFET_06V0_MEYER = dict(NFET_06V0, tox=1.5e-8, cgso=0.3e-9, cgdo=0.3e-9)
+PFET_06V0_MEYER = dict(PFET_06V0, tox=1.5e-8, cgso=0.3e-9, cgdo=0.3e-9)
+COX_AREA = 3.9 * 8.854214871e-12 / 1.5e-8   # F/m^2
+COV_WIDTH = 0.3e-9                          # F/m
+
+
+def lumped_gate_cap(W, L):
+    return 0.5 * COX_AREA * W * L + COV_WIDTH * W
 
 _P = 1e-12
 CLKN_PWL = ([0.0, 50000 * _P, 51020 * _P, 100000 * _P, 101020 * _P, 400000 * _P, 401020 * _P, 500000 * _P, 501020 * _P,
@@ -54,10 +73,11 @@ def _card(base, **over):
     return c
 
 
-def dff_circuit(mc_vto=None, mc_kp=None):
+def dff_circuit(mc_vto=None, mc_kp=None, meyer=False):
     """gf180 DFF (dffnq_4) test bench.  Sweepable parameter ``vdd`` (default 5 V) scales the
     supply and the PWL stimulus amplitude together.  ``mc_vto`` / ``mc_kp`` (optional Param names)
-    add Monte-Carlo shifts: vto += type * params[mc_vto], kp *= params[mc_kp]."""
+    add Monte-Carlo shifts: vto += type * params[mc_vto], kp *= params[mc_kp].  ``meyer`` selects
+    the Meyer-charge card variant (see the card comment above)."""
     c = Circuit("gf180 dffnq_4 test bench (synthetic level-1 cards)")
     amp = Param("vdd", scale=1.0 / 5.0)
     c.V("VVDD", "VDD", "0", dc=Param("vdd"))
@@ -68,7 +88,10 @@ def dff_circuit(mc_vto=None, mc_kp=None):
     c.V("VCLKN", "CLKN", "0", dc=0.0, wave=("pwl",) + CLKN_PWL, scale=amp)
     c.V("VD", "D", "0", dc=0.0, wave=("pwl",) + D_PWL, scale=amp)
     for (nm, d, g, s, b, W, L) in DFF_FETS:
-        base = NFET_06V0 if nm.startswith("tn") else PFET_06V0
+        if meyer:
+            base = NFET_06V0_MEYER if nm.startswith("tn") else PFET_06V0_MEYER
+        else:
+            base = NFET_06V0 if nm.startswith("tn") else PFET_06V0
         card = dict(base)
         if mc_vto is not None:
             card["vto"] = Param(mc_vto, scale=float(base["type"]), offset=base["vto"])
@@ -76,6 +99,11 @@ def dff_circuit(mc_vto=None, mc_kp=None):
             card["kp"] = Param(mc_kp, scale=base["kp"])
         c.MOS1("X_" + nm, d, g, s, b, card, w=W, l=L)
     c.C("CQ", "Q_tmp", "0", 1.7205e-13)
+    if not meyer:
+        for (nm, d, g, s, b, W, L) in DFF_FETS:
+            cg = lumped_gate_cap(W, L)
+            c.C("Cgs_" + nm, g, s, cg)
+            c.C("Cgd_" + nm, g, d, cg)
     return c
 
 
@@ -91,6 +119,10 @@ def inverter_circuit():
     c.MOS1("X_tn", "Q", "D", "0", "0", NFET_06V0, w=0.36e-6, l=0.6e-6)
     c.MOS1("X_tp", "Q", "D", "VDD", "VDD", PFET_06V0, w=0.495e-6, l=0.5e-6)
     c.C("CQ", "Q", "0", 1e-15)
+    for nm, d, g, s, W, L in (("tn", "Q", "D", "0", 0.36e-6, 0.6e-6), ("tp", "Q", "D", "VDD", 0.495e-6, 0.5e-6)):
+        cg = lumped_gate_cap(W, L)
+        c.C("Cgs_" + nm, g, s, cg)
+        c.C("Cgd_" + nm, g, d, cg)
     return c
 
 

@@ -34,7 +34,7 @@ struct Driver {
   int *nhist = nullptr, *order = nullptr, *k = nullptr, *status = nullptr, *bp_idx = nullptr, *save_idx = nullptr, *dcstate = nullptr, *action = nullptr;
   long long* cnt = nullptr;   // [B][4]
   double *u0 = nullptr, *u1 = nullptr, *u2 = nullptr, *up = nullptr, *beta = nullptr;
-  double *atol = nullptr, *breaks = nullptr, *save_t = nullptr, *out = nullptr;
+  double *atol = nullptr, *emask = nullptr, *breaks = nullptr, *save_t = nullptr, *out = nullptr;
   int* obs = nullptr;
   int* nactive = nullptr;
   size_t out_cap = 0, brk_cap = 0, save_cap = 0, obs_cap = 0;
@@ -54,7 +54,7 @@ int ensure_driver(CadnipHandle* h) {
   TRY(dalloc(&d->bp_idx, B)); TRY(dalloc(&d->save_idx, B)); TRY(dalloc(&d->dcstate, B)); TRY(dalloc(&d->action, B));
   TRY(dalloc(&d->cnt, B * 4));
   TRY(dalloc(&d->u0, B * n)); TRY(dalloc(&d->u1, B * n)); TRY(dalloc(&d->u2, B * n)); TRY(dalloc(&d->up, B * n)); TRY(dalloc(&d->beta, B * n));
-  TRY(dalloc(&d->atol, n)); TRY(dalloc(&d->nactive, 1));
+  TRY(dalloc(&d->atol, n)); TRY(dalloc(&d->emask, n)); TRY(dalloc(&d->nactive, 1));
   return CADNIP_OK;
 }
 
@@ -73,8 +73,8 @@ struct TranArgs {
   int *active, *flags;
   double *t, *h, *hprev, *hpp; int *nhist, *order, *k, *status, *bp_idx, *save_idx; long long* cnt;
   double *u0, *u1, *u2, *up, *beta;
-  const double *atol, *breaks, *save_t; const int* obs; double* out; int* nactive;
-  int B, n, n_limits, n_break, n_save, n_obs;
+  const double *atol, *emask, *breaks, *save_t; const int* obs; double* out; int* nactive;
+  int B, n, n_limits, n_break, n_save, n_obs, n_err;
   double t0, t1, reltol, h0, hmin, hmax, newton_tol;
   int max_newton, max_order, use_pcnr;
 };
@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(64) k_tran_update(TranArgs a) {
     double w = 1.0 / (a.atol[i] + a.reltol * fabs(u0[i]));
     s1 += (d * w) * (d * w);
     double e = un - up[i];
-    double w2 = 1.0 / (a.atol[i] + a.reltol * fmax(fabs(u0[i]), fabs(un)));
+    double w2 = a.emask[i] / (a.atol[i] + a.reltol * fmax(fabs(u0[i]), fabs(un)));
     s2 += (e * w2) * (e * w2);
     u[i] = un;
   }
@@ -204,11 +204,11 @@ __global__ void __launch_bounds__(64) k_tran_update(TranArgs a) {
   if (conv) {
     double errn = 0.0;
     bool accept = true;
-    if (nhist >= 2) {
+    if (nhist >= 2 && a.n_err > 0) {
       double errc;
       if (ord == 1) errc = h / (h + hprev);
       else { double w = h / hprev; errc = ((1.0 + w) * h / (1.0 + 2.0 * w)) / (h + hprev + hpp); }
-      errn = errc * sqrt(s2 / n);
+      errn = errc * sqrt(s2 / a.n_err);
       accept = errn <= 1.0;
     }
     if (accept) {
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(64) k_tran_update(TranArgs a) {
       bool landed = (bp < a.n_break && tn == a.breaks[bp]);
       int nh_new = nhist + 1 > 3 ? 3 : nhist + 1;
       double hnext;
-      if (nhist >= 2) {
+      if (nhist >= 2 && a.n_err > 0) {
         double fac = errn > 0.0 ? 0.9 * pow(errn, -1.0 / (ord + 1)) : 2.0;
         fac = fmin(2.0, fmax(0.2, fac));
         hnext = h * fac;
@@ -378,10 +378,14 @@ int dc_newton(CadnipHandle* h, double abstol, int maxiters, int use_pcnr, int co
     hipLaunchKernelGGL(k_dc_update, dim3(h->B), dim3(64), 0, h->stream, a);
     int running = 0;
     rc = count_running(h, &running); if (rc) break;
-    if (iters_total) *iters_total += running;
     if (running == 0) break;
   }
   h->initjct = saved_initjct;
+  if (!rc && iters_total) {   // Newton solves actually performed (== the reference's returned iteration count)
+    std::vector<long long> cnt((size_t)h->B * 4);
+    HIP_TRY(hipMemcpy(cnt.data(), d->cnt, cnt.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    for (int i = 0; i < h->B; ++i) *iters_total += cnt[(size_t)i * 4];
+  }
   return rc;
 }
 
@@ -393,10 +397,20 @@ void cadnip_driver_free(CadnipHandle* h) {
   if (!h || !h->drv) return;
   Driver* d = h->drv;
   void* ptrs[] = {d->t, d->h, d->hprev, d->hpp, d->nhist, d->order, d->k, d->status, d->bp_idx, d->save_idx, d->dcstate, d->action, d->cnt,
-                  d->u0, d->u1, d->u2, d->up, d->beta, d->atol, d->breaks, d->save_t, d->out, d->obs, d->nactive};
+                  d->u0, d->u1, d->u2, d->up, d->beta, d->atol, d->emask, d->breaks, d->save_t, d->out, d->obs, d->nactive};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete d;
   h->drv = nullptr;
+}
+
+int cadnip_tran_state(CadnipHandle* h, double* t_host, double* h_host, int32_t* order_host) {
+  if (!h || !h->drv) return CADNIP_NOTREADY;
+  Driver* d = h->drv;
+  size_t B = h->B;
+  if (t_host) HIP_TRY(hipMemcpy(t_host, d->t, B * sizeof(double), hipMemcpyDeviceToHost));
+  if (h_host) HIP_TRY(hipMemcpy(h_host, d->h, B * sizeof(double), hipMemcpyDeviceToHost));
+  if (order_host) HIP_TRY(hipMemcpy(order_host, d->order, B * sizeof(int), hipMemcpyDeviceToHost));
+  return CADNIP_OK;
 }
 
 int cadnip_dc_run(CadnipHandle* h, const CadnipDCOpts* o, double* u_host, int32_t* converged_host, CadnipRunStats* st) {
@@ -531,14 +545,19 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
   for (int i = 0; i < n_obs; ++i) obs[i] = o->n_obs > 0 ? o->obs[i] : i;
   HIP_TRY(hipMemcpyAsync(d->obs, obs.data(), n_obs * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(d->atol, o->abstol, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  std::vector<double> emask(n, 1.0);
+  int n_err = (int)n;
+  if (o->err_mask) { n_err = 0; for (size_t i = 0; i < n; ++i) { emask[i] = o->err_mask[i] != 0.0 ? 1.0 : 0.0; n_err += emask[i] != 0.0; } }
+  HIP_TRY(hipMemcpyAsync(d->emask, emask.data(), n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   const double span = o->t1 - o->t0;
   double hmax = o->hmax > 0 ? o->hmax : span / 50.0;
   double h0 = o->h0 > 0 ? o->h0 : span * 1e-6;
   double hmin = o->hmin > 0 ? o->hmin : span * 1e-14;
   TranArgs a{h->d_u, h->d_du, h->d_delta, h->d_limit_w, h->d_t, h->d_gamma, h->d_active, h->d_flags,
              d->t, d->h, d->hprev, d->hpp, d->nhist, d->order, d->k, d->status, d->bp_idx, d->save_idx, d->cnt,
-             d->u0, d->u1, d->u2, d->up, d->beta, d->atol, d->breaks, d->save_t, d->obs, d->out, d->nactive,
-             h->B, h->n, h->n_limits, o->n_break, o->n_save, n_obs,
+             d->u0, d->u1, d->u2, d->up, d->beta, d->atol, d->emask, d->breaks, d->save_t, d->obs, d->out, d->nactive,
+             h->B, h->n, h->n_limits, o->n_break, o->n_save, n_obs, n_err,
              o->t0, o->t1, o->reltol, h0, hmin, hmax, o->newton_tol > 0 ? o->newton_tol : 1e-3,
              o->max_newton > 0 ? o->max_newton : 10, o->max_order > 0 ? o->max_order : 2, o->use_pcnr};
   int saved_mode = h->spec.mode;

@@ -22,7 +22,7 @@ EXPORTS = [
     "cadnip_create", "cadnip_destroy", "cadnip_set_params", "cadnip_set_spec", "cadnip_set_initjct",
     "cadnip_rebuild", "cadnip_residual", "cadnip_jacobian", "cadnip_get_GCb", "cadnip_analyze",
     "cadnip_analyze_values", "cadnip_factor", "cadnip_solve", "cadnip_lu_stats", "cadnip_dc_run",
-    "cadnip_tran_run", "cadnip_dev_ptr", "cadnip_stream", "cadnip_set_u", "cadnip_get_u", "cadnip_get_flags",
+    "cadnip_tran_run", "cadnip_tran_state", "cadnip_dev_ptr", "cadnip_stream", "cadnip_set_u", "cadnip_get_u", "cadnip_get_flags",
     "cadnip_sync", "cadnip_profile_enable", "cadnip_profile_read", "cadnip_version",
     "cadnip_host_lu_analyze", "cadnip_host_lu_size", "cadnip_host_lu_get", "cadnip_host_lu_free",
 ]
@@ -71,7 +71,7 @@ class DCOptsC(C.Structure):
 
 
 class TranOptsC(C.Structure):
-    _fields_ = [("t0", C.c_double), ("t1", C.c_double), ("reltol", C.c_double), ("abstol", _D), ("h0", C.c_double),
+    _fields_ = [("t0", C.c_double), ("t1", C.c_double), ("reltol", C.c_double), ("abstol", _D), ("err_mask", _D), ("h0", C.c_double),
                 ("hmin", C.c_double), ("hmax", C.c_double), ("max_newton", C.c_int32), ("max_order", C.c_int32),
                 ("use_pcnr", C.c_int32), ("newton_tol", C.c_double), ("n_break", C.c_int32), ("breaks", _D),
                 ("n_save", C.c_int32), ("save_t", _D), ("n_obs", C.c_int32), ("obs", _I),
@@ -269,8 +269,14 @@ class Handle:
         return u, conv.astype(bool), _stats(st)
 
     def tran_run(self, t0, t1, abstol, reltol=1e-4, breaks=(), save_t=(), obs=None, h0=0.0, hmin=0.0, hmax=0.0,
-                 max_newton=10, max_order=2, use_pcnr=True, newton_tol=1e-3, max_iterations=0, fused=False):
+                 max_newton=10, max_order=2, use_pcnr=False, newton_tol=1e-3, max_iterations=0, fused=False,
+                 err_mask="differential"):
         at = np.ascontiguousarray(np.broadcast_to(np.asarray(abstol, dtype=np.float64), (self.st.n,)))
+        if isinstance(err_mask, str):
+            em = self.st.differential_mask() if err_mask == "differential" else np.ones(self.st.n)
+        else:
+            em = np.ones(self.st.n) if err_mask is None else np.asarray(err_mask, dtype=np.float64)
+        em = np.ascontiguousarray(em, dtype=np.float64)
         br = np.ascontiguousarray(np.asarray(breaks, dtype=np.float64))
         sv = np.ascontiguousarray(np.asarray(save_t, dtype=np.float64))
         ob = np.ascontiguousarray(np.asarray(obs if obs is not None else [], dtype=np.int32))
@@ -278,13 +284,18 @@ class Handle:
         out = np.zeros((self.B, sv.size, n_obs))
         per = np.zeros((self.B, 4), dtype=np.int64)
         st = RunStatsC()
-        o = TranOptsC(t0, t1, reltol, _dp(at), h0, hmin, hmax, max_newton, max_order, int(use_pcnr), newton_tol,
+        o = TranOptsC(t0, t1, reltol, _dp(at), _dp(em), h0, hmin, hmax, max_newton, max_order, int(use_pcnr), newton_tol,
                       br.size, _dp(br) if br.size else None, sv.size, _dp(sv) if sv.size else None,
                       ob.size, _ip(ob) if ob.size else None, max_iterations, int(fused))
         rc = self.lib.cadnip_tran_run(self.h, C.byref(o), _dp(out), per.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(st))
         if rc not in (OK, NOCONV):
             _check(rc, "cadnip_tran_run")
         return out, per, _stats(st)
+
+    def tran_state(self):
+        t, hh, o = np.empty(self.B), np.empty(self.B), np.empty(self.B, dtype=np.int32)
+        _check(self.lib.cadnip_tran_state(self.h, _dp(t), _dp(hh), _ip(o)), "cadnip_tran_state")
+        return t, hh, o
 
     # -- misc ------------------------------------------------------------------------------------
     def set_u(self, u):

@@ -109,6 +109,14 @@ class Structure:
             return self.n_nodes + self.n_currents + self.n_charges + self.limit_names.index(name)
         raise KeyError(name)
 
+    def differential_mask(self):
+        """1.0 for unknowns that appear differentiated (columns of C with at least one stamp), 0.0 for
+        algebraic ones.  Column-wise counterpart of detect_differential_vars (solve.jl:2041-2058)."""
+        m = np.zeros(self.n)
+        has = np.diff(self.c_ptr) > 0
+        m[np.unique(self.colidx[has])] = 1.0
+        return m
+
     def state_abstol(self, vntol=1e-6, iabstol=1e-12, chgtol=1e-14):
         """build.jl:276-283."""
         tol = np.empty(self.n)

@@ -169,6 +169,10 @@ typedef struct {
   double t0, t1;
   double reltol;
   const double* abstol;     /* [n] per-unknown absolute tolerance (state_abstol, build.jl:276-283) */
+  const double* err_mask;   /* [n] 1 = unknown takes part in the local-error test, 0 = excluded; NULL = all.
+                               The driver's default excludes algebraic unknowns (V-source currents jump at
+                               source breakpoints), i.e. it tests the differential unknowns -- the columns of C
+                               (cf. detect_differential_vars, solve.jl:2041-2058, and IDA's suppressalg) */
   double h0;                /* initial step (<=0: automatic) */
   double hmin, hmax;        /* hmax <= 0: (t1-t0)/50 */
   int32_t max_newton;       /* IDA max_nonlinear_iters = 10, sweeps.jl:600 */
@@ -195,6 +199,9 @@ int cadnip_dc_run(CadnipHandle* h, const CadnipDCOpts* o, double* u_host, int32_
 /* starts from the handle's current state u (e.g. left by cadnip_dc_run in :tranop mode);
  * out_host [B][n_save][n_obs]; per_inst_host [B][4] = {newton_iters, accepted, rejected, status} */
 int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, int64_t* per_inst_host, CadnipRunStats* st);
+
+/* per-instance integrator state after / during a run: time reached, current step size, order */
+int cadnip_tran_state(CadnipHandle* h, double* t_host, double* h_host, int32_t* order_host);
 
 /* ---- misc -------------------------------------------------------------------------------- */
 typedef enum { CADNIP_BUF_U = 0, CADNIP_BUF_G = 1, CADNIP_BUF_C = 2, CADNIP_BUF_B = 3, CADNIP_BUF_J = 4,

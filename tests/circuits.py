@@ -4,8 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cadnip_jl_amd as cj
 from cadnip_jl_amd import benchmarks as bm
 
-NM = dict(bm.NFET_06V0)
-PM = dict(bm.PFET_06V0)
+NM = dict(bm.NFET_06V0_MEYER)
+PM = dict(bm.PFET_06V0_MEYER)
 
 
 def divider(v=5.0, r1=1e3, r2=1e3):
@@ -108,5 +108,5 @@ ALL_STAMP = {
     "divider": (divider, {}), "linear_zoo": (linear_zoo, {}), "diode": (diode_rectifier, {}),
     "diode_nolimit": (lambda: diode_rectifier(False), {}), "diode_chain": (diode_chain, {}),
     "nonlinear_zoo": (nonlinear_zoo, {}), "inverter": (inverter_dc, {}), "mos1_rd": (mos1_rd, {}),
-    "dff": (bm.dff_circuit, {"vdd": 5.0}),
+    "dff": (bm.dff_circuit, {"vdd": 5.0}), "dff_meyer": (lambda: bm.dff_circuit(meyer=True), {"vdd": 5.0}),
 }
