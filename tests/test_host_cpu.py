@@ -1,0 +1,256 @@
+"""CPU suite, part 2: product host logic, the C ABI's symbol table, the LU program, and the
+oracle's two restatements against each other.  No compute call touches a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import cadnip_jl_amd as cj
+from cadnip_jl_amd import api, benchmarks as bm, hip
+from cadnip_jl_amd.structure import TYPE_ID
+from oracle import mna_ref as M
+from oracle.netlist_ref import make_builder
+from tests import circuits as tc
+from tests.port_util import make_port, analyze_port
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "cadnip_hip.h")).read()
+    declared = set(re.findall(r"\b(cadnip_[A-Za-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = hip.load_library()
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), "libcadnip_hip.so does not export %s" % sym
+    assert declared == set(hip.EXPORTS)
+    assert b"gfx950" in lib.cadnip_version()
+
+
+@pytest.mark.parametrize("name", list(tc.ALL_STAMP))
+def test_product_structure_matches_oracle_discovery(name):
+    """Product structure discovery (device table) == oracle's literal builder passes: sizes, names, the
+    unified pattern in the reference's CSC order, COO counts."""
+    mk, params = tc.ALL_STAMP[name]
+    circ = mk()
+    st = cj.discover(circ, params)
+    b = make_builder(circ.to_dicts(params))
+    spec = M.MNASpec(mode="tran")
+    ctx = M.build_with_detection(b, {}, spec)
+    cs = M.compile_structure(b, {}, spec, ctx=ctx)
+    assert (st.n, st.n_nodes, st.n_currents, st.n_charges, st.n_limits) == (cs.n, ctx.n_nodes, ctx.n_currents, ctx.n_charges, ctx.n_limits)
+    assert st.node_names == ctx.node_names and st.current_names == ctx.current_names
+    assert st.charge_names == ctx.charge_names and st.limit_names == ctx.limit_names
+    assert np.array_equal(st.ref_colptr, cs.colptr) and np.array_equal(st.ref_rowval, cs.rowval)
+    assert (st.n_coo_g, st.n_coo_c, st.n_coo_b) == (cs.G_n_coo, cs.C_n_coo, cs.n_b_deferred)
+    assert np.allclose(st.limit_init, cs.limit_init)
+    # CSR <-> reference nz permutation is a bijection consistent with the pattern
+    rows = np.repeat(np.arange(st.n), np.diff(st.rowptr))
+    assert np.array_equal(st.ref_rowval[st.to_ref_nz], rows)
+    assert sorted(st.to_ref_nz.tolist()) == list(range(st.nnz))
+
+
+def test_dff_sizes():
+    st = cj.discover(bm.dff_circuit(meyer=True), {"vdd": 5.0})
+    assert (st.n, st.n_nodes, st.n_currents, st.n_charges, st.n_limits) == (265, 18, 7, 120, 120)   # SURVEY.md appendix A.2 estimate
+    st = cj.discover(bm.dff_circuit(), {"vdd": 5.0})
+    assert st.n == 18 + 7 + 90 + 120 and st.mos1_vdep == (False, True, True, True)
+
+
+@pytest.mark.parametrize("name", ["linear_zoo", "nonlinear_zoo", "inverter", "mos1_rd", "dff", "dff_meyer"])
+def test_cpu_port_stamps_match_literal_oracle(name):
+    """The compiled port (Dual<3>, hoisted setup/temp) vs the literal Python restatement (width-14 duals,
+    per-call setup/temp): G, C, b, limit_w at random operating points, several temperatures."""
+    mk, params = tc.ALL_STAMP[name]
+    circ = mk()
+    rng = np.random.default_rng(5)
+    for temp, t, mode in ((27.0, 0.0, "tran"), (-40.0, 1.3e-3 if "dff" not in name else 2.005e-7, "tran"), (125.0, 0.0, "dcop")):
+        st, port = make_port(circ, params, temp, mode)
+        b = make_builder(circ.to_dicts(params))
+        spec = M.MNASpec(mode=mode, temp=temp)
+        ctx = M.build_with_detection(b, {}, spec)
+        cs = M.compile_structure(b, {}, spec, ctx=ctx)
+        ws = M.create_workspace(cs, ctx=ctx)
+        for trial in range(2):
+            u = rng.random(st.n) * (5.0 if trial else 1.0) - 0.3
+            M.fast_rebuild(ws, u, t)
+            G, C, bb, lw = port.rebuild(u, t)
+            Gr, Cr = np.empty(st.nnz), np.empty(st.nnz)
+            Gr[st.to_ref_nz], Cr[st.to_ref_nz] = G, C
+            for got, ref in ((Gr, cs.G.data), (Cr, cs.C.data), (bb, ws.dctx.b)):
+                assert np.max(np.abs(got - ref)) <= 1e-12 * max(np.max(np.abs(ref)), 1e-300), (name, temp, trial)
+            if st.n_limits:
+                assert np.max(np.abs(lw - ws.dctx.limit_w)) <= 1e-12 * max(1.0, np.max(np.abs(lw)))
+        port.close()
+
+
+@pytest.mark.parametrize("name", ["diode", "diode_chain", "inverter", "mos1_rd"])
+def test_cpu_port_dc_matches_literal_oracle(name):
+    mk, params = tc.ALL_STAMP[name]
+    circ = mk()
+    st, port = make_port(circ, params, 27.0, "dcop")
+    analyze_port(st, port, 5.0)
+    u, ok, it = port.dc(abstol=1e-10)
+    b = make_builder(circ.to_dicts(params))
+    spec = M.MNASpec(mode="dcop")
+    ctx = M.build_with_detection(b, {}, spec)
+    cs = M.compile_structure(b, {}, spec, ctx=ctx)
+    ws = M.create_workspace(cs, ctx=ctx)
+    uo, oko, ito = M.dc_pcnr_newton(cs, ws, np.zeros(cs.n), abstol=1e-10)
+    assert ok and oko and it == ito
+    assert np.max(np.abs(u - uo) / np.maximum(np.abs(uo), 1.0)) < 1e-9
+    port.close()
+
+
+def test_cpu_port_rc_charge_analytic():
+    # test/mna/core.jl:785-912: V(t) = 5 (1 - exp(-t/tau)) at t in {tau/2, tau, 2tau, 3tau, 5tau}, rtol 1e-3 (DAE path)
+    c = cj.Circuit()
+    c.V("v1", "vin", "0", dc=0.0, wave=("pwl", [0.0, 1e-9], [0.0, 5.0]))
+    c.R("r1", "vin", "out", 1e3)
+    c.C("c1", "out", "0", 1e-6)
+    st, port = make_port(c, {}, 27.0, "tranop")
+    analyze_port(st, port, 5.0)
+    u0, ok, _ = port.dc(abstol=1e-9)
+    assert ok
+    port.set_spec(mode="tran")
+    tau = 1e-3
+    ts = np.array([0.5, 1.0, 2.0, 3.0, 5.0]) * tau
+    out, _, stats, _ = port.tran(u0, 0.0, 5e-3, 1e-9, 1e-6, breaks=[1e-9], save_t=ts, obs=[st.index_of("out")], err_mask=st.differential_mask())
+    assert stats["status"] == 1
+    assert np.allclose(out[:, 0], 5.0 * (1 - np.exp(-ts / tau)), rtol=1e-3)
+    port.close()
+
+
+def test_cpu_port_dff_transient_logic_pins():
+    # test/gf180_dff.jl:29-33 logic-level pins (race-free ones; see tests/test_gpu_drivers.py)
+    circ = bm.dff_circuit()
+    st, port = make_port(circ, {"vdd": 5.0}, 27.0, "tranop")
+    analyze_port(st, port, 5.0)
+    u0, ok, _ = port.dc(abstol=1e-9)
+    assert ok
+    port.set_spec(mode="tran")
+    from cadnip_jl_amd.structure import expand_breakpoints
+    ts = np.array([t for t, _ in bm.DFF_Q_PINS])
+    out, _, stats, _ = port.tran(u0, 0.0, 7e-7, st.state_abstol(vntol=1e-6, iabstol=1e-9, chgtol=1e-6), 1e-4,
+                                 breaks=expand_breakpoints(st.breakpoints, bm.DFF_TSPAN), save_t=ts, obs=[st.index_of("Q")],
+                                 err_mask=st.differential_mask())
+    assert stats["status"] == 1
+    q = out[:, 0]
+    assert abs(q[0]) < 0.05 and abs(q[1]) < 0.05 and abs(q[4] - 5.0) < 0.05
+    port.close()
+
+
+def _emulate_lu(P, vals, rhs, n):
+    lu = np.zeros(P["rowptr"][-1])
+    lu[P["load_dst"]] = vals[P["load_src"]]
+    for lev in range(len(P["lev_ptr"]) - 1):
+        new = {}
+        for e in range(P["lev_ptr"][lev], P["lev_ptr"][lev + 1]):
+            acc = lu[P["ent_pos"][e]]
+            for t in range(P["ent_ptr"][e], P["ent_ptr"][e + 1]):
+                acc -= lu[P["term_a"][t]] * lu[P["term_b"][t]]
+            if P["ent_diag"][e] >= 0:
+                acc /= lu[P["ent_diag"][e]]
+            new[P["ent_pos"][e]] = acc
+        for k, v in new.items():       # level-synchronous, like the GPU kernel
+            lu[k] = v
+    y = rhs[P["rperm"]].copy()
+    for lev in range(len(P["fwd_lev_ptr"]) - 1):
+        new = {}
+        for r in range(P["fwd_lev_ptr"][lev], P["fwd_lev_ptr"][lev + 1]):
+            i = P["fwd_rows"][r]
+            new[i] = y[i] - sum(lu[p] * y[P["col"][p]] for p in range(P["rowptr"][i], P["diag"][i]))
+        for k, v in new.items():
+            y[k] = v
+    for lev in range(len(P["bwd_lev_ptr"]) - 1):
+        new = {}
+        for r in range(P["bwd_lev_ptr"][lev], P["bwd_lev_ptr"][lev + 1]):
+            i = P["bwd_rows"][r]
+            new[i] = (y[i] - sum(lu[p] * y[P["col"][p]] for p in range(P["diag"][i] + 1, P["rowptr"][i + 1]))) / lu[P["diag"][i]]
+        for k, v in new.items():
+            y[k] = v
+    x = np.zeros(n)
+    x[P["cperm"]] = y
+    return x
+
+
+def test_symbolic_lu_program_solves_mna_systems():
+    """Host symbolic phase (Markowitz order, fill, level schedule): emulate the GPU kernel's level-synchronous
+    execution in numpy and check backward error; zero diagonals (V-source rows) included."""
+    rng = np.random.default_rng(1)
+    for n in (5, 40, 150):
+        A = sp.random(n, n, density=min(0.5, 4.0 / n), random_state=int(rng.integers(1 << 30)), format="lil")
+        for i in range(n):
+            if i % 3:
+                A[i, i] = rng.random() + 1
+            A[i, (i + 1) % n] = rng.random() - 0.5
+            A[(i + 1) % n, i] = rng.random() - 0.5
+        A = A.tocsr()
+        A.sort_indices()
+        P = hip.host_lu_analyze(n, A.indptr, A.indices, A.data)
+        rhs = rng.random(n)
+        x = _emulate_lu(P, A.data, rhs, n)
+        assert np.max(np.abs(A @ x - rhs) / (abs(A) @ np.abs(x) + 1.0)) < 1e-9   # threshold (1e-3) pivoting allows growth
+        # every LU entry is written by exactly one program entry, in an order consistent with its inputs
+        pos_level = {}
+        for lev in range(len(P["lev_ptr"]) - 1):
+            for e in range(P["lev_ptr"][lev], P["lev_ptr"][lev + 1]):
+                assert P["ent_pos"][e] not in pos_level
+                pos_level[P["ent_pos"][e]] = lev
+        for lev in range(len(P["lev_ptr"]) - 1):
+            for e in range(P["lev_ptr"][lev], P["lev_ptr"][lev + 1]):
+                deps = list(P["term_a"][P["ent_ptr"][e]:P["ent_ptr"][e + 1]]) + list(P["term_b"][P["ent_ptr"][e]:P["ent_ptr"][e + 1]])
+                if P["ent_diag"][e] >= 0:
+                    deps.append(P["ent_diag"][e])
+                assert all(pos_level.get(d, -1) < lev for d in deps)
+
+
+def test_symbolic_lu_dff_has_almost_no_fill():
+    st, port = make_port(bm.dff_circuit(), {"vdd": 5.0})
+    prog = analyze_port(st, port, 5.0)
+    assert prog["rowptr"][-1] <= st.nnz + 40
+    port.close()
+
+
+def test_singular_matrix_is_reported():
+    A = sp.csr_matrix(np.array([[1.0, 2.0], [2.0, 4.0]]))
+    with pytest.raises(hip.SingularException):
+        hip.host_lu_analyze(2, A.indptr, A.indices, A.data)
+
+
+def test_sweep_algebra():
+    # src/sweeps.jl:150-330 / test/sweep.jl: product order (first axis fastest), tandem, serial
+    ps = api.ProductSweep(a=[1, 2, 3], b=[10, 20])
+    assert list(ps) == [{"a": 1, "b": 10}, {"a": 2, "b": 10}, {"a": 3, "b": 10}, {"a": 1, "b": 20}, {"a": 2, "b": 20}, {"a": 3, "b": 20}]
+    assert len(ps) == 6
+    assert list(api.TandemSweep(a=[1, 2], b=[3, 4])) == [{"a": 1, "b": 3}, {"a": 2, "b": 4}]
+    assert len(api.SerialSweep(api.Sweep(a=[1, 2]), api.Sweep(a=[5]))) == 3
+    with pytest.raises(ValueError):
+        api.TandemSweep(a=[1, 2], b=[3])
+    mc = api.MNACircuit(tc.divider(), {})
+    with pytest.raises(KeyError):
+        api.CircuitSweep(mc, api.Sweep(nope=[1.0]))
+    mc2 = api.MNACircuit(bm.dff_circuit(), {"vdd": 5.0})
+    assert api.alter(mc2, vdd=4.5).params["vdd"] == 4.5 and mc2.params["vdd"] == 5.0
+    with pytest.raises(KeyError):
+        api.alter(mc2, nope=1.0)
+
+
+def test_pack_params_temperature_and_sweep_axes():
+    circ = bm.dff_circuit()
+    st = cj.discover(circ, {"vdd": 5.0})
+    B = 3
+    packed = cj.pack_params(st, circ, {"vdd": np.array([4.5, 5.0, 5.5])}, np.array([-40.0, 27.0, 125.0]), B)
+    blk = {b.type: (b, p) for b, p in zip(st.blocks, packed)}
+    vb, vp = blk["V"]
+    assert vp.shape == (B, 2, vb.count)
+    assert np.allclose(vp[:, 0, 0], [4.5, 5.0, 5.5])                   # VVDD dc follows vdd
+    assert np.allclose(vp[:, 1, 5], np.array([4.5, 5.0, 5.5]) / 5.0)   # clock amplitude scale
+    mb, mp = blk["MOS1"]
+    from cadnip_jl_amd import mos1_params as m1
+    kT = 1.38064852e-23 / 1.6021766208e-19
+    assert np.allclose(mp[:, m1.P_VT, 0], (np.array([-40.0, 27.0, 125.0]) + 273.15) * kT)
+    assert np.all(np.diff(mp[:, m1.P_BETA, 0]) < 0)                    # mobility falls with temperature
