@@ -24,8 +24,9 @@ def _port_run(circ, params, temp, u0, ts, obs, vscale):
     return out, stats
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("points", [[{}], [{"vdd": 4.5, "temp": -40.0}, {"vdd": 5.5, "temp": 125.0}, {"vdd": 4.5, "temp": 125.0}, {"vdd": 5.2, "temp": 60.0}]])
-def test_dff_transient_matches_port(points):
+def test_dff_transient_matches_port(points, fused):
     circ = bm.dff_circuit()
     mc = api.MNACircuit(circ, {"vdd": 5.0})
     sim = api.BatchSimulator(mc, points)
@@ -37,7 +38,7 @@ def test_dff_transient_matches_port(points):
     obs = list(range(st.n_nodes)) + [st.index_of("X_tn10_sp_mos1_Q_b_0")]
     sim.h.set_spec(mode="tran")
     breaks = expand_breakpoints(st.breakpoints, bm.DFF_TSPAN)
-    out, per, stats = sim.h.tran_run(0.0, 7e-7, st.state_abstol(**ABSTOL), 1e-4, breaks=breaks, save_t=ts, obs=obs)
+    out, per, stats = sim.h.tran_run(0.0, 7e-7, st.state_abstol(**ABSTOL), 1e-4, breaks=breaks, save_t=ts, obs=obs, fused=fused)
     assert stats["n_failed"] == 0
     for i, pt in enumerate(points):
         params = {"vdd": pt.get("vdd", 5.0)}

@@ -18,7 +18,7 @@ sim.h.set_spec(mode="tran")
 atol = st.state_abstol(vntol=1e-6, iabstol=1e-9, chgtol=1e-6)
 ts=np.array([150e-9,250e-9,450e-9,550e-9,700e-9])
 t0=time.time()
-out, per, stats = sim.h.tran_run(0.0, 7e-7, atol, 1e-4, breaks=breaks, save_t=ts, obs=[qi])
+out, per, stats = sim.h.tran_run(0.0, 7e-7, atol, 1e-4, breaks=breaks, save_t=ts, obs=[qi], fused=bool(int(sys.argv[2])) if len(sys.argv)>2 else False)
 print("wall", time.time()-t0, stats)
 t,hh,o = sim.h.tran_state()
 bad = np.where(per[:,3]!=1)[0]
