@@ -1,0 +1,139 @@
+# CadnipHIP.jl -- the reference-side binding of libcadnip_hip.so (include/cadnip_hip.h).
+#
+# This is the `ccall` shim a Cadnip.jl maintainer adds to route the transient hot path through the
+# MI355X library.  It subtypes nothing new: it provides a `GPUEvalWorkspace` that is passed as SciML's
+# `p` exactly where `EvalWorkspace` is passed today (src/mna/solve.jl:2138-2160, 2497-2519), with
+# `fast_rebuild!` / `fast_residual!` / `fast_jacobian!` methods of the same signatures
+# (src/mna/precompile.jl:493-603) and a KLU-shaped linear solver (src/mna/solve.jl:612-613,667-670).
+#
+# Julia is not installed in the build environment, so this file is shipped as source only (it is not
+# executed by the test-suite); every `ccall` below matches a prototype in include/cadnip_hip.h and the
+# Python ctypes binding cadnip.jl_amd/hip.py exercises the same entry points on the GPU.
+module CadnipHIP
+
+using SparseArrays, LinearAlgebra
+
+const LIB = get(ENV, "CADNIP_HIP_LIB", "libcadnip_hip.so")
+
+const CADNIP_OK, CADNIP_BADARG, CADNIP_SINGULAR, CADNIP_NONFINITE, CADNIP_HIPERROR, CADNIP_NOTREADY, CADNIP_NOCONV = 0:6
+
+# error convention of the reference: exceptions (src/mna/solve.jl:887-897 catches these two)
+function check(rc::Cint, what)
+    rc == CADNIP_OK && return nothing
+    rc == CADNIP_SINGULAR && throw(LinearAlgebra.SingularException(0))
+    rc == CADNIP_NONFINITE && throw(DomainError(what, "non-finite stamp value"))
+    error("$what failed with status $rc")
+end
+
+struct CadnipDeviceBlock            # == typedef struct CadnipDeviceBlock
+    type::Int32; count::Int32
+    n_nodes::Int32; nodes::Ptr{Int32}
+    n_ipar::Int32; ipar::Ptr{Int32}
+    n_par::Int32
+    g_base::Int32; c_base::Int32; b_base::Int32
+    n_g::Int32; n_c::Int32; n_b::Int32
+end
+
+struct CadnipStructure              # == typedef struct CadnipStructure
+    n::Int32; n_nodes::Int32; n_currents::Int32; n_charges::Int32; n_limits::Int32
+    nnz::Int32; rowptr::Ptr{Int32}; colidx::Ptr{Int32}; to_ref_nz::Ptr{Int32}
+    n_blocks::Int32; blocks::Ptr{CadnipDeviceBlock}
+    n_wave_data::Int32; wave_data::Ptr{Float64}
+    ns_g::Int32; ns_c::Int32; ns_b::Int32
+    g_ptr::Ptr{Int32}; g_slots::Ptr{Int32}; c_ptr::Ptr{Int32}; c_slots::Ptr{Int32}; b_ptr::Ptr{Int32}; b_slots::Ptr{Int32}
+    diag_nz::Ptr{Int32}; limit_init::Ptr{Float64}
+end
+
+struct CadnipSpec
+    mode::Int32; gmin::Float64; gshunt::Float64; srcFact::Float64
+end
+
+"""
+    GPUEvalWorkspace
+
+Drop-in for `MNA.EvalWorkspace` (src/mna/precompile.jl:168-172).  Holds the library handle plus the
+host mirrors the integrator reads (`b`, `limit_w`), and remembers the (u, t) of the last stamping so
+that `fast_residual!` and `fast_jacobian!` at the same point share one restamp (the reference restamps
+in each: precompile.jl:548,572).
+"""
+mutable struct GPUEvalWorkspace
+    handle::Ptr{Cvoid}
+    n::Int; nnz::Int; n_limits::Int
+    keep::Vector{Any}                 # arrays the C structure points into
+    last_u::Vector{Float64}; last_t::Float64; stamped::Bool
+    gamma::Vector{Float64}; tbuf::Vector{Float64}
+    J_ref::Vector{Float64}            # J in the reference's CSC nzval order
+end
+
+"""
+    export_structure(cs::MNA.CompiledStructure, ctx::MNA.MNAContext, table) -> GPUEvalWorkspace
+
+Build the `CadnipStructure` from what Cadnip already has: the unified CSC pattern of `cs.G`
+(precompile.jl:413-421) converted to CSR + `to_ref_nz`, and the device table `table` (one entry per
+instance: type id, resolved node indices, slot bases) produced by walking `ctx`'s COO streams in stamp
+order -- `cs.G_coo_to_idx[k]` is exactly the nz each G slot gathers into (value_only.jl:395-421).
+"""
+function export_structure(n, n_nodes, n_currents, n_charges, n_limits,
+                          rowptr::Vector{Int32}, colidx::Vector{Int32}, to_ref_nz::Vector{Int32},
+                          blocks::Vector{CadnipDeviceBlock}, wave_data::Vector{Float64},
+                          ns::NTuple{3,Int32}, g_ptr, g_slots, c_ptr, c_slots, b_ptr, b_slots,
+                          diag_nz::Vector{Int32}, limit_init::Vector{Float64}; n_instances=1, device=0)
+    keep = Any[rowptr, colidx, to_ref_nz, blocks, wave_data, g_ptr, g_slots, c_ptr, c_slots, b_ptr, b_slots, diag_nz, limit_init]
+    s = Ref(CadnipStructure(n, n_nodes, n_currents, n_charges, n_limits, length(colidx), pointer(rowptr), pointer(colidx),
+            pointer(to_ref_nz), length(blocks), pointer(blocks), length(wave_data), pointer(wave_data), ns[1], ns[2], ns[3],
+            pointer(g_ptr), pointer(g_slots), pointer(c_ptr), pointer(c_slots), pointer(b_ptr), pointer(b_slots),
+            pointer(diag_nz), pointer(limit_init)))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve keep check(ccall((:cadnip_create, LIB), Cint, (Ref{CadnipStructure}, Int32, Int32, Ref{Ptr{Cvoid}}), s, n_instances, device, h), "cadnip_create")
+    GPUEvalWorkspace(h[], n, length(colidx), n_limits, keep, zeros(n), NaN, false, zeros(1), zeros(1), zeros(length(colidx)))
+end
+
+set_params!(ws::GPUEvalWorkspace, block::Integer, par::Array{Float64,3}) =
+    check(ccall((:cadnip_set_params, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), ws.handle, block, par), "cadnip_set_params")
+
+function set_spec!(ws::GPUEvalWorkspace; mode::Symbol=:tran, gmin=1e-12, gshunt=0.0, srcFact=1.0)
+    m = mode === :dcop ? 0 : mode === :tran ? 1 : 2
+    check(ccall((:cadnip_set_spec, LIB), Cint, (Ptr{Cvoid}, Ref{CadnipSpec}), ws.handle, Ref(CadnipSpec(m, gmin, gshunt, srcFact))), "cadnip_set_spec")
+end
+
+# ---- the three callbacks ---------------------------------------------------------------------------
+"fast_rebuild!(ws, u, t)  -- src/mna/precompile.jl:493-537"
+function fast_rebuild!(ws::GPUEvalWorkspace, u::AbstractVector, t::Real)
+    ws.tbuf[1] = Float64(t)
+    check(ccall((:cadnip_rebuild, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ws.handle, u, ws.tbuf), "cadnip_rebuild")
+    copyto!(ws.last_u, u); ws.last_t = Float64(t); ws.stamped = true
+    return nothing
+end
+
+_same_point(ws, u, t) = ws.stamped && ws.last_t == Float64(t) && ws.last_u == u
+
+"fast_residual!(resid, du, u, ws, t)  -- src/mna/precompile.jl:546-557"
+function fast_residual!(resid::AbstractVector, du::AbstractVector, u::AbstractVector, ws::GPUEvalWorkspace, t::Real)
+    _same_point(ws, u, t) || fast_rebuild!(ws, u, t)
+    check(ccall((:cadnip_residual, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), ws.handle, du, u, resid), "cadnip_residual")
+    return nothing
+end
+
+"fast_jacobian!(J, du, u, ws, gamma, t)  -- src/mna/precompile.jl:568-585; J shares cs.G's colptr/rowval"
+function fast_jacobian!(J::SparseMatrixCSC, du::AbstractVector, u::AbstractVector, ws::GPUEvalWorkspace, gamma::Real, t::Real)
+    _same_point(ws, u, t) || fast_rebuild!(ws, u, t)
+    ws.gamma[1] = Float64(gamma)
+    check(ccall((:cadnip_jacobian, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ws.handle, ws.gamma, nonzeros(J)), "cadnip_jacobian")
+    return nothing
+end
+
+# ---- KLU-shaped linear solver: symbolic once, numeric refactor per Jacobian, solve per iteration -----------
+analyze!(ws::GPUEvalWorkspace) = check(ccall((:cadnip_analyze, LIB), Cint, (Ptr{Cvoid}, Int32), ws.handle, 0), "cadnip_analyze")
+factor!(ws::GPUEvalWorkspace) = check(ccall((:cadnip_factor, LIB), Cint, (Ptr{Cvoid},), ws.handle), "cadnip_factor")
+function solve!(x::Vector{Float64}, ws::GPUEvalWorkspace, rhs::Vector{Float64})
+    check(ccall((:cadnip_solve, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ws.handle, rhs, x), "cadnip_solve")
+    return x
+end
+
+# SciML closures identical in shape to make_workspace_dae_residual / _jacobian (src/mna/solve.jl:2497-2519)
+make_gpu_dae_residual() = (resid, du, u, ws::GPUEvalWorkspace, t) -> fast_residual!(resid, du, u, ws, t)
+make_gpu_dae_jacobian() = (J, du, u, ws::GPUEvalWorkspace, gamma, t) -> fast_jacobian!(J, du, u, ws, gamma, t)
+
+Base.close(ws::GPUEvalWorkspace) = (ccall((:cadnip_destroy, LIB), Cvoid, (Ptr{Cvoid},), ws.handle); ws.handle = C_NULL; nothing)
+
+end # module
