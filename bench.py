@@ -31,7 +31,7 @@ ABSTOL = dict(vntol=1e-6, iabstol=1e-9, chgtol=1e-6)
 RELTOL = 1e-4
 
 
-def algorithmic_bytes(st, B):
+def algorithmic_bytes(st, B, nnz_lu, rounds=8):
     """Per-launch algorithmic bytes of each hot-path kernel for a batch of B instances
     (SURVEY.md section 8d / DESIGN.md section 5: every array counted once per required read or write)."""
     out = {}
@@ -46,6 +46,13 @@ def algorithmic_bytes(st, B):
     n_coo = st.n_coo_g + st.n_coo_c + st.n_coo_b
     out["assemble"] = B * (8 * n_coo + 8 * (2 * st.nnz + st.n)) + 4 * (n_coo + 2 * st.nnz + st.n)
     out["residual"] = B * (2 * 8 * st.nnz + 8 * 4 * st.n) + 4 * (st.nnz + st.n + 1)
+    out["lu_factor_solve"] = B * (8 * 2 * st.nnz + 8 * nnz_lu + 8 * 2 * st.n)
+    out["tran_update"] = B * 8 * 8 * st.n
+    # fused kernels: one launch = `rounds` Newton iterations of every instance; B_iter = sum of the per-op rows
+    b_iter = sum(v for k, v in out.items() if k.startswith("stamp_")) + out["assemble"] + out["residual"] + out["lu_factor_solve"] + out["tran_update"]
+    out["fused_newton"] = rounds * b_iter
+    out["fused2_newton"] = rounds * b_iter
+    out["B_iter_per_instance"] = b_iter // B
     return out
 
 
@@ -54,9 +61,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--instances", type=int, default=1024, help="sweep instances resident per GPU")
+    ap.add_argument("--instances", type=int, default=2048, help="sweep instances resident per GPU (32 Vdd x instances/32 temps)")
     ap.add_argument("--cpu-sample", type=int, default=160, help="corner points timed on the host for cpu_baseline")
-    ap.add_argument("--fused", type=int, default=int(os.environ.get("CADNIP_FUSED", "0")))
+    ap.add_argument("--fused", type=int, default=int(os.environ.get("CADNIP_FUSED", "2")),
+                    help="0 = one kernel per op (the drop-in ABI path), 1 = fused v1, 2 = fused v2 (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -96,7 +104,7 @@ def main():
             raise RuntimeError("DC initialisation failed on rank %d" % rank)
         sim.h.set_spec(mode="tran")
         out, per, stats = sim.h.tran_run(bm.DFF_TSPAN[0], bm.DFF_TSPAN[1], atol, RELTOL, breaks=breaks, save_t=save_t, obs=obs,
-                                         fused=bool(args.fused))
+                                         fused=int(args.fused))
         if stats["n_failed"]:
             raise RuntimeError("%d transient(s) failed on rank %d" % (stats["n_failed"], rank))
         if world > 1:   # final gather of the result blocks over RCCL / xGMI
@@ -133,13 +141,14 @@ def main():
         one_step()
         prof = sim.h.profile_read()
         sim.h.profile(False)
-        ab = algorithmic_bytes(st, B)
+        ab = algorithmic_bytes(st, B, sim.h.lu_stats()["nnz_lu"])
         dom = max(prof.items(), key=lambda kv: kv[1][0])
         kernels = {k: {"ms_total": round(v[0], 3), "calls": int(v[1]), "avg_us": round(1e3 * v[0] / max(v[1], 1), 3)} for k, v in prof.items()}
         name = dom[0]
         avg_s = dom[1][0] / max(dom[1][1], 1) * 1e-3
         roof = {"bound": "hbm", "kernel": name, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "avg_launch_us": round(avg_s * 1e6, 3), "kernels": kernels}
+        roof["B_iter_per_instance"] = int(ab["B_iter_per_instance"])
         if name in ab:
             roof["algorithmic_bytes_per_launch"] = int(ab[name])
             roof["achieved"] = round(ab[name] / avg_s / 1e9, 3)

@@ -117,6 +117,7 @@ void cadnip_destroy(CadnipHandle* h) {
                   h->d_ent_diag, h->d_ent_ptr, h->d_term_a, h->d_term_b, h->d_lev_ptr, h->d_lu_rowptr, h->d_lu_col, h->d_lu_diag, h->d_rperm,
                   h->d_cperm, h->d_fwd_rows, h->d_fwd_lev_ptr, h->d_bwd_rows, h->d_bwd_lev_ptr};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (h->d_f2tab) (void)hipFree(h->d_f2tab);
   for (auto& b : h->blocks) { if (b.d_nodes) (void)hipFree(b.d_nodes); if (b.d_ipar) (void)hipFree(b.d_ipar); if (b.d_par) (void)hipFree(b.d_par); }
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -355,6 +356,7 @@ int upload_lu(CadnipHandle* h) {
   TRY(dev_upload(&h->d_bwd_rows, P.bwd_rows)); TRY(dev_upload(&h->d_bwd_lev_ptr, P.bwd_lev_ptr));
   TRY(dev_alloc(&h->d_LU, (size_t)h->B * P.nnz_lu));
   h->analyzed = true;
+  h->fused2_dirty = true;
   return CADNIP_OK;
 }
 }  // namespace cadnip

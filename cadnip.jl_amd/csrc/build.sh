@@ -4,5 +4,5 @@ set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../libcadnip_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
-hipcc $FLAGS -shared -o $OUT kernels.hip api.hip driver.hip fused.hip symbolic.cpp "$@"
+hipcc $FLAGS -shared -o $OUT kernels.hip api.hip driver.hip fused.hip fused2.hip symbolic.cpp "$@"
 echo "built $(realpath $OUT)"

@@ -99,34 +99,34 @@ __device__ inline double source_value(const DevCtx& d, double dc, double scale) 
 // ------------------------------------------------------------------------------------------
 // linear devices
 // ------------------------------------------------------------------------------------------
-__device__ inline void conductance4(const SlotOut& s, int k0, double g) { s.G(k0, g); s.G(k0 + 1, -g); s.G(k0 + 2, -g); s.G(k0 + 3, g); }
-__device__ inline void capacitance4(const SlotOut& s, int k0, double c) { s.C(k0, c); s.C(k0 + 1, -c); s.C(k0 + 2, -c); s.C(k0 + 3, c); }
-__device__ inline void branch4(const SlotOut& s) { s.G(0, 1.0); s.G(1, -1.0); s.G(2, 1.0); s.G(3, -1.0); }
+template <class Out> __device__ inline void conductance4(const Out& s, int k0, double g) { s.G(k0, g); s.G(k0 + 1, -g); s.G(k0 + 2, -g); s.G(k0 + 3, g); }
+template <class Out> __device__ inline void capacitance4(const Out& s, int k0, double c) { s.C(k0, c); s.C(k0 + 1, -c); s.C(k0 + 2, -c); s.C(k0 + 3, c); }
+template <class Out> __device__ inline void branch4(const Out& s) { s.G(0, 1.0); s.G(1, -1.0); s.G(2, 1.0); s.G(3, -1.0); }
 
-__device__ inline void stamp_resistor(const DevCtx& d, const double*, const SlotOut& s, double*) { conductance4(s, 0, par_of(d, 0)); }
-__device__ inline void stamp_capacitor(const DevCtx& d, const double*, const SlotOut& s, double*) { capacitance4(s, 0, par_of(d, 0)); }
-__device__ inline void stamp_inductor(const DevCtx& d, const double*, const SlotOut& s, double*) { branch4(s); s.C(0, -par_of(d, 0)); }
-__device__ inline void stamp_vsource(const DevCtx& d, const double*, const SlotOut& s, double*) {
+template <class Out> __device__ inline void stamp_resistor(const DevCtx& d, const double*, const Out& s, double*) { conductance4(s, 0, par_of(d, 0)); }
+template <class Out> __device__ inline void stamp_capacitor(const DevCtx& d, const double*, const Out& s, double*) { capacitance4(s, 0, par_of(d, 0)); }
+template <class Out> __device__ inline void stamp_inductor(const DevCtx& d, const double*, const Out& s, double*) { branch4(s); s.C(0, -par_of(d, 0)); }
+template <class Out> __device__ inline void stamp_vsource(const DevCtx& d, const double*, const Out& s, double*) {
   branch4(s);
   s.B(0, source_value(d, par_of(d, 0), par_of(d, 1)));
 }
-__device__ inline void stamp_isource(const DevCtx& d, const double*, const SlotOut& s, double*) {
+template <class Out> __device__ inline void stamp_isource(const DevCtx& d, const double*, const Out& s, double*) {
   double i = source_value(d, par_of(d, 0), par_of(d, 1));
   s.B(0, i); s.B(1, -i);
 }
-__device__ inline void stamp_vcvs(const DevCtx& d, const double*, const SlotOut& s, double*) {
+template <class Out> __device__ inline void stamp_vcvs(const DevCtx& d, const double*, const Out& s, double*) {
   double a = par_of(d, 0);
   s.G(0, 1.0); s.G(1, -1.0); s.G(2, 1.0); s.G(3, -1.0); s.G(4, -a); s.G(5, a);
 }
-__device__ inline void stamp_vccs(const DevCtx& d, const double*, const SlotOut& s, double*) {
+template <class Out> __device__ inline void stamp_vccs(const DevCtx& d, const double*, const Out& s, double*) {
   double gm = par_of(d, 0);
   s.G(0, -gm); s.G(1, gm); s.G(2, gm); s.G(3, -gm);
 }
-__device__ inline void stamp_ccvs(const DevCtx& d, const double*, const SlotOut& s, double*) {
+template <class Out> __device__ inline void stamp_ccvs(const DevCtx& d, const double*, const Out& s, double*) {
   s.G(0, 1.0); s.G(1, -1.0); s.G(2, 1.0); s.G(3, -1.0);
   s.G(4, 1.0); s.G(5, -1.0); s.G(6, 1.0); s.G(7, -1.0); s.G(8, -par_of(d, 0));
 }
-__device__ inline void stamp_cccs(const DevCtx& d, const double*, const SlotOut& s, double*) {
+template <class Out> __device__ inline void stamp_cccs(const DevCtx& d, const double*, const Out& s, double*) {
   double a = par_of(d, 0);
   s.G(0, 1.0); s.G(1, -1.0); s.G(2, 1.0); s.G(3, -1.0); s.G(4, -a); s.G(5, a);
 }
@@ -149,7 +149,7 @@ __device__ inline double pnjlim(double vnew, double vold, double vt, double vcri
   return vnew;
 }
 
-__device__ inline void stamp_diode(const DevCtx& d, const double* u, const SlotOut& s, double* limit_w_base) {
+template <class Out> __device__ inline void stamp_diode(const DevCtx& d, const double* u, const Out& s, double* limit_w_base) {
   int p = node_of(d, 0), n = node_of(d, 1), l = node_of(d, 2);
   double Is = par_of(d, 0), nVt = par_of(d, 1), vcrit = par_of(d, 2);
   double V0 = volt(u, p) - volt(u, n);
@@ -173,7 +173,7 @@ __device__ inline void stamp_diode(const DevCtx& d, const double* u, const SlotO
   s.B(0, -Ieq); s.B(1, Ieq);
 }
 
-__device__ inline void stamp_diodecap(const DevCtx& d, const double* u, const SlotOut& s, double*) {
+template <class Out> __device__ inline void stamp_diodecap(const DevCtx& d, const double* u, const Out& s, double*) {
   int p = node_of(d, 0), n = node_of(d, 1);
   double Is = par_of(d, 0), nVt = par_of(d, 1), Cj0 = par_of(d, 2), Vj = par_of(d, 3), m = par_of(d, 4);
   double V0 = volt(u, p) - volt(u, n);
@@ -188,7 +188,7 @@ __device__ inline void stamp_diodecap(const DevCtx& d, const double* u, const Sl
 }
 
 // SimpleMOSFET (devices.jl:1667-1749)
-__device__ inline void stamp_simplemos(const DevCtx& d, const double* u, const SlotOut& s, double*) {
+template <class Out> __device__ inline void stamp_simplemos(const DevCtx& d, const double* u, const Out& s, double*) {
   double Vd = volt(u, node_of(d, 0)), Vg = volt(u, node_of(d, 1)), Vs = volt(u, node_of(d, 2));
   double Vth = par_of(d, 0), K = par_of(d, 1), lam = par_of(d, 2), Cgd = par_of(d, 3), Cgs = par_of(d, 4);
   double Vgs = Vg - Vs, Vds = Vd - Vs, Ids, gm, gds;
@@ -392,7 +392,7 @@ __device__ inline D3 m1_qdep(const D3& v, double Cb, double Cbsw, double tBulkPo
   return D3(0.0);
 }
 
-__device__ inline void stamp_mos1(const DevCtx& d, const double* u, const SlotOut& s, double* limit_w_base) {
+template <class Out> __device__ inline void stamp_mos1(const DevCtx& d, const double* u, const Out& s, double* limit_w_base) {
   const double CS = CADNIP_CHARGE_SCALE;
   int nd = node_of(d, 0), ng = node_of(d, 1), ns = node_of(d, 2), nb = node_of(d, 3), ndi = node_of(d, 4), nsi = node_of(d, 5);
   int l0 = node_of(d, 6), l1 = node_of(d, 7), l2 = node_of(d, 8), l3 = node_of(d, 9);
@@ -456,11 +456,16 @@ __device__ inline void stamp_mos1(const DevCtx& d, const double* u, const SlotOu
                    par_of(d, M1_MJSW), par_of(d, M1_F2S), par_of(d, M1_F3S), par_of(d, M1_F4S));
   D3 qbd = m1_qdep(dvbd, par_of(d, M1_CBD), par_of(d, M1_CBDSW), par_of(d, M1_TBULKPOT), par_of(d, M1_TDEPCAP), par_of(d, M1_MJ),
                    par_of(d, M1_MJSW), par_of(d, M1_F2D), par_of(d, M1_F3D), par_of(d, M1_F4D));
-  D3 mcgs, mcgd, mcgb;
-  if (mode > 0) m1_qmeyer(a, dvgd, dvon, vdsat, tPhi, OxideCap, mcgs, mcgd, mcgb);
-  else m1_qmeyer(dvgd, a, dvon, vdsat, tPhi, OxideCap, mcgd, mcgs, mcgb);
-  D3 capgs = mcgs + mcgs + par_of(d, M1_CGSOV), capgd = mcgd + mcgd + par_of(d, M1_CGDOV), capgb = mcgb + mcgb + par_of(d, M1_CGBOV);
-  D3 qgs = capgs * ((ms * a) / mu), qgd = capgd * ((ms * dvgd) / mu), qgb = capgb * ((ms * dvgb) / mu);   // reactive part of ceqg* mos1.va:1140-1147
+  // Meyer gate charges.  With OxideCap == 0 (no tox) meyer_scale is 0 (mos1.va:1042-1048): every gate-charge
+  // term is exactly zero (value and partials), so the whole block is skipped -- same numbers, no work.
+  D3 qgs(0.0), qgd(0.0), qgb(0.0);
+  if (OxideCap != 0.0) {
+    D3 mcgs, mcgd, mcgb;
+    if (mode > 0) m1_qmeyer(a, dvgd, dvon, vdsat, tPhi, OxideCap, mcgs, mcgd, mcgb);
+    else m1_qmeyer(dvgd, a, dvon, vdsat, tPhi, OxideCap, mcgd, mcgs, mcgb);
+    D3 capgs = mcgs + mcgs + par_of(d, M1_CGSOV), capgd = mcgd + mcgd + par_of(d, M1_CGDOV), capgb = mcgb + mcgb + par_of(d, M1_CGBOV);
+    qgs = capgs * ((ms * a) / mu); qgd = capgd * ((ms * dvgd) / mu); qgb = capgb * ((ms * dvgb) / mu);   // reactive part of ceqg* mos1.va:1140-1147
+  }
   D3 cdreq = (mode >= 0 ? type : -type) * cdrain;
   // branch contributions (mos1.va:1164-1169), split into resistive (Ir) and reactive (q) parts; I(d), I(s) are linear
   double gd = par_of(d, M1_GD), gs = par_of(d, M1_GS);

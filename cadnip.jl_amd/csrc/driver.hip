@@ -22,6 +22,7 @@
 #include <chrono>
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <vector>
 #include "internal.hpp"
@@ -374,6 +375,10 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
              h->B, h->n, h->n_limits, o->n_break, o->n_save, n_obs, n_err,
              o->t0, o->t1, o->reltol, h0, hmin, hmax, o->newton_tol > 0 ? o->newton_tol : 1e-3,
              o->max_newton > 0 ? o->max_newton : 10, o->max_order > 0 ? o->max_order : 2, o->use_pcnr};
+  if (o->fused == 2 && getenv("CADNIP_F2_PROF") && !h->d_f2prof) {
+    HIP_TRY(hipMalloc((void**)&h->d_f2prof, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(h->d_f2prof, 0, 8 * sizeof(unsigned long long)));
+  }
   int saved_mode = h->spec.mode;
   h->spec.mode = 1;   // :tran
   hipLaunchKernelGGL(k_tran_init, dim3(h->B), dim3(64), 0, h->stream, a);
@@ -385,7 +390,7 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
   const int check_every = 8;
   while (running > 0 && launches < max_it) {
     if (o->fused) {
-      rc = launch_fused_rounds(h, a, check_every); if (rc) break;
+      rc = (o->fused == 2) ? launch_fused2_rounds(h, a, check_every) : launch_fused_rounds(h, a, check_every); if (rc) break;
       launches += check_every;
       rc = count_running(h, &running); if (rc) break;
       continue;
@@ -402,6 +407,16 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
   }
   HIP_TRY(hipStreamSynchronize(h->stream));
   double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+  if (h->d_f2prof) {
+    unsigned long long pc[8];
+    HIP_TRY(hipMemcpy(pc, h->d_f2prof, sizeof(pc), hipMemcpyDeviceToHost));
+    const char* nm[6] = {"load+zero", "stamp", "J*u", "factor", "solve", "update"};
+    double tot = 0; for (int i = 0; i < 6; ++i) tot += (double)pc[i];
+    fprintf(stderr, "[cadnip f2 prof] wave-rounds %llu; cycles per wave-round:", pc[7]);
+    for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %.0f (%.0f%%)", nm[i], (double)pc[i] / (double)(pc[7] ? pc[7] : 1), 100.0 * pc[i] / tot);
+    fprintf(stderr, "\n");
+    HIP_TRY(hipMemset(h->d_f2prof, 0, sizeof(pc)));
+  }
   h->spec.mode = saved_mode;
   if (rc) return rc;
   std::vector<long long> cnt(B * 4);

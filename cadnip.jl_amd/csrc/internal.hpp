@@ -78,6 +78,12 @@ struct CadnipHandle {
   int *d_term_a = nullptr, *d_term_b = nullptr, *d_lev_ptr = nullptr;
   int *d_lu_rowptr = nullptr, *d_lu_col = nullptr, *d_lu_diag = nullptr, *d_rperm = nullptr, *d_cperm = nullptr;
   int *d_fwd_rows = nullptr, *d_fwd_lev_ptr = nullptr, *d_bwd_rows = nullptr, *d_bwd_lev_ptr = nullptr;
+  // fused v2: packed uint16 structure tables (fused2.hip), rebuilt when the LU program changes
+  unsigned short* d_f2tab = nullptr;
+  int f2off[32] = {0};
+  int f2len = 0;
+  bool fused2_dirty = true;
+  unsigned long long* d_f2prof = nullptr;   // diagnostic phase-cycle counters, allocated by CADNIP_F2_PROF=1
   // driver state (allocated lazily)
   struct Driver* drv = nullptr;
   // profiling
@@ -102,6 +108,7 @@ int launch_factor_solve(CadnipHandle* h, bool fuse_jacobian, const double* d_rhs
 int upload_lu(CadnipHandle* h);
 struct TranArgs;                                                          // tran_ctrl.hpp
 int launch_fused_rounds(CadnipHandle* h, const TranArgs& t, int rounds);  // fused.hip
+int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds); // fused2.hip
 struct ProfScope {
   CadnipHandle* h; int idx;
   ProfScope(CadnipHandle* h, const char* name);

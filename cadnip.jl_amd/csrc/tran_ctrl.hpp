@@ -6,6 +6,13 @@
 
 namespace cadnip {
 
+// Wave-level synchronisation: every controller function is executed by ONE 64-lane wave per sweep
+// instance (several instances may share a workgroup in the fused kernel, each taking its own control
+// path), so ordering is needed only among the lanes of the calling wave: a workgroup-scope fence
+// (waits for the wave's outstanding LDS / global traffic; a workgroup's waves share one L1) plus a
+// compiler-level wave barrier.  Never s_barrier here.
+#define CADNIP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -150,7 +157,7 @@ __device__ inline void tran_update_body(const TranArgs& a, int inst, int tid) {
         hnext = h * fac;
       } else hnext = 2.0 * h;
       double new_hprev = h, new_hpp = hprev;
-      __syncthreads();
+      CADNIP_WAVE_SYNC();
       if (landed) {
         ++bp;
         nh_new = 1;
@@ -168,7 +175,7 @@ __device__ inline void tran_update_body(const TranArgs& a, int inst, int tid) {
         return;
       }
       if (hnext < a.hmin) hnext = a.hmin;
-      __syncthreads();
+      CADNIP_WAVE_SYNC();
       prepare_step(a, inst, tid, tn, hnext, nh_new, new_hprev, new_hpp);
     } else {
       double fac = 0.9 * pow(errn, -1.0 / (ord + 1));
@@ -176,7 +183,7 @@ __device__ inline void tran_update_body(const TranArgs& a, int inst, int tid) {
       double hn = h * fac;
       if (tid == 0) a.cnt[(size_t)inst * 4 + 2] += 1;
       if (hn < a.hmin) { if (tid == 0) { a.status[inst] = -1; a.active[inst] = 0; } return; }
-      __syncthreads();
+      CADNIP_WAVE_SYNC();
       prepare_step(a, inst, tid, t, hn, nhist, hprev, hpp);
     }
   } else {
@@ -184,14 +191,14 @@ __device__ inline void tran_update_body(const TranArgs& a, int inst, int tid) {
       double hn = 0.25 * h;
       if (tid == 0) a.cnt[(size_t)inst * 4 + 3] += 1;
       if (hn < a.hmin) { if (tid == 0) { a.status[inst] = -2; a.active[inst] = 0; } return; }
-      __syncthreads();
+      CADNIP_WAVE_SYNC();
       prepare_step(a, inst, tid, t, hn, nhist, hprev, hpp);
     } else {
       if (a.use_pcnr && a.n_limits > 0) {
         const double* lw = a.limit_w + (size_t)inst * n;
         for (int i = n - a.n_limits + tid; i < n; i += 64) u[i] = lw[i];
       }
-      __syncthreads();
+      CADNIP_WAVE_SYNC();
       for (int i = tid; i < n; i += 64) du[i] = a0 * u[i] + beta[i];
       if (tid == 0) a.k[inst] = k + 1;
     }

@@ -5,7 +5,8 @@ from cadnip_jl_amd import api, benchmarks as bm
 from cadnip_jl_amd.structure import expand_breakpoints
 mc = api.MNACircuit(bm.dff_circuit(), {"vdd": 5.0})
 nv = int(sys.argv[1]) if len(sys.argv)>1 else 4
-pts = list(api.ProductSweep(vdd=np.linspace(4.5,5.5,nv), temp=np.linspace(-40,125,nv)))
+nt = int(sys.argv[3]) if len(sys.argv)>3 else nv
+pts = list(api.ProductSweep(vdd=np.linspace(4.5,5.5,nv), temp=np.linspace(-40,125,nt)))
 sim = api.BatchSimulator(mc, pts)
 st=sim.st
 sim.analyze()
@@ -18,7 +19,7 @@ sim.h.set_spec(mode="tran")
 atol = st.state_abstol(vntol=1e-6, iabstol=1e-9, chgtol=1e-6)
 ts=np.array([150e-9,250e-9,450e-9,550e-9,700e-9])
 t0=time.time()
-out, per, stats = sim.h.tran_run(0.0, 7e-7, atol, 1e-4, breaks=breaks, save_t=ts, obs=[qi], fused=bool(int(sys.argv[2])) if len(sys.argv)>2 else False)
+out, per, stats = sim.h.tran_run(0.0, 7e-7, atol, 1e-4, breaks=breaks, save_t=ts, obs=[qi], fused=int(sys.argv[2]) if len(sys.argv)>2 else 0)
 print("wall", time.time()-t0, stats)
 t,hh,o = sim.h.tran_state()
 bad = np.where(per[:,3]!=1)[0]
