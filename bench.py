@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--fused", type=int, default=int(os.environ.get("CADNIP_FUSED", "2")),
                     help="0 = one kernel per op (the drop-in ABI path), 1 = fused v1, 2 = fused v2 (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--calib-copy", type=int, default=0,
+                    help="also run the 8 B/lane fp64 calibration copy of this many MiB (for rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE runs)")
     args = ap.parse_args()
 
     import torch
@@ -111,6 +113,8 @@ def main():
             sweep_shard.gather_blocks(out, world, dev)
         return stats["newton_iters"] + dcs["newton_iters"], out, stats
 
+    if args.calib_copy:
+        sim.h.debug_copy(args.calib_copy * (1 << 20) // 8, 4)
     for _ in range(args.warmup):
         one_step()
     if world > 1:
@@ -153,6 +157,15 @@ def main():
             roof["algorithmic_bytes_per_launch"] = int(ab[name])
             roof["achieved"] = round(ab[name] / avg_s / 1e9, 3)
             roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 5)
+        # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950
+        # correction calibrated with k_calib_copy_f64; profiles/*_pmc_summary.json) -- only when it is the same kernel / batch
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_fused2_B2048_pmc_summary.json")))
+            if name in pmc and pmc[name]["instances"] == B:
+                roof["traffic"] = pmc[name]["hbm_bytes_per_launch"]
+                roof["traffic_source"] = "profiles/r01_fused2_B2048_pmc_summary.json"
+        except (OSError, ValueError, KeyError):
+            pass
         if "stamp_mos1" in prof and name != "stamp_mos1":
             s_avg = prof["stamp_mos1"][0] / max(prof["stamp_mos1"][1], 1) * 1e-3
             roof["stamp_mos1_GBps"] = round(ab["stamp_mos1"] / s_avg / 1e9, 3)

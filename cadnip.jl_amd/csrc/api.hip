@@ -320,6 +320,10 @@ int cadnip_get_flags(CadnipHandle* h, int32_t* flags_host) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   return CADNIP_OK;
 }
+int cadnip_debug_copy(CadnipHandle* h, int64_t n_doubles, int32_t reps) {
+  if (!h || n_doubles <= 0 || reps <= 0) return CADNIP_BADARG;
+  return launch_calib_copy(h, (long)n_doubles, reps);
+}
 int cadnip_sync(CadnipHandle* h) { if (!h) return CADNIP_BADARG; HIP_TRY(hipStreamSynchronize(h->stream)); return CADNIP_OK; }
 
 int cadnip_profile_enable(CadnipHandle* h, int32_t on) {

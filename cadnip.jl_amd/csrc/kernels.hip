@@ -232,6 +232,21 @@ __global__ void k_lu(LUArgs a) {
   }
 }
 
+__global__ void __launch_bounds__(256) k_calib_copy_f64(const double* __restrict__ a, double* __restrict__ b, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) b[i] = a[i];
+}
+
+int launch_calib_copy(CadnipHandle* h, long n, int reps) {
+  double *a = nullptr, *b = nullptr;
+  HIP_TRY(hipMalloc((void**)&a, n * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&b, n * sizeof(double)));
+  HIP_TRY(hipMemsetAsync(a, 0, n * sizeof(double), h->stream));
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_calib_copy_f64, dim3(2048), dim3(256), 0, h->stream, a, b, n);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  (void)hipFree(a); (void)hipFree(b);
+  return CADNIP_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------

@@ -23,7 +23,7 @@ EXPORTS = [
     "cadnip_rebuild", "cadnip_residual", "cadnip_jacobian", "cadnip_get_GCb", "cadnip_analyze",
     "cadnip_analyze_values", "cadnip_factor", "cadnip_solve", "cadnip_lu_stats", "cadnip_dc_run",
     "cadnip_tran_run", "cadnip_tran_state", "cadnip_dev_ptr", "cadnip_stream", "cadnip_set_u", "cadnip_get_u", "cadnip_get_flags",
-    "cadnip_sync", "cadnip_profile_enable", "cadnip_profile_read", "cadnip_version",
+    "cadnip_sync", "cadnip_debug_copy", "cadnip_profile_enable", "cadnip_profile_read", "cadnip_version",
     "cadnip_host_lu_analyze", "cadnip_host_lu_size", "cadnip_host_lu_get", "cadnip_host_lu_free",
 ]
 
@@ -305,6 +305,9 @@ class Handle:
         u = np.empty((self.B, self.st.n))
         _check(self.lib.cadnip_get_u(self.h, _dp(u)), "cadnip_get_u")
         return u
+
+    def debug_copy(self, n_doubles, reps=1):
+        _check(self.lib.cadnip_debug_copy(self.h, C.c_int64(n_doubles), C.c_int32(reps)), "cadnip_debug_copy")
 
     def profile(self, on=True):
         _check(self.lib.cadnip_profile_enable(self.h, C.c_int32(1 if on else 0)), "cadnip_profile_enable")

@@ -217,6 +217,10 @@ int cadnip_sync(CadnipHandle* h);
 int cadnip_profile_enable(CadnipHandle* h, int32_t on);
 int cadnip_profile_read(CadnipHandle* h, int32_t max_entries, const char** names, double* ms, int64_t* calls);
 const char* cadnip_version(void);
+/* PMC calibration aid (MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE must be calibrated on a known
+ * byte count in the kernel's own access width): streams n_doubles fp64 values src -> dst with 8 B per lane,
+ * `reps` times, through a kernel named k_calib_copy_f64.  Known traffic: 8*n_doubles read + 8*n_doubles written per rep. */
+int cadnip_debug_copy(CadnipHandle* h, int64_t n_doubles, int32_t reps);
 
 /* ---- host-only helpers (no GPU needed): run the symbolic phase on any CSR matrix and read the
  * resulting program back; used by the CPU test-suite to validate the LU program --------------- */
