@@ -87,6 +87,7 @@ int cadnip_create(const CadnipStructure* s, int32_t n_instances, int32_t device,
       }
     }
     if (b.type == CADNIP_DEV_MOS1 && (b.n_par != CADNIP_MOS1_NPAR || b.n_nodes != 14)) { cadnip_destroy(h); return CADNIP_BADARG; }
+    b.h_nodes.assign(sb.nodes, sb.nodes + (size_t)b.n_nodes * b.count);
     TRY(dev_upload(&b.d_nodes, sb.nodes, (size_t)b.n_nodes * b.count));
     TRY(dev_upload(&b.d_ipar, sb.ipar, (size_t)(b.n_ipar > 0 ? b.n_ipar : 1) * b.count));
     TRY(dev_alloc(&b.d_par, (size_t)h->B * b.n_par * b.count));

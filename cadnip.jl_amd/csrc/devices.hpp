@@ -16,8 +16,27 @@ namespace cadnip {
 
 #define CADNIP_CHARGE_SCALE 1e12   // /root/reference/src/mna/contrib.jl:39
 
-struct DevCtx {
-  const int* __restrict__ nodes;   // [n_nodes][count]
+// Diagnostic build only (build.sh --trace -> libcadnip_hip_trace.so): cycle timeline of wave 0 of workgroup 0.
+// Each point adds the cycles since the previous point to its own bucket; read back with cadnip_debug_trace.
+#ifdef CADNIP_TRACE
+static __device__ unsigned long long g_trace_sum[64], g_trace_cnt[64];
+__shared__ unsigned long long g_trace_last;
+#define CADNIP_TRACE_POINT(id)                                                                          \
+  do {                                                                                                  \
+    if (blockIdx.x == 0 && threadIdx.x < 64) {                                                          \
+      unsigned long long _t = clock64();                                                                \
+      if (threadIdx.x == 0) {                                                                           \
+        atomicAdd(&g_trace_sum[id], _t - g_trace_last); atomicAdd(&g_trace_cnt[id], 1ull); g_trace_last = _t; \
+      }                                                                                                 \
+    }                                                                                                   \
+  } while (0)
+#else
+#define CADNIP_TRACE_POINT(id) do {} while (0)
+#endif
+
+// NodeT: int in HBM (per-op kernels) or int16 in LDS (fused kernel); -1 = ground either way
+template <class NodeT> struct DevCtxT {
+  const NodeT* __restrict__ nodes; // [n_nodes][count]
   const int* __restrict__ ipar;    // [n_ipar][count]
   const double* __restrict__ par;  // this instance: [n_par][count]
   const double* __restrict__ wave; // shared wave tables
@@ -27,6 +46,7 @@ struct DevCtx {
   int mode;                        // 0 dcop, 1 tran, 2 tranop
   int initjct;
 };
+typedef DevCtxT<int> DevCtx;
 
 // slot writers: S points at this instance's slot buffer; bases are per block
 struct SlotOut {
@@ -37,10 +57,23 @@ struct SlotOut {
   __device__ __forceinline__ void G(int k, double v) const { g[k * count + dev] = v; }
   __device__ __forceinline__ void C(int k, double v) const { c[k * count + dev] = v; }
   __device__ __forceinline__ void B(int k, double v) const { b[k * count + dev] = v; }
+  // batch forms: slots k0 .. k0+N-1 (the fused kernel's writer pipelines its table reads over a batch)
+  template <int N> __device__ __forceinline__ void Gv(int k0, const double (&v)[N]) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) G(k0 + i, v[i]);
+  }
+  template <int N> __device__ __forceinline__ void Cv(int k0, const double (&v)[N]) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) C(k0 + i, v[i]);
+  }
+  template <int N> __device__ __forceinline__ void Bv(int k0, const double (&v)[N]) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) B(k0 + i, v[i]);
+  }
 };
 
-__device__ __forceinline__ int node_of(const DevCtx& d, int k) { return d.nodes[k * d.count + d.dev]; }
-__device__ __forceinline__ double par_of(const DevCtx& d, int k) { return d.par[k * d.count + d.dev]; }
+template <class Ctx> __device__ __forceinline__ int node_of(const Ctx& d, int k) { return d.nodes[k * d.count + d.dev]; }
+template <class Ctx> __device__ __forceinline__ double par_of(const Ctx& d, int k) { return d.par[k * d.count + d.dev]; }
 __device__ __forceinline__ double volt(const double* u, int node) { return node < 0 ? 0.0 : u[node]; }
 
 // ------------------------------------------------------------------------------------------
@@ -79,7 +112,7 @@ __device__ inline double sind_deg(double deg) {
 }
 
 // get_source_value (devices.jl:352-360): :dcop -> dc, otherwise tran(t)
-__device__ inline double source_value(const DevCtx& d, double dc, double scale) {
+template <class Ctx> __device__ inline double source_value(const Ctx& d, double dc, double scale) {
   int kind = d.ipar[0 * d.count + d.dev];
   if (kind == 0 || d.mode == 0) return dc;
   int off = d.ipar[1 * d.count + d.dev];
@@ -99,34 +132,34 @@ __device__ inline double source_value(const DevCtx& d, double dc, double scale) 
 // ------------------------------------------------------------------------------------------
 // linear devices
 // ------------------------------------------------------------------------------------------
-template <class Out> __device__ inline void conductance4(const Out& s, int k0, double g) { s.G(k0, g); s.G(k0 + 1, -g); s.G(k0 + 2, -g); s.G(k0 + 3, g); }
-template <class Out> __device__ inline void capacitance4(const Out& s, int k0, double c) { s.C(k0, c); s.C(k0 + 1, -c); s.C(k0 + 2, -c); s.C(k0 + 3, c); }
-template <class Out> __device__ inline void branch4(const Out& s) { s.G(0, 1.0); s.G(1, -1.0); s.G(2, 1.0); s.G(3, -1.0); }
+template <class Out> __device__ inline void conductance4(const Out& s, int k0, double g) { const double v[4] = {g, -g, -g, g}; s.Gv(k0, v); }
+template <class Out> __device__ inline void capacitance4(const Out& s, int k0, double c) { const double v[4] = {c, -c, -c, c}; s.Cv(k0, v); }
+template <class Out> __device__ inline void branch4(const Out& s) { const double v[4] = {1.0, -1.0, 1.0, -1.0}; s.Gv(0, v); }
 
-template <class Out> __device__ inline void stamp_resistor(const DevCtx& d, const double*, const Out& s, double*) { conductance4(s, 0, par_of(d, 0)); }
-template <class Out> __device__ inline void stamp_capacitor(const DevCtx& d, const double*, const Out& s, double*) { capacitance4(s, 0, par_of(d, 0)); }
-template <class Out> __device__ inline void stamp_inductor(const DevCtx& d, const double*, const Out& s, double*) { branch4(s); s.C(0, -par_of(d, 0)); }
-template <class Out> __device__ inline void stamp_vsource(const DevCtx& d, const double*, const Out& s, double*) {
+template <class Ctx, class Out> __device__ inline void stamp_resistor(const Ctx& d, const double*, const Out& s, double*) { conductance4(s, 0, par_of(d, 0)); }
+template <class Ctx, class Out> __device__ inline void stamp_capacitor(const Ctx& d, const double*, const Out& s, double*) { capacitance4(s, 0, par_of(d, 0)); }
+template <class Ctx, class Out> __device__ inline void stamp_inductor(const Ctx& d, const double*, const Out& s, double*) { branch4(s); s.C(0, -par_of(d, 0)); }
+template <class Ctx, class Out> __device__ inline void stamp_vsource(const Ctx& d, const double*, const Out& s, double*) {
   branch4(s);
   s.B(0, source_value(d, par_of(d, 0), par_of(d, 1)));
 }
-template <class Out> __device__ inline void stamp_isource(const DevCtx& d, const double*, const Out& s, double*) {
+template <class Ctx, class Out> __device__ inline void stamp_isource(const Ctx& d, const double*, const Out& s, double*) {
   double i = source_value(d, par_of(d, 0), par_of(d, 1));
   s.B(0, i); s.B(1, -i);
 }
-template <class Out> __device__ inline void stamp_vcvs(const DevCtx& d, const double*, const Out& s, double*) {
+template <class Ctx, class Out> __device__ inline void stamp_vcvs(const Ctx& d, const double*, const Out& s, double*) {
   double a = par_of(d, 0);
   s.G(0, 1.0); s.G(1, -1.0); s.G(2, 1.0); s.G(3, -1.0); s.G(4, -a); s.G(5, a);
 }
-template <class Out> __device__ inline void stamp_vccs(const DevCtx& d, const double*, const Out& s, double*) {
+template <class Ctx, class Out> __device__ inline void stamp_vccs(const Ctx& d, const double*, const Out& s, double*) {
   double gm = par_of(d, 0);
   s.G(0, -gm); s.G(1, gm); s.G(2, gm); s.G(3, -gm);
 }
-template <class Out> __device__ inline void stamp_ccvs(const DevCtx& d, const double*, const Out& s, double*) {
+template <class Ctx, class Out> __device__ inline void stamp_ccvs(const Ctx& d, const double*, const Out& s, double*) {
   s.G(0, 1.0); s.G(1, -1.0); s.G(2, 1.0); s.G(3, -1.0);
   s.G(4, 1.0); s.G(5, -1.0); s.G(6, 1.0); s.G(7, -1.0); s.G(8, -par_of(d, 0));
 }
-template <class Out> __device__ inline void stamp_cccs(const DevCtx& d, const double*, const Out& s, double*) {
+template <class Ctx, class Out> __device__ inline void stamp_cccs(const Ctx& d, const double*, const Out& s, double*) {
   double a = par_of(d, 0);
   s.G(0, 1.0); s.G(1, -1.0); s.G(2, 1.0); s.G(3, -1.0); s.G(4, -a); s.G(5, a);
 }
@@ -149,7 +182,7 @@ __device__ inline double pnjlim(double vnew, double vold, double vt, double vcri
   return vnew;
 }
 
-template <class Out> __device__ inline void stamp_diode(const DevCtx& d, const double* u, const Out& s, double* limit_w_base) {
+template <class Ctx, class Out> __device__ inline void stamp_diode(const Ctx& d, const double* u, const Out& s, double* limit_w_base) {
   int p = node_of(d, 0), n = node_of(d, 1), l = node_of(d, 2);
   double Is = par_of(d, 0), nVt = par_of(d, 1), vcrit = par_of(d, 2);
   double V0 = volt(u, p) - volt(u, n);
@@ -173,7 +206,7 @@ template <class Out> __device__ inline void stamp_diode(const DevCtx& d, const d
   s.B(0, -Ieq); s.B(1, Ieq);
 }
 
-template <class Out> __device__ inline void stamp_diodecap(const DevCtx& d, const double* u, const Out& s, double*) {
+template <class Ctx, class Out> __device__ inline void stamp_diodecap(const Ctx& d, const double* u, const Out& s, double*) {
   int p = node_of(d, 0), n = node_of(d, 1);
   double Is = par_of(d, 0), nVt = par_of(d, 1), Cj0 = par_of(d, 2), Vj = par_of(d, 3), m = par_of(d, 4);
   double V0 = volt(u, p) - volt(u, n);
@@ -188,7 +221,7 @@ template <class Out> __device__ inline void stamp_diodecap(const DevCtx& d, cons
 }
 
 // SimpleMOSFET (devices.jl:1667-1749)
-template <class Out> __device__ inline void stamp_simplemos(const DevCtx& d, const double* u, const Out& s, double*) {
+template <class Ctx, class Out> __device__ inline void stamp_simplemos(const Ctx& d, const double* u, const Out& s, double*) {
   double Vd = volt(u, node_of(d, 0)), Vg = volt(u, node_of(d, 1)), Vs = volt(u, node_of(d, 2));
   double Vth = par_of(d, 0), K = par_of(d, 1), lam = par_of(d, 2), Cgd = par_of(d, 3), Cgs = par_of(d, 4);
   double Vgs = Vg - Vs, Vds = Vd - Vs, Ids, gm, gds;
@@ -392,7 +425,7 @@ __device__ inline D3 m1_qdep(const D3& v, double Cb, double Cbsw, double tBulkPo
   return D3(0.0);
 }
 
-template <class Out> __device__ inline void stamp_mos1(const DevCtx& d, const double* u, const Out& s, double* limit_w_base) {
+template <class Ctx, class Out> __device__ inline void stamp_mos1(const Ctx& d, const double* u, const Out& s, double* limit_w_base) {
   const double CS = CADNIP_CHARGE_SCALE;
   int nd = node_of(d, 0), ng = node_of(d, 1), ns = node_of(d, 2), nb = node_of(d, 3), ndi = node_of(d, 4), nsi = node_of(d, 5);
   int l0 = node_of(d, 6), l1 = node_of(d, 7), l2 = node_of(d, 8), l3 = node_of(d, 9);
@@ -400,6 +433,7 @@ template <class Out> __device__ inline void stamp_mos1(const DevCtx& d, const do
   double type = par_of(d, M1_TYPE), vt = par_of(d, M1_VT), tPhi = par_of(d, M1_TPHI), tVbi = par_of(d, M1_TVBI);
   double gamma = par_of(d, M1_GAMMA), lambda = par_of(d, M1_LAMBDA), Beta = par_of(d, M1_BETA), OxideCap = par_of(d, M1_OXCAP);
   double mf = par_of(d, M1_MFACTOR), gmin_m = par_of(d, M1_GMIN) / mf;
+  CADNIP_TRACE_POINT(20);
   // ---- limiting (mos1.va:919-980), on values
   double o_vgs = type * u[l0], o_vds = type * u[l1], o_vbs = type * u[l2], o_vbd = type * u[l3];
   int omode = o_vds >= 0 ? 1 : -1;
@@ -425,9 +459,13 @@ template <class Out> __device__ inline void stamp_mos1(const DevCtx& d, const do
   if (d.initjct) { vbs = -1; vgs = type * par_of(d, M1_TVTO); vds = 0; vbd = vbs - vds; }   // mos1.va:969-974
   double w_gs = type * vgs, w_ds = type * vds, w_bs = type * vbs, w_bd = type * vbd;
   limit_w_base[l0] = w_gs; limit_w_base[l1] = w_ds; limit_w_base[l2] = w_bs; limit_w_base[l3] = w_bd;
+  CADNIP_TRACE_POINT(21);
   // g_lim rows (vasim.jl:3134-3136)
-#pragma unroll
-  for (int lb = 0; lb < 4; ++lb) { s.G(3 * lb, 1.0); s.G(3 * lb + 1, -1.0); s.G(3 * lb + 2, 1.0); }
+  {
+    const double gl[12] = {1.0, -1.0, 1.0, 1.0, -1.0, 1.0, 1.0, -1.0, 1.0, 1.0, -1.0, 1.0};
+    s.Gv(0, gl);
+  }
+  CADNIP_TRACE_POINT(22);
   // ---- evaluation on pass-through duals anchored at w
   D3 a = D3::seed(type * w_gs, 0), b = D3::seed(type * w_ds, 1), c = D3::seed(type * w_bs, 2);   // load_vgs, load_vds, load_vbs
   D3 dvbd = c - b, dvgd = a - b, dvgb = a - c;
@@ -436,6 +474,7 @@ template <class Out> __device__ inline void stamp_mos1(const DevCtx& d, const do
   else { D3 x = c / vt; D3 e = dexp(709.0 < x.v ? D3(709.0) : x); cbs = par_of(d, M1_SSATCUR) * (e - 1.0) + gmin_m * c; }
   if (dvbd.v <= -3 * vt) cbd = gmin_m * dvbd - par_of(d, M1_DSATCUR);
   else { D3 x = dvbd / vt; D3 e = dexp(709.0 < x.v ? D3(709.0) : x); cbd = par_of(d, M1_DSATCUR) * (e - 1.0) + gmin_m * dvbd; }
+  CADNIP_TRACE_POINT(23);
   int mode = b.v >= 0 ? 1 : -1;
   D3 sel = mode == 1 ? c : dvbd, sarg;
   if (sel.v <= 0) sarg = dsqrt(tPhi - sel);
@@ -451,6 +490,7 @@ template <class Out> __device__ inline void stamp_mos1(const DevCtx& d, const do
     if (vgst.v <= vdsm.v) cdrain = betap * vgst * vgst * 0.5;
     else cdrain = betap * vdsm * (vgst - 0.5 * vdsm);
   }
+  CADNIP_TRACE_POINT(24);
   double ms = OxideCap == 0 ? 0.0 : OxideCap, mu = OxideCap == 0 ? 1.0 : OxideCap;   // meyer_scale / meyer_unscale mos1.va:1042-1048
   D3 qbs = m1_qdep(c, par_of(d, M1_CBS), par_of(d, M1_CBSSW), par_of(d, M1_TBULKPOT), par_of(d, M1_TDEPCAP), par_of(d, M1_MJ),
                    par_of(d, M1_MJSW), par_of(d, M1_F2S), par_of(d, M1_F3S), par_of(d, M1_F4S));
@@ -466,6 +506,7 @@ template <class Out> __device__ inline void stamp_mos1(const DevCtx& d, const do
     D3 capgs = mcgs + mcgs + par_of(d, M1_CGSOV), capgd = mcgd + mcgd + par_of(d, M1_CGDOV), capgb = mcgb + mcgb + par_of(d, M1_CGBOV);
     qgs = capgs * ((ms * a) / mu); qgd = capgd * ((ms * dvgd) / mu); qgb = capgb * ((ms * dvgb) / mu);   // reactive part of ceqg* mos1.va:1140-1147
   }
+  CADNIP_TRACE_POINT(25);
   D3 cdreq = (mode >= 0 ? type : -type) * cdrain;
   // branch contributions (mos1.va:1164-1169), split into resistive (Ir) and reactive (q) parts; I(d), I(s) are linear
   double gd = par_of(d, M1_GD), gs = par_of(d, M1_GS);
@@ -492,34 +533,44 @@ template <class Out> __device__ inline void stamp_mos1(const DevCtx& d, const do
   Iv[2] += gs * (Vs - Vsi); dI[2][2] += gs; dI[2][5] -= gs;
   Iv[4] += gd * (Vdi - Vd); dI[4][4] += gd; dI[4][0] -= gd;
   Iv[5] += gs * (Vsi - Vs); dI[5][5] += gs; dI[5][2] -= gs;
+  double Ib[6];
 #pragma unroll
   for (int br = 0; br < 6; ++br) {
     double Ieq = mf * Iv[br];
+    double g[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { double g = mf * dI[br][k]; s.G(12 + 6 * br + k, g); Ieq = Ieq + (-g * Vk[k]); }
+    for (int k = 0; k < 6; ++k) { g[k] = mf * dI[br][k]; Ieq = Ieq + (-g[k] * Vk[k]); }
+    s.Gv(12 + 6 * br, g);
     Ieq = Ieq + (mf * type * Ir[br].p[0]) * dW_gs;
     Ieq = Ieq + (mf * type * Ir[br].p[1]) * dW_ds;
     Ieq = Ieq + (mf * type * Ir[br].p[2]) * dW_bs;
-    s.B(br, -Ieq);
+    Ib[br] = -Ieq;
   }
+  s.Bv(0, Ib);
+  CADNIP_TRACE_POINT(26);
   int vdep = d.ipar[d.dev];
+  {
+    const double cs4[4] = {1.0 / CS, 1.0 / CS, 1.0 / CS, 1.0 / CS};   // charge-state formulation (vasim.jl:3433-3472)
+    s.Cv(0, cs4);
+  }
+  double qb[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     double fa = mf * type * q[r].p[0], fb = mf * type * q[r].p[1], fc = mf * type * q[r].p[2];
-    double dq[6] = {0.0, fa, 0.0, fc, fb, -(fa + fb + fc)};
-    // charge-state formulation (vasim.jl:3433-3472)
-    s.C(r, 1.0 / CS);
-    s.G(48 + 7 * r, 1.0);
+    const double dq[6] = {0.0, fa, 0.0, fc, fb, -(fa + fb + fc)};
+    const double gq[7] = {1.0, -CS * dq[0], -CS * dq[1], -CS * dq[2], -CS * dq[3], -CS * dq[4], -CS * dq[5]};
+    s.Gv(48 + 7 * r, gq);
     double bc = mf * q[r].v;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { s.G(48 + 7 * r + 1 + k, -CS * dq[k]); bc -= dq[k] * Vk[k]; }
+    for (int k = 0; k < 6; ++k) bc -= dq[k] * Vk[k];
     bc += fa * dW_gs; bc += fb * dW_ds; bc += fc * dW_bs;
-    s.B(6 + r, CS * bc);
+    qb[r] = CS * bc;
     // linear form (vasim.jl:3474-3482), used when the branch was not flagged voltage dependent
-#pragma unroll
-    for (int k = 0; k < 6; ++k) s.C(4 + 6 * r + k, dq[k]);
+    s.Cv(4 + 6 * r, dq);
   }
+  s.Bv(6, qb);
   (void)vdep;
+  CADNIP_TRACE_POINT(27);
 }
 
 }  // namespace cadnip

@@ -77,15 +77,30 @@ __global__ void __launch_bounds__(64) k_tran_init(TranArgs a) {
   }
   __syncthreads();
   if (tid == 0) {
-    a.t[inst] = a.t0; a.hprev[inst] = a.h0; a.hpp[inst] = a.h0; a.nhist[inst] = 1; a.status[inst] = 0; a.bp_idx[inst] = bp; a.save_idx[inst] = si;
-    a.active[inst] = 1; a.flags[inst] = 0;
+    a.flags[inst] = 0;
     for (int c = 0; c < 4; ++c) a.cnt[(size_t)inst * 4 + c] = 0;
   }
   __syncthreads();
-  prepare_step(a, inst, tid, a.t0, a.h0, 1, a.h0, a.h0);
+  StepState s;
+  s.t = a.t0; s.h = a.h0; s.hprev = a.h0; s.hpp = a.h0; s.tn = a.t0; s.a0 = 0.0;
+  s.nhist = 1; s.ord = 1; s.k = 0; s.status = 0; s.bp = bp; s.si = si;
+  s.c_newton = s.c_accept = s.c_reject = s.c_fail = 0;
+  GlobalVecs v(a, inst);
+  prepare_step(a, v, s, tid, a.t0, a.h0, 1, a.h0, a.h0);
+  store_state(a, inst, tid, s);
 }
 
-__global__ void __launch_bounds__(64) k_tran_update(TranArgs a) { tran_update_body(a, blockIdx.x, threadIdx.x); }
+__global__ void __launch_bounds__(64) k_tran_update(TranArgs a) {
+  const int inst = blockIdx.x, tid = threadIdx.x;
+  StepState s = load_state(a, inst);
+  if (s.status != 0) return;
+  const int bad = a.flags[inst] & 1;
+  CADNIP_WAVE_SYNC();
+  if (tid == 0) a.flags[inst] = 0;
+  GlobalVecs v(a, inst);
+  tran_update_body(a, v, s, inst, tid, bad);
+  store_state(a, inst, tid, s);
+}
 
 __global__ void k_count_running(const int* status, int B, int* nactive) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -375,10 +390,6 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
              h->B, h->n, h->n_limits, o->n_break, o->n_save, n_obs, n_err,
              o->t0, o->t1, o->reltol, h0, hmin, hmax, o->newton_tol > 0 ? o->newton_tol : 1e-3,
              o->max_newton > 0 ? o->max_newton : 10, o->max_order > 0 ? o->max_order : 2, o->use_pcnr};
-  if (o->fused == 2 && getenv("CADNIP_F2_PROF") && !h->d_f2prof) {
-    HIP_TRY(hipMalloc((void**)&h->d_f2prof, 8 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(h->d_f2prof, 0, 8 * sizeof(unsigned long long)));
-  }
   int saved_mode = h->spec.mode;
   h->spec.mode = 1;   // :tran
   hipLaunchKernelGGL(k_tran_init, dim3(h->B), dim3(64), 0, h->stream, a);
@@ -390,7 +401,7 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
   const int check_every = 8;
   while (running > 0 && launches < max_it) {
     if (o->fused) {
-      rc = (o->fused == 2) ? launch_fused2_rounds(h, a, check_every) : launch_fused_rounds(h, a, check_every); if (rc) break;
+      rc = launch_fused2_rounds(h, a, check_every); if (rc) break;
       launches += check_every;
       rc = count_running(h, &running); if (rc) break;
       continue;
@@ -407,16 +418,6 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
   }
   HIP_TRY(hipStreamSynchronize(h->stream));
   double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
-  if (h->d_f2prof) {
-    unsigned long long pc[8];
-    HIP_TRY(hipMemcpy(pc, h->d_f2prof, sizeof(pc), hipMemcpyDeviceToHost));
-    const char* nm[6] = {"load+zero", "stamp", "J*u", "factor", "solve", "update"};
-    double tot = 0; for (int i = 0; i < 6; ++i) tot += (double)pc[i];
-    fprintf(stderr, "[cadnip f2 prof] wave-rounds %llu; cycles per wave-round:", pc[7]);
-    for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %.0f (%.0f%%)", nm[i], (double)pc[i] / (double)(pc[7] ? pc[7] : 1), 100.0 * pc[i] / tot);
-    fprintf(stderr, "\n");
-    HIP_TRY(hipMemset(h->d_f2prof, 0, sizeof(pc)));
-  }
   h->spec.mode = saved_mode;
   if (rc) return rc;
   std::vector<long long> cnt(B * 4);

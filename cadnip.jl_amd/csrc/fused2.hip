@@ -1,21 +1,29 @@
-// fused2.hip -- fused Newton kernel, second generation: WPB sweep instances per workgroup, one wave each,
-// the circuit *structure* resident in LDS and shared by the workgroup's instances.
+// fused2.hip -- the fused transient Newton kernel: WPB sweep instances per workgroup, one 64-lane wave each,
+// the circuit *structure* resident in LDS and shared by the workgroup's instances, the instance's Jacobian,
+// right-hand side, solution and BDF history term resident in LDS for all the Newton rounds of a launch.
 //
-// Why: for DFF-class circuits one Newton iteration of one instance is a chain of short, dependent phases
-// (stamp -> assemble -> refactor over ~30 dependency levels -> two triangular solves -> update).  With one
-// wave per instance nothing hides a global-memory index load inside such a chain, and the LDS footprint
-// of fused v1 (slot buffer + G + C) admits only ~3 waves per CU.  Here
-//   * every index / program array (slot -> LU position, CSR pattern, LU entry program, level schedules)
-//     is copied once per launch into LDS as uint16 and read from there by all WPB instances;
-//   * there is no slot buffer and no G / C: each stamp value is accumulated straight into the instance's
-//     LDS-resident Jacobian  J = G + a0*C  (at its LU position) with ds_add_f64, and into the residual via
-//        r = C*du + G*u - b = J*u + C*beta - b      (du = a0*u + beta, BDF),
-//     so per instance only  lu[nnz_lu] + u,beta,r,y[n]  live in LDS (16 KB for the DFF);
+// One Newton round of one instance (DFF class: n = 235, 1091 LU entries) is a chain of short dependent phases.
+// Nothing here is HBM-bound; the cost is LDS round trips on the critical path, so the kernel is organised to
+// keep that chain short:
+//   * no slot buffer and no G / C: each stamp value is accumulated straight into the instance's LDS-resident
+//        J = G + a0*C           (at its LU position, ds_add_f64)
+//        r = C*du + G*u - b = J*u + C*beta - b      (du = a0*u + beta, BDF)   (in pivot-row order)
+//     Stamps are branch-free: a slot whose row or column is ground accumulates into a per-lane trash word, so
+//     the table read and the atomic of consecutive stamps pipeline instead of waiting on each other.
+//   * refactorisation, forward substitution and back substitution are ONE entry-wise program
+//        W[pos] = (W[pos] - sum_k W[a_k]*W[b_k]) [/ W[piv]]
+//     over the work array W = [ LU | rhs ]: forward substitution is the LU recurrence of an extra column, so its
+//     entries join the factorisation's dependency levels instead of forming a second sweep; back substitution
+//     follows in place.  Entries and terms are packed (8 B / 4 B), the dot product of an entry is spread over up
+//     to 16 lanes and summed with DPP, level descriptors are prefetched one level ahead.
+//   * the step controller's scalars live in registers for the whole launch, u and beta in LDS; HBM is touched
+//     for device parameters, the predictor / history vectors and the outputs.
 //   * a wave never waits for another wave: all synchronisation is wave-level (tran_ctrl.hpp).
 // Summation order inside an nz differs from the per-op path (slot-major instead of COO order), so results
 // agree with it to rounding (1e-13 relative), not bit for bit; the per-op path remains the reference ABI.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <algorithm>
 #include <vector>
 #include "devices.hpp"
 #include "internal.hpp"
@@ -24,54 +32,84 @@
 namespace cadnip {
 
 typedef unsigned short u16;
+typedef unsigned long long u64;
 #define NOPOS 0xFFFFu
+#define F2_TRASH 64   // per-instance trash words (one per lane) that absorb stamps into ground rows / columns
 
-enum { T_GPOS = 0, T_CPOS, T_CROW, T_CCOL, T_BROW, T_NZROW, T_COLIDX, T_LOADDST, T_ENTPOS, T_ENTDIAG, T_ENTPTR, T_TERMA, T_TERMB, T_LEVPTR,
-       T_LUROWPTR, T_LUCOL, T_LUDIAG, T_RPERM, T_CPERM, T_FWDROWS, T_FWDLEV, T_BWDROWS, T_BWDLEV, T_NTAB };
+// table sections (offsets in 32-bit words, every section 8-byte aligned)
+enum { S_GPOS = 0, S_CDESC, S_BROW, S_NZ, S_ENT, S_TERM, S_LEV, S_QINV, S_NODES, S_NSEC };
 
 struct F2Block {
-  const int* nodes; const int* ipar; const double* par;
-  int type, count, n_par, g_base, c_base, b_base;
+  const int* ipar; const double* par;
+  int type, count, n_par, g_base, c_base, b_base, nodes_off;
 };
 
 struct F2Args {
   F2Block blk[CADNIP_DEV_NTYPES];
   int n_blk;
   const double* wave;
-  const u16* tab;            // packed uint16 tables in global memory
-  int off[T_NTAB];           // offsets (in u16 units) of each table inside `tab`
-  int tab_len;               // total u16 count (even)
-  int n, nnz, nnz_lu, n_lev, n_fwd_lev, n_bwd_lev, rounds, B;
-  unsigned long long* prof;   // diagnostic: per-phase cycle sums [8] (null in production launches)
+  const unsigned* tab;       // packed tables in global memory
+  int off[S_NSEC];
+  int tab_len;               // 32-bit words (even)
+  int n, nnz, nnz_lu, n_pass, rounds, B;
   TranArgs t;
 };
 
-// stamp writer that accumulates straight into J (LU array) and the residual
+// stamp writer: accumulates into J (LU positions) and the residual; all targets are offsets into W
 struct AccumOut {
-  double* lu; double* r; const double* beta; double a0;
-  const u16 *gpos, *cpos, *crow, *ccol, *brow;   // already offset to this device block
+  double* W; const double* betas; double a0;
+  const u16* gpos; const u64* cdesc; const u16* brow;   // already offset to this device block
   int count, dev;
-  // exact zeros are skipped: the accumulators start at +0.0, so adding them would change nothing
   __device__ __forceinline__ void G(int k, double v) const {
-    if (v == 0.0) return;
-    unsigned p = gpos[k * count + dev];
-    if (p != NOPOS) atomicAdd(&lu[p], v);
+    if (__builtin_constant_p(v) && v == 0.0) return;     // structurally zero stamps cost nothing
+    atomicAdd(&W[gpos[k * count + dev]], v);
   }
   __device__ __forceinline__ void C(int k, double v) const {
-    if (v == 0.0) return;
-    int idx = k * count + dev;
-    unsigned p = cpos[idx];
-    if (p != NOPOS) { atomicAdd(&lu[p], a0 * v); atomicAdd(&r[crow[idx]], v * beta[ccol[idx]]); }
+    if (__builtin_constant_p(v) && v == 0.0) return;
+    const u64 d = cdesc[k * count + dev];
+    atomicAdd(&W[(unsigned)d & 0xFFFFu], a0 * v);
+    atomicAdd(&W[(unsigned)(d >> 16) & 0xFFFFu], v * betas[(unsigned)(d >> 32) & 0xFFFFu]);
   }
   __device__ __forceinline__ void B(int k, double v) const {
-    if (v == 0.0) return;
-    unsigned row = brow[k * count + dev];
-    if (row != NOPOS) atomicAdd(&r[row], -v);
+    if (__builtin_constant_p(v) && v == 0.0) return;
+    atomicAdd(&W[brow[k * count + dev]], -v);
+  }
+  // batch forms: all table reads of the batch are issued before its first atomic, so a batch costs one LDS
+  // round trip plus the atomics' issue slots instead of one dependent read -> atomic chain per stamp
+  template <int N> __device__ __forceinline__ void Gv(int k0, const double (&v)[N]) const {
+    unsigned p[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = gpos[(k0 + i) * count + dev];
+#pragma unroll
+    for (int i = 0; i < N; ++i) if (!(__builtin_constant_p(v[i]) && v[i] == 0.0)) atomicAdd(&W[p[i]], v[i]);
+  }
+  template <int N> __device__ __forceinline__ void Cv(int k0, const double (&v)[N]) const {
+    u64 d[N];
+    double bt[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) d[i] = cdesc[(k0 + i) * count + dev];
+#pragma unroll
+    for (int i = 0; i < N; ++i) bt[i] = betas[(unsigned)(d[i] >> 32) & 0xFFFFu];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (!(__builtin_constant_p(v[i]) && v[i] == 0.0)) {
+        atomicAdd(&W[(unsigned)d[i] & 0xFFFFu], a0 * v[i]);
+        atomicAdd(&W[(unsigned)(d[i] >> 16) & 0xFFFFu], v[i] * bt[i]);
+      }
+  }
+  template <int N> __device__ __forceinline__ void Bv(int k0, const double (&v)[N]) const {
+    unsigned p[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = brow[(k0 + i) * count + dev];
+#pragma unroll
+    for (int i = 0; i < N; ++i) if (!(__builtin_constant_p(v[i]) && v[i] == 0.0)) atomicAdd(&W[p[i]], -v[i]);
   }
 };
 
+typedef DevCtxT<short> LdsCtx;
+
 template <class Out>
-__device__ __forceinline__ void dispatch_stamp2(int type, const DevCtx& d, const double* u, const Out& s, double* lw) {
+__device__ __forceinline__ void dispatch_stamp2(int type, const LdsCtx& d, const double* u, const Out& s, double* lw) {
   switch (type) {
     case CADNIP_DEV_RESISTOR: stamp_resistor(d, u, s, lw); break;
     case CADNIP_DEV_CAPACITOR: stamp_capacitor(d, u, s, lw); break;
@@ -89,193 +127,336 @@ __device__ __forceinline__ void dispatch_stamp2(int type, const DevCtx& d, const
   }
 }
 
+// controller vector policy of the fused kernel (see tran_ctrl.hpp): u, beta and the Newton step in LDS
+struct FusedVecs {
+  double *us, *betas; const double* W; const u16* qinv;
+  double *up, *u0, *u1, *u2; const double* lw;
+  __device__ __forceinline__ double get_delta(int i) const { return W[qinv[i]]; }
+  __device__ __forceinline__ double get_u(int i) const { return us[i]; }
+  __device__ __forceinline__ void set_u(int i, double v) const { us[i] = v; }
+  __device__ __forceinline__ double get_beta(int i) const { return betas[i]; }
+  __device__ __forceinline__ void set_beta(int i, double v) const { betas[i] = v; }
+  __device__ __forceinline__ void set_du(int, double) const {}   // du is rebuilt from u and beta when the kernel exits
+  __device__ __forceinline__ double get_lw(int i) const { return lw[i]; }
+};
+
 template <int WPB>
 __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
   extern __shared__ double sm[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = f.n;
   // ---- shared tables: one cooperative copy per launch
-  u16* tab = (u16*)sm;
   {
-    const unsigned* src = (const unsigned*)f.tab;
-    unsigned* dst = (unsigned*)tab;
+    const uint2* src = (const uint2*)f.tab;
+    uint2* dst = (uint2*)sm;
     for (int i = tid; i < f.tab_len / 2; i += 64 * WPB) dst[i] = src[i];
   }
   __syncthreads();
   const int inst = blockIdx.x * WPB + w;
   if (inst >= f.B) return;
-  const int tab_dbl = (f.tab_len * 2 + 7) / 8;            // doubles occupied by the tables
-  const int per = f.nnz_lu + 4 * n;                       // doubles per instance
-  double* lu = sm + tab_dbl + (size_t)w * per;
-  double* us = lu + f.nnz_lu;
-  double* betas = us + n;
-  double* rs = betas + n;
-  double* y = rs + n;
-  const u16 *gpos = tab + f.off[T_GPOS], *cpos = tab + f.off[T_CPOS], *crow = tab + f.off[T_CROW], *ccol = tab + f.off[T_CCOL], *brow = tab + f.off[T_BROW];
-  const u16 *nzrow = tab + f.off[T_NZROW], *colidx = tab + f.off[T_COLIDX], *load_dst = tab + f.off[T_LOADDST];
-  const u16 *ent_pos = tab + f.off[T_ENTPOS], *ent_diag = tab + f.off[T_ENTDIAG], *ent_ptr = tab + f.off[T_ENTPTR];
-  const u16 *term_a = tab + f.off[T_TERMA], *term_b = tab + f.off[T_TERMB], *lev_ptr = tab + f.off[T_LEVPTR];
-  const u16 *lu_rowptr = tab + f.off[T_LUROWPTR], *lu_col = tab + f.off[T_LUCOL], *lu_diag = tab + f.off[T_LUDIAG];
-  const u16 *rperm = tab + f.off[T_RPERM], *cperm = tab + f.off[T_CPERM];
-  const u16 *fwd_rows = tab + f.off[T_FWDROWS], *fwd_lev = tab + f.off[T_FWDLEV], *bwd_rows = tab + f.off[T_BWDROWS], *bwd_lev = tab + f.off[T_BWDLEV];
   const TranArgs& a = f.t;
-  const double* ug = a.u + (size_t)inst * n;
-  const double* betag = a.beta + (size_t)inst * n;
-  double* delta = a.delta + (size_t)inst * n;
+  StepState st = load_state(a, inst);
+  if (st.status != 0) return;
+  const unsigned* tab = (const unsigned*)sm;
+  const int tab_dbl = f.tab_len / 2;
+  const int nW = f.nnz_lu + n + F2_TRASH;                 // LU | rhs | trash : zeroed every round
+  const int per = nW + 2 * n;                             // ... | u | beta
+  double* W = sm + tab_dbl + (size_t)w * per;
+  double* us = W + nW;
+  double* betas = us + n;
+  const u16* gpos = (const u16*)(tab + f.off[S_GPOS]);
+  const u64* cdesc = (const u64*)(tab + f.off[S_CDESC]);
+  const u16* brow = (const u16*)(tab + f.off[S_BROW]);
+  const u64* nzd = (const u64*)(tab + f.off[S_NZ]);
+  const u64* laned = (const u64*)(tab + f.off[S_ENT]);
+  const unsigned* term = tab + f.off[S_TERM];
+  const u64* passd = (const u64*)(tab + f.off[S_LEV]);
+  const u16* qinv = (const u16*)(tab + f.off[S_QINV]);
+  const short* nodes = (const short*)(tab + f.off[S_NODES]);
+  double* ug = a.u + (size_t)inst * n;
+  double* betag = a.beta + (size_t)inst * n;
   double* lw = a.limit_w + (size_t)inst * n;
-#define F2_STAMP(k) do { if (f.prof) { unsigned long long _t = clock64(); if (lane == 0) atomicAdd(&f.prof[k], _t - tstamp); tstamp = _t; } } while (0)
-  unsigned long long tstamp = f.prof ? clock64() : 0;
+  const size_t vo = (size_t)inst * n;
+  const FusedVecs vec{us, betas, W, qinv, a.up + vo, a.u0 + vo, a.u1 + vo, a.u2 + vo, lw};
+  for (int i = lane; i < n; i += 64) { us[i] = ug[i]; betas[i] = betag[i]; }
+#ifdef CADNIP_TRACE
+  if (blockIdx.x == 0 && tid == 0) g_trace_last = clock64();
+#endif
   for (int round = 0; round < f.rounds; ++round) {
-    if (a.status[inst] != 0) break;
-    const double tcur = a.tcur[inst], a0 = a.gamma[inst];
-    for (int i = lane; i < n; i += 64) { us[i] = ug[i]; betas[i] = betag[i]; rs[i] = 0.0; }
-    for (int p = lane; p < f.nnz_lu; p += 64) lu[p] = 0.0;
+    CADNIP_TRACE_POINT(17);
+    for (int i = lane; i < nW; i += 64) W[i] = 0.0;
     CADNIP_WAVE_SYNC();
-    F2_STAMP(0);
+    CADNIP_TRACE_POINT(0);
     // ---- stamp: accumulate J (at LU positions) and the C*beta - b part of the residual
+    const double tcur = st.tn, a0 = st.a0;
     for (int bi = 0; bi < f.n_blk; ++bi) {
       const F2Block& B = f.blk[bi];
       for (int dev = lane; dev < B.count; dev += 64) {
-        DevCtx d{B.nodes, B.ipar, B.par + (size_t)inst * B.n_par * B.count, f.wave, B.count, dev, tcur, 1, 0};
-        AccumOut s{lu, rs, betas, a0, gpos + B.g_base, cpos + B.c_base, crow + B.c_base, ccol + B.c_base, brow + B.b_base, B.count, dev};
+        LdsCtx d{nodes + B.nodes_off, B.ipar, B.par + (size_t)inst * B.n_par * B.count, f.wave, B.count, dev, tcur, 1, 0};
+        AccumOut s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev};
         dispatch_stamp2(B.type, d, us, s, lw);
       }
+      CADNIP_TRACE_POINT(8 + bi);
     }
     CADNIP_WAVE_SYNC();
-    F2_STAMP(1);
-    // ---- r += J*u  (J still unfactored in the LU array)
-    for (int p = lane; p < f.nnz; p += 64) atomicAdd(&rs[nzrow[p]], lu[load_dst[p]] * us[colidx[p]]);
-    CADNIP_WAVE_SYNC();
-    F2_STAMP(2);
-    // ---- refactor (entry-wise left-looking, level by level)
-    for (int lev = 0; lev < f.n_lev; ++lev) {
-      const int e0 = lev_ptr[lev], e1 = lev_ptr[lev + 1], E = e1 - e0;
-      int lpe = 1;                                   // lanes per entry: split each dot product over lpe lanes
-      while (lpe * 2 * E <= 64) lpe *= 2;
-      if (lpe == 1) {
-        for (int e = e0 + lane; e < e1; e += 64) {
-          const int pos = ent_pos[e];
-          double acc = lu[pos];
-          const int t1 = ent_ptr[e + 1];
-          for (int t = ent_ptr[e]; t < t1; ++t) acc -= lu[term_a[t]] * lu[term_b[t]];
-          const unsigned dg = ent_diag[e];
-          if (dg != NOPOS) acc /= lu[dg];
-          lu[pos] = acc;
-        }
-      } else {
-        const int idx = lane / lpe, sub = lane - idx * lpe, e = e0 + idx;
-        double part = 0.0;
-        if (idx < E) { const int t1 = ent_ptr[e + 1]; for (int t = ent_ptr[e] + sub; t < t1; t += lpe) part += lu[term_a[t]] * lu[term_b[t]]; }
-        for (int o = lpe >> 1; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-        if (idx < E && sub == 0) {
-          const int pos = ent_pos[e];
-          double acc = lu[pos] - part;
-          const unsigned dg = ent_diag[e];
-          if (dg != NOPOS) acc /= lu[dg];
-          lu[pos] = acc;
-        }
+    CADNIP_TRACE_POINT(1);
+    // ---- r += J*u  (J still unfactored in the LU array), four entries per lane in flight
+    for (int p0 = 0; p0 < f.nnz; p0 += 256) {
+      u64 d[4];
+      double v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int p = p0 + q * 64 + lane; d[q] = nzd[p < f.nnz ? p : f.nnz - 1]; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = W[(unsigned)d[q] & 0xFFFFu] * us[(unsigned)(d[q] >> 32) & 0xFFFFu];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool ok = p0 + q * 64 + lane < f.nnz;
+        atomicAdd(&W[ok ? ((unsigned)(d[q] >> 16) & 0xFFFFu) : (unsigned)(f.nnz_lu + n + lane)], ok ? v[q] : 0.0);
       }
-      CADNIP_WAVE_SYNC();
     }
-    F2_STAMP(3);
+    CADNIP_WAVE_SYNC();
+    CADNIP_TRACE_POINT(2);
+    // ---- refactor + forward + backward substitution: one entry-wise program, executed pass by pass.  A pass gives
+    // every lane one descriptor (entry, its share of the entry's terms, the width 2^lg of the entry's lane group);
+    // a dependency level is one or more passes and ends with a fence.  Software pipeline: pass descriptors are
+    // fetched two passes ahead, lane descriptor and first term one pass ahead, so the chain inside a pass is
+    // operand reads -> fma -> DPP sum -> [divide] -> write.
     int bad = 0;
-    for (int i = lane; i < n; i += 64) { double dd = lu[lu_diag[i]]; if (dd == 0.0 || !isfinite(dd)) bad = 1; }
-    if (bad) atomicOr(&a.flags[inst], 1);
-    for (int i = lane; i < n; i += 64) y[i] = rs[rperm[i]];
-    CADNIP_WAVE_SYNC();
-    for (int lev = 0; lev < f.n_fwd_lev; ++lev) {
-      const int r0 = fwd_lev[lev], r1 = fwd_lev[lev + 1], R = r1 - r0;
-      int lpe = 1;
-      while (lpe * 2 * R <= 64) lpe *= 2;
-      if (lpe == 1) {
-        for (int r = r0 + lane; r < r1; r += 64) {
-          const int i = fwd_rows[r];
-          double acc = y[i];
-          const int p1 = lu_diag[i];
-          for (int p = lu_rowptr[i]; p < p1; ++p) acc -= lu[p] * y[lu_col[p]];
-          y[i] = acc;
-        }
-      } else {
-        const int idx = lane / lpe, sub = lane - idx * lpe;
-        const int i = idx < R ? fwd_rows[r0 + idx] : 0;
-        double part = 0.0;
-        if (idx < R) { const int p1 = lu_diag[i]; for (int p = lu_rowptr[i] + sub; p < p1; p += lpe) part += lu[p] * y[lu_col[p]]; }
-        for (int o = lpe >> 1; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-        if (idx < R && sub == 0) y[i] -= part;
+    if (f.n_pass > 0) {
+      u64 pd = passd[0], pd1 = passd[1];
+      u64 D;
+      unsigned T0;
+      {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pd), hi = __builtin_amdgcn_readfirstlane((unsigned)(pd >> 32));
+        const int T = hi & 0x7F;
+        D = laned[lo + (lane < T ? lane : T - 1)];
+        T0 = term[(unsigned)(D >> 32) & 0xFFFFu];
       }
-      CADNIP_WAVE_SYNC();
-    }
-    for (int lev = 0; lev < f.n_bwd_lev; ++lev) {
-      const int r0 = bwd_lev[lev], r1 = bwd_lev[lev + 1], R = r1 - r0;
-      int lpe = 1;
-      while (lpe * 2 * R <= 64) lpe *= 2;
-      if (lpe == 1) {
-        for (int r = r0 + lane; r < r1; r += 64) {
-          const int i = bwd_rows[r];
-          double acc = y[i];
-          const int dp = lu_diag[i], p1 = lu_rowptr[i + 1];
-          for (int p = dp + 1; p < p1; ++p) acc -= lu[p] * y[lu_col[p]];
-          y[i] = acc / lu[dp];
+      for (int pi = 0; pi < f.n_pass; ++pi) {
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(pd >> 32));
+        const int T = hi & 0x7F, maxlg = (hi >> 8) & 7, hasdiv = (hi >> 11) & 1, fence = (hi >> 12) & 1, multi = (hi >> 13) & 1;
+        const bool act = lane < T;
+        const unsigned pos = (unsigned)D & 0xFFFFu, dg = (unsigned)(D >> 16) & 0xFFFFu, t0 = (unsigned)(D >> 32) & 0xFFFFu;
+        const unsigned dhi = (unsigned)(D >> 48);
+        const int nt = act ? (int)(dhi & 0xFFu) : 0, lg = (dhi >> 8) & 7;
+        const bool leader = act && ((dhi >> 12) & 1u);
+        // (1) operands of this pass
+        const double acc0 = W[pos];
+        double piv = W[dg == NOPOS ? pos : dg];
+        const double av = W[T0 & 0xFFFFu], bv = W[T0 >> 16];
+        // (2) prefetch for the next passes
+        const unsigned lo1 = __builtin_amdgcn_readfirstlane((unsigned)pd1), hi1 = __builtin_amdgcn_readfirstlane((unsigned)(pd1 >> 32));
+        const int T1 = hi1 & 0x7F;
+        const u64 Dn = laned[lo1 + (lane < T1 ? lane : (T1 > 0 ? T1 - 1 : 0))];
+        const u64 pd2 = passd[pi + 2];
+        __builtin_amdgcn_sched_barrier(0);
+        // (3) dot product share, group sum, finish
+        double part = nt > 0 ? av * bv : 0.0;
+        if (multi)
+          for (int t = 1; t < nt; ++t) { const unsigned tm = term[t0 + t]; part = fma(W[tm & 0xFFFFu], W[tm >> 16], part); }
+        if (maxlg >= 1) { const double o = dpp_f64<0xB1>(part); part += lg >= 1 ? o : 0.0; }
+        if (maxlg >= 2) { const double o = dpp_f64<0x4E>(part); part += lg >= 2 ? o : 0.0; }
+        if (maxlg >= 3) { const double o = dpp_f64<0x141>(part); part += lg >= 3 ? o : 0.0; }
+        if (maxlg >= 4) { const double o = dpp_f64<0x140>(part); part += lg >= 4 ? o : 0.0; }
+        double acc = acc0 - part;
+        if (hasdiv) {
+          if (dg == NOPOS) piv = 1.0;
+          else if (act && (piv == 0.0 || !isfinite(piv))) bad = 1;
+          acc = acc / piv;
         }
-      } else {
-        const int idx = lane / lpe, sub = lane - idx * lpe;
-        const int i = idx < R ? bwd_rows[r0 + idx] : 0;
-        const int dp = lu_diag[i];
-        double part = 0.0;
-        if (idx < R) { const int p1 = lu_rowptr[i + 1]; for (int p = dp + 1 + sub; p < p1; p += lpe) part += lu[p] * y[lu_col[p]]; }
-        for (int o = lpe >> 1; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-        if (idx < R && sub == 0) y[i] = (y[i] - part) / lu[dp];
+        if (leader) W[pos] = acc;
+        const unsigned T0n = term[(unsigned)(Dn >> 32) & 0xFFFFu];
+        if (fence) CADNIP_WAVE_SYNC();
+        D = Dn; T0 = T0n; pd = pd1; pd1 = pd2;
       }
-      CADNIP_WAVE_SYNC();
     }
-    for (int i = lane; i < n; i += 64) delta[cperm[i]] = y[i];
+    CADNIP_TRACE_POINT(3);
+    // ---- Newton update + step controller (registers / LDS; HBM only for history and outputs)
+    tran_update_body(a, vec, st, inst, lane, bad);
     CADNIP_WAVE_SYNC();
-    F2_STAMP(4);
-    tran_update_body(a, inst, lane);
-    CADNIP_WAVE_SYNC();
-    F2_STAMP(5);
-    if (f.prof && lane == 0) atomicAdd(&f.prof[7], 1ull);
+    CADNIP_TRACE_POINT(16);
+    if (st.status != 0) break;
   }
+  {
+    double* dug = a.du + (size_t)inst * n;
+    const double a0 = st.a0;
+    for (int i = lane; i < n; i += 64) { double x = us[i], b = betas[i]; ug[i] = x; betag[i] = b; dug[i] = a0 * x + b; }
+  }
+  store_state(a, inst, lane, st);
 }
 
-// ---- host side: build the packed uint16 tables once per (structure, LU program) -----------------------------
+// ---- host side: build the packed tables once per (structure, LU program) ------------------------------------
 struct F2Tables {
-  std::vector<u16> data;
-  int off[T_NTAB];
-  void add(int which, const std::vector<int>& v) {
-    off[which] = (int)data.size();
-    for (int x : v) data.push_back(x < 0 ? (u16)NOPOS : (u16)x);
-    if (data.size() & 1) data.push_back(0);
+  std::vector<unsigned> data;   // 32-bit words
+  int off[S_NSEC];
+  void begin(int which) { if (data.size() & 1) data.push_back(0); off[which] = (int)data.size(); }
+  void add16(const std::vector<int>& v) {
+    for (size_t i = 0; i < v.size(); i += 2) data.push_back((unsigned)(v[i] & 0xFFFF) | ((i + 1 < v.size() ? (unsigned)(v[i + 1] & 0xFFFF) : 0u) << 16));
   }
+  void add32(unsigned x) { data.push_back(x); }
+  void add64(u64 x) { data.push_back((unsigned)x); data.push_back((unsigned)(x >> 32)); }
 };
+static inline u64 pack4(unsigned a, unsigned b, unsigned c, unsigned d) {
+  return (u64)(a & 0xFFFFu) | ((u64)(b & 0xFFFFu) << 16) | ((u64)(c & 0xFFFFu) << 32) | ((u64)(d & 0xFFFFu) << 48);
+}
 
-static bool f2_prepare(CadnipHandle* h, F2Tables& T, std::vector<int>& gs, std::vector<int>& cs, std::vector<int>& cr, std::vector<int>& cc, std::vector<int>& br,
-                       const std::vector<int>& g_ptr, const std::vector<int>& g_slots, const std::vector<int>& c_ptr, const std::vector<int>& c_slots,
-                       const std::vector<int>& b_ptr, const std::vector<int>& b_slots) {
+static bool f2_prepare(CadnipHandle* h, F2Tables& T, const std::vector<int>& g_ptr, const std::vector<int>& g_slots, const std::vector<int>& c_ptr,
+                       const std::vector<int>& c_slots, const std::vector<int>& b_ptr, const std::vector<int>& b_slots) {
   const LUProgram& P = h->lu;
-  if (h->n >= 65535 || P.nnz_lu >= 65535 || h->ns_g >= 65535 || h->ns_c >= 65535 || h->ns_b >= 65535 || (int)P.term_a.size() >= 65535) return false;
+  const int n = h->n, nnz_lu = P.nnz_lu;
+  const int y0 = nnz_lu, trash0 = nnz_lu + n;                 // W offsets
+  if (trash0 + F2_TRASH >= 65535 || n >= 32767) return false;
+  std::vector<int> pinv(n), qinv(n);
+  for (int k = 0; k < n; ++k) { pinv[P.rperm[k]] = k; qinv[P.cperm[k]] = k; }
   std::vector<int> dst(h->nnz, 0);
   for (size_t k = 0; k < P.load_src.size(); ++k) dst[P.load_src[k]] = P.load_dst[k];
-  gs.assign(h->ns_g, -1); cs.assign(h->ns_c, -1); cr.assign(h->ns_c, -1); cc.assign(h->ns_c, -1); br.assign(h->ns_b, -1);
-  for (int i = 0; i < h->n; ++i)
+  // slot -> W offset.  A slot that no nz gathers (ground row / column) goes to the trash word of its lane.
+  std::vector<int> gs(h->ns_g, -1), cpos(h->ns_c, -1), crow(h->ns_c, 0), ccol(h->ns_c, 0), br(h->ns_b, -1);
+  for (int i = 0; i < n; ++i)
     for (int e = h->h_rowptr[i]; e < h->h_rowptr[i + 1]; ++e) {
       for (int p = g_ptr[e]; p < g_ptr[e + 1]; ++p) gs[g_slots[p]] = dst[e];
-      for (int p = c_ptr[e]; p < c_ptr[e + 1]; ++p) { cs[c_slots[p]] = dst[e]; cr[c_slots[p]] = i; cc[c_slots[p]] = h->h_colidx[e]; }
+      for (int p = c_ptr[e]; p < c_ptr[e + 1]; ++p) { cpos[c_slots[p]] = dst[e]; crow[c_slots[p]] = y0 + pinv[i]; ccol[c_slots[p]] = h->h_colidx[e]; }
     }
-  for (int i = 0; i < h->n; ++i) for (int p = b_ptr[i]; p < b_ptr[i + 1]; ++p) br[b_slots[p]] = i;
-  T.add(T_GPOS, gs); T.add(T_CPOS, cs); T.add(T_CROW, cr); T.add(T_CCOL, cc); T.add(T_BROW, br);
-  std::vector<int> nzrow(h->nnz);
-  for (int i = 0; i < h->n; ++i) for (int e = h->h_rowptr[i]; e < h->h_rowptr[i + 1]; ++e) nzrow[e] = i;
-  T.add(T_NZROW, nzrow); T.add(T_COLIDX, h->h_colidx); T.add(T_LOADDST, dst);
-  T.add(T_ENTPOS, P.ent_pos); T.add(T_ENTDIAG, P.ent_diag); T.add(T_ENTPTR, P.ent_ptr); T.add(T_TERMA, P.term_a); T.add(T_TERMB, P.term_b); T.add(T_LEVPTR, P.lev_ptr);
-  T.add(T_LUROWPTR, P.lu_rowptr); T.add(T_LUCOL, P.lu_col); T.add(T_LUDIAG, P.lu_diag); T.add(T_RPERM, P.rperm); T.add(T_CPERM, P.cperm);
-  T.add(T_FWDROWS, P.fwd_rows); T.add(T_FWDLEV, P.fwd_lev_ptr); T.add(T_BWDROWS, P.bwd_rows); T.add(T_BWDLEV, P.bwd_lev_ptr);
+  for (int i = 0; i < n; ++i) for (int p = b_ptr[i]; p < b_ptr[i + 1]; ++p) br[b_slots[p]] = y0 + pinv[i];
+  // the lane that writes slot s of a block is ((s - base) % count) % 64
+  std::vector<int> lane_g(h->ns_g, 0), lane_c(h->ns_c, 0), lane_b(h->ns_b, 0);
+  for (auto& b : h->blocks) {
+    if (b.count == 0) continue;
+    for (int s = 0; s < b.n_g * b.count; ++s) lane_g[b.g_base + s] = (s % b.count) & 63;
+    for (int s = 0; s < b.n_c * b.count; ++s) lane_c[b.c_base + s] = (s % b.count) & 63;
+    for (int s = 0; s < b.n_b * b.count; ++s) lane_b[b.b_base + s] = (s % b.count) & 63;
+  }
+  for (int s = 0; s < h->ns_g; ++s) if (gs[s] < 0) gs[s] = trash0 + lane_g[s];
+  for (int s = 0; s < h->ns_b; ++s) if (br[s] < 0) br[s] = trash0 + lane_b[s];
+  T.begin(S_GPOS); T.add16(gs);
+  T.begin(S_CDESC);
+  for (int s = 0; s < h->ns_c; ++s) {
+    if (cpos[s] < 0) T.add64(pack4(trash0 + lane_c[s], trash0 + lane_c[s], 0, 0));
+    else T.add64(pack4(cpos[s], crow[s], ccol[s], 0));
+  }
+  T.begin(S_BROW); T.add16(br);
+  T.begin(S_NZ);
+  for (int i = 0; i < n; ++i) for (int e = h->h_rowptr[i]; e < h->h_rowptr[i + 1]; ++e) T.add64(pack4(dst[e], y0 + pinv[i], h->h_colidx[e], 0));
+  // ---- unified entry program: factor entries, forward substitution as an extra column, back substitution in place
+  struct Ent { int pos, dg, lvl; std::vector<int> a, b; };
+  std::vector<Ent> ents;
+  std::vector<int> plev(nnz_lu, -1);
+  const int nF = (int)P.lev_ptr.size() - 1;
+  for (int L = 0; L < nF; ++L)
+    for (int e = P.lev_ptr[L]; e < P.lev_ptr[L + 1]; ++e) {
+      Ent x; x.pos = P.ent_pos[e]; x.dg = P.ent_diag[e]; x.lvl = L;
+      for (int t = P.ent_ptr[e]; t < P.ent_ptr[e + 1]; ++t) { x.a.push_back(P.term_a[t]); x.b.push_back(P.term_b[t]); }
+      plev[x.pos] = L;
+      ents.push_back(std::move(x));
+    }
+  int maxlev = nF - 1;
+  std::vector<int> ylev(n, -1);
+  for (int i = 0; i < n; ++i) {
+    Ent x; x.pos = y0 + i; x.dg = -1; x.lvl = -1;
+    for (int p = P.lu_rowptr[i]; p < P.lu_diag[i]; ++p) {
+      const int k = P.lu_col[p];
+      x.a.push_back(p); x.b.push_back(y0 + k);
+      x.lvl = std::max(x.lvl, std::max(plev[p], ylev[k]) + 1);
+    }
+    if (x.a.empty()) continue;
+    ylev[i] = x.lvl;
+    maxlev = std::max(maxlev, x.lvl);
+    ents.push_back(std::move(x));
+  }
+  std::vector<int> xlev(n, 0);
+  for (int i = n - 1; i >= 0; --i) {
+    Ent x; x.pos = y0 + i; x.dg = P.lu_diag[i]; x.lvl = maxlev + 1;
+    for (int p = P.lu_diag[i] + 1; p < P.lu_rowptr[i + 1]; ++p) {
+      const int j = P.lu_col[p];
+      x.a.push_back(p); x.b.push_back(y0 + j);
+      x.lvl = std::max(x.lvl, xlev[j] + 1);
+    }
+    xlev[i] = x.lvl;
+    ents.push_back(std::move(x));
+  }
+  std::stable_sort(ents.begin(), ents.end(), [](const Ent& p, const Ent& q) { return p.lvl < q.lvl; });
+  size_t n_terms = 0;
+  for (auto& e : ents) n_terms += e.a.size();
+  if (n_terms >= 65535) return false;
+  // Levels -> passes of 64 lane descriptors.  An entry with nt terms gets a group of min(cap, pow2ceil(nt)) lanes
+  // (aligned, so a DPP butterfly sums it); groups are packed widest first; cap is chosen per level to minimise
+  // passes*2 + dot-product iterations.
+  auto p2c = [](size_t x) { size_t r = 1; while (r < x) r *= 2; return r; };
+  std::vector<u64> pass_words, lane_words;
+  std::vector<unsigned> terms;
+  for (size_t i = 0; i < ents.size();) {
+    size_t j = i;
+    while (j < ents.size() && ents[j].lvl == ents[i].lvl) ++j;
+    const size_t E = j - i;
+    size_t best_cost = (size_t)-1;
+    int best_cap = 1;
+    for (int cap = 16; cap >= 1; cap >>= 1) {
+      std::vector<size_t> L(E);
+      size_t total = 0;
+      for (size_t e = 0; e < E; ++e) { L[e] = std::min((size_t)cap, p2c(std::max<size_t>(ents[i + e].a.size(), 1))); total += L[e]; }
+      std::vector<size_t> ord(E);
+      for (size_t e = 0; e < E; ++e) ord[e] = e;
+      std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return L[x] > L[y]; });
+      const size_t passes = (total + 63) / 64;
+      std::vector<size_t> it(passes, 1);
+      size_t off = 0;
+      for (size_t e : ord) { const size_t nt = ents[i + e].a.size(); it[off / 64] = std::max(it[off / 64], (nt + L[e] - 1) / L[e]); off += L[e]; }
+      size_t cost = 0;
+      for (size_t p = 0; p < passes; ++p) cost += 2 + it[p] - 1;
+      if (cost < best_cost) { best_cost = cost; best_cap = cap; }
+    }
+    std::vector<size_t> L(E), ord(E);
+    for (size_t e = 0; e < E; ++e) { L[e] = std::min((size_t)best_cap, p2c(std::max<size_t>(ents[i + e].a.size(), 1))); ord[e] = e; }
+    std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return L[x] > L[y]; });
+    const size_t base = lane_words.size();
+    std::vector<int> lane_lg, lane_nt, lane_div;
+    for (size_t e : ord) {
+      const Ent& x = ents[i + e];
+      int lg = 0;
+      while (((size_t)1 << lg) < L[e]) ++lg;
+      for (size_t sub = 0; sub < L[e]; ++sub) {
+        const size_t t0 = terms.size();
+        size_t nt = 0;
+        for (size_t t = sub; t < x.a.size(); t += L[e], ++nt) terms.push_back((unsigned)x.a[t] | ((unsigned)x.b[t] << 16));
+        if (nt > 255 || t0 >= 65535) return false;
+        lane_words.push_back(pack4(x.pos, x.dg < 0 ? NOPOS : x.dg, (unsigned)t0, (unsigned)(nt | ((unsigned)lg << 8) | ((sub == 0 ? 1u : 0u) << 12))));
+        lane_lg.push_back(lg); lane_nt.push_back((int)nt); lane_div.push_back(x.dg >= 0);
+      }
+    }
+    const size_t total = lane_words.size() - base;
+    for (size_t off = 0; off < total; off += 64) {
+      const size_t T = std::min<size_t>(64, total - off);
+      unsigned maxlg = 0, hasdiv = 0, multi = 0;
+      for (size_t l = off; l < off + T; ++l) { maxlg = std::max(maxlg, (unsigned)lane_lg[l]); hasdiv |= (unsigned)lane_div[l]; multi |= lane_nt[l] > 1 ? 1u : 0u; }
+      const unsigned fence = off + 64 >= total ? 1u : 0u;
+      if (base + off >= ((size_t)1 << 31)) return false;
+      pass_words.push_back((u64)(base + off) | ((u64)(T | (maxlg << 8) | (hasdiv << 11) | (fence << 12) | (multi << 13)) << 32));
+    }
+    i = j;
+  }
+  terms.push_back(0);   // a lane without terms still prefetches term[t0]
+  T.begin(S_ENT); for (u64 wv : lane_words) T.add64(wv);
+  std::vector<u64>& lev_words = pass_words;
+  T.begin(S_TERM); for (unsigned t : terms) T.add32(t);
+  h->f2_n_lev = (int)lev_words.size();
+  T.begin(S_LEV); for (u64 wv : lev_words) T.add64(wv);
+  T.add64(0); T.add64(0);   // two empty passes: the kernel reads pass descriptors two ahead
+  std::vector<int> qoff(n);
+  for (int j = 0; j < n; ++j) qoff[j] = y0 + qinv[j];
+  T.begin(S_QINV); T.add16(qoff);
+  T.begin(S_NODES);
+  h->f2_nodes_off.clear();
+  {
+    std::vector<int> all;
+    for (auto& b : h->blocks) { h->f2_nodes_off.push_back((int)all.size()); all.insert(all.end(), b.h_nodes.begin(), b.h_nodes.end()); }
+    T.add16(all);
+  }
+  if (T.data.size() & 1) T.data.push_back(0);
   return true;
 }
 
 int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds) {
   if (!h->analyzed) return CADNIP_NOTREADY;
   if (h->spec.gshunt != 0.0 || h->spec.srcFact < 1.0) return CADNIP_BADARG;   // homotopies run on the per-op path
-  static_assert(T_NTAB <= 32, "f2off too small");
   if (!h->d_f2tab || h->fused2_dirty) {
     // host copies of the gather lists are needed to invert them: read back once
     std::vector<int> g_ptr(h->nnz + 1), c_ptr(h->nnz + 1), b_ptr(h->n + 1);
@@ -287,13 +468,12 @@ int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds) {
     if (!c_slots.empty()) HIP_TRY(hipMemcpy(c_slots.data(), h->d_c_slots, c_slots.size() * 4, hipMemcpyDeviceToHost));
     if (!b_slots.empty()) HIP_TRY(hipMemcpy(b_slots.data(), h->d_b_slots, b_slots.size() * 4, hipMemcpyDeviceToHost));
     F2Tables T;
-    std::vector<int> gs, cs, cr, cc, br;
-    if (!f2_prepare(h, T, gs, cs, cr, cc, br, g_ptr, g_slots, c_ptr, c_slots, b_ptr, b_slots)) return CADNIP_BADARG;
+    if (!f2_prepare(h, T, g_ptr, g_slots, c_ptr, c_slots, b_ptr, b_slots)) return CADNIP_BADARG;
     if (h->d_f2tab) (void)hipFree(h->d_f2tab);
     h->d_f2tab = nullptr;
-    HIP_TRY(hipMalloc((void**)&h->d_f2tab, T.data.size() * sizeof(u16)));
-    HIP_TRY(hipMemcpy(h->d_f2tab, T.data.data(), T.data.size() * sizeof(u16), hipMemcpyHostToDevice));
-    for (int i = 0; i < T_NTAB; ++i) h->f2off[i] = T.off[i];
+    HIP_TRY(hipMalloc((void**)&h->d_f2tab, T.data.size() * sizeof(unsigned)));
+    HIP_TRY(hipMemcpy(h->d_f2tab, T.data.data(), T.data.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    for (int i = 0; i < S_NSEC; ++i) h->f2off[i] = T.off[i];
     h->f2len = (int)T.data.size();
     h->fused2_dirty = false;
   }
@@ -301,23 +481,24 @@ int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds) {
   const LUProgram& P = h->lu;
   F2Args f;
   f.n_blk = 0;
-  for (auto& b : h->blocks) {
+  for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
+    auto& b = h->blocks[bi];
     if (b.count == 0) continue;
-    f.blk[f.n_blk++] = F2Block{b.d_nodes, b.d_ipar, b.d_par, b.type, b.count, b.n_par, b.g_base, b.c_base, b.b_base};
+    f.blk[f.n_blk++] = F2Block{b.d_ipar, b.d_par, b.type, b.count, b.n_par, b.g_base, b.c_base, b.b_base, h->f2_nodes_off[bi]};
   }
+  // the heaviest device type first: its parameter loads are in flight while the table copy settles
   for (int i = 0; i < f.n_blk; ++i)
     for (int j = i + 1; j < f.n_blk; ++j)
       if ((f.blk[j].type == CADNIP_DEV_MOS1) > (f.blk[i].type == CADNIP_DEV_MOS1)) { F2Block tmp = f.blk[i]; f.blk[i] = f.blk[j]; f.blk[j] = tmp; }
   f.wave = h->d_wave;
   f.tab = h->d_f2tab;
-  for (int i = 0; i < T_NTAB; ++i) f.off[i] = h->f2off[i];
+  for (int i = 0; i < S_NSEC; ++i) f.off[i] = h->f2off[i];
   f.tab_len = h->f2len;
   f.n = h->n; f.nnz = h->nnz; f.nnz_lu = P.nnz_lu;
-  f.n_lev = (int)P.lev_ptr.size() - 1; f.n_fwd_lev = (int)P.fwd_lev_ptr.size() - 1; f.n_bwd_lev = (int)P.bwd_lev_ptr.size() - 1;
+  f.n_pass = h->f2_n_lev;
   f.rounds = rounds; f.B = h->B; f.t = t;
-  f.prof = h->d_f2prof;
-  const size_t tab_dbl = ((size_t)h->f2len * 2 + 7) / 8;
-  const size_t per = (size_t)P.nnz_lu + 4 * (size_t)h->n;
+  const size_t tab_dbl = (size_t)h->f2len / 2;
+  const size_t per = (size_t)P.nnz_lu + 3 * (size_t)h->n + F2_TRASH;
   const size_t lds_cap = 160 * 1024;
   // waves (= instances) per workgroup: 8 when they fit and there are enough instances to fill the chip, else 4, 2, 1
   int wpb = 8;
@@ -336,4 +517,23 @@ int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds) {
   return CADNIP_OK;
 }
 
+#ifdef CADNIP_TRACE
+int trace_read(unsigned long long* sum, unsigned long long* cnt, int reset) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(sum, HIP_SYMBOL(g_trace_sum), 64 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_trace_cnt), 64 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[64] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_trace_sum), z, sizeof(z)));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_trace_cnt), z, sizeof(z)));
+  }
+  return CADNIP_OK;
+}
+#endif
+
 }  // namespace cadnip
+
+#ifdef CADNIP_TRACE
+// diagnostic library only: not part of include/cadnip_hip.h
+extern "C" int cadnip_debug_trace(unsigned long long* sum, unsigned long long* cnt, int reset) { return cadnip::trace_read(sum, cnt, reset); }
+#endif

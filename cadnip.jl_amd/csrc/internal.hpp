@@ -39,6 +39,7 @@ struct DeviceBlock {
   int type, count, n_nodes, n_ipar, n_par;
   int g_base, c_base, b_base, n_g, n_c, n_b;
   int* d_nodes = nullptr;
+  std::vector<int> h_nodes;  // host copy (the fused kernel keeps an int16 copy in LDS)
   int* d_ipar = nullptr;
   double* d_par = nullptr;   // [B][n_par][count]
 };
@@ -78,12 +79,13 @@ struct CadnipHandle {
   int *d_term_a = nullptr, *d_term_b = nullptr, *d_lev_ptr = nullptr;
   int *d_lu_rowptr = nullptr, *d_lu_col = nullptr, *d_lu_diag = nullptr, *d_rperm = nullptr, *d_cperm = nullptr;
   int *d_fwd_rows = nullptr, *d_fwd_lev_ptr = nullptr, *d_bwd_rows = nullptr, *d_bwd_lev_ptr = nullptr;
-  // fused v2: packed uint16 structure tables (fused2.hip), rebuilt when the LU program changes
-  unsigned short* d_f2tab = nullptr;
-  int f2off[32] = {0};
-  int f2len = 0;
+  // fused kernel: packed structure tables (fused2.hip), rebuilt when the LU program changes
+  unsigned int* d_f2tab = nullptr;
+  int f2off[16] = {0};      // section offsets in 32-bit words
+  int f2len = 0;            // 32-bit words
+  int f2_n_lev = 0;
+  std::vector<int> f2_nodes_off;   // per device block: offset (int16 units) of its node table inside the NODES section
   bool fused2_dirty = true;
-  unsigned long long* d_f2prof = nullptr;   // diagnostic phase-cycle counters, allocated by CADNIP_F2_PROF=1
   // driver state (allocated lazily)
   struct Driver* drv = nullptr;
   // profiling
@@ -108,7 +110,6 @@ int launch_factor_solve(CadnipHandle* h, bool fuse_jacobian, const double* d_rhs
 int upload_lu(CadnipHandle* h);
 int launch_calib_copy(CadnipHandle* h, long n, int reps);
 struct TranArgs;                                                          // tran_ctrl.hpp
-int launch_fused_rounds(CadnipHandle* h, const TranArgs& t, int rounds);  // fused.hip
 int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds); // fused2.hip
 struct ProfScope {
   CadnipHandle* h; int idx;

@@ -1,5 +1,11 @@
-// tran_ctrl.hpp -- device-side transient controller shared by the per-op driver (driver.hip) and the
-// fused per-instance Newton kernel (fused.hip).  See driver.hip for the integration method.
+// tran_ctrl.hpp -- device-side transient controller shared by the per-op driver (driver.hip: k_tran_init,
+// k_tran_update) and the fused Newton kernel (fused2.hip).  See driver.hip for the integration method.
+//
+// The controller is written once, over two small policies:
+//   * StepState   -- the per-instance scalars (t, h, order, Newton counter, ...).  A kernel loads them into
+//                    registers once, runs any number of Newton rounds on them, and stores them back once.
+//   * a vector policy V -- where the per-unknown vectors live.  GlobalVecs: everything in HBM (per-op path).
+//                    The fused kernel supplies its own (u, beta and the Newton step in LDS, history in HBM).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -13,10 +19,28 @@ namespace cadnip {
 // compiler-level wave barrier.  Never s_barrier here.
 #define CADNIP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- cross-lane sums on DPP (no LDS round trips) -----------------------------------------------------
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over aligned groups of `width` consecutive lanes (width = 1, 2, 4, 8 or 16; uniform), result in every
+// lane of the group.  Must be called with all 64 lanes active.
+__device__ __forceinline__ double group_sum16(double v, int width) {
+  if (width >= 2) v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  if (width >= 4) v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+  if (width >= 8) v += dpp_f64<0x141>(v);   // row_half_mirror
+  if (width >= 16) v += dpp_f64<0x140>(v);  // row_mirror
   return v;
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v = group_sum16(v, 16);
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 __device__ __forceinline__ int wave_any(int v) { return __any(v); }
 
@@ -34,33 +58,71 @@ struct TranArgs {
   int max_newton, max_order, use_pcnr;
 };
 
+struct StepState {
+  double t, h, hprev, hpp, tn, a0;   // accepted time, step in flight, the two previous steps, t + h, BDF leading coefficient
+  int nhist, ord, k, status, bp, si; // history depth, order, Newton counter, 0 running / 1 done / <0 failed, next breakpoint / save index
+  int c_newton, c_accept, c_reject, c_fail;   // counter increments since load
+};
+
+__device__ inline StepState load_state(const TranArgs& a, int inst) {
+  StepState s;
+  s.t = a.t[inst]; s.h = a.h[inst]; s.hprev = a.hprev[inst]; s.hpp = a.hpp[inst]; s.tn = a.tcur[inst]; s.a0 = a.gamma[inst];
+  s.nhist = a.nhist[inst]; s.ord = a.order[inst]; s.k = a.k[inst]; s.status = a.status[inst]; s.bp = a.bp_idx[inst]; s.si = a.save_idx[inst];
+  s.c_newton = s.c_accept = s.c_reject = s.c_fail = 0;
+  return s;
+}
+__device__ inline void store_state(const TranArgs& a, int inst, int tid, const StepState& s) {
+  if (tid != 0) return;
+  a.t[inst] = s.t; a.h[inst] = s.h; a.hprev[inst] = s.hprev; a.hpp[inst] = s.hpp; a.tcur[inst] = s.tn; a.gamma[inst] = s.a0;
+  a.nhist[inst] = s.nhist; a.order[inst] = s.ord; a.k[inst] = s.k; a.status[inst] = s.status; a.bp_idx[inst] = s.bp; a.save_idx[inst] = s.si;
+  a.active[inst] = s.status == 0 ? 1 : 0;
+  long long* c = a.cnt + (size_t)inst * 4;
+  c[0] += s.c_newton; c[1] += s.c_accept; c[2] += s.c_reject; c[3] += s.c_fail;
+}
+
+// every per-unknown vector in HBM (per-op path)
+struct GlobalVecs {
+  double *u, *du, *up, *beta, *u0, *u1, *u2;
+  const double *delta, *lw;
+  __device__ GlobalVecs(const TranArgs& a, int inst) {
+    const size_t o = (size_t)inst * a.n;
+    u = a.u + o; du = a.du + o; up = a.up + o; beta = a.beta + o; u0 = a.u0 + o; u1 = a.u1 + o; u2 = a.u2 + o; delta = a.delta + o; lw = a.limit_w + o;
+  }
+  __device__ __forceinline__ double get_delta(int i) const { return delta[i]; }
+  __device__ __forceinline__ double get_u(int i) const { return u[i]; }
+  __device__ __forceinline__ void set_u(int i, double v) const { u[i] = v; }
+  __device__ __forceinline__ double get_beta(int i) const { return beta[i]; }
+  __device__ __forceinline__ void set_beta(int i, double v) const { beta[i] = v; }
+  __device__ __forceinline__ void set_du(int i, double v) const { du[i] = v; }
+  __device__ __forceinline__ double get_lw(int i) const { return lw[i]; }
+};
+
 // Set up the step that starts at (t, history) with proposed size h: clip to the next stop,
 // pick order from the available history, extrapolate the predictor, BDF coefficients.
-__device__ inline void prepare_step(const TranArgs& a, int inst, int tid, double t, double h, int nhist, double hprev, double hpp) {
+template <class V>
+__device__ inline void prepare_step(const TranArgs& a, const V& v, StepState& s, int tid, double t, double h, int nhist, double hprev, double hpp) {
   const int n = a.n;
   double tstop = a.t1;
-  int bp = a.bp_idx[inst];
-  if (bp < a.n_break && a.breaks[bp] < tstop) tstop = a.breaks[bp];
+  if (s.bp < a.n_break && a.breaks[s.bp] < tstop) tstop = a.breaks[s.bp];
   double rem = tstop - t, tn;
   if (h >= rem * (1.0 - 1e-9)) { h = rem; tn = tstop; }
   else if (2.0 * h > rem) { h = 0.5 * rem; tn = t + h; }
   else tn = t + h;
-  double* u = a.u + (size_t)inst * n;
-  double* du = a.du + (size_t)inst * n;
-  double* up = a.up + (size_t)inst * n;
-  double* beta = a.beta + (size_t)inst * n;
-  const double* u0 = a.u0 + (size_t)inst * n;
-  const double* u1 = a.u1 + (size_t)inst * n;
-  const double* u2 = a.u2 + (size_t)inst * n;
   int ord;
   double a0;
   if (nhist <= 1) {
     ord = 1; a0 = 1.0 / h;
-    for (int i = tid; i < n; i += 64) { double p = u0[i]; up[i] = p; u[i] = p; double b = -u0[i] / h; beta[i] = b; du[i] = a0 * p + b; }
+    for (int i = tid; i < n; i += 64) { double p = v.u0[i]; v.up[i] = p; v.set_u(i, p); double b = -p / h; v.set_beta(i, b); v.set_du(i, a0 * p + b); }
   } else if (nhist == 2 || a.max_order < 2) {
     ord = 1; a0 = 1.0 / h;
     double w = h / hprev;
-    for (int i = tid; i < n; i += 64) { double p = u0[i] + w * (u0[i] - u1[i]); up[i] = p; u[i] = p; double b = -u0[i] / h; beta[i] = b; du[i] = a0 * p + b; }
+    for (int i = tid; i < n; i += 64) {
+      double x0 = v.u0[i];
+      double p = x0 + w * (x0 - v.u1[i]);
+      v.up[i] = p; v.set_u(i, p);
+      double b = -x0 / h;
+      v.set_beta(i, b); v.set_du(i, a0 * p + b);
+    }
   } else {
     ord = 2;
     double w = h / hprev;
@@ -71,139 +133,126 @@ __device__ inline void prepare_step(const TranArgs& a, int inst, int tid, double
     double L1 = (x - 0.0) * (x - x2) / ((x1 - 0.0) * (x1 - x2));
     double L2 = (x - 0.0) * (x - x1) / ((x2 - 0.0) * (x2 - x1));
     for (int i = tid; i < n; i += 64) {
-      double p = L0 * u0[i] + L1 * u1[i] + L2 * u2[i];
-      up[i] = p; u[i] = p;
-      double b = a1 * u0[i] + a2 * u1[i];
-      beta[i] = b; du[i] = a0 * p + b;
+      double x0 = v.u0[i], xm1 = v.u1[i];
+      double p = L0 * x0 + L1 * xm1 + L2 * v.u2[i];
+      v.up[i] = p; v.set_u(i, p);
+      double b = a1 * x0 + a2 * xm1;
+      v.set_beta(i, b); v.set_du(i, a0 * p + b);
     }
   }
-  if (tid == 0) { a.h[inst] = h; a.order[inst] = ord; a.k[inst] = 0; a.tcur[inst] = tn; a.gamma[inst] = a0; }
+  s.h = h; s.ord = ord; s.k = 0; s.tn = tn; s.a0 = a0;
 }
 
-__device__ inline void save_outputs(const TranArgs& a, int inst, int tid, double told, double tn, const double* unew, const double* u0, const double* u1,
-                             int nhist_before, double hprev) {
-  int si = a.save_idx[inst];
-  double hh = tn - told;
+template <class V>
+__device__ inline void save_outputs(const TranArgs& a, const V& v, StepState& s, int inst, int tid) {
+  const double told = s.t, tn = s.tn, hh = tn - told;
+  int si = s.si;
   while (si < a.n_save && a.save_t[si] <= tn * (1.0 + 1e-15)) {
     double ts = a.save_t[si];
     double* o = a.out + ((size_t)inst * a.n_save + si) * a.n_obs;
-    if (nhist_before >= 2) {   // quadratic through (tn,unew) (told,u0) (told-hprev,u1)
-      double x = ts - told, xa = hh, xc = -hprev;
+    if (s.nhist >= 2) {   // quadratic through (tn,unew) (told,u0) (told-hprev,u1)
+      double x = ts - told, xa = hh, xc = -s.hprev;
       double La = (x - 0.0) * (x - xc) / ((xa - 0.0) * (xa - xc));
       double Lb = (x - xa) * (x - xc) / ((0.0 - xa) * (0.0 - xc));
       double Lc = (x - xa) * (x - 0.0) / ((xc - xa) * (xc - 0.0));
-      for (int j = tid; j < a.n_obs; j += 64) { int i = a.obs[j]; o[j] = La * unew[i] + Lb * u0[i] + Lc * u1[i]; }
+      for (int j = tid; j < a.n_obs; j += 64) { int i = a.obs[j]; o[j] = La * v.get_u(i) + Lb * v.u0[i] + Lc * v.u1[i]; }
     } else {
-      double s = (ts - told) / hh;
-      for (int j = tid; j < a.n_obs; j += 64) { int i = a.obs[j]; o[j] = u0[i] + s * (unew[i] - u0[i]); }
+      double sc = (ts - told) / hh;
+      for (int j = tid; j < a.n_obs; j += 64) { int i = a.obs[j]; double x0 = v.u0[i]; o[j] = x0 + sc * (v.get_u(i) - x0); }
     }
     ++si;
   }
-  if (tid == 0) a.save_idx[inst] = si;
+  s.si = si;
 }
 
-// One Newton update + step controller for sweep instance `inst`, executed by one 64-lane wave.
-__device__ inline void tran_update_body(const TranArgs& a, int inst, int tid) {
+// One Newton update + step controller for one sweep instance, executed by one 64-lane wave.  `bad` is the
+// wave-uniform "linear solve failed" flag of this round.  The caller guarantees s.status == 0.
+template <class V>
+__device__ inline void tran_update_body(const TranArgs& a, const V& v, StepState& s, int inst, int tid, int bad) {
   const int n = a.n;
-  if (a.status[inst] != 0) return;
-  double* u = a.u + (size_t)inst * n;
-  double* du = a.du + (size_t)inst * n;
-  const double* delta = a.delta + (size_t)inst * n;
-  double* u0 = a.u0 + (size_t)inst * n;
-  double* u1 = a.u1 + (size_t)inst * n;
-  double* u2 = a.u2 + (size_t)inst * n;
-  const double* up = a.up + (size_t)inst * n;
-  const double* beta = a.beta + (size_t)inst * n;
-  const double t = a.t[inst], h = a.h[inst], hprev = a.hprev[inst], hpp = a.hpp[inst], tn = a.tcur[inst], a0 = a.gamma[inst];
-  const int nhist = a.nhist[inst], ord = a.order[inst], k = a.k[inst];
-  int bad = (a.flags[inst] & 1);
+  const double h = s.h, hprev = s.hprev, hpp = s.hpp;
   double s1 = 0.0, s2 = 0.0;
   for (int i = tid; i < n; i += 64) {
-    double d = delta[i];
-    double un = u[i] - d;
+    double d = v.get_delta(i);
+    double un = v.get_u(i) - d;
     if (!isfinite(d)) bad = 1;
-    double w = 1.0 / (a.atol[i] + a.reltol * fabs(u0[i]));
+    double x0 = v.u0[i], at = a.atol[i];
+    double w = 1.0 / (at + a.reltol * fabs(x0));
     s1 += (d * w) * (d * w);
-    double e = un - up[i];
-    double w2 = a.emask[i] / (a.atol[i] + a.reltol * fmax(fabs(u0[i]), fabs(un)));
+    double e = un - v.up[i];
+    double w2 = a.emask[i] / (at + a.reltol * fmax(fabs(x0), fabs(un)));
     s2 += (e * w2) * (e * w2);
-    u[i] = un;
+    v.set_u(i, un);
   }
   s1 = wave_sum(s1); s2 = wave_sum(s2);
   bad = wave_any(bad);
   const double dnorm = sqrt(s1 / n);
-  if (tid == 0) { a.cnt[(size_t)inst * 4 + 0] += 1; a.flags[inst] = 0; }
+  s.c_newton += 1;
   const bool conv = !bad && dnorm < a.newton_tol;
   if (conv) {
     double errn = 0.0;
     bool accept = true;
-    if (nhist >= 2 && a.n_err > 0) {
+    const bool tested = s.nhist >= 2 && a.n_err > 0;
+    if (tested) {
       double errc;
-      if (ord == 1) errc = h / (h + hprev);
+      if (s.ord == 1) errc = h / (h + hprev);
       else { double w = h / hprev; errc = ((1.0 + w) * h / (1.0 + 2.0 * w)) / (h + hprev + hpp); }
       errn = errc * sqrt(s2 / a.n_err);
       accept = errn <= 1.0;
     }
     if (accept) {
-      save_outputs(a, inst, tid, t, tn, u, u0, u1, nhist, hprev);
-      for (int i = tid; i < n; i += 64) { double v1 = u1[i], v0 = u0[i]; u2[i] = v1; u1[i] = v0; u0[i] = u[i]; }
-      int bp = a.bp_idx[inst];
-      bool landed = (bp < a.n_break && tn == a.breaks[bp]);
-      int nh_new = nhist + 1 > 3 ? 3 : nhist + 1;
+      CADNIP_WAVE_SYNC();
+      save_outputs(a, v, s, inst, tid);
+      for (int i = tid; i < n; i += 64) { double v1 = v.u1[i], v0 = v.u0[i]; v.u2[i] = v1; v.u1[i] = v0; v.u0[i] = v.get_u(i); }
+      const double tn = s.tn;
+      bool landed = (s.bp < a.n_break && tn == a.breaks[s.bp]);
+      int nh_new = s.nhist + 1 > 3 ? 3 : s.nhist + 1;
       double hnext;
-      if (nhist >= 2 && a.n_err > 0) {
-        double fac = errn > 0.0 ? 0.9 * pow(errn, -1.0 / (ord + 1)) : 2.0;
+      if (tested) {
+        double fac = errn > 0.0 ? 0.9 * pow(errn, -1.0 / (s.ord + 1)) : 2.0;
         fac = fmin(2.0, fmax(0.2, fac));
         hnext = h * fac;
       } else hnext = 2.0 * h;
-      double new_hprev = h, new_hpp = hprev;
-      CADNIP_WAVE_SYNC();
       if (landed) {
-        ++bp;
+        ++s.bp;
         nh_new = 1;
         double tstop = a.t1;
-        if (bp < a.n_break && a.breaks[bp] < tstop) tstop = a.breaks[bp];
+        if (s.bp < a.n_break && a.breaks[s.bp] < tstop) tstop = a.breaks[s.bp];
         hnext = 0.1 * fmin(h, tstop - tn);
       }
       hnext = fmin(hnext, a.hmax);
-      if (tid == 0) {
-        a.t[inst] = tn; a.hprev[inst] = new_hprev; a.hpp[inst] = new_hpp; a.nhist[inst] = nh_new; a.bp_idx[inst] = bp;
-        a.cnt[(size_t)inst * 4 + 1] += 1;
-      }
-      if (tn >= a.t1) {
-        if (tid == 0) { a.status[inst] = 1; a.active[inst] = 0; }
-        return;
-      }
+      s.t = tn; s.hpp = hprev; s.hprev = h; s.nhist = nh_new;
+      s.c_accept += 1;
+      if (tn >= a.t1) { s.status = 1; return; }
       if (hnext < a.hmin) hnext = a.hmin;
       CADNIP_WAVE_SYNC();
-      prepare_step(a, inst, tid, tn, hnext, nh_new, new_hprev, new_hpp);
+      prepare_step(a, v, s, tid, tn, hnext, nh_new, s.hprev, s.hpp);
     } else {
-      double fac = 0.9 * pow(errn, -1.0 / (ord + 1));
+      double fac = 0.9 * pow(errn, -1.0 / (s.ord + 1));
       fac = fmin(0.9, fmax(0.1, fac));
       double hn = h * fac;
-      if (tid == 0) a.cnt[(size_t)inst * 4 + 2] += 1;
-      if (hn < a.hmin) { if (tid == 0) { a.status[inst] = -1; a.active[inst] = 0; } return; }
+      s.c_reject += 1;
+      if (hn < a.hmin) { s.status = -1; return; }
       CADNIP_WAVE_SYNC();
-      prepare_step(a, inst, tid, t, hn, nhist, hprev, hpp);
+      prepare_step(a, v, s, tid, s.t, hn, s.nhist, hprev, hpp);
     }
   } else {
-    if (bad || k + 1 >= a.max_newton) {
+    if (bad || s.k + 1 >= a.max_newton) {
       double hn = 0.25 * h;
-      if (tid == 0) a.cnt[(size_t)inst * 4 + 3] += 1;
-      if (hn < a.hmin) { if (tid == 0) { a.status[inst] = -2; a.active[inst] = 0; } return; }
+      s.c_fail += 1;
+      if (hn < a.hmin) { s.status = -2; return; }
       CADNIP_WAVE_SYNC();
-      prepare_step(a, inst, tid, t, hn, nhist, hprev, hpp);
+      prepare_step(a, v, s, tid, s.t, hn, s.nhist, hprev, hpp);
     } else {
-      if (a.use_pcnr && a.n_limits > 0) {
-        const double* lw = a.limit_w + (size_t)inst * n;
-        for (int i = n - a.n_limits + tid; i < n; i += 64) u[i] = lw[i];
-      }
       CADNIP_WAVE_SYNC();
-      for (int i = tid; i < n; i += 64) du[i] = a0 * u[i] + beta[i];
-      if (tid == 0) a.k[inst] = k + 1;
+      if (a.use_pcnr && a.n_limits > 0)
+        for (int i = n - a.n_limits + tid; i < n; i += 64) v.set_u(i, v.get_lw(i));
+      CADNIP_WAVE_SYNC();
+      const double a0 = s.a0;
+      for (int i = tid; i < n; i += 64) v.set_du(i, a0 * v.get_u(i) + v.get_beta(i));
+      s.k += 1;
     }
   }
 }
-
 
 }  // namespace cadnip
