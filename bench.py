@@ -31,6 +31,9 @@ ABSTOL = dict(vntol=1e-6, iabstol=1e-9, chgtol=1e-6)
 RELTOL = 1e-4
 
 
+PMC_SUMMARY = "r01b_fused_B2048_pmc_summary.json"   # committed rocprofv3 --pmc passes of this kernel at this batch size
+
+
 def algorithmic_bytes(st, B, nnz_lu, rounds=8):
     """Per-launch algorithmic bytes of each hot-path kernel for a batch of B instances
     (SURVEY.md section 8d / DESIGN.md section 5: every array counted once per required read or write)."""
@@ -142,7 +145,7 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel: one extra, event-timed step (not part of `value`) -------
         sim.h.profile(True)
-        one_step()
+        _, _, pstats = one_step()
         prof = sim.h.profile_read()
         sim.h.profile(False)
         ab = algorithmic_bytes(st, B, sim.h.lu_stats()["nnz_lu"])
@@ -154,16 +157,22 @@ def main():
                 "avg_launch_us": round(avg_s * 1e6, 3), "kernels": kernels}
         roof["B_iter_per_instance"] = int(ab["B_iter_per_instance"])
         if name in ab:
-            roof["algorithmic_bytes_per_launch"] = int(ab[name])
-            roof["achieved"] = round(ab[name] / avg_s / 1e9, 3)
+            per_launch = ab[name]
+            if name.startswith("fused"):
+                # a fused launch runs up to 8 Newton rounds of every instance still active: count the iterations actually done
+                per_launch = ab["B_iter_per_instance"] * pstats["newton_iters"] / max(dom[1][1], 1)
+                roof["newton_iters_per_launch"] = round(pstats["newton_iters"] / max(dom[1][1], 1), 1)
+            roof["algorithmic_bytes_per_launch"] = int(per_launch)
+            roof["achieved"] = round(per_launch / avg_s / 1e9, 3)
             roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 5)
         # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950
         # correction calibrated with k_calib_copy_f64; profiles/*_pmc_summary.json) -- only when it is the same kernel / batch
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_fused2_B2048_pmc_summary.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_SUMMARY)))
             if name in pmc and pmc[name]["instances"] == B:
                 roof["traffic"] = pmc[name]["hbm_bytes_per_launch"]
-                roof["traffic_source"] = "profiles/r01_fused2_B2048_pmc_summary.json"
+                roof["traffic_source"] = "profiles/" + PMC_SUMMARY
+                roof["wave_time_shares"] = {k: round(v, 3) for k, v in pmc[name].get("wave_time_shares", {}).items()}
         except (OSError, ValueError, KeyError):
             pass
         if "stamp_mos1" in prof and name != "stamp_mos1":

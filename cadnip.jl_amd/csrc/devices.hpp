@@ -259,9 +259,9 @@ DUAL_BIN(+, a.v + b.v, a.p[i] + b.p[i])
 DUAL_BIN(-, a.v - b.v, a.p[i] - b.p[i])
 DUAL_BIN(*, a.v * b.v, a.p[i] * b.v + b.p[i] * a.v)
 template <int N> __device__ __forceinline__ Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) {
-  Dual<N> r; double q = a.v / b.v; r.v = q;
+  Dual<N> r; double ib = 1.0 / b.v, q = a.v * ib; r.v = q;   // one division per dual quotient
 #pragma unroll
-  for (int i = 0; i < N; ++i) r.p[i] = (a.p[i] - q * b.p[i]) / b.v;
+  for (int i = 0; i < N; ++i) r.p[i] = (a.p[i] - q * b.p[i]) * ib;
   return r;
 }
 template <int N> __device__ __forceinline__ Dual<N> operator+(const Dual<N>& a, double b) { Dual<N> r = a; r.v += b; return r; }
@@ -282,15 +282,16 @@ template <int N> __device__ __forceinline__ Dual<N> operator*(const Dual<N>& a, 
 }
 template <int N> __device__ __forceinline__ Dual<N> operator*(double b, const Dual<N>& a) { return a * b; }
 template <int N> __device__ __forceinline__ Dual<N> operator/(const Dual<N>& a, double b) {
-  Dual<N> r; r.v = a.v / b;
+  Dual<N> r; double ib = 1.0 / b; r.v = a.v * ib;
 #pragma unroll
-  for (int i = 0; i < N; ++i) r.p[i] = a.p[i] / b;
+  for (int i = 0; i < N; ++i) r.p[i] = a.p[i] * ib;
   return r;
 }
 template <int N> __device__ __forceinline__ Dual<N> operator/(double b, const Dual<N>& a) {
-  Dual<N> r; double q = b / a.v; r.v = q;
+  Dual<N> r; double ia = 1.0 / a.v, q = b * ia; r.v = q;
+  const double f = -q * ia;
 #pragma unroll
-  for (int i = 0; i < N; ++i) r.p[i] = (-q / a.v) * a.p[i];
+  for (int i = 0; i < N; ++i) r.p[i] = f * a.p[i];
   return r;
 }
 template <int N> __device__ __forceinline__ Dual<N> dsqrt(const Dual<N>& a) {
@@ -306,9 +307,9 @@ template <int N> __device__ __forceinline__ Dual<N> dexp(const Dual<N>& a) {
   return r;
 }
 template <int N> __device__ __forceinline__ Dual<N> dlog(const Dual<N>& a) {
-  Dual<N> r; r.v = log(a.v);
+  Dual<N> r; r.v = log(a.v); const double ia = 1.0 / a.v;
 #pragma unroll
-  for (int i = 0; i < N; ++i) r.p[i] = a.p[i] / a.v;
+  for (int i = 0; i < N; ++i) r.p[i] = a.p[i] * ia;
   return r;
 }
 

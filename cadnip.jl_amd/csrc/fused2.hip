@@ -129,8 +129,17 @@ __device__ __forceinline__ void dispatch_stamp2(int type, const LdsCtx& d, const
 
 // controller vector policy of the fused kernel (see tran_ctrl.hpp): u, beta and the Newton step in LDS
 struct FusedVecs {
+  static constexpr int KPF = 4;   // per-lane elements of u0 / up / atol / emask fetched ahead of the update (covers n <= 256)
   double *us, *betas; const double* W; const u16* qinv;
   double *up, *u0, *u1, *u2; const double* lw;
+  double pf_u0[KPF], pf_up[KPF], pf_at[KPF], pf_em[KPF];
+  __device__ __forceinline__ void prefetch(const TranArgs& a, int lane) {
+#pragma unroll
+    for (int k = 0; k < KPF; ++k) {
+      const int i = lane + 64 * k < a.n ? lane + 64 * k : 0;   // clamped, no select on the loaded value: nothing waits here
+      pf_u0[k] = u0[i]; pf_up[k] = up[i]; pf_at[k] = a.atol[i]; pf_em[k] = a.emask[i];
+    }
+  }
   __device__ __forceinline__ double get_delta(int i) const { return W[qinv[i]]; }
   __device__ __forceinline__ double get_u(int i) const { return us[i]; }
   __device__ __forceinline__ void set_u(int i, double v) const { us[i] = v; }
@@ -176,7 +185,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
   double* betag = a.beta + (size_t)inst * n;
   double* lw = a.limit_w + (size_t)inst * n;
   const size_t vo = (size_t)inst * n;
-  const FusedVecs vec{us, betas, W, qinv, a.up + vo, a.u0 + vo, a.u1 + vo, a.u2 + vo, lw};
+  FusedVecs vec{us, betas, W, qinv, a.up + vo, a.u0 + vo, a.u1 + vo, a.u2 + vo, lw};
   for (int i = lane; i < n; i += 64) { us[i] = ug[i]; betas[i] = betag[i]; }
 #ifdef CADNIP_TRACE
   if (blockIdx.x == 0 && tid == 0) g_trace_last = clock64();
@@ -190,8 +199,25 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
     const double tcur = st.tn, a0 = st.a0;
     for (int bi = 0; bi < f.n_blk; ++bi) {
       const F2Block& B = f.blk[bi];
-      for (int dev = lane; dev < B.count; dev += 64) {
-        LdsCtx d{nodes + B.nodes_off, B.ipar, B.par + (size_t)inst * B.n_par * B.count, f.wave, B.count, dev, tcur, 1, 0};
+      const double* par = B.par + (size_t)inst * B.n_par * B.count;
+      int dev0 = lane;
+      if (B.type == CADNIP_DEV_CAPACITOR || B.type == CADNIP_DEV_RESISTOR) {
+        // one-parameter two-terminal devices: the HBM loads of up to four device passes are issued together
+        double pv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int dev = lane + 64 * q; pv[q] = par[dev < B.count ? dev : 0]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int dev = lane + 64 * q;
+          if (dev < B.count) {
+            AccumOut s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev};
+            if (B.type == CADNIP_DEV_CAPACITOR) capacitance4(s, 0, pv[q]); else conductance4(s, 0, pv[q]);
+          }
+        }
+        dev0 = lane + 256;
+      }
+      for (int dev = dev0; dev < B.count; dev += 64) {
+        LdsCtx d{nodes + B.nodes_off, B.ipar, par, f.wave, B.count, dev, tcur, 1, 0};
         AccumOut s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev};
         dispatch_stamp2(B.type, d, us, s, lw);
       }
@@ -199,16 +225,17 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
     }
     CADNIP_WAVE_SYNC();
     CADNIP_TRACE_POINT(1);
-    // ---- r += J*u  (J still unfactored in the LU array), four entries per lane in flight
-    for (int p0 = 0; p0 < f.nnz; p0 += 256) {
-      u64 d[4];
-      double v[4];
+    vec.prefetch(a, lane);   // HBM operands of the update: in flight while the linear solve runs out of LDS
+    // ---- r += J*u  (J still unfactored in the LU array), eight entries per lane in flight
+    for (int p0 = 0; p0 < f.nnz; p0 += 512) {
+      u64 d[8];
+      double v[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { const int p = p0 + q * 64 + lane; d[q] = nzd[p < f.nnz ? p : f.nnz - 1]; }
+      for (int q = 0; q < 8; ++q) { const int p = p0 + q * 64 + lane; d[q] = nzd[p < f.nnz ? p : f.nnz - 1]; }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = W[(unsigned)d[q] & 0xFFFFu] * us[(unsigned)(d[q] >> 32) & 0xFFFFu];
+      for (int q = 0; q < 8; ++q) v[q] = W[(unsigned)d[q] & 0xFFFFu] * us[(unsigned)(d[q] >> 32) & 0xFFFFu];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 8; ++q) {
         const bool ok = p0 + q * 64 + lane < f.nnz;
         atomicAdd(&W[ok ? ((unsigned)(d[q] >> 16) & 0xFFFFu) : (unsigned)(f.nnz_lu + n + lane)], ok ? v[q] : 0.0);
       }
@@ -251,6 +278,8 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
         __builtin_amdgcn_sched_barrier(0);
         // (3) dot product share, group sum, finish
         double part = nt > 0 ? av * bv : 0.0;
+        const unsigned T0n = term[(unsigned)(Dn >> 32) & 0xFFFFu];   // next pass's first term: its read overlaps the arithmetic below
+        __builtin_amdgcn_sched_barrier(0);
         if (multi)
           for (int t = 1; t < nt; ++t) { const unsigned tm = term[t0 + t]; part = fma(W[tm & 0xFFFFu], W[tm >> 16], part); }
         if (maxlg >= 1) { const double o = dpp_f64<0xB1>(part); part += lg >= 1 ? o : 0.0; }
@@ -261,10 +290,9 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
         if (hasdiv) {
           if (dg == NOPOS) piv = 1.0;
           else if (act && (piv == 0.0 || !isfinite(piv))) bad = 1;
-          acc = acc / piv;
+          acc = fast_div(acc, piv);
         }
         if (leader) W[pos] = acc;
-        const unsigned T0n = term[(unsigned)(Dn >> 32) & 0xFFFFu];
         if (fence) CADNIP_WAVE_SYNC();
         D = Dn; T0 = T0n; pd = pd1; pd1 = pd2;
       }

@@ -14,10 +14,12 @@ namespace cadnip {
 
 // Wave-level synchronisation: every controller function is executed by ONE 64-lane wave per sweep
 // instance (several instances may share a workgroup in the fused kernel, each taking its own control
-// path), so ordering is needed only among the lanes of the calling wave: a workgroup-scope fence
-// (waits for the wave's outstanding LDS / global traffic; a workgroup's waves share one L1) plus a
-// compiler-level wave barrier.  Never s_barrier here.
-#define CADNIP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+// path), so ordering is needed only among the lanes of the calling wave.  A wave's LDS operations, and
+// its vector-memory operations, execute in issue order, so data written by one lane is seen by a later
+// read of another lane of the same wave without waiting: a wavefront-scope fence (no instructions, it
+// only stops the compiler from moving memory operations across it) plus a wave barrier is enough.
+// Never s_barrier here.
+#define CADNIP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 // ---- cross-lane sums on DPP (no LDS round trips) -----------------------------------------------------
 template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
@@ -43,6 +45,16 @@ __device__ __forceinline__ double wave_sum(double v) {
   return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 __device__ __forceinline__ int wave_any(int v) { return __any(v); }
+
+// a / b for finite, non-zero, normal-range b (pivots, positive error weights): v_rcp_f64 + two Newton steps +
+// one residual correction, about 1 ulp; none of IEEE division's range scaling.
+__device__ __forceinline__ double fast_div(double a, double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  const double q = a * r;
+  return fma(fma(-b, q, a), r, q);
+}
 
 // ------------------------------------------------------------------------------------------
 // transient controller
@@ -82,6 +94,7 @@ __device__ inline void store_state(const TranArgs& a, int inst, int tid, const S
 
 // every per-unknown vector in HBM (per-op path)
 struct GlobalVecs {
+  static constexpr int KPF = 0;
   double *u, *du, *up, *beta, *u0, *u1, *u2;
   const double *delta, *lw;
   __device__ GlobalVecs(const TranArgs& a, int inst) {
@@ -172,18 +185,23 @@ __device__ inline void tran_update_body(const TranArgs& a, const V& v, StepState
   const int n = a.n;
   const double h = s.h, hprev = s.hprev, hpp = s.hpp;
   double s1 = 0.0, s2 = 0.0;
-  for (int i = tid; i < n; i += 64) {
+  auto elem = [&](int i, double x0, double at, double upv, double em) {
     double d = v.get_delta(i);
     double un = v.get_u(i) - d;
     if (!isfinite(d)) bad = 1;
-    double x0 = v.u0[i], at = a.atol[i];
-    double w = 1.0 / (at + a.reltol * fabs(x0));
+    double w = fast_div(1.0, at + a.reltol * fabs(x0));
     s1 += (d * w) * (d * w);
-    double e = un - v.up[i];
-    double w2 = a.emask[i] / (at + a.reltol * fmax(fabs(x0), fabs(un)));
+    double e = un - upv;
+    double w2 = fast_div(em, at + a.reltol * fmax(fabs(x0), fabs(un)));
     s2 += (e * w2) * (e * w2);
     v.set_u(i, un);
+  };
+  // the first V::KPF elements of each lane may have been prefetched into registers by the policy
+  if constexpr (V::KPF > 0) {
+#pragma unroll
+    for (int k = 0; k < V::KPF; ++k) { const int i = tid + 64 * k; if (i < n) elem(i, v.pf_u0[k], v.pf_at[k], v.pf_up[k], v.pf_em[k]); }
   }
+  for (int i = tid + 64 * V::KPF; i < n; i += 64) elem(i, v.u0[i], a.atol[i], v.up[i], a.emask[i]);
   s1 = wave_sum(s1); s2 = wave_sum(s2);
   bad = wave_any(bad);
   const double dnorm = sqrt(s1 / n);
