@@ -286,7 +286,7 @@ class Handle:
         st = RunStatsC()
         o = TranOptsC(t0, t1, reltol, _dp(at), _dp(em), h0, hmin, hmax, max_newton, max_order, int(use_pcnr), newton_tol,
                       br.size, _dp(br) if br.size else None, sv.size, _dp(sv) if sv.size else None,
-                      ob.size, _ip(ob) if ob.size else None, max_iterations, int(fused))  # fused: 0 per-op, 1 fused v1, 2 fused v2
+                      ob.size, _ip(ob) if ob.size else None, max_iterations, int(fused))  # fused: 0 = one kernel per op, non-zero = fused Newton kernel
         rc = self.lib.cadnip_tran_run(self.h, C.byref(o), _dp(out), per.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(st))
         if rc not in (OK, NOCONV):
             _check(rc, "cadnip_tran_run")

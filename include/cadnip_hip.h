@@ -183,7 +183,7 @@ typedef struct {
   int32_t n_save;  const double* save_t; /* sorted output times (saveat) */
   int32_t n_obs;   const int32_t* obs;   /* unknown indices to record; n_obs = 0 -> all n */
   int64_t max_iterations;   /* safety bound on lock-step Newton launches */
-  int32_t fused;            /* 1 = fused per-instance Newton kernel, 0 = one kernel per op */
+  int32_t fused;            /* non-zero = fused per-instance Newton kernel (csrc/fused2.hip), 0 = one kernel per op */
 } CadnipTranOpts;
 
 typedef struct {

@@ -24,7 +24,7 @@ def _port_run(circ, params, temp, u0, ts, obs, vscale):
     return out, stats
 
 
-@pytest.mark.parametrize("fused", [0, 1, 2])
+@pytest.mark.parametrize("fused", [0, 1])
 @pytest.mark.parametrize("points", [[{}], [{"vdd": 4.5, "temp": -40.0}, {"vdd": 5.5, "temp": 125.0}, {"vdd": 4.5, "temp": 125.0}, {"vdd": 5.2, "temp": 60.0}]])
 def test_dff_transient_matches_port(points, fused):
     circ = bm.dff_circuit()
@@ -45,9 +45,9 @@ def test_dff_transient_matches_port(points, fused):
         # the port starts from the GPU's DC state: the flop's DC point is not unique (see test_gpu_drivers)
         ref, rst = _port_run(circ, params, pt.get("temp", 27.0), u0[i], ts, obs, sim.vscale())
         assert rst["status"] == 1
-        # identical decision path: same Newton / step / reject counts.  (fused = 2 accumulates stamps in a different
-        # order -- rounding-level differences in the residual -- so its counts are only required to be close.)
-        if fused != 2:
+        # identical decision path: same Newton / step / reject counts.  (The fused kernel accumulates stamps in a
+        # different order -- rounding-level differences in the residual -- so its counts are only required to be close.)
+        if fused == 0:
             assert (per[i, 0], per[i, 1], per[i, 2]) == (rst["newton_iters"], rst["accepted"], rst["rejected"]), (pt, per[i], rst)
         else:
             assert abs(per[i, 0] - rst["newton_iters"]) <= 0.01 * rst["newton_iters"], (pt, per[i], rst)
