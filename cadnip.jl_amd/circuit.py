@@ -71,6 +71,15 @@ class Circuit:
     def F(self, name, op, on, ip, in_, gain):
         return self._add("F", name, (op, on, ip, in_), {"gain": gain})
 
+    def BV(self, name, p, n, expr, scale=1.0):
+        """BehavioralVoltageSource (devices.jl:1003-1029, stamp :1079-1102): V(p,n) = scale * expr, expr a string
+        over V(node) / V(a,b) / t (bsource.py).  Stamped as a fixed source at the current iterate."""
+        return self._add("BV", name, (p, n), {"expr": str(expr), "scale": scale})
+
+    def BI(self, name, p, n, expr, scale=1.0):
+        """BehavioralCurrentSource (devices.jl:1032-1058, stamp :1118-1131): scale * expr flows into p."""
+        return self._add("BI", name, (p, n), {"expr": str(expr), "scale": scale})
+
     def D(self, name, p, n, Is=1e-14, Vt=0.026, n_=1.0, limit=True):
         return self._add("D", name, (p, n), {"Is": Is, "Vt": Vt, "n": n_, "limit": bool(limit)})
 

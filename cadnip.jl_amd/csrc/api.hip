@@ -86,6 +86,28 @@ int cadnip_create(const CadnipStructure* s, int32_t n_instances, int32_t device,
         if (kind < 0 || kind > 3 || off < 0 || off + need > s->n_wave_data || (kind == CADNIP_WAVE_PWL && len < 1)) { cadnip_destroy(h); return CADNIP_BADARG; }
       }
     }
+    if (b.type == CADNIP_DEV_BVSOURCE || b.type == CADNIP_DEV_BISOURCE) {
+      // walk every postfix program once: operands in range, stack depth within bounds, exactly one result
+      if (b.n_ipar < 2 || b.n_par < 1) { cadnip_destroy(h); return CADNIP_BADARG; }
+      for (int d = 0; d < b.count; ++d) {
+        int off = sb.ipar[d], len = sb.ipar[b.count + d], sp = 0;
+        bool ok = off >= 0 && len > 0 && off + len <= s->n_wave_data;
+        for (int i = 0; ok && i < len;) {
+          int op = (int)s->wave_data[off + i++];
+          if (op == CADNIP_BOP_CONST) { ok = i < len; ++i; ++sp; }
+          else if (op == CADNIP_BOP_V) {
+            ok = i + 1 < len;
+            if (ok) { double a = s->wave_data[off + i], c = s->wave_data[off + i + 1]; ok = a >= -1 && a < s->n && c >= -1 && c < s->n; }
+            i += 2; ++sp;
+          } else if (op == CADNIP_BOP_TIME) ++sp;
+          else if (op >= CADNIP_BOP_ADD && op <= CADNIP_BOP_MAX) { ok = sp >= 2; --sp; }
+          else if (op >= CADNIP_BOP_NEG && op <= CADNIP_BOP_COS) ok = sp >= 1;
+          else ok = false;
+          if (sp > CADNIP_BSRC_MAX_STACK) ok = false;
+        }
+        if (!ok || sp != 1) { cadnip_destroy(h); return CADNIP_BADARG; }
+      }
+    }
     if (b.type == CADNIP_DEV_MOS1 && (b.n_par != CADNIP_MOS1_NPAR || b.n_nodes != 14)) { cadnip_destroy(h); return CADNIP_BADARG; }
     b.h_nodes.assign(sb.nodes, sb.nodes + (size_t)b.n_nodes * b.count);
     TRY(dev_upload(&b.d_nodes, sb.nodes, (size_t)b.n_nodes * b.count));
@@ -189,6 +211,30 @@ int cadnip_jacobian(CadnipHandle* h, const double* gamma_host, double* J_ref_nz_
   if (J_ref_nz_host) TRY(readback_ref_order(h, h->d_J, J_ref_nz_host));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return CADNIP_OK;
+}
+
+// ODE form (src/mna/solve.jl:2241-2276): du = b - G u,  J = -G
+int cadnip_ode_rhs(CadnipHandle* h, const double* u_host, const double* t_host, double* du_host) {
+  if (!h || !du_host) return CADNIP_BADARG;
+  size_t B = h->B, n = h->n;
+  if (u_host) { TRY(upload_state(h, u_host, t_host)); TRY(launch_rebuild(h)); }
+  HIP_TRY(hipMemsetAsync(h->d_du, 0, B * n * sizeof(double), h->stream));
+  TRY(launch_residual(h, h->d_du));                       // G u - b
+  TRY(launch_negate(h, h->d_resid, (long)(B * n)));
+  HIP_TRY(hipMemcpyAsync(du_host, h->d_resid, B * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (size_t k = 0; k < B * n; ++k) if (du_host[k] - du_host[k] != 0.0) return CADNIP_NONFINITE;
+  return CADNIP_OK;
+}
+
+int cadnip_ode_jacobian(CadnipHandle* h, const double* u_host, const double* t_host, double* J_ref_nz_host) {
+  if (!h || !J_ref_nz_host) return CADNIP_BADARG;
+  if (u_host) { TRY(upload_state(h, u_host, t_host)); TRY(launch_rebuild(h)); }
+  HIP_TRY(hipMemsetAsync(h->d_gamma, 0, (size_t)h->B * sizeof(double), h->stream));
+  TRY(launch_jacobian(h));                                // G + 0*C
+  TRY(launch_negate(h, h->d_J, (long)((size_t)h->B * h->nnz)));
+  TRY(readback_ref_order(h, h->d_J, J_ref_nz_host));
+  return check_nonfinite(h);
 }
 
 int cadnip_get_GCb(CadnipHandle* h, double* G_ref_nz, double* C_ref_nz, double* b, double* limit_w) {

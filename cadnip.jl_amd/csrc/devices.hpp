@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include "../../include/cadnip_hip.h"
 
 namespace cadnip {
 
@@ -162,6 +163,59 @@ template <class Ctx, class Out> __device__ inline void stamp_ccvs(const Ctx& d, 
 template <class Ctx, class Out> __device__ inline void stamp_cccs(const Ctx& d, const double*, const Out& s, double*) {
   double a = par_of(d, 0);
   s.G(0, 1.0); s.G(1, -1.0); s.G(2, 1.0); s.G(3, -1.0); s.G(4, -a); s.G(5, a);
+}
+
+// ------------------------------------------------------------------------------------------
+// behavioural sources (devices.jl:1079-1131): value_fn(get_voltage) as a postfix program (include/cadnip_hip.h)
+// ------------------------------------------------------------------------------------------
+template <class Ctx> __device__ inline double bsrc_value(const Ctx& d, const double* u) {
+  const int off = d.ipar[0 * d.count + d.dev], len = d.ipar[1 * d.count + d.dev];
+  const double* pr = d.wave + off;
+  double st[CADNIP_BSRC_MAX_STACK];
+  int sp = 0;
+  for (int i = 0; i < len;) {
+    const int op = (int)pr[i++];
+    if (op == CADNIP_BOP_CONST) st[sp++] = pr[i++];
+    else if (op == CADNIP_BOP_V) { const int a = (int)pr[i], b = (int)pr[i + 1]; i += 2; st[sp++] = volt(u, a) - volt(u, b); }
+    else if (op == CADNIP_BOP_TIME) st[sp++] = d.t;
+    else if (op < CADNIP_BOP_NEG) {
+      const double y = st[--sp], x = st[sp - 1];
+      double r;
+      switch (op) {
+        case CADNIP_BOP_ADD: r = x + y; break;
+        case CADNIP_BOP_SUB: r = x - y; break;
+        case CADNIP_BOP_MUL: r = x * y; break;
+        case CADNIP_BOP_DIV: r = x / y; break;
+        case CADNIP_BOP_POW: r = pow(x, y); break;
+        case CADNIP_BOP_MIN: r = fmin(x, y); break;
+        default: r = fmax(x, y); break;
+      }
+      st[sp - 1] = r;
+    } else {
+      const double x = st[sp - 1];
+      double r;
+      switch (op) {
+        case CADNIP_BOP_NEG: r = -x; break;
+        case CADNIP_BOP_EXP: r = exp(x); break;
+        case CADNIP_BOP_LOG: r = log(x); break;
+        case CADNIP_BOP_SQRT: r = sqrt(x); break;
+        case CADNIP_BOP_ABS: r = fabs(x); break;
+        case CADNIP_BOP_TANH: r = tanh(x); break;
+        case CADNIP_BOP_SIN: r = sin(x); break;
+        default: r = cos(x); break;
+      }
+      st[sp - 1] = r;
+    }
+  }
+  return par_of(d, 0) * st[0];
+}
+template <class Ctx, class Out> __device__ inline void stamp_bvsource(const Ctx& d, const double* u, const Out& s, double*) {
+  branch4(s);
+  s.B(0, bsrc_value(d, u));
+}
+template <class Ctx, class Out> __device__ inline void stamp_bisource(const Ctx& d, const double* u, const Out& s, double*) {
+  const double i = bsrc_value(d, u);
+  s.B(0, i); s.B(1, -i);
 }
 
 // ------------------------------------------------------------------------------------------

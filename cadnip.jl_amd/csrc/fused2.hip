@@ -124,6 +124,8 @@ __device__ __forceinline__ void dispatch_stamp2(int type, const LdsCtx& d, const
     case CADNIP_DEV_DIODECAP: stamp_diodecap(d, u, s, lw); break;
     case CADNIP_DEV_SIMPLEMOS: stamp_simplemos(d, u, s, lw); break;
     case CADNIP_DEV_MOS1: stamp_mos1(d, u, s, lw); break;
+    case CADNIP_DEV_BVSOURCE: stamp_bvsource(d, u, s, lw); break;
+    case CADNIP_DEV_BISOURCE: stamp_bisource(d, u, s, lw); break;
   }
 }
 

@@ -109,6 +109,7 @@ int launch_solve(CadnipHandle* h, const double* d_rhs, double* d_x);
 int launch_factor_solve(CadnipHandle* h, bool fuse_jacobian, const double* d_rhs, double* d_x);
 int upload_lu(CadnipHandle* h);
 int launch_calib_copy(CadnipHandle* h, long n, int reps);
+int launch_negate(CadnipHandle* h, double* d_x, long n);
 struct TranArgs;                                                          // tran_ctrl.hpp
 int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds); // fused2.hip
 struct ProfScope {

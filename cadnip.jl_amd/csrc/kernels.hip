@@ -6,6 +6,7 @@
 // in LDS.  All per-instance arrays are instance-major; inside an instance the device SoA
 // layout makes consecutive lanes touch consecutive addresses.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdio.h>
 #include <string.h>
 #include "devices.hpp"
@@ -70,6 +71,8 @@ __global__ void __launch_bounds__(256) k_stamp(StampArgs a) {
   else if (TYPE == CADNIP_DEV_DIODECAP) stamp_diodecap(d, u, s, lw);
   else if (TYPE == CADNIP_DEV_SIMPLEMOS) stamp_simplemos(d, u, s, lw);
   else if (TYPE == CADNIP_DEV_MOS1) stamp_mos1(d, u, s, lw);
+  else if (TYPE == CADNIP_DEV_BVSOURCE) stamp_bvsource(d, u, s, lw);
+  else if (TYPE == CADNIP_DEV_BISOURCE) stamp_bisource(d, u, s, lw);
 }
 
 template <int TYPE>
@@ -236,6 +239,16 @@ __global__ void __launch_bounds__(256) k_calib_copy_f64(const double* __restrict
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) b[i] = a[i];
 }
 
+__global__ void k_negate(double* x, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = -x[i];
+}
+int launch_negate(CadnipHandle* h, double* d_x, long n) {
+  if (n <= 0) return CADNIP_OK;
+  hipLaunchKernelGGL(k_negate, dim3((unsigned)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, h->stream, d_x, n);
+  HIP_TRY(hipGetLastError());
+  return CADNIP_OK;
+}
+
 int launch_calib_copy(CadnipHandle* h, long n, int reps) {
   double *a = nullptr, *b = nullptr;
   HIP_TRY(hipMalloc((void**)&a, n * sizeof(double)));
@@ -262,7 +275,7 @@ int launch_rebuild(CadnipHandle* h) {
       CASE(CADNIP_DEV_ISOURCE, "stamp_isource") CASE(CADNIP_DEV_VCVS, "stamp_vcvs") CASE(CADNIP_DEV_VCCS, "stamp_vccs")
       CASE(CADNIP_DEV_CCVS, "stamp_ccvs") CASE(CADNIP_DEV_CCCS, "stamp_cccs") CASE(CADNIP_DEV_DIODE, "stamp_diode")
       CASE(CADNIP_DEV_DIODECAP, "stamp_diodecap") CASE(CADNIP_DEV_SIMPLEMOS, "stamp_simplemos")
-      CASE(CADNIP_DEV_MOS1, "stamp_mos1")
+      CASE(CADNIP_DEV_MOS1, "stamp_mos1") CASE(CADNIP_DEV_BVSOURCE, "stamp_bvsource") CASE(CADNIP_DEV_BISOURCE, "stamp_bisource")
 #undef CASE
       default: return CADNIP_BADARG;
     }

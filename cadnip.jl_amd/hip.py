@@ -20,7 +20,7 @@ STATUS_NAMES = {0: "CADNIP_OK", 1: "CADNIP_BADARG", 2: "CADNIP_SINGULAR", 3: "CA
 # every symbol declared in include/cadnip_hip.h
 EXPORTS = [
     "cadnip_create", "cadnip_destroy", "cadnip_set_params", "cadnip_set_spec", "cadnip_set_initjct",
-    "cadnip_rebuild", "cadnip_residual", "cadnip_jacobian", "cadnip_get_GCb", "cadnip_analyze",
+    "cadnip_rebuild", "cadnip_residual", "cadnip_jacobian", "cadnip_ode_rhs", "cadnip_ode_jacobian", "cadnip_get_GCb", "cadnip_analyze",
     "cadnip_analyze_values", "cadnip_factor", "cadnip_solve", "cadnip_lu_stats", "cadnip_dc_run",
     "cadnip_tran_run", "cadnip_tran_state", "cadnip_dev_ptr", "cadnip_stream", "cadnip_set_u", "cadnip_get_u", "cadnip_get_flags",
     "cadnip_sync", "cadnip_debug_copy", "cadnip_profile_enable", "cadnip_profile_read", "cadnip_version",
@@ -224,6 +224,20 @@ class Handle:
         g = self._b(gamma)
         J = np.empty((self.B, self.st.nnz)) if readback else None
         _check(self.lib.cadnip_jacobian(self.h, _dp(g), _dp(J) if readback else None), "cadnip_jacobian")
+        return J
+
+    def ode_rhs(self, u, t=0.0):
+        """rhs!(du, u, p, t) of the ODE form (src/mna/solve.jl:2241-2248): restamp, du = b - G*u."""
+        ua, ta = self._bn(u), self._b(t)
+        du = np.empty((self.B, self.st.n))
+        _check(self.lib.cadnip_ode_rhs(self.h, _dp(ua), _dp(ta), _dp(du)), "cadnip_ode_rhs")
+        return du
+
+    def ode_jacobian(self, u, t=0.0):
+        """jac!(J, u, p, t) of the ODE form (src/mna/solve.jl:2251-2276): restamp, J = -G in the reference's nz order."""
+        ua, ta = self._bn(u), self._b(t)
+        J = np.empty((self.B, self.st.nnz))
+        _check(self.lib.cadnip_ode_jacobian(self.h, _dp(ua), _dp(ta), _dp(J)), "cadnip_ode_jacobian")
         return J
 
     def get_GCb(self):

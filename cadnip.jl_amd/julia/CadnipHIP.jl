@@ -122,6 +122,16 @@ function fast_jacobian!(J::SparseMatrixCSC, du::AbstractVector, u::AbstractVecto
     return nothing
 end
 
+# ---- ODE form (src/mna/solve.jl:2241-2276): mass matrix cs.C, rhs! = b - G*u, jac! = -G ------------------------
+function ode_rhs!(du::AbstractVector, u::AbstractVector, ws::GPUEvalWorkspace, t::Real)
+    ws.tbuf[1] = Float64(t)
+    check(ccall((:cadnip_ode_rhs, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), ws.handle, u, ws.tbuf, du), "cadnip_ode_rhs")
+end
+function ode_jac!(J::SparseMatrixCSC, u::AbstractVector, ws::GPUEvalWorkspace, t::Real)
+    ws.tbuf[1] = Float64(t)
+    check(ccall((:cadnip_ode_jacobian, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), ws.handle, u, ws.tbuf, nonzeros(J)), "cadnip_ode_jacobian")
+end
+
 # ---- KLU-shaped linear solver: symbolic once, numeric refactor per Jacobian, solve per iteration -----------
 analyze!(ws::GPUEvalWorkspace) = check(ccall((:cadnip_analyze, LIB), Cint, (Ptr{Cvoid}, Int32), ws.handle, 0), "cadnip_analyze")
 factor!(ws::GPUEvalWorkspace) = check(ccall((:cadnip_factor, LIB), Cint, (Ptr{Cvoid},), ws.handle), "cadnip_factor")

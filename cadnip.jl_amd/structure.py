@@ -22,12 +22,13 @@ from typing import Dict, List
 
 import numpy as np
 
+from . import bsource
 from . import mos1_params as m1
 from .circuit import Circuit, resolve
 
 # device type ids: keep in sync with CadnipDeviceType in include/cadnip_hip.h
 TYPE_ID = {"R": 0, "C": 1, "L": 2, "V": 3, "I": 4, "E": 5, "G": 6, "H": 7, "F": 8,
-           "D": 9, "DCAP": 10, "SMOS": 11, "MOS1": 12}
+           "D": 9, "DCAP": 10, "SMOS": 11, "MOS1": 12, "BV": 13, "BI": 14}
 WAVE_DC, WAVE_PWL, WAVE_PULSE, WAVE_SIN = 0, 1, 2, 3
 
 # (n_local_nodes, n_g, n_c, n_b, n_par, n_ipar) per type
@@ -37,6 +38,7 @@ SHAPE = {
     "G": (4, 4, 0, 0, 1, 0), "H": (6, 9, 0, 0, 1, 0), "F": (5, 6, 0, 0, 1, 0),
     "D": (3, 7, 0, 2, 3, 1), "DCAP": (2, 4, 4, 2, 5, 0), "SMOS": (3, 6, 8, 2, 5, 0),
     "MOS1": (14, 76, 28, 10, m1.NPAR, 1),
+    "BV": (3, 4, 0, 1, 1, 2), "BI": (2, 0, 0, 2, 1, 2),
 }
 
 GND = -1
@@ -157,6 +159,8 @@ PROGRAMS = {
     "F": [("G", 0, 2, 4), ("G", 1, 3, 4), ("G", 2, 4, 2), ("G", 3, 4, 3), ("G", 4, 0, 4), ("G", 5, 1, 4)],
     "D": [("G", 0, 2, 2), ("G", 1, 2, 0), ("G", 2, 2, 1)] + _prog_conductance(0, 1, 3) + [("b", 0, 0, None), ("b", 1, 1, None)],
     "DCAP": _prog_conductance(0, 1) + [("b", 0, 0, None), ("b", 1, 1, None)] + _prog_cap(0, 1),
+    "BV": _branch_pairs(0, 1, 2) + [("b", 0, 2, None)],       # devices.jl:1079-1102
+    "BI": [("b", 0, 0, None), ("b", 1, 1, None)],             # devices.jl:1118-1131
     "SMOS": [("G", 0, 0, 0), ("G", 1, 0, 1), ("G", 2, 0, 2), ("G", 3, 2, 0), ("G", 4, 2, 1), ("G", 5, 2, 2),
              ("b", 0, 0, None), ("b", 1, 2, None)] + _prog_cap(1, 2, 0) + _prog_cap(1, 0, 4),
 }
@@ -356,6 +360,7 @@ def discover(circuit: Circuit, params: Dict[str, float]) -> Structure:
     order: List[str] = []
     breakpoints = []
     vdep = detect_mos1_vdep(circuit, params)
+    pending_bsrc = []   # (ipar list, tokens): programs are encoded once every node has its index
     recs = []   # (stream, seq-order implicit, type, dev_in_block, local_slot, row_typed, col_typed)
     for di, dev in enumerate(circuit.devices):
         ty = dev.type
@@ -365,7 +370,7 @@ def discover(circuit: Circuit, params: Dict[str, float]) -> Structure:
         nodes = [A.node(nm) for nm in dev.nodes]
         ipar = []
         prog = PROGRAMS.get(ty)
-        if ty in ("L", "V"):
+        if ty in ("L", "V", "BV"):
             nodes.append(A.current("I_" + dev.name))
         elif ty == "E":
             nodes.append(A.current("I_" + dev.name))
@@ -379,6 +384,13 @@ def discover(circuit: Circuit, params: Dict[str, float]) -> Structure:
             bp = wave_breakpoints(dev.wave)
             if bp is not None:
                 breakpoints.append(bp)
+        if ty in ("BV", "BI"):
+            ipar = [0, 0]
+            tokens = bsource.compile_expr(dev.params["expr"])
+            for tok in tokens:           # get_voltage(name) touches its nodes in evaluation order
+                if tok[0] == "v":
+                    A.node(tok[1]); A.node(tok[2])
+            pending_bsrc.append((ipar, tokens))
         if ty == "D":
             lim = bool(dev.params.get("limit", True))
             ipar = [1 if lim else 0]
@@ -416,6 +428,14 @@ def discover(circuit: Circuit, params: Dict[str, float]) -> Structure:
             recs.append((stream, ty, d_in_block, k, row, col))
     n_nodes, n_cur, n_q, n_l = len(A.node_names), len(A.current_names), len(A.charge_names), len(A.limit_names)
     n = n_nodes + n_cur + n_q + n_l
+    for ipar, tokens in pending_bsrc:
+        def node_index(nm):
+            if nm in ("0", "gnd", "gnd!"):
+                return -1
+            return A.node_idx[nm]      # KeyError: the expression names a node no device connects to
+        prog = bsource.encode(tokens, node_index)
+        ipar[0], ipar[1] = len(wave_data), len(prog)
+        wave_data.extend(prog)
     # blocks
     blocks: List[Block] = []
     gb = cb = bb = 0
@@ -507,6 +527,8 @@ def pack_params(st: Structure, circuit: Circuit, params: Dict[str, np.ndarray], 
             elif ty in ("V", "I"):
                 arr[:, 0, j] = g("dc")
                 arr[:, 1, j] = g("scale")
+            elif ty in ("BV", "BI"):
+                arr[:, 0, j] = g("scale")
             elif ty in ("E", "F"):
                 arr[:, 0, j] = g("gain")
             elif ty == "G":

@@ -58,12 +58,28 @@ typedef enum {
   CADNIP_DEV_MOS1 = 12,      /* models/VADistillerModels.jl/va/mos1.va via vasim.jl:3319-3521;
                                 nodes d,g,s,b,d_int,s_int,lim[4],q[4]; par: CADNIP_MOS1_NPAR derived
                                 (setup+temp hoisted, mos1.va:695-897) values; ipar: flags       */
-  CADNIP_DEV_NTYPES = 13
+  CADNIP_DEV_BVSOURCE = 13,  /* devices.jl:1079-1102 BehavioralVoltageSource  nodes p,n,I   par: scale   ipar: program off,len */
+  CADNIP_DEV_BISOURCE = 14,  /* devices.jl:1118-1131 BehavioralCurrentSource  nodes p,n     par: scale   ipar: program off,len */
+  CADNIP_DEV_NTYPES = 15
 } CadnipDeviceType;
 
 #define CADNIP_MOS1_NPAR 36
 
 typedef enum { CADNIP_WAVE_DC = 0, CADNIP_WAVE_PWL = 1, CADNIP_WAVE_PULSE = 2, CADNIP_WAVE_SIN = 3 } CadnipWaveKind;
+
+/* Behavioural sources: `value_fn(get_voltage)` of the reference is a Julia closure; across the C ABI it is a
+ * postfix program of doubles stored in wave_data[off .. off+len): opcode [operands].  The value is evaluated at the
+ * current iterate and stamped as a fixed source (no Jacobian entries), exactly as devices.jl:1079-1131 does. */
+typedef enum CadnipBsrcOp {
+  CADNIP_BOP_CONST = 0,   /* + value                     */
+  CADNIP_BOP_V = 1,       /* + unknown index p, n (-1 = ground): pushes u[p] - u[n] */
+  CADNIP_BOP_TIME = 2,
+  CADNIP_BOP_ADD = 10, CADNIP_BOP_SUB = 11, CADNIP_BOP_MUL = 12, CADNIP_BOP_DIV = 13, CADNIP_BOP_POW = 14,
+  CADNIP_BOP_MIN = 15, CADNIP_BOP_MAX = 16,
+  CADNIP_BOP_NEG = 20, CADNIP_BOP_EXP = 21, CADNIP_BOP_LOG = 22, CADNIP_BOP_SQRT = 23, CADNIP_BOP_ABS = 24,
+  CADNIP_BOP_TANH = 25, CADNIP_BOP_SIN = 26, CADNIP_BOP_COS = 27
+} CadnipBsrcOp;
+#define CADNIP_BSRC_MAX_STACK 16
 
 /* One block per device type.  Node / ipar arrays are shared by all instances (structure);
  * parameters are per instance and set with cadnip_set_params.
@@ -135,6 +151,13 @@ int cadnip_set_initjct(CadnipHandle* h, int32_t on);            /* DirectStampCo
 int cadnip_rebuild(CadnipHandle* h, const double* u_host, const double* t_host);
 int cadnip_residual(CadnipHandle* h, const double* du_host, const double* u_host, double* resid_host);
 int cadnip_jacobian(CadnipHandle* h, const double* gamma_host, double* J_ref_nz_host /* may be NULL */);
+/* ODE-form callbacks (mass matrix C constant; used by the reference with FBDF / QNDF / Rodas):
+ *   cadnip_ode_rhs      == rhs!(du, u, p, t):  restamp at (u, t), du = b - G u      src/mna/solve.jl:2241-2248
+ *   cadnip_ode_jacobian == jac!(J, u, p, t):   restamp at (u, t), J = -G            src/mna/solve.jl:2251-2276
+ * J comes back in the reference's CSC nzval order (jac_prototype = -cs.G, solve.jl:2285); the mass matrix is
+ * cadnip_get_GCb's C.  u_host NULL = reuse the stamps of the last rebuild. */
+int cadnip_ode_rhs(CadnipHandle* h, const double* u_host, const double* t_host, double* du_host);
+int cadnip_ode_jacobian(CadnipHandle* h, const double* u_host, const double* t_host, double* J_ref_nz_host);
 /* parity / debug read-back in the reference's CSC nzval order (any pointer may be NULL) */
 int cadnip_get_GCb(CadnipHandle* h, double* G_ref_nz, double* C_ref_nz, double* b, double* limit_w);
 

@@ -89,6 +89,32 @@ double source(const Port& P, const Block& B, int d, double t) {
   return scale * v;
 }
 
+// behavioural source value: postfix program in the wave table (include/cadnip_hip.h CadnipBsrcOp), devices.jl:1079-1131
+double bsrc(const Port& P, const Block& B, int d, const double* u, double t) {
+  const double* pr = P.wave.data() + B.ipar[d];
+  const int len = B.ipar[B.count + d];
+  std::vector<double> st;
+  for (int i = 0; i < len;) {
+    int op = (int)pr[i++];
+    if (op == 0) st.push_back(pr[i++]);
+    else if (op == 1) { int a = (int)pr[i], b = (int)pr[i + 1]; i += 2; st.push_back((a < 0 ? 0.0 : u[a]) - (b < 0 ? 0.0 : u[b])); }
+    else if (op == 2) st.push_back(t);
+    else if (op < 20) {
+      double y = st.back(); st.pop_back();
+      double x = st.back(), r;
+      switch (op) { case 10: r = x + y; break; case 11: r = x - y; break; case 12: r = x * y; break; case 13: r = x / y; break;
+                    case 14: r = std::pow(x, y); break; case 15: r = std::fmin(x, y); break; default: r = std::fmax(x, y); }
+      st.back() = r;
+    } else {
+      double x = st.back(), r;
+      switch (op) { case 20: r = -x; break; case 21: r = std::exp(x); break; case 22: r = std::log(x); break; case 23: r = std::sqrt(x); break;
+                    case 24: r = std::fabs(x); break; case 25: r = std::tanh(x); break; case 26: r = std::sin(x); break; default: r = std::cos(x); }
+      st.back() = r;
+    }
+  }
+  return B.par[d] * st[0];
+}
+
 // ---- 3-wide dual (JacobianTag dual restricted to vgs, vds, vbs) ---------------------------------
 struct D3 { double v, a, b, c; };
 inline D3 mk(double v) { return {v, 0, 0, 0}; }
@@ -323,6 +349,8 @@ void rebuild(Port& P, const double* u, double t) {
           cap4(0, par(4)); cap4(4, par(3));
         } break;
         case 12: stamp_mos1(P, B, d, u, s); break;
+        case 13: br4(); s.B(0, bsrc(P, B, d, u, t)); break;
+        case 14: { double i = bsrc(P, B, d, u, t); s.B(0, i); s.B(1, -i); } break;
       }
     }
   }

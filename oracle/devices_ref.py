@@ -174,6 +174,23 @@ def stamp_isource(ctx, p, n, dc, tran=None, t=0.0, mode="dcop", name="I"):  # de
     ctx.stamp_b(n, -i)
 
 
+def stamp_behavioral_vsource(ctx, p, n, value_fn, name="B", get_voltage=None):  # devices.jl:1079-1102
+    I = ctx.alloc_current("I_" + name)
+    ctx.stamp_G(p, I, 1.0)
+    ctx.stamp_G(n, I, -1.0)
+    ctx.stamp_G(I, p, 1.0)
+    ctx.stamp_G(I, n, -1.0)
+    v = value_fn(get_voltage) if get_voltage is not None else 0.0
+    ctx.stamp_b(I, v)
+    return I
+
+
+def stamp_behavioral_isource(ctx, p, n, value_fn, get_voltage=None):  # devices.jl:1118-1131
+    i = value_fn(get_voltage) if get_voltage is not None else 0.0
+    ctx.stamp_b(p, i)
+    ctx.stamp_b(n, -i)
+
+
 def stamp_vcvs(ctx, op, on, ip, in_, gain, name="E"):  # devices.jl:760-775
     I = ctx.alloc_current("I_" + name)
     ctx.stamp_G(op, I, 1.0)

@@ -595,6 +595,16 @@ def fast_jacobian(J_nz, du, u, ws, gamma, t):  # precompile.jl:568-585
     J_nz[:] = cs.G.data + gamma * cs.C.data
 
 
+def ode_rhs(du, u, ws, t):  # rhs! of the ODE form, solve.jl:2241-2248: du = b - G*u
+    fast_rebuild(ws, u, t)
+    du[:] = ws.dctx.b - ws.structure.G @ np.asarray(u)
+
+
+def ode_jac(J_nz, u, ws, t):  # jac! of the ODE form, solve.jl:2251-2276: J = -G (mass matrix cs.C constant)
+    fast_rebuild(ws, u, t)
+    J_nz[:] = -ws.structure.G.data
+
+
 # =============================================================================
 # Structure detection                                      solve.jl:1793-1822
 # =============================================================================

@@ -49,6 +49,23 @@ def make_wave(spec, scale=1.0):
     return w if scale == 1.0 else _Scaled(w, scale)
 
 
+def behavioral_fn(expr, t, scale=1.0):
+    """``value_fn(get_voltage)`` of a behavioural source (devices.jl:1003-1058) from expression text: evaluated by the
+    Python interpreter itself, node names quoted first (the product compiles the same text to a postfix program)."""
+    import math
+    import re
+    src = re.sub(r"\b[vV]\(([^()]*)\)", lambda m: "V(%s)" % ", ".join(repr(a.strip()) for a in m.group(1).split(",")), expr)
+    src = src.replace("^", "**")
+    code = compile(src, "<bsource>", "eval")
+
+    def value_fn(get_voltage):
+        ns = {"V": lambda a, b="0": get_voltage(a) - get_voltage(b), "t": t, "time": t, "exp": math.exp, "log": math.log,
+              "sqrt": math.sqrt, "abs": abs, "tanh": math.tanh, "sin": math.sin, "cos": math.cos, "min": min, "max": max,
+              "pow": math.pow, "__builtins__": {}}
+        return scale * eval(code, ns)
+    return value_fn
+
+
 def make_builder(devices):
     def builder(params, spec, t, x=ZERO_VECTOR, ctx=None):
         if ctx is None:
@@ -78,6 +95,15 @@ def make_builder(devices):
                 D.stamp_ccvs(ctx, nodes[0], nodes[1], nodes[2], nodes[3], g("rm"), name)
             elif ty == "F":
                 D.stamp_cccs(ctx, nodes[0], nodes[1], nodes[2], nodes[3], g("gain"), name)
+            elif ty in ("BV", "BI"):
+                def get_voltage(nm, ctx=ctx, x=x):
+                    i = ctx.get_node(nm)
+                    return 0.0 if i == 0 else float(x[i - 1])
+                fn = behavioral_fn(dev["expr"], t, g("scale", 1.0))
+                if ty == "BV":
+                    D.stamp_behavioral_vsource(ctx, nodes[0], nodes[1], fn, name, get_voltage)
+                else:
+                    D.stamp_behavioral_isource(ctx, nodes[0], nodes[1], fn, get_voltage)
             elif ty == "D":
                 D.stamp_diode(ctx, nodes[0], nodes[1], x, g("Is", 1e-14), g("Vt", 0.026), g("n", 1.0),
                               bool(dev.get("limit", True)), name)

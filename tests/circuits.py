@@ -104,9 +104,23 @@ def mos1_rd():
     return c
 
 
+def behavioral():
+    """Behavioural V and I sources (devices.jl:1003-1131) over node voltages and time; the current source is a
+    contraction (|d i/d v| R < 1) so the fixed-source Newton iteration of the reference converges."""
+    c = cj.Circuit()
+    c.V("v1", "in", "0", dc=2.0)
+    c.R("r1", "in", "x", 1.0)
+    c.BI("b1", "x", "0", "-0.1*V(x)**2")
+    c.BV("b2", "y", "0", "2*V(x) + tanh(V(in, x)) - min(V(x), 0.5)*exp(-abs(V(in))) + 1e3*t", scale=0.5)
+    c.R("r2", "y", "z", 1e3)
+    c.BI("b3", "z", "0", "sqrt(abs(V(y))) * cos(V(x)) / max(1, V(in)^2)")
+    c.R("r3", "z", "0", 2e3)
+    return c
+
+
 ALL_STAMP = {
     "divider": (divider, {}), "linear_zoo": (linear_zoo, {}), "diode": (diode_rectifier, {}),
     "diode_nolimit": (lambda: diode_rectifier(False), {}), "diode_chain": (diode_chain, {}),
-    "nonlinear_zoo": (nonlinear_zoo, {}), "inverter": (inverter_dc, {}), "mos1_rd": (mos1_rd, {}),
+    "nonlinear_zoo": (nonlinear_zoo, {}), "behavioral": (behavioral, {}), "inverter": (inverter_dc, {}), "mos1_rd": (mos1_rd, {}),
     "dff": (bm.dff_circuit, {"vdd": 5.0}), "dff_meyer": (lambda: bm.dff_circuit(meyer=True), {"vdd": 5.0}),
 }

@@ -60,6 +60,21 @@ def test_dc_matches_oracle_pcnr(name):
         assert ito <= 10
 
 
+def test_behavioral_sources_dc_fixed_point():
+    """devices.jl:1079-1131: behavioural sources enter b only, so the DC Newton loop is the fixed-point iteration
+    x <- 2 - 0.1 x^2 (closed-form limit) -- GPU, oracle and closed form agree; a time-dependent term is live in tran mode."""
+    circ = tc.behavioral()
+    uo, oko, ito = _oracle_dc(circ, {}, "dcop")
+    sim = api.BatchSimulator(api.MNACircuit(circ, {}, api.MNASpec(mode="dcop")))
+    u, conv, st = sim.dc(abstol=1e-10, maxiters=200)
+    assert oko and conv[0]
+    xs = (-1.0 + np.sqrt(1.8)) / 0.2
+    assert abs(u[0, sim.st.index_of("x")] - xs) < 1e-9
+    assert np.max(np.abs(u[0] - uo) / np.maximum(np.abs(uo), 1.0)) < 1e-9
+    assert st["newton_iters"] == ito
+    sim.close()
+
+
 def test_dc_sweep_divider_grid():
     # test/sweep.jl:299-312: I = -1/(R1+R2) over a 20x20 grid
     c = cj.Circuit()

@@ -67,6 +67,12 @@ def test_rebuild_matches_oracle(name, mode, t):
         assert _close(r, rr, scale=max(np.max(np.abs(cs.G.data)) * max(1.0, np.max(np.abs(u))), np.max(np.abs(rr)), 1e-30))
         J = h.jacobian(1e7)[0]
         assert _close(J, cs.G.data + 1e7 * cs.C.data)
+        # ODE form (solve.jl:2241-2276): du = b - G u, J = -G, each with its own restamp
+        du_ref, J_ref = np.empty(st.n), np.empty(st.nnz)
+        M.ode_rhs(du_ref, u, ws, t)
+        M.ode_jac(J_ref, u, ws, t)
+        assert _close(h.ode_rhs(u, t)[0], du_ref, scale=max(np.max(np.abs(cs.G.data)) * max(1.0, np.max(np.abs(u))), np.max(np.abs(du_ref)), 1e-30))
+        assert _close(h.ode_jacobian(u, t)[0], J_ref, scale=max(np.max(np.abs(cs.G.data)), 1e-30))
     h.close()
 
 

@@ -60,7 +60,7 @@ def test_dff_sizes():
     assert st.n == 18 + 7 + 90 + 120 and st.mos1_vdep == (False, True, True, True)
 
 
-@pytest.mark.parametrize("name", ["linear_zoo", "nonlinear_zoo", "inverter", "mos1_rd", "dff", "dff_meyer"])
+@pytest.mark.parametrize("name", ["linear_zoo", "nonlinear_zoo", "behavioral", "inverter", "mos1_rd", "dff", "dff_meyer"])
 def test_cpu_port_stamps_match_literal_oracle(name):
     """The compiled port (Dual<3>, hoisted setup/temp) vs the literal Python restatement (width-14 duals,
     per-call setup/temp): G, C, b, limit_w at random operating points, several temperatures."""
@@ -103,6 +103,32 @@ def test_cpu_port_dc_matches_literal_oracle(name):
     assert ok and oko and it == ito
     assert np.max(np.abs(u - uo) / np.maximum(np.abs(uo), 1.0)) < 1e-9
     port.close()
+
+
+def test_behavioral_sources_fixed_point():
+    """Behavioural sources are stamped as fixed sources at the current iterate (devices.jl:1079-1131: b only, no
+    Jacobian), so Newton on them is the fixed-point iteration x <- 2 - 0.1 x^2; its limit is the closed form
+    x* = (-1 + sqrt(1.8)) / 0.2.  Literal oracle (plain Newton loop, solve.jl:542-578) and the C++ port agree."""
+    circ = tc.behavioral()
+    b = make_builder(circ.to_dicts({}))
+    spec = M.MNASpec(mode="dcop")
+    ctx = M.build_with_detection(b, {}, spec)
+    cs = M.compile_structure(b, {}, spec, ctx=ctx)
+    ws = M.create_workspace(cs, ctx=ctx)
+    uo, oko, ito = M.dc_newton_plain(cs, ws, np.zeros(cs.n), abstol=1e-10, maxiters=200)
+    xs = (-1.0 + np.sqrt(1.8)) / 0.2
+    assert oko and abs(uo[cs.node_names.index("x")] - xs) < 1e-9
+    y = 0.5 * (2 * xs + np.tanh(2.0 - xs) - min(xs, 0.5) * np.exp(-2.0))
+    assert abs(uo[cs.node_names.index("y")] - y) < 1e-9
+    st, port = make_port(circ, {}, 27.0, "dcop")
+    analyze_port(st, port, 5.0)
+    u, ok, it = port.dc(abstol=1e-10, maxiters=200)
+    assert ok and np.max(np.abs(u - uo)) < 1e-9
+    port.close()
+    # the expression compiler rejects what the stamp kernels cannot interpret
+    for bad in ("V(x) if 1 else 2", "foo(V(x))", "x + 1", "V(a, b, c)"):
+        with pytest.raises((ValueError, SyntaxError)):
+            cj.bsource.compile_expr(bad)
 
 
 def test_cpu_port_rc_charge_analytic():
