@@ -154,6 +154,18 @@ int cadnip_set_params(CadnipHandle* h, int32_t block, const double* par_host) {
   auto& b = h->blocks[block];
   HIP_TRY(hipMemcpyAsync(b.d_par, par_host, (size_t)h->B * b.n_par * b.count * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (b.type == CADNIP_DEV_MOS1) {
+    // the fused kernel's two-lanes-per-MOSFET stamp (devices.hpp: stamp_mos1_pair) applies when no instance has series
+    // resistances (gd, gs) or a Meyer gate charge (OxideCap): parameter rows 30, 31 and 8 of the derived card
+    bool plain = true;
+    for (size_t i = 0; i < (size_t)h->B && plain; ++i) {
+      const double* p = par_host + i * b.n_par * b.count;
+      for (int d = 0; d < b.count; ++d)
+        if (p[(size_t)CADNIP_MOS1_PAR_GD * b.count + d] != 0.0 || p[(size_t)CADNIP_MOS1_PAR_GS * b.count + d] != 0.0 ||
+            p[(size_t)CADNIP_MOS1_PAR_OXCAP * b.count + d] != 0.0) { plain = false; break; }
+    }
+    b.mos1_plain = plain;
+  }
   return CADNIP_OK;
 }
 

@@ -35,6 +35,14 @@ __shared__ unsigned long long g_trace_last;
 #define CADNIP_TRACE_POINT(id) do {} while (0)
 #endif
 
+// swap a double between lanes 2j and 2j+1 (DPP quad_perm [1,0,3,2]); all lanes of the wave must be active
+__device__ __forceinline__ double dpp_pair_swap(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
 // NodeT: int in HBM (per-op kernels) or int16 in LDS (fused kernel); -1 = ground either way
 template <class NodeT> struct DevCtxT {
   const NodeT* __restrict__ nodes; // [n_nodes][count]
@@ -62,6 +70,10 @@ struct SlotOut {
   template <int N> __device__ __forceinline__ void Gv(int k0, const double (&v)[N]) const {
 #pragma unroll
     for (int i = 0; i < N; ++i) G(k0 + i, v[i]);
+  }
+  template <int N> __device__ __forceinline__ void Gk(const int (&k)[N], const double (&v)[N]) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) G(k[i], v[i]);
   }
   template <int N> __device__ __forceinline__ void Cv(int k0, const double (&v)[N]) const {
 #pragma unroll
@@ -382,6 +394,7 @@ template <int N> __device__ __forceinline__ Dual<N> dlog(const Dual<N>& a) {
 enum { M1_TYPE = 0, M1_VT, M1_TPHI, M1_TVBI, M1_TVTO, M1_GAMMA, M1_LAMBDA, M1_BETA, M1_OXCAP, M1_SSATCUR, M1_DSATCUR,
        M1_SVCRIT, M1_DVCRIT, M1_CBS, M1_CBSSW, M1_CBD, M1_CBDSW, M1_TBULKPOT, M1_TDEPCAP, M1_F2S, M1_F3S, M1_F4S,
        M1_F2D, M1_F3D, M1_F4D, M1_MJ, M1_MJSW, M1_CGSOV, M1_CGDOV, M1_CGBOV, M1_GD, M1_GS, M1_MFACTOR, M1_GMIN };
+static_assert(M1_OXCAP == 8 && M1_GD == 30 && M1_GS == 31, "keep CADNIP_MOS1_PAR_* (internal.hpp) in step");
 
 __device__ inline double m1_fetlim(double vnew, double vold, double vto) {   // DEVfetlim mos1.va:542-605
   double vlimited = vnew;
@@ -480,16 +493,10 @@ __device__ inline D3 m1_qdep(const D3& v, double Cb, double Cbsw, double tBulkPo
   return D3(0.0);
 }
 
-template <class Ctx, class Out> __device__ inline void stamp_mos1(const Ctx& d, const double* u, const Out& s, double* limit_w_base) {
-  const double CS = CADNIP_CHARGE_SCALE;
-  int nd = node_of(d, 0), ng = node_of(d, 1), ns = node_of(d, 2), nb = node_of(d, 3), ndi = node_of(d, 4), nsi = node_of(d, 5);
-  int l0 = node_of(d, 6), l1 = node_of(d, 7), l2 = node_of(d, 8), l3 = node_of(d, 9);
-  double Vd = volt(u, nd), Vg = volt(u, ng), Vs = volt(u, ns), Vb = volt(u, nb), Vdi = volt(u, ndi), Vsi = volt(u, nsi);
-  double type = par_of(d, M1_TYPE), vt = par_of(d, M1_VT), tPhi = par_of(d, M1_TPHI), tVbi = par_of(d, M1_TVBI);
-  double gamma = par_of(d, M1_GAMMA), lambda = par_of(d, M1_LAMBDA), Beta = par_of(d, M1_BETA), OxideCap = par_of(d, M1_OXCAP);
-  double mf = par_of(d, M1_MFACTOR), gmin_m = par_of(d, M1_GMIN) / mf;
-  CADNIP_TRACE_POINT(20);
-  // ---- limiting (mos1.va:919-980), on values
+// $limit sites of the load section (mos1.va:919-980): limited branch voltages w = (vgs, vds, vbs, vbd), sign-adjusted
+template <class Ctx>
+__device__ inline void m1_limit(const Ctx& d, const double* u, double type, double vt, double tPhi, double tVbi, double gamma, double Vg, double Vb,
+                                double Vdi, double Vsi, int l0, int l1, int l2, int l3, double& w_gs, double& w_ds, double& w_bs, double& w_bd) {
   double o_vgs = type * u[l0], o_vds = type * u[l1], o_vbs = type * u[l2], o_vbd = type * u[l3];
   int omode = o_vds >= 0 ? 1 : -1;
   double osel = omode == 1 ? o_vbs : o_vbd, osarg;
@@ -512,7 +519,48 @@ template <class Ctx, class Out> __device__ inline void stamp_mos1(const Ctx& d, 
   if (vds >= 0) { vbs = m1_pnjlim(vbs, o_vbs, vt, par_of(d, M1_SVCRIT)); vbd = vbs - vds; }
   else { vbd = m1_pnjlim(vbd, o_vbd, vt, par_of(d, M1_DVCRIT)); vbs = vbd + vds; }
   if (d.initjct) { vbs = -1; vgs = type * par_of(d, M1_TVTO); vds = 0; vbd = vbs - vds; }   // mos1.va:969-974
-  double w_gs = type * vgs, w_ds = type * vds, w_bs = type * vbs, w_bd = type * vbd;
+  w_gs = type * vgs; w_ds = type * vds; w_bs = type * vbs; w_bd = type * vbd;
+}
+
+// junction current of one bulk diode (mos1.va:983-998)
+__device__ inline D3 m1_junction(const D3& v, double vt, double gmin_m, double isat) {
+  if (v.v <= -3 * vt) return gmin_m * v - isat;
+  D3 x = v / vt;
+  D3 e = dexp(709.0 < x.v ? D3(709.0) : x);
+  return isat * (e - 1.0) + gmin_m * v;
+}
+
+// threshold, saturation voltage and drain current (mos1.va:1000-1040)
+__device__ inline void m1_channel(const D3& a, const D3& b, const D3& c, const D3& dvbd, const D3& dvgd, double tPhi, double tVbi, double type,
+                                  double gamma, double lambda, double Beta, int& mode, D3& dvon, D3& vdsat, D3& cdrain) {
+  mode = b.v >= 0 ? 1 : -1;
+  D3 sel = mode == 1 ? c : dvbd, sarg;
+  if (sel.v <= 0) sarg = dsqrt(tPhi - sel);
+  else { double s0 = sqrt(tPhi); sarg = s0 - sel / (s0 + s0); if (0 > sarg.v) sarg = D3(0.0); }
+  dvon = tVbi * type + gamma * sarg;
+  D3 vgst = (mode == 1 ? a : dvgd) - dvon;
+  vdsat = vgst.v > 0 ? vgst : D3(0.0);
+  if (vgst.v <= 0) cdrain = D3(0.0);
+  else {
+    D3 vdsm = b * (double)mode;
+    D3 betap = Beta * (1.0 + lambda * vdsm);
+    if (vgst.v <= vdsm.v) cdrain = betap * vgst * vgst * 0.5;
+    else cdrain = betap * vdsm * (vgst - 0.5 * vdsm);
+  }
+}
+
+template <class Ctx, class Out> __device__ inline void stamp_mos1(const Ctx& d, const double* u, const Out& s, double* limit_w_base) {
+  const double CS = CADNIP_CHARGE_SCALE;
+  int nd = node_of(d, 0), ng = node_of(d, 1), ns = node_of(d, 2), nb = node_of(d, 3), ndi = node_of(d, 4), nsi = node_of(d, 5);
+  int l0 = node_of(d, 6), l1 = node_of(d, 7), l2 = node_of(d, 8), l3 = node_of(d, 9);
+  double Vd = volt(u, nd), Vg = volt(u, ng), Vs = volt(u, ns), Vb = volt(u, nb), Vdi = volt(u, ndi), Vsi = volt(u, nsi);
+  double type = par_of(d, M1_TYPE), vt = par_of(d, M1_VT), tPhi = par_of(d, M1_TPHI), tVbi = par_of(d, M1_TVBI);
+  double gamma = par_of(d, M1_GAMMA), lambda = par_of(d, M1_LAMBDA), Beta = par_of(d, M1_BETA), OxideCap = par_of(d, M1_OXCAP);
+  double mf = par_of(d, M1_MFACTOR), gmin_m = par_of(d, M1_GMIN) / mf;
+  CADNIP_TRACE_POINT(20);
+  // ---- limiting (mos1.va:919-980), on values
+  double w_gs, w_ds, w_bs, w_bd;
+  m1_limit(d, u, type, vt, tPhi, tVbi, gamma, Vg, Vb, Vdi, Vsi, l0, l1, l2, l3, w_gs, w_ds, w_bs, w_bd);
   limit_w_base[l0] = w_gs; limit_w_base[l1] = w_ds; limit_w_base[l2] = w_bs; limit_w_base[l3] = w_bd;
   CADNIP_TRACE_POINT(21);
   // g_lim rows (vasim.jl:3134-3136)
@@ -524,27 +572,12 @@ template <class Ctx, class Out> __device__ inline void stamp_mos1(const Ctx& d, 
   // ---- evaluation on pass-through duals anchored at w
   D3 a = D3::seed(type * w_gs, 0), b = D3::seed(type * w_ds, 1), c = D3::seed(type * w_bs, 2);   // load_vgs, load_vds, load_vbs
   D3 dvbd = c - b, dvgd = a - b, dvgb = a - c;
-  D3 cbs, cbd;                                           // junction currents mos1.va:983-998
-  if (c.v <= -3 * vt) cbs = gmin_m * c - par_of(d, M1_SSATCUR);
-  else { D3 x = c / vt; D3 e = dexp(709.0 < x.v ? D3(709.0) : x); cbs = par_of(d, M1_SSATCUR) * (e - 1.0) + gmin_m * c; }
-  if (dvbd.v <= -3 * vt) cbd = gmin_m * dvbd - par_of(d, M1_DSATCUR);
-  else { D3 x = dvbd / vt; D3 e = dexp(709.0 < x.v ? D3(709.0) : x); cbd = par_of(d, M1_DSATCUR) * (e - 1.0) + gmin_m * dvbd; }
+  D3 cbs = m1_junction(c, vt, gmin_m, par_of(d, M1_SSATCUR));       // junction currents mos1.va:983-998
+  D3 cbd = m1_junction(dvbd, vt, gmin_m, par_of(d, M1_DSATCUR));
   CADNIP_TRACE_POINT(23);
-  int mode = b.v >= 0 ? 1 : -1;
-  D3 sel = mode == 1 ? c : dvbd, sarg;
-  if (sel.v <= 0) sarg = dsqrt(tPhi - sel);
-  else { double s0 = sqrt(tPhi); sarg = s0 - sel / (s0 + s0); if (0 > sarg.v) sarg = D3(0.0); }
-  D3 dvon = tVbi * type + gamma * sarg;
-  D3 vgst = (mode == 1 ? a : dvgd) - dvon;
-  D3 vdsat = vgst.v > 0 ? vgst : D3(0.0);
-  D3 cdrain;
-  if (vgst.v <= 0) cdrain = D3(0.0);
-  else {
-    D3 vdsm = b * (double)mode;
-    D3 betap = Beta * (1.0 + lambda * vdsm);
-    if (vgst.v <= vdsm.v) cdrain = betap * vgst * vgst * 0.5;
-    else cdrain = betap * vdsm * (vgst - 0.5 * vdsm);
-  }
+  int mode;
+  D3 dvon, vdsat, cdrain;
+  m1_channel(a, b, c, dvbd, dvgd, tPhi, tVbi, type, gamma, lambda, Beta, mode, dvon, vdsat, cdrain);
   CADNIP_TRACE_POINT(24);
   double ms = OxideCap == 0 ? 0.0 : OxideCap, mu = OxideCap == 0 ? 1.0 : OxideCap;   // meyer_scale / meyer_unscale mos1.va:1042-1048
   D3 qbs = m1_qdep(c, par_of(d, M1_CBS), par_of(d, M1_CBSSW), par_of(d, M1_TBULKPOT), par_of(d, M1_TDEPCAP), par_of(d, M1_MJ),
@@ -625,6 +658,126 @@ template <class Ctx, class Out> __device__ inline void stamp_mos1(const Ctx& d, 
   }
   s.Bv(6, qb);
   (void)vdep;
+  CADNIP_TRACE_POINT(27);
+}
+
+
+// ---- sp_mos1 on a lane PAIR (fused kernel) -----------------------------------------------------------------------
+// The DFF has 30 MOSFETs: one lane per device leaves half of a 64-lane wave idle.  Here lanes 2j and 2j+1 serve
+// device j.  Both lanes evaluate the shared part (limiting, channel current); the source-side lane (side 0) and the
+// drain-side lane (side 1) each evaluate ONE bulk junction and ONE depletion charge -- the same code on different
+// operands -- and swap the results with a DPP quad_perm; then each lane emits half of the stamps, again with one
+// instruction stream: rows (b | d_int), half of row s_int each, charge rows (g | b) and (d_int | s_int), half of the
+// g_lim block each.  Applies when no device of the wave has series resistances (gd = gs = 0, the usual card);
+// otherwise the caller falls back to stamp_mos1 on the even lanes.  `valid` = this lane's device exists.
+__device__ __forceinline__ D3 m1_swap_pair(const D3& x) {
+  D3 r;
+  r.v = dpp_pair_swap(x.v);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) r.p[i] = dpp_pair_swap(x.p[i]);
+  return r;
+}
+__device__ __forceinline__ D3 m1_sel(bool c, const D3& x, const D3& y) {
+  D3 r;
+  r.v = c ? x.v : y.v;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) r.p[i] = c ? x.p[i] : y.p[i];
+  return r;
+}
+
+
+template <class Ctx, class Out>
+__device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out& s, double* limit_w_base, int side, bool valid) {
+  const double CS = CADNIP_CHARGE_SCALE;
+  const bool D = side != 0;
+  int nd = node_of(d, 0), ng = node_of(d, 1), ns = node_of(d, 2), nb = node_of(d, 3), ndi = node_of(d, 4), nsi = node_of(d, 5);
+  int l0 = node_of(d, 6), l1 = node_of(d, 7), l2 = node_of(d, 8), l3 = node_of(d, 9);
+  double Vd = volt(u, nd), Vg = volt(u, ng), Vs = volt(u, ns), Vb = volt(u, nb), Vdi = volt(u, ndi), Vsi = volt(u, nsi);
+  double type = par_of(d, M1_TYPE), vt = par_of(d, M1_VT), tPhi = par_of(d, M1_TPHI), tVbi = par_of(d, M1_TVBI);
+  double gamma = par_of(d, M1_GAMMA), lambda = par_of(d, M1_LAMBDA), Beta = par_of(d, M1_BETA);
+  double mf = par_of(d, M1_MFACTOR), gmin_m = par_of(d, M1_GMIN) / mf;
+  // this lane's junction: source side or drain side
+  const double isat = par_of(d, D ? M1_DSATCUR : M1_SSATCUR);
+  const double Cb = par_of(d, D ? M1_CBD : M1_CBS), Cbsw = par_of(d, D ? M1_CBDSW : M1_CBSSW);
+  const double f2 = par_of(d, D ? M1_F2D : M1_F2S), f3 = par_of(d, D ? M1_F3D : M1_F3S), f4 = par_of(d, D ? M1_F4D : M1_F4S);
+  CADNIP_TRACE_POINT(20);
+  double w_gs, w_ds, w_bs, w_bd;
+  m1_limit(d, u, type, vt, tPhi, tVbi, gamma, Vg, Vb, Vdi, Vsi, l0, l1, l2, l3, w_gs, w_ds, w_bs, w_bd);
+  if (valid && !D) { limit_w_base[l0] = w_gs; limit_w_base[l1] = w_ds; limit_w_base[l2] = w_bs; limit_w_base[l3] = w_bd; }
+  CADNIP_TRACE_POINT(21);
+  {   // g_lim rows (vasim.jl:3134-3136): two limit variables per lane
+    const double gl[6] = {1.0, -1.0, 1.0, 1.0, -1.0, 1.0};
+    s.Gv(6 * side, gl);
+  }
+  CADNIP_TRACE_POINT(22);
+  D3 a = D3::seed(type * w_gs, 0), b = D3::seed(type * w_ds, 1), c = D3::seed(type * w_bs, 2);
+  D3 dvbd = c - b, dvgd = a - b;
+  const D3 vj = m1_sel(D, dvbd, c);
+  const D3 cj = m1_junction(vj, vt, gmin_m, isat), co = m1_swap_pair(cj);
+  const D3 cbs = m1_sel(D, co, cj), cbd = m1_sel(D, cj, co);
+  CADNIP_TRACE_POINT(23);
+  int mode;
+  D3 dvon, vdsat, cdrain;
+  m1_channel(a, b, c, dvbd, dvgd, tPhi, tVbi, type, gamma, lambda, Beta, mode, dvon, vdsat, cdrain);
+  CADNIP_TRACE_POINT(24);
+  const D3 qj = m1_qdep(vj, Cb, Cbsw, par_of(d, M1_TBULKPOT), par_of(d, M1_TDEPCAP), par_of(d, M1_MJ), par_of(d, M1_MJSW), f2, f3, f4);
+  const D3 qo = m1_swap_pair(qj);
+  const D3 qbs = m1_sel(D, qo, qj), qbd = m1_sel(D, qj, qo);
+  CADNIP_TRACE_POINT(25);
+  const D3 cdreq = (mode >= 0 ? type : -type) * cdrain;
+  const double dW_gs = (Vg - Vsi) - w_gs, dW_ds = (Vdi - Vsi) - w_ds, dW_bs = (Vb - Vsi) - w_bs;   // lim_rhs deltas
+  const double Vk[6] = {Vd, Vg, Vs, Vb, Vdi, Vsi};
+  // one current row: G entries of d/dV_g, d/dV_b, d/dV_dint, d/dV_sint (columns 1, 3, 4, 5) and the equivalent current
+  auto row = [&](const D3& I, double (&g)[6], double& Ieq) {
+    const double fa = type * I.p[0], fb = type * I.p[1], fc = type * I.p[2];
+    g[0] = 0.0; g[1] = mf * fa; g[2] = 0.0; g[3] = mf * fc; g[4] = mf * fb; g[5] = mf * -(fa + fb + fc);
+    Ieq = mf * I.v;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Ieq = Ieq + (-g[k] * Vk[k]);
+    Ieq = Ieq + (mf * type * I.p[0]) * dW_gs;
+    Ieq = Ieq + (mf * type * I.p[1]) * dW_ds;
+    Ieq = Ieq + (mf * type * I.p[2]) * dW_bs;
+  };
+  {   // rows I(b) | I(d_int)   (mos1.va:1164-1169)
+    const D3 I3 = type * cbs + type * cbd, I4 = -1.0 * (type * cbd - cdreq);
+    double g[6], Ieq;
+    row(m1_sel(D, I4, I3), g, Ieq);
+    const int br = 3 + side;
+    s.Gv(12 + 6 * br, g);
+    s.B(br, -Ieq);
+  }
+  {   // row I(s_int): both lanes form it, each emits two of its four entries; the source-side lane owns the b entry
+    const D3 I5 = -1.0 * (cdreq + type * cbs);
+    double g[6], Ieq;
+    row(I5, g, Ieq);
+    const int k2[2] = {12 + 30 + (D ? 4 : 1), 12 + 30 + (D ? 5 : 3)};
+    const double v2[2] = {D ? g[4] : g[1], D ? g[5] : g[3]};
+    s.Gk(k2, v2);
+    s.B(5, D ? 0.0 : -Ieq);
+  }
+  CADNIP_TRACE_POINT(26);
+  {   // charge-state columns (vasim.jl:3433-3472): two per lane
+    const double cs2[2] = {1.0 / CS, 1.0 / CS};
+    s.Cv(2 * side, cs2);
+  }
+  // reactive rows: branch charges of g, b, d_int, s_int.  Meyer charges vanish with OxideCap == 0; the pair path is only
+  // taken then (caller), so q_g = 0, q_b = type (qbs + qbd), q_dint = -type qbd, q_sint = -type qbs
+  const D3 q0(0.0), q1 = type * qbs + type * qbd, q2 = -1.0 * (type * qbd), q3 = -1.0 * (type * qbs);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int r = 2 * it + side;
+    const D3 q = it == 0 ? m1_sel(D, q1, q0) : m1_sel(D, q3, q2);
+    const double fa = mf * type * q.p[0], fb = mf * type * q.p[1], fc = mf * type * q.p[2];
+    const double dq[6] = {0.0, fa, 0.0, fc, fb, -(fa + fb + fc)};
+    const double gq[7] = {1.0, -CS * dq[0], -CS * dq[1], -CS * dq[2], -CS * dq[3], -CS * dq[4], -CS * dq[5]};
+    s.Gv(48 + 7 * r, gq);
+    double bc = mf * q.v;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bc -= dq[k] * Vk[k];
+    bc += fa * dW_gs; bc += fb * dW_ds; bc += fc * dW_bs;
+    s.B(6 + r, CS * bc);
+    s.Cv(4 + 6 * r, dq);
+  }
   CADNIP_TRACE_POINT(27);
 }
 

@@ -23,6 +23,7 @@
 // agree with it to rounding (1e-13 relative), not bit for bit; the per-op path remains the reference ABI.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <vector>
 #include "devices.hpp"
@@ -41,7 +42,7 @@ enum { S_GPOS = 0, S_CDESC, S_BROW, S_NZ, S_ENT, S_TERM, S_LEV, S_QINV, S_NODES,
 
 struct F2Block {
   const int* ipar; const double* par;
-  int type, count, n_par, g_base, c_base, b_base, nodes_off;
+  int type, count, n_par, g_base, c_base, b_base, nodes_off, mos1_plain;
 };
 
 struct F2Args {
@@ -55,24 +56,28 @@ struct F2Args {
   TranArgs t;
 };
 
-// stamp writer: accumulates into J (LU positions) and the residual; all targets are offsets into W
-struct AccumOut {
+// stamp writer: accumulates into J (LU positions) and the residual; all targets are offsets into W.
+// GUARD: a lane whose `sink` is non-zero (no device behind it) sends every stamp to that trash word instead.
+template <bool GUARD>
+struct AccumOutT {
   double* W; const double* betas; double a0;
   const u16* gpos; const u64* cdesc; const u16* brow;   // already offset to this device block
   int count, dev;
+  unsigned sink;
+  __device__ __forceinline__ unsigned tg(unsigned p) const { return GUARD && sink ? sink : p; }
   __device__ __forceinline__ void G(int k, double v) const {
     if (__builtin_constant_p(v) && v == 0.0) return;     // structurally zero stamps cost nothing
-    atomicAdd(&W[gpos[k * count + dev]], v);
+    atomicAdd(&W[tg(gpos[k * count + dev])], v);
   }
   __device__ __forceinline__ void C(int k, double v) const {
     if (__builtin_constant_p(v) && v == 0.0) return;
     const u64 d = cdesc[k * count + dev];
-    atomicAdd(&W[(unsigned)d & 0xFFFFu], a0 * v);
-    atomicAdd(&W[(unsigned)(d >> 16) & 0xFFFFu], v * betas[(unsigned)(d >> 32) & 0xFFFFu]);
+    atomicAdd(&W[tg((unsigned)d & 0xFFFFu)], a0 * v);
+    atomicAdd(&W[tg((unsigned)(d >> 16) & 0xFFFFu)], v * betas[(unsigned)(d >> 32) & 0xFFFFu]);
   }
   __device__ __forceinline__ void B(int k, double v) const {
     if (__builtin_constant_p(v) && v == 0.0) return;
-    atomicAdd(&W[brow[k * count + dev]], -v);
+    atomicAdd(&W[tg(brow[k * count + dev])], -v);
   }
   // batch forms: all table reads of the batch are issued before its first atomic, so a batch costs one LDS
   // round trip plus the atomics' issue slots instead of one dependent read -> atomic chain per stamp
@@ -81,7 +86,14 @@ struct AccumOut {
 #pragma unroll
     for (int i = 0; i < N; ++i) p[i] = gpos[(k0 + i) * count + dev];
 #pragma unroll
-    for (int i = 0; i < N; ++i) if (!(__builtin_constant_p(v[i]) && v[i] == 0.0)) atomicAdd(&W[p[i]], v[i]);
+    for (int i = 0; i < N; ++i) if (!(__builtin_constant_p(v[i]) && v[i] == 0.0)) atomicAdd(&W[tg(p[i])], v[i]);
+  }
+  template <int N> __device__ __forceinline__ void Gk(const int (&k)[N], const double (&v)[N]) const {
+    unsigned p[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = gpos[k[i] * count + dev];
+#pragma unroll
+    for (int i = 0; i < N; ++i) atomicAdd(&W[tg(p[i])], v[i]);
   }
   template <int N> __device__ __forceinline__ void Cv(int k0, const double (&v)[N]) const {
     u64 d[N];
@@ -93,8 +105,8 @@ struct AccumOut {
 #pragma unroll
     for (int i = 0; i < N; ++i)
       if (!(__builtin_constant_p(v[i]) && v[i] == 0.0)) {
-        atomicAdd(&W[(unsigned)d[i] & 0xFFFFu], a0 * v[i]);
-        atomicAdd(&W[(unsigned)(d[i] >> 16) & 0xFFFFu], v[i] * bt[i]);
+        atomicAdd(&W[tg((unsigned)d[i] & 0xFFFFu)], a0 * v[i]);
+        atomicAdd(&W[tg((unsigned)(d[i] >> 16) & 0xFFFFu)], v[i] * bt[i]);
       }
   }
   template <int N> __device__ __forceinline__ void Bv(int k0, const double (&v)[N]) const {
@@ -102,9 +114,10 @@ struct AccumOut {
 #pragma unroll
     for (int i = 0; i < N; ++i) p[i] = brow[(k0 + i) * count + dev];
 #pragma unroll
-    for (int i = 0; i < N; ++i) if (!(__builtin_constant_p(v[i]) && v[i] == 0.0)) atomicAdd(&W[p[i]], -v[i]);
+    for (int i = 0; i < N; ++i) if (!(__builtin_constant_p(v[i]) && v[i] == 0.0)) atomicAdd(&W[tg(p[i])], -v[i]);
   }
 };
+typedef AccumOutT<false> AccumOut;
 
 typedef DevCtxT<short> LdsCtx;
 
@@ -212,15 +225,27 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
         for (int q = 0; q < 4; ++q) {
           const int dev = lane + 64 * q;
           if (dev < B.count) {
-            AccumOut s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev};
+            AccumOut s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev, 0u};
             if (B.type == CADNIP_DEV_CAPACITOR) capacitance4(s, 0, pv[q]); else conductance4(s, 0, pv[q]);
           }
         }
         dev0 = lane + 256;
       }
+      if (B.type == CADNIP_DEV_MOS1 && B.mos1_plain) {
+        // two lanes per MOSFET (devices.hpp: stamp_mos1_pair), 32 devices per wave pass
+        const int side = lane & 1;
+        for (int d0 = 0; d0 < B.count; d0 += 32) {
+          const int dv = d0 + (lane >> 1);
+          const bool valid = dv < B.count;
+          LdsCtx d{nodes + B.nodes_off, B.ipar, par, f.wave, B.count, valid ? dv : B.count - 1, tcur, 1, 0};
+          AccumOutT<true> s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, d.dev, valid ? 0u : (unsigned)(f.nnz_lu + n + lane)};
+          stamp_mos1_pair(d, us, s, lw, side, valid);
+        }
+        dev0 = B.count;
+      }
       for (int dev = dev0; dev < B.count; dev += 64) {
         LdsCtx d{nodes + B.nodes_off, B.ipar, par, f.wave, B.count, dev, tcur, 1, 0};
-        AccumOut s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev};
+        AccumOut s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev, 0u};
         dispatch_stamp2(B.type, d, us, s, lw);
       }
       CADNIP_TRACE_POINT(8 + bi);
@@ -514,7 +539,7 @@ int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds) {
   for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
     auto& b = h->blocks[bi];
     if (b.count == 0) continue;
-    f.blk[f.n_blk++] = F2Block{b.d_ipar, b.d_par, b.type, b.count, b.n_par, b.g_base, b.c_base, b.b_base, h->f2_nodes_off[bi]};
+    f.blk[f.n_blk++] = F2Block{b.d_ipar, b.d_par, b.type, b.count, b.n_par, b.g_base, b.c_base, b.b_base, h->f2_nodes_off[bi], (b.mos1_plain && !getenv("CADNIP_NO_PAIR")) ? 1 : 0};
   }
   // the heaviest device type first: its parameter loads are in flight while the table copy settles
   for (int i = 0; i < f.n_blk; ++i)

@@ -5,6 +5,10 @@
 #include <string>
 #include <vector>
 #include "../../include/cadnip_hip.h"
+// rows of the derived sp_mos1 parameter card (devices.hpp: enum M1_*) that cadnip_set_params inspects
+#define CADNIP_MOS1_PAR_OXCAP 8
+#define CADNIP_MOS1_PAR_GD 30
+#define CADNIP_MOS1_PAR_GS 31
 
 #define HIP_TRY(expr)                                                     \
   do {                                                                    \
@@ -40,6 +44,7 @@ struct DeviceBlock {
   int g_base, c_base, b_base, n_g, n_c, n_b;
   int* d_nodes = nullptr;
   std::vector<int> h_nodes;  // host copy (the fused kernel keeps an int16 copy in LDS)
+  bool mos1_plain = false;   // sp_mos1 block: every instance has gd = gs = OxideCap = 0 (set by cadnip_set_params)
   int* d_ipar = nullptr;
   double* d_par = nullptr;   // [B][n_par][count]
 };
