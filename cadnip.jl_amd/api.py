@@ -213,6 +213,22 @@ def nameat(sol, name, t):
 # ------------------------------------------------------------------------------------------------
 # batched simulator
 # ------------------------------------------------------------------------------------------------
+def clip_sample(J, headroom=1e6):
+    """|J| of one or more sample Jacobians ([.., nnz]) for the symbolic phase, each sample clipped to ``headroom`` times
+    the median of its non-zero magnitudes (non-finite entries count as the cap).  A random probe point can forward-bias
+    an exponential junction by volts: its conductance (1e30 and more) would swamp every other entry of the sample, and
+    the pivot search -- which eliminates numerically -- would see a singular matrix where only the probe was absurd."""
+    a = np.abs(np.atleast_2d(np.asarray(J, dtype=float)))
+    out = np.empty_like(a)
+    for i, row in enumerate(a):
+        fin = np.isfinite(row)
+        nz = row[fin & (row > 0)]
+        cap = headroom * float(np.median(nz)) if nz.size else 0.0
+        r = np.where(fin, row, cap)
+        out[i] = np.minimum(r, cap) if nz.size else 0.0
+    return out
+
+
 class BatchSimulator:
     """One structure, B resident sweep instances on one GPU."""
 
@@ -256,7 +272,8 @@ class BatchSimulator:
 
     def analyze(self, gamma=1e9, n_samples=6, seed=1234):
         """Symbolic LU phase on the element-wise max |G + gamma*C| over several operating points
-        (cold start with initjct, zero, and random points), so the static pivot order suits all."""
+        (cold start with initjct, zero, and random points), so the static pivot order suits all.
+        Each sample is clipped (``clip_sample``) before it enters the max."""
         rng = np.random.default_rng(seed)
         st, h = self.st, self.h
         vs = self.vscale()
@@ -274,7 +291,7 @@ class BatchSimulator:
             h.rebuild(u, 0.0)
             h.set_initjct(False)
             J = h.jacobian(gamma)
-            acc = np.maximum(acc, np.max(np.abs(np.nan_to_num(J, nan=0.0, posinf=0.0, neginf=0.0)), axis=0))
+            acc = np.maximum(acc, np.max(clip_sample(J), axis=0))
         h.analyze_values(acc)
         self._analyzed = True
 

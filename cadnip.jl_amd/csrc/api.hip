@@ -272,7 +272,7 @@ int cadnip_analyze(CadnipHandle* h, int32_t sample_instance) {
   HIP_TRY(hipMemcpyAsync(vals.data(), h->d_J + (size_t)sample_instance * h->nnz, (size_t)h->nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   std::string err;
-  int rc = lu_analyze(h->n, h->h_rowptr, h->h_colidx, vals, 1e-3, h->lu, err);
+  int rc = lu_analyze(h->n, h->h_rowptr, h->h_colidx, vals, 1e-3, false, h->lu, err);
   if (rc) { fprintf(stderr, "[cadnip_hip] analyze: %s\n", err.c_str()); return rc; }
   return upload_lu(h);
 }
@@ -281,7 +281,7 @@ int cadnip_analyze_values(CadnipHandle* h, const double* J_csr_host) {
   if (!h || !J_csr_host) return CADNIP_BADARG;
   std::vector<double> vals(J_csr_host, J_csr_host + h->nnz);
   std::string err;
-  int rc = lu_analyze(h->n, h->h_rowptr, h->h_colidx, vals, 1e-3, h->lu, err);
+  int rc = lu_analyze(h->n, h->h_rowptr, h->h_colidx, vals, 1e-3, true, h->lu, err);
   if (rc) { fprintf(stderr, "[cadnip_hip] analyze: %s\n", err.c_str()); return rc; }
   return upload_lu(h);
 }
@@ -299,13 +299,13 @@ static const std::vector<int>* host_lu_array(const CadnipHostLU* lu, int which) 
   }
   return nullptr;
 }
-int cadnip_host_lu_analyze(int32_t n, const int32_t* rowptr, const int32_t* colidx, const double* vals, double pivot_tol, CadnipHostLU** out) {
+int cadnip_host_lu_analyze(int32_t n, const int32_t* rowptr, const int32_t* colidx, const double* vals, double pivot_tol, int32_t sample, CadnipHostLU** out) {
   if (n <= 0 || !rowptr || !colidx || !vals || !out) return CADNIP_BADARG;
   CadnipHostLU* lu = new CadnipHostLU();
   std::vector<int> rp(rowptr, rowptr + n + 1), ci(colidx, colidx + rowptr[n]);
   std::vector<double> v(vals, vals + rowptr[n]);
   std::string err;
-  int rc = lu_analyze(n, rp, ci, v, pivot_tol, lu->p, err);
+  int rc = lu_analyze(n, rp, ci, v, pivot_tol, sample != 0, lu->p, err);
   if (rc) { delete lu; return rc; }
   *out = lu;
   return CADNIP_OK;

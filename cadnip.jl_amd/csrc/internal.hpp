@@ -104,7 +104,7 @@ struct CadnipHandle {
 namespace cadnip {
 // symbolic.cpp
 int lu_analyze(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, const std::vector<double>& vals,
-               double pivot_tol, LUProgram& out, std::string& err);
+               double pivot_tol, bool sample, LUProgram& out, std::string& err);
 // kernels.hip launchers (all asynchronous on h->stream)
 int launch_rebuild(CadnipHandle* h);                       // stamps + assemble at (d_u, d_t)
 int launch_residual(CadnipHandle* h, const double* d_du);  // d_resid = C du + G u - b

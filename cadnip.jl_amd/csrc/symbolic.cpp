@@ -25,15 +25,34 @@
 
 namespace cadnip {
 
+static int lu_analyze_mode(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, const std::vector<double>& vals,
+                           double pivot_tol, bool magnitudes, LUProgram& out, std::string& err);
+
+// The pivot search eliminates numerically on the sample.  A sample assembled from several operating points is not
+// the Jacobian of any one state, so cancellation in it can fake a singular matrix (two nodes tied by the same huge
+// sampled conductance).  When the signed elimination fails, the search is repeated on magnitudes
+// (|a_ij| + |l_ik u_kj|, no cancellation): a structurally non-singular pattern then always yields an order.
+// `sample` = vals is such a composite; for the Jacobian of one state a singular result is reported as is.
 int lu_analyze(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, const std::vector<double>& vals,
-               double pivot_tol, LUProgram& out, std::string& err) {
+               double pivot_tol, bool sample, LUProgram& out, std::string& err) {
+  int rc = lu_analyze_mode(n, rowptr, colidx, vals, pivot_tol, false, out, err);
+  if (rc == CADNIP_SINGULAR && sample) {
+    std::string err2;
+    int rc2 = lu_analyze_mode(n, rowptr, colidx, vals, pivot_tol, true, out, err2);
+    if (rc2 == CADNIP_OK) { err.clear(); return rc2; }
+  }
+  return rc;
+}
+
+static int lu_analyze_mode(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, const std::vector<double>& vals,
+                           double pivot_tol, bool magnitudes, LUProgram& out, std::string& err) {
   out = LUProgram();
   out.n = n;
   std::vector<std::map<int, double>> rows(n);
   std::vector<std::set<int>> cols(n);
   for (int i = 0; i < n; ++i)
     for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) {
-      rows[i][colidx[p]] = vals[p];
+      rows[i][colidx[p]] = magnitudes ? std::fabs(vals[p]) : vals[p];
       cols[colidx[p]].insert(i);
     }
   std::vector<char> rdone(n, 0);
@@ -87,7 +106,8 @@ int lu_analyze(int n, const std::vector<int>& rowptr, const std::vector<int>& co
         int j = kv.first;
         if (j == bj) continue;
         auto it = rows[i].find(j);
-        if (it == rows[i].end()) { rows[i][j] = -f * kv.second; cols[j].insert(i); }
+        if (it == rows[i].end()) { rows[i][j] = magnitudes ? std::fabs(f * kv.second) : -f * kv.second; cols[j].insert(i); }
+        else if (magnitudes) it->second = std::fabs(it->second) + std::fabs(f * kv.second);
         else it->second -= f * kv.second;
       }
       rows[i].erase(bj);

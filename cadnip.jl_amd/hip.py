@@ -342,14 +342,14 @@ LU_ARRAYS = ("rperm", "cperm", "rowptr", "col", "diag", "load_src", "load_dst", 
              "term_a", "term_b", "lev_ptr", "fwd_rows", "fwd_lev_ptr", "bwd_rows", "bwd_lev_ptr")
 
 
-def host_lu_analyze(n, rowptr, colidx, vals, pivot_tol=1e-3):
+def host_lu_analyze(n, rowptr, colidx, vals, pivot_tol=1e-3, sample=False):
     """Host-only symbolic phase (no GPU needed): returns the LU program as a dict of int32 arrays."""
     lib = load_library()
     rp = np.ascontiguousarray(rowptr, dtype=np.int32)
     ci = np.ascontiguousarray(colidx, dtype=np.int32)
     v = np.ascontiguousarray(vals, dtype=np.float64)
     p = C.c_void_p()
-    _check(lib.cadnip_host_lu_analyze(C.c_int32(n), _ip(rp), _ip(ci), _dp(v), C.c_double(pivot_tol), C.byref(p)),
+    _check(lib.cadnip_host_lu_analyze(C.c_int32(n), _ip(rp), _ip(ci), _dp(v), C.c_double(pivot_tol), C.c_int32(int(sample)), C.byref(p)),
            "cadnip_host_lu_analyze")
     out = {}
     try:

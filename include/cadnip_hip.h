@@ -252,7 +252,9 @@ typedef enum { CADNIP_LU_RPERM = 0, CADNIP_LU_CPERM, CADNIP_LU_ROWPTR, CADNIP_LU
                CADNIP_LU_LOAD_DST, CADNIP_LU_ENT_POS, CADNIP_LU_ENT_DIAG, CADNIP_LU_ENT_PTR, CADNIP_LU_TERM_A, CADNIP_LU_TERM_B,
                CADNIP_LU_LEV_PTR, CADNIP_LU_FWD_ROWS, CADNIP_LU_FWD_LEV_PTR, CADNIP_LU_BWD_ROWS, CADNIP_LU_BWD_LEV_PTR,
                CADNIP_LU_NARRAYS } CadnipLUArray;
-int cadnip_host_lu_analyze(int32_t n, const int32_t* rowptr, const int32_t* colidx, const double* vals, double pivot_tol, CadnipHostLU** out);
+/* sample != 0: `vals` is a composite magnitude sample (as cadnip_analyze_values takes), not one state's Jacobian: a
+ * numerically singular sample is re-analysed on magnitudes instead of being reported (csrc/symbolic.cpp) */
+int cadnip_host_lu_analyze(int32_t n, const int32_t* rowptr, const int32_t* colidx, const double* vals, double pivot_tol, int32_t sample, CadnipHostLU** out);
 int32_t cadnip_host_lu_size(const CadnipHostLU* lu, int32_t which);
 int cadnip_host_lu_get(const CadnipHostLU* lu, int32_t which, int32_t* dst);
 void cadnip_host_lu_free(CadnipHostLU* lu);

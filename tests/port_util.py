@@ -1,5 +1,6 @@
 """Helpers that put one sweep instance of a product Structure onto the CPU port (oracle)."""
 import numpy as np
+from cadnip_jl_amd import api
 
 import cadnip_jl_amd as cj
 from cadnip_jl_amd import hip
@@ -32,7 +33,7 @@ def analyze_port(st, port, vscale, gamma=1e9, seed=1234, n_samples=6):
             u[st.n_nodes:st.n_nodes + st.n_currents] = 0.0
         G, C, b, lw = port.rebuild(u, 0.0)
         port.set_spec(initjct=0)
-        acc = np.maximum(acc, np.abs(np.nan_to_num(G + gamma * C, nan=0.0, posinf=0.0, neginf=0.0)))
-    prog = hip.host_lu_analyze(st.n, st.rowptr, st.colidx, acc)
+        acc = np.maximum(acc, api.clip_sample(G + gamma * C)[0])
+    prog = hip.host_lu_analyze(st.n, st.rowptr, st.colidx, acc, sample=True)
     port.set_lu(prog)
     return prog

@@ -5,7 +5,9 @@ unknown at every save time, relative to max(|value|, 1) (volts / scaled charges 
 import numpy as np
 import pytest
 
+import cadnip_jl_amd as cj
 from cadnip_jl_amd import api, benchmarks as bm
+from tests import circuits as tc
 from cadnip_jl_amd.structure import expand_breakpoints
 from tests.port_util import make_port, analyze_port
 
@@ -54,3 +56,79 @@ def test_dff_transient_matches_port(points, fused):
         err = np.max(np.abs(out[i] - ref) / np.maximum(np.abs(ref), 1.0))
         assert err <= REL_TOL, (pt, err)
     sim.close()
+
+
+def _meyer_inverter():
+    """Inverter with `tox` cards (Meyer gate charge) and series resistances: the sp_mos1 path that is NOT lane-paired."""
+    c = cj.Circuit()
+    nm, pm = dict(bm.NFET_06V0_MEYER), dict(bm.PFET_06V0_MEYER)
+    nm.update(rd=30.0, rs=20.0)
+    c.V("vdd", "vdd", "0", dc=5.0)
+    c.V("vin", "in", "0", dc=0.0, wave=("pwl", [0.0, 2e-9, 4e-9, 12e-9, 14e-9], [0.0, 0.0, 5.0, 5.0, 0.0]))
+    c.MOS1("mn", "out", "in", "0", "0", nm, l=0.6e-6, w=0.36e-6)
+    c.MOS1("mp", "out", "in", "vdd", "vdd", pm, l=0.5e-6, w=0.495e-6)
+    c.C("cl", "out", "0", 5e-15)
+    return c
+
+
+def _rc_ladder(n_sections=80):
+    """More two-terminal devices than lanes in a wave (device loops with several passes), n > 64."""
+    c = cj.Circuit()
+    c.V("v1", "n0", "0", dc=0.0, wave=("pulse", 0.0, 1.0, 1e-6, 1e-6, 1e-6, 5e-6, 2e-5))
+    for k in range(n_sections):
+        c.R("r%d" % k, "n%d" % k, "n%d" % (k + 1), 100.0 + k)
+        c.C("c%d" % k, "n%d" % (k + 1), "0", 1e-9)
+    return c
+
+
+def _nonlinear_tran():
+    """SimpleMOSFET amplifier, a reverse-biased junction capacitor and a PCNR-limited diode clamp."""
+    c = cj.Circuit()
+    c.V("v1", "vdd", "0", dc=3.0)
+    c.V("v2", "in", "0", dc=0.0, wave=("pwl", [0.0, 2e-7, 1.2e-6], [0.0, 0.0, 1.5]))
+    c.R("r1", "vdd", "out", 10e3)
+    c.SMOS("m1", "out", "in", "0", Vth=0.5, K=1e-3, lambda_=0.02)
+    c.DCAP("d1", "0", "out", Is=1e-14, Cj0=2e-12)
+    c.R("r2", "out", "y", 5e3)
+    c.D("d2", "y", "0", Is=1e-14)
+    c.C("c1", "y", "0", 1e-12)
+    return c
+
+
+FUSED_CASES = {
+    # name: (circuit factory, params, tspan, saveat, observed unknowns, abstol)
+    "rc": (tc.rc_charge, {}, (0.0, 3e-3), [1e-4, 1e-3, 3e-3], ["out"], 1e-9),
+    "linear_zoo": (tc.linear_zoo, {}, (0.0, 4e-3), [5e-4, 1.5e-3, 2.5e-3, 4e-3], ["c", "d", "e", "f", "g", "k", "I_l1"], 1e-9),
+    "nonlinear": (_nonlinear_tran, {}, (0.0, 2e-6), [2e-7, 7e-7, 1.2e-6, 2e-6], ["out", "y"], 1e-9),
+    "diode_limited": (tc.diode_rectifier, {}, (0.0, 1e-6), [1e-7, 1e-6], ["out"], 1e-9),
+    "behavioral": (tc.behavioral, {}, (0.0, 1e-3), [1e-4, 1e-3], ["x", "y", "z"], 1e-9),
+    "inverter": (bm.inverter_circuit, {"vdd": 5.0}, (0.0, 4e-7), [5e-8, 1.05e-7, 1.5e-7, 2.05e-7, 4e-7], ["Q"], 1e-9),
+    "meyer_inverter_rd": (_meyer_inverter, {}, (0.0, 2e-8), [3e-9, 8e-9, 1.3e-8, 2e-8], ["out"], 1e-9),
+    "rc_ladder": (_rc_ladder, {}, (0.0, 2e-5), [2e-6, 5e-6, 1e-5, 2e-5], ["n1", "n40", "n80"], 1e-9),
+}
+
+
+@pytest.mark.parametrize("name", list(FUSED_CASES))
+def test_fused_kernel_matches_per_op_path(name):
+    """The fused Newton kernel (the benchmark path) against the per-op kernels on circuits that exercise every device
+    type, limit variables, behavioural sources, the un-paired sp_mos1 path, device loops longer than a wave and n < 64:
+    same step sequence to within a few decisions, recorded values to 1e-9 of the signal scale."""
+    mk, params, tspan, saveat, names, abstol = FUSED_CASES[name]
+    circ = mk()
+    got = {}
+    for fused in (0, 1):
+        sim = api.BatchSimulator(api.MNACircuit(circ, params))
+        st = sim.st
+        obs = [st.index_of(nm) for nm in names]
+        out, per, stats = sim.tran(tspan, np.full(st.n, abstol), 1e-6, np.array(saveat), obs=obs, fused=fused)
+        assert stats["n_failed"] == 0, (name, fused, stats)
+        got[fused] = (out[0], per[0])
+        sim.close()
+    a, b = got[0][0], got[1][0]
+    scale = max(1.0, float(np.max(np.abs(a))))
+    same_path = tuple(got[0][1][:3]) == tuple(got[1][1][:3])     # Newton iterations, accepted and rejected steps
+    # identical step sequence: rounding-level agreement; a step decision that flipped on rounding moves the recorded
+    # values by a fraction of the local error tolerance (reltol = 1e-6 here), never more
+    tol = 1e-9 * scale + 10 * abstol if same_path else 100 * 1e-6 * scale
+    assert np.max(np.abs(a - b)) <= tol, (name, same_path, np.max(np.abs(a - b)))
+    assert abs(int(got[0][1][0]) - int(got[1][1][0])) <= max(3, 0.02 * got[0][1][0]), (name, got[0][1], got[1][1])
