@@ -55,7 +55,7 @@ int ensure_driver(CadnipHandle* h) {
   TRY(dalloc(&d->bp_idx, B)); TRY(dalloc(&d->save_idx, B)); TRY(dalloc(&d->dcstate, B)); TRY(dalloc(&d->action, B));
   TRY(dalloc(&d->cnt, B * 4));
   TRY(dalloc(&d->u0, B * n)); TRY(dalloc(&d->u1, B * n)); TRY(dalloc(&d->u2, B * n)); TRY(dalloc(&d->up, B * n)); TRY(dalloc(&d->beta, B * n));
-  TRY(dalloc(&d->atol, n)); TRY(dalloc(&d->emask, n)); TRY(dalloc(&d->nactive, 1));
+  TRY(dalloc(&d->atol, n)); TRY(dalloc(&d->emask, n)); TRY(dalloc(&d->nactive, 2));
   return CADNIP_OK;
 }
 
@@ -398,14 +398,40 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
   int64_t launches = 0;
   const int64_t max_it = o->max_iterations > 0 ? o->max_iterations : 50000000;
   int rc = CADNIP_OK, running = h->B;
-  const int check_every = 8;
-  while (running > 0 && launches < max_it) {
-    if (o->fused) {
+  // Newton rounds between two looks at the running-instance count.  A fused launch loads the structure tables and each
+  // instance's state once and ends when its slowest wave has done its rounds (measured, DFF sweep: 8 rounds per launch
+  // 38.8 M iterations/s, 64: 43.2, 1024: 44.8, one launch for the whole transient: 45.2).
+  const int check_every = o->fused ? 1024 : 8;
+  if (o->fused) {
+    // The host stays one launch ahead: launch k+1 is queued before the running-instance count of launch k is read,
+    // so the GPU never waits for the host between launches.  Once every instance has finished, the one launch
+    // already in the queue finds nothing to do (each wave reads its status and exits).
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    HIP_TRY(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    int slot = 0;
+    bool have_prev = false;
+    while (launches < max_it) {
       rc = launch_fused2_rounds(h, a, check_every); if (rc) break;
       launches += check_every;
-      rc = count_running(h, &running); if (rc) break;
-      continue;
+      if (hipMemsetAsync(d->nactive + slot, 0, sizeof(int), h->stream) != hipSuccess) { rc = CADNIP_HIPERROR; break; }
+      hipLaunchKernelGGL(k_count_running, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, d->status, h->B, d->nactive + slot);
+      if (hipMemcpyAsync(h->h_pinned + slot, d->nactive + slot, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+          hipEventRecord(ev[slot], h->stream) != hipSuccess) { rc = CADNIP_HIPERROR; break; }
+      if (have_prev) {
+        if (hipEventSynchronize(ev[1 - slot]) != hipSuccess) { rc = CADNIP_HIPERROR; break; }
+        running = h->h_pinned[1 - slot];
+        if (running == 0) break;
+      }
+      have_prev = true;
+      slot ^= 1;
     }
+    hipError_t es = hipStreamSynchronize(h->stream);
+    (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
+    if (es != hipSuccess) { set_last_error("hipStreamSynchronize", es); return CADNIP_HIPERROR; }
+    if (!rc && running > 0) rc = count_running(h, &running);
+  }
+  while (!o->fused && running > 0 && launches < max_it) {
     for (int c = 0; c < check_every; ++c) {
       rc = launch_rebuild(h); if (rc) break;
       rc = launch_residual(h, h->d_du); if (rc) break;
