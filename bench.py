@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--instances", type=int, default=2048, help="sweep instances resident per GPU (32 Vdd x instances/32 temps)")
+    ap.add_argument("--instances", type=int, default=4096, help="sweep instances per GPU (32 Vdd x instances/32 temps); 2048 are resident at a time, the rest queue in-kernel")
     ap.add_argument("--cpu-sample", type=int, default=160, help="corner points timed on the host for cpu_baseline")
     ap.add_argument("--fused", type=int, default=int(os.environ.get("CADNIP_FUSED", "2")),
                     help="0 = one kernel per op (the drop-in ABI path), 1 = fused v1, 2 = fused v2 (default)")
@@ -205,7 +205,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "gf180 DFF transient 0-700 ns (synthetic sp_mos1 level-1 card, 30 MOSFETs, n=%d, nnz=%d), "
-                                   "%d Vdd x temp corner instances resident per GPU; step = DC init + full transient of the batch"
+                                   "%d Vdd x temp corner instances per GPU (state resident in HBM; 8 per CU in flight, the rest handed out by the kernel's instance queue); step = DC init + full transient of the batch"
                                    % (st.n, st.nnz, B),
                        "instances_per_gpu": B, "instances_total": B * world, "abstol": ABSTOL, "reltol": RELTOL,
                        "fused": int(args.fused), "newton_iters_per_step": int(iters // max(args.steps, 1)),

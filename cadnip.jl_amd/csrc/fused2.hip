@@ -53,6 +53,7 @@ struct F2Args {
   int off[S_NSEC];
   int tab_len;               // 32-bit words (even)
   int n, nnz, nnz_lu, n_pass, rounds, B;
+  int* queue;                // next not-yet-resident instance (relative to gridDim.x * WPB); zeroed before every launch
   TranArgs t;
 };
 
@@ -175,11 +176,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
     for (int i = tid; i < f.tab_len / 2; i += 64 * WPB) dst[i] = src[i];
   }
   __syncthreads();
-  const int inst = blockIdx.x * WPB + w;
-  if (inst >= f.B) return;
   const TranArgs& a = f.t;
-  StepState st = load_state(a, inst);
-  if (st.status != 0) return;
   const unsigned* tab = (const unsigned*)sm;
   const int tab_dbl = f.tab_len / 2;
   const int nW = f.nnz_lu + n + F2_TRASH;                 // LU | rhs | trash : zeroed every round
@@ -196,16 +193,31 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
   const u64* passd = (const u64*)(tab + f.off[S_LEV]);
   const u16* qinv = (const u16*)(tab + f.off[S_QINV]);
   const short* nodes = (const short*)(tab + f.off[S_NODES]);
+#ifdef CADNIP_TRACE
+  if (blockIdx.x == 0 && tid == 0) g_trace_last = clock64();
+#endif
+  // A wave works through instances one after the other: its first one by position, further ones from a queue shared
+  // by the grid (instances beyond the resident waves, in index order).  `budget` caps the wave's rounds per launch.
+  int inst = blockIdx.x * WPB + w;
+  int budget = f.rounds;
+  for (;;) {
+  StepState st;
+  bool have = false;
+  while (inst < f.B) {
+    st = load_state(a, inst);
+    if (st.status == 0) { have = true; break; }
+    int nx = 0;
+    if (lane == 0) nx = atomicAdd(f.queue, 1);
+    inst = (int)gridDim.x * WPB + __builtin_amdgcn_readfirstlane(nx);
+  }
+  if (!have || budget <= 0) break;
   double* ug = a.u + (size_t)inst * n;
   double* betag = a.beta + (size_t)inst * n;
   double* lw = a.limit_w + (size_t)inst * n;
   const size_t vo = (size_t)inst * n;
   FusedVecs vec{us, betas, W, qinv, a.up + vo, a.u0 + vo, a.u1 + vo, a.u2 + vo, lw};
   for (int i = lane; i < n; i += 64) { us[i] = ug[i]; betas[i] = betag[i]; }
-#ifdef CADNIP_TRACE
-  if (blockIdx.x == 0 && tid == 0) g_trace_last = clock64();
-#endif
-  for (int round = 0; round < f.rounds; ++round) {
+  for (; budget > 0; --budget) {
     CADNIP_TRACE_POINT(17);
     for (int i = lane; i < nW; i += 64) W[i] = 0.0;
     CADNIP_WAVE_SYNC();
@@ -329,7 +341,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
     tran_update_body(a, vec, st, inst, lane, bad);
     CADNIP_WAVE_SYNC();
     CADNIP_TRACE_POINT(16);
-    if (st.status != 0) break;
+    if (st.status != 0) { --budget; break; }
   }
   {
     double* dug = a.du + (size_t)inst * n;
@@ -337,6 +349,12 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
     for (int i = lane; i < n; i += 64) { double x = us[i], b = betas[i]; ug[i] = x; betag[i] = b; dug[i] = a0 * x + b; }
   }
   store_state(a, inst, lane, st);
+  CADNIP_WAVE_SYNC();
+  if (st.status == 0) break;                // out of budget in the middle of this instance: the next launch resumes it
+  int nx = 0;
+  if (lane == 0) nx = atomicAdd(f.queue, 1);
+  inst = (int)gridDim.x * WPB + __builtin_amdgcn_readfirstlane(nx);
+  }
 }
 
 // ---- host side: build the packed tables once per (structure, LU program) ------------------------------------
@@ -560,7 +578,17 @@ int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds) {
   while (wpb > 1 && ((tab_dbl + wpb * per) * 8 > lds_cap || (h->B + wpb - 1) / wpb < 256)) wpb >>= 1;
   size_t shmem = (tab_dbl + wpb * per) * 8;
   if (shmem > lds_cap) return CADNIP_BADARG;
-  int grid = (h->B + wpb - 1) / wpb;
+  // resident workgroups only: the instances beyond them are handed out by the in-kernel queue as waves become free
+  if (h->n_cu <= 0) {
+    int cu = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, h->device));
+    h->n_cu = cu > 0 ? cu : 256;
+  }
+  if (!h->d_f2queue) HIP_TRY(hipMalloc((void**)&h->d_f2queue, sizeof(int)));
+  HIP_TRY(hipMemsetAsync(h->d_f2queue, 0, sizeof(int), h->stream));
+  f.queue = h->d_f2queue;
+  const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(lds_cap / shmem, (size_t)(32 / wpb)));
+  int grid = std::min((h->B + wpb - 1) / wpb, h->n_cu * wg_per_cu);
 #define LAUNCH(W)                                                                                                      \
   do {                                                                                                                 \
     if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_fused2<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \

@@ -91,6 +91,8 @@ struct CadnipHandle {
   int f2_n_lev = 0;
   std::vector<int> f2_nodes_off;   // per device block: offset (int16 units) of its node table inside the NODES section
   bool fused2_dirty = true;
+  int* d_f2queue = nullptr;   // fused kernel: dynamic instance queue
+  int n_cu = 0;
   // driver state (allocated lazily)
   struct Driver* drv = nullptr;
   // profiling

@@ -26,3 +26,7 @@ bad = np.where(per[:,3]!=1)[0]
 print("failed:", bad, [pts[i] for i in bad], t[bad], hh[bad], per[bad])
 print("newton per inst min/max", per[:,0].min(), per[:,0].max(), "steps", per[:,1].min(), per[:,1].max())
 print(np.round(out[:,:,0],3)[:8])
+print("newton per inst: mean %.1f  p50 %.0f  p90 %.0f  max %d  -> max/mean %.3f" % (per[:,0].mean(), np.percentile(per[:,0],50), np.percentile(per[:,0],90), per[:,0].max(), per[:,0].max()/per[:,0].mean()))
+w = per[:,0].reshape(-1, 8) if len(pts) % 8 == 0 else None
+if w is not None:
+    print("per-workgroup (8 consecutive instances) max: mean over WGs %.1f, overall max %d; efficiency of static assignment = mean/max = %.3f" % (w.max(axis=1).mean(), w.max(), per[:,0].mean()/w.max()))
