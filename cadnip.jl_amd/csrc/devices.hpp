@@ -256,7 +256,7 @@ template <class Ctx, class Out> __device__ inline void stamp_diode(const Ctx& d,
   if (d.ipar[d.dev]) {
     double vold = u[l];
     double w = d.initjct ? vcrit : pnjlim(V0, vold, nVt, vcrit);
-    limit_w_base[l] = w;                       // record_limit_w! (value_only.jl:384)
+    if (limit_w_base) limit_w_base[l] = w;     // record_limit_w! (value_only.jl:384); null = nobody reads it (fused transient without PCNR)
     s.G(0, 1.0); s.G(1, -1.0); s.G(2, 1.0);    // g_lim row (devices.jl:1228-1231)
     double xarg = w / nVt;
     if (xarg > 80.0) { double e80 = exp(80.0); I0 = Is * (e80 * (1.0 + (xarg - 80.0)) - 1.0); Gd = Is / nVt * e80; }
@@ -561,7 +561,7 @@ template <class Ctx, class Out> __device__ inline void stamp_mos1(const Ctx& d, 
   // ---- limiting (mos1.va:919-980), on values
   double w_gs, w_ds, w_bs, w_bd;
   m1_limit(d, u, type, vt, tPhi, tVbi, gamma, Vg, Vb, Vdi, Vsi, l0, l1, l2, l3, w_gs, w_ds, w_bs, w_bd);
-  limit_w_base[l0] = w_gs; limit_w_base[l1] = w_ds; limit_w_base[l2] = w_bs; limit_w_base[l3] = w_bd;
+  if (limit_w_base) { limit_w_base[l0] = w_gs; limit_w_base[l1] = w_ds; limit_w_base[l2] = w_bs; limit_w_base[l3] = w_bd; }
   CADNIP_TRACE_POINT(21);
   // g_lim rows (vasim.jl:3134-3136)
   {
@@ -703,7 +703,7 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
   CADNIP_TRACE_POINT(20);
   double w_gs, w_ds, w_bs, w_bd;
   m1_limit(d, u, type, vt, tPhi, tVbi, gamma, Vg, Vb, Vdi, Vsi, l0, l1, l2, l3, w_gs, w_ds, w_bs, w_bd);
-  if (valid && !D) { limit_w_base[l0] = w_gs; limit_w_base[l1] = w_ds; limit_w_base[l2] = w_bs; limit_w_base[l3] = w_bd; }
+  if (limit_w_base && valid && !D) { limit_w_base[l0] = w_gs; limit_w_base[l1] = w_ds; limit_w_base[l2] = w_bs; limit_w_base[l3] = w_bd; }
   CADNIP_TRACE_POINT(21);
   {   // g_lim rows (vasim.jl:3134-3136): two limit variables per lane
     const double gl[6] = {1.0, -1.0, 1.0, 1.0, -1.0, 1.0};

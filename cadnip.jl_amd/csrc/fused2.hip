@@ -47,7 +47,7 @@ struct F2Block {
 
 struct F2Args {
   F2Block blk[CADNIP_DEV_NTYPES];
-  int n_blk;
+  int n_blk, rc_blk;         // rc_blk: index of the first capacitor / resistor block (-1 = none)
   const double* wave;
   const unsigned* tab;       // packed tables in global memory
   int off[S_NSEC];
@@ -213,10 +213,19 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
   if (!have || budget <= 0) break;
   double* ug = a.u + (size_t)inst * n;
   double* betag = a.beta + (size_t)inst * n;
-  double* lw = a.limit_w + (size_t)inst * n;
+  // limit_w is read only by the PCNR corrector of the update: without it the stamps need not write it (each write is an
+  // HBM store that later vector-memory waits would queue behind)
+  double* lw = a.use_pcnr ? a.limit_w + (size_t)inst * n : nullptr;
   const size_t vo = (size_t)inst * n;
   FusedVecs vec{us, betas, W, qinv, a.up + vo, a.u0 + vo, a.u1 + vo, a.u2 + vo, lw};
   for (int i = lane; i < n; i += 64) { us[i] = ug[i]; betas[i] = betag[i]; }
+  double rc_val[2] = {0.0, 0.0};   // values of the first capacitor / resistor block: constant for the instance, kept in registers
+  if (f.rc_blk >= 0) {
+    const F2Block& B = f.blk[f.rc_blk];
+    const double* par = B.par + (size_t)inst * B.n_par * B.count;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { const int dev = lane + 64 * q; rc_val[q] = par[dev < B.count ? dev : 0]; }
+  }
   for (; budget > 0; --budget) {
     CADNIP_TRACE_POINT(17);
     for (int i = lane; i < nW; i += 64) W[i] = 0.0;
@@ -228,20 +237,17 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
       const F2Block& B = f.blk[bi];
       const double* par = B.par + (size_t)inst * B.n_par * B.count;
       int dev0 = lane;
-      if (B.type == CADNIP_DEV_CAPACITOR || B.type == CADNIP_DEV_RESISTOR) {
-        // one-parameter two-terminal devices: the HBM loads of up to four device passes are issued together
-        double pv[4];
+      if (bi == f.rc_blk) {
+        // first capacitor / resistor block: its (round-invariant) values were fetched once per instance
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int dev = lane + 64 * q; pv[q] = par[dev < B.count ? dev : 0]; }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 2; ++q) {
           const int dev = lane + 64 * q;
           if (dev < B.count) {
             AccumOut s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev, 0u};
-            if (B.type == CADNIP_DEV_CAPACITOR) capacitance4(s, 0, pv[q]); else conductance4(s, 0, pv[q]);
+            if (B.type == CADNIP_DEV_CAPACITOR) capacitance4(s, 0, rc_val[q]); else conductance4(s, 0, rc_val[q]);
           }
         }
-        dev0 = lane + 256;
+        dev0 = lane + 128;
       }
       if (B.type == CADNIP_DEV_MOS1 && B.mos1_plain) {
         // two lanes per MOSFET (devices.hpp: stamp_mos1_pair), 32 devices per wave pass
@@ -408,7 +414,17 @@ static bool f2_prepare(CadnipHandle* h, F2Tables& T, const std::vector<int>& g_p
   }
   T.begin(S_BROW); T.add16(br);
   T.begin(S_NZ);
-  for (int i = 0; i < n; ++i) for (int e = h->h_rowptr[i]; e < h->h_rowptr[i + 1]; ++e) T.add64(pack4(dst[e], y0 + pinv[i], h->h_colidx[e], 0));
+  {
+    // J*u adds every entry's product into its row with an LDS atomic, 64 entries per instruction.  In CSR order a long
+    // row would put up to 64 same-address atomics into one instruction; ordered by (position within the row, row) the
+    // entries of one instruction belong to different rows.
+    std::vector<std::pair<int, int>> order;   // (rank in row, csr entry)
+    for (int i = 0; i < n; ++i) for (int e = h->h_rowptr[i]; e < h->h_rowptr[i + 1]; ++e) order.push_back({e - h->h_rowptr[i], e});
+    std::stable_sort(order.begin(), order.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first < y.first; });
+    std::vector<int> row_of(h->nnz);
+    for (int i = 0; i < n; ++i) for (int e = h->h_rowptr[i]; e < h->h_rowptr[i + 1]; ++e) row_of[e] = i;
+    for (auto& oe : order) { const int e = oe.second; T.add64(pack4(dst[e], y0 + pinv[row_of[e]], h->h_colidx[e], 0)); }
+  }
   // ---- unified entry program: factor entries, forward substitution as an extra column, back substitution in place
   struct Ent { int pos, dg, lvl; std::vector<int> a, b; };
   std::vector<Ent> ents;
@@ -563,6 +579,9 @@ int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds) {
   for (int i = 0; i < f.n_blk; ++i)
     for (int j = i + 1; j < f.n_blk; ++j)
       if ((f.blk[j].type == CADNIP_DEV_MOS1) > (f.blk[i].type == CADNIP_DEV_MOS1)) { F2Block tmp = f.blk[i]; f.blk[i] = f.blk[j]; f.blk[j] = tmp; }
+  f.rc_blk = -1;
+  for (int i = 0; i < f.n_blk; ++i)
+    if (f.blk[i].type == CADNIP_DEV_CAPACITOR || f.blk[i].type == CADNIP_DEV_RESISTOR) { f.rc_blk = i; break; }
   f.wave = h->d_wave;
   f.tab = h->d_f2tab;
   for (int i = 0; i < S_NSEC; ++i) f.off[i] = h->f2off[i];
