@@ -144,6 +144,7 @@ void cadnip_destroy(CadnipHandle* h) {
   for (auto& b : h->blocks) { if (b.d_nodes) (void)hipFree(b.d_nodes); if (b.d_ipar) (void)hipFree(b.d_ipar); if (b.d_par) (void)hipFree(b.d_par); }
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->d_f2queue) (void)hipFree(h->d_f2queue);
+  if (h->d_f2blk) (void)hipFree(h->d_f2blk);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);

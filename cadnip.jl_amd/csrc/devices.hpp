@@ -720,10 +720,6 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
   D3 dvon, vdsat, cdrain;
   m1_channel(a, b, c, dvbd, dvgd, tPhi, tVbi, type, gamma, lambda, Beta, mode, dvon, vdsat, cdrain);
   CADNIP_TRACE_POINT(24);
-  const D3 qj = m1_qdep(vj, Cb, Cbsw, par_of(d, M1_TBULKPOT), par_of(d, M1_TDEPCAP), par_of(d, M1_MJ), par_of(d, M1_MJSW), f2, f3, f4);
-  const D3 qo = m1_swap_pair(qj);
-  const D3 qbs = m1_sel(D, qo, qj), qbd = m1_sel(D, qj, qo);
-  CADNIP_TRACE_POINT(25);
   const D3 cdreq = (mode >= 0 ? type : -type) * cdrain;
   const double dW_gs = (Vg - Vsi) - w_gs, dW_ds = (Vdi - Vsi) - w_ds, dW_bs = (Vb - Vsi) - w_bs;   // lim_rhs deltas
   const double Vk[6] = {Vd, Vg, Vs, Vb, Vdi, Vsi};
@@ -756,6 +752,11 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
     s.B(5, D ? 0.0 : -Ieq);
   }
   CADNIP_TRACE_POINT(26);
+  // depletion charge of this lane's junction (after the current rows: fewer values live at once), swapped like the current
+  const D3 qj = m1_qdep(vj, Cb, Cbsw, par_of(d, M1_TBULKPOT), par_of(d, M1_TDEPCAP), par_of(d, M1_MJ), par_of(d, M1_MJSW), f2, f3, f4);
+  const D3 qo = m1_swap_pair(qj);
+  const D3 qbs = m1_sel(D, qo, qj), qbd = m1_sel(D, qj, qo);
+  CADNIP_TRACE_POINT(25);
   {   // charge-state columns (vasim.jl:3433-3472): two per lane
     const double cs2[2] = {1.0 / CS, 1.0 / CS};
     s.Cv(2 * side, cs2);

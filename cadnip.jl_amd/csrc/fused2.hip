@@ -45,8 +45,20 @@ struct F2Block {
   int type, count, n_par, g_base, c_base, b_base, nodes_off, mos1_plain;
 };
 
+// The device blocks are read through a pointer: an array inside the by-value argument struct, indexed by the block
+// loop's counter, would be copied to scratch memory and re-read from there (an HBM-latency load) at every use.
+typedef const __attribute__((address_space(4))) F2Block* F2BlockPtr;   // constant address space: uniform reads become scalar loads
+
+__device__ __forceinline__ F2Block load_block(const F2Block* blk, int i) {
+  F2BlockPtr q = (F2BlockPtr)blk + i;
+  F2Block b;
+  b.ipar = q->ipar; b.par = q->par; b.type = q->type; b.count = q->count; b.n_par = q->n_par; b.g_base = q->g_base; b.c_base = q->c_base;
+  b.b_base = q->b_base; b.nodes_off = q->nodes_off; b.mos1_plain = q->mos1_plain;
+  return b;
+}
+
 struct F2Args {
-  F2Block blk[CADNIP_DEV_NTYPES];
+  const F2Block* blk;        // [n_blk] in device memory
   int n_blk, rc_blk;         // rc_blk: index of the first capacitor / resistor block (-1 = none)
   const double* wave;
   const unsigned* tab;       // packed tables in global memory
@@ -168,7 +180,8 @@ struct FusedVecs {
 template <int WPB>
 __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
   extern __shared__ double sm[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = f.n;
+  // w is the same for all lanes of a wave: say so (readfirstlane), or every address derived from it lives in VGPRs
+  const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), n = f.n;
   // ---- shared tables: one cooperative copy per launch
   {
     const uint2* src = (const uint2*)f.tab;
@@ -205,9 +218,10 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
   bool have = false;
   while (inst < f.B) {
     st = load_state(a, inst);
+    make_uniform(st);
     if (st.status == 0) { have = true; break; }
     int nx = 0;
-    if (lane == 0) nx = atomicAdd(f.queue, 1);
+    if (lane0 == 0) nx = atomicAdd(f.queue, 1);
     inst = (int)gridDim.x * WPB + __builtin_amdgcn_readfirstlane(nx);
   }
   if (!have || budget <= 0) break;
@@ -218,15 +232,19 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
   double* lw = a.use_pcnr ? a.limit_w + (size_t)inst * n : nullptr;
   const size_t vo = (size_t)inst * n;
   FusedVecs vec{us, betas, W, qinv, a.up + vo, a.u0 + vo, a.u1 + vo, a.u2 + vo, lw};
-  for (int i = lane; i < n; i += 64) { us[i] = ug[i]; betas[i] = betag[i]; }
+  for (int i = lane0; i < n; i += 64) { us[i] = ug[i]; betas[i] = betag[i]; }
   double rc_val[2] = {0.0, 0.0};   // values of the first capacitor / resistor block: constant for the instance, kept in registers
   if (f.rc_blk >= 0) {
-    const F2Block& B = f.blk[f.rc_blk];
+    const F2Block B = load_block(f.blk, f.rc_blk);
     const double* par = B.par + (size_t)inst * B.n_par * B.count;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) { const int dev = lane + 64 * q; rc_val[q] = par[dev < B.count ? dev : 0]; }
+    for (int q = 0; q < 2; ++q) { const int dev = lane0 + 64 * q; rc_val[q] = par[dev < B.count ? dev : 0]; }
   }
   for (; budget > 0; --budget) {
+    // Addresses derived from the lane id are loop invariant; hoisted out of the round loop they would have to live in
+    // (and spill from) vector registers for the whole instance.  An opaque copy per round keeps them local.
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
     CADNIP_TRACE_POINT(17);
     for (int i = lane; i < nW; i += 64) W[i] = 0.0;
     CADNIP_WAVE_SYNC();
@@ -234,7 +252,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
     // ---- stamp: accumulate J (at LU positions) and the C*beta - b part of the residual
     const double tcur = st.tn, a0 = st.a0;
     for (int bi = 0; bi < f.n_blk; ++bi) {
-      const F2Block& B = f.blk[bi];
+      const F2Block B = load_block(f.blk, bi);
       const double* par = B.par + (size_t)inst * B.n_par * B.count;
       int dev0 = lane;
       if (bi == f.rc_blk) {
@@ -345,6 +363,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
     CADNIP_TRACE_POINT(3);
     // ---- Newton update + step controller (registers / LDS; HBM only for history and outputs)
     tran_update_body(a, vec, st, inst, lane, bad);
+    make_uniform(st);
     CADNIP_WAVE_SYNC();
     CADNIP_TRACE_POINT(16);
     if (st.status != 0) { --budget; break; }
@@ -352,13 +371,13 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
   {
     double* dug = a.du + (size_t)inst * n;
     const double a0 = st.a0;
-    for (int i = lane; i < n; i += 64) { double x = us[i], b = betas[i]; ug[i] = x; betag[i] = b; dug[i] = a0 * x + b; }
+    for (int i = lane0; i < n; i += 64) { double x = us[i], b = betas[i]; ug[i] = x; betag[i] = b; dug[i] = a0 * x + b; }
   }
-  store_state(a, inst, lane, st);
+  store_state(a, inst, lane0, st);
   CADNIP_WAVE_SYNC();
   if (st.status == 0) break;                // out of budget in the middle of this instance: the next launch resumes it
   int nx = 0;
-  if (lane == 0) nx = atomicAdd(f.queue, 1);
+  if (lane0 == 0) nx = atomicAdd(f.queue, 1);
   inst = (int)gridDim.x * WPB + __builtin_amdgcn_readfirstlane(nx);
   }
 }
@@ -569,19 +588,23 @@ int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds) {
   ProfScope ps(h, "fused2_newton");
   const LUProgram& P = h->lu;
   F2Args f;
+  F2Block hb[CADNIP_DEV_NTYPES];
   f.n_blk = 0;
-  for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
+  for (size_t bi = 0; bi < h->blocks.size() && f.n_blk < CADNIP_DEV_NTYPES; ++bi) {
     auto& b = h->blocks[bi];
     if (b.count == 0) continue;
-    f.blk[f.n_blk++] = F2Block{b.d_ipar, b.d_par, b.type, b.count, b.n_par, b.g_base, b.c_base, b.b_base, h->f2_nodes_off[bi], (b.mos1_plain && !getenv("CADNIP_NO_PAIR")) ? 1 : 0};
+    hb[f.n_blk++] = F2Block{b.d_ipar, b.d_par, b.type, b.count, b.n_par, b.g_base, b.c_base, b.b_base, h->f2_nodes_off[bi], (b.mos1_plain && !getenv("CADNIP_NO_PAIR")) ? 1 : 0};
   }
-  // the heaviest device type first: its parameter loads are in flight while the table copy settles
+  // the heaviest device type first
   for (int i = 0; i < f.n_blk; ++i)
     for (int j = i + 1; j < f.n_blk; ++j)
-      if ((f.blk[j].type == CADNIP_DEV_MOS1) > (f.blk[i].type == CADNIP_DEV_MOS1)) { F2Block tmp = f.blk[i]; f.blk[i] = f.blk[j]; f.blk[j] = tmp; }
+      if ((hb[j].type == CADNIP_DEV_MOS1) > (hb[i].type == CADNIP_DEV_MOS1)) { F2Block tmp = hb[i]; hb[i] = hb[j]; hb[j] = tmp; }
   f.rc_blk = -1;
   for (int i = 0; i < f.n_blk; ++i)
-    if (f.blk[i].type == CADNIP_DEV_CAPACITOR || f.blk[i].type == CADNIP_DEV_RESISTOR) { f.rc_blk = i; break; }
+    if (hb[i].type == CADNIP_DEV_CAPACITOR || hb[i].type == CADNIP_DEV_RESISTOR) { f.rc_blk = i; break; }
+  if (!h->d_f2blk) HIP_TRY(hipMalloc((void**)&h->d_f2blk, sizeof(hb)));
+  HIP_TRY(hipMemcpyAsync(h->d_f2blk, hb, sizeof(F2Block) * (size_t)f.n_blk, hipMemcpyHostToDevice, h->stream));
+  f.blk = (const F2Block*)h->d_f2blk;
   f.wave = h->d_wave;
   f.tab = h->d_f2tab;
   for (int i = 0; i < S_NSEC; ++i) f.off[i] = h->f2off[i];
@@ -592,22 +615,24 @@ int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds) {
   const size_t tab_dbl = (size_t)h->f2len / 2;
   const size_t per = (size_t)P.nnz_lu + 3 * (size_t)h->n + F2_TRASH;
   const size_t lds_cap = 160 * 1024;
-  // waves (= instances) per workgroup: 8 when they fit and there are enough instances to fill the chip, else 4, 2, 1
-  int wpb = 8;
-  while (wpb > 1 && ((tab_dbl + wpb * per) * 8 > lds_cap || (h->B + wpb - 1) / wpb < 256)) wpb >>= 1;
-  size_t shmem = (tab_dbl + wpb * per) * 8;
-  if (shmem > lds_cap) return CADNIP_BADARG;
-  // resident workgroups only: the instances beyond them are handed out by the in-kernel queue as waves become free
   if (h->n_cu <= 0) {
     int cu = 0;
     HIP_TRY(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, h->device));
     h->n_cu = cu > 0 ? cu : 256;
   }
+  // waves (= instances) per workgroup: 8 (two waves per SIMD) when they fit into LDS and the batch gives at least half of
+  // the CUs such a workgroup; else 4, 2, 1
+  int wpb = 8;
+  while (wpb > 1 && ((tab_dbl + wpb * per) * 8 > lds_cap || (h->B + wpb - 1) / wpb < h->n_cu / 2)) wpb >>= 1;
+  size_t shmem = (tab_dbl + wpb * per) * 8;
+  if (shmem > lds_cap) return CADNIP_BADARG;
+  // resident workgroups only: the instances beyond them are handed out by the in-kernel queue as waves become free
   if (!h->d_f2queue) HIP_TRY(hipMalloc((void**)&h->d_f2queue, sizeof(int)));
   HIP_TRY(hipMemsetAsync(h->d_f2queue, 0, sizeof(int), h->stream));
   f.queue = h->d_f2queue;
   const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(lds_cap / shmem, (size_t)(32 / wpb)));
   int grid = std::min((h->B + wpb - 1) / wpb, h->n_cu * wg_per_cu);
+  if (getenv("CADNIP_F2_DEBUG")) fprintf(stderr, "[cadnip f2] B %d n_cu %d wpb %d grid %d shmem %zu rounds %d\n", h->B, h->n_cu, wpb, grid, shmem, rounds);
 #define LAUNCH(W)                                                                                                      \
   do {                                                                                                                 \
     if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_fused2<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \

@@ -92,6 +92,7 @@ struct CadnipHandle {
   std::vector<int> f2_nodes_off;   // per device block: offset (int16 units) of its node table inside the NODES section
   bool fused2_dirty = true;
   int* d_f2queue = nullptr;   // fused kernel: dynamic instance queue
+  void* d_f2blk = nullptr;    // fused kernel: device-block descriptors
   int n_cu = 0;
   // driver state (allocated lazily)
   struct Driver* drv = nullptr;

@@ -76,6 +76,20 @@ struct StepState {
   int c_newton, c_accept, c_reject, c_fail;   // counter increments since load
 };
 
+// All lanes of the wave hold the same StepState; saying so (readfirstlane) lets it live in scalar registers, which
+// matters in the fused kernel where vector registers are the scarce resource.
+__device__ __forceinline__ double uniform_f64(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ void make_uniform(StepState& s) {
+  s.t = uniform_f64(s.t); s.h = uniform_f64(s.h); s.hprev = uniform_f64(s.hprev); s.hpp = uniform_f64(s.hpp);
+  s.tn = uniform_f64(s.tn); s.a0 = uniform_f64(s.a0);
+  s.nhist = __builtin_amdgcn_readfirstlane(s.nhist); s.ord = __builtin_amdgcn_readfirstlane(s.ord); s.k = __builtin_amdgcn_readfirstlane(s.k);
+  s.status = __builtin_amdgcn_readfirstlane(s.status); s.bp = __builtin_amdgcn_readfirstlane(s.bp); s.si = __builtin_amdgcn_readfirstlane(s.si);
+  s.c_newton = __builtin_amdgcn_readfirstlane(s.c_newton); s.c_accept = __builtin_amdgcn_readfirstlane(s.c_accept);
+  s.c_reject = __builtin_amdgcn_readfirstlane(s.c_reject); s.c_fail = __builtin_amdgcn_readfirstlane(s.c_fail);
+}
+
 __device__ inline StepState load_state(const TranArgs& a, int inst) {
   StepState s;
   s.t = a.t[inst]; s.h = a.h[inst]; s.hprev = a.hprev[inst]; s.hpp = a.hpp[inst]; s.tn = a.tcur[inst]; s.a0 = a.gamma[inst];

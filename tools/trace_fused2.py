@@ -19,9 +19,9 @@ ORDER = [17, 0, 20, 21, 22, 23, 24, 25, 26, 27, 8, 9, 10, 11, 12, 1, 2, 3, 4, 5,
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-    nv = int(round(B ** 0.5))
+    nv = 32
     mc = api.MNACircuit(bm.dff_circuit(), {"vdd": 5.0})
-    pts = list(api.ProductSweep(vdd=np.linspace(4.5, 5.5, nv), temp=np.linspace(-40, 125, B // nv)))
+    pts = list(api.ProductSweep(vdd=np.linspace(4.5, 5.5, nv), temp=np.linspace(-40, 125, max(1, B // nv))))
     sim = api.BatchSimulator(mc, pts)
     st = sim.st
     sim.analyze()
