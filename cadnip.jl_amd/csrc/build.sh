@@ -5,6 +5,8 @@ cd "$(dirname "$0")"
 OUT=../libcadnip_hip.so
 # `build.sh --trace` builds the diagnostic library (cycle timeline of one wave, devices.hpp CADNIP_TRACE_POINT)
 if [ "${1:-}" = "--trace" ]; then shift; OUT=../libcadnip_hip_trace.so; set -- -DCADNIP_TRACE "$@"; fi
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
+# -disable-machine-licm: the fused kernel runs two waves per SIMD (256 VGPRs); hoisting loop-invariant constants and
+# address arithmetic out of its round loop costs 80 more spilled VGPRs, each reloaded from scratch (HBM latency) at every use
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable -mllvm -disable-machine-licm"
 hipcc $FLAGS -shared -o $OUT kernels.hip api.hip driver.hip fused2.hip symbolic.cpp "$@"
 echo "built $(realpath $OUT)"

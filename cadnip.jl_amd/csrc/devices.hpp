@@ -693,13 +693,10 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
   int nd = node_of(d, 0), ng = node_of(d, 1), ns = node_of(d, 2), nb = node_of(d, 3), ndi = node_of(d, 4), nsi = node_of(d, 5);
   int l0 = node_of(d, 6), l1 = node_of(d, 7), l2 = node_of(d, 8), l3 = node_of(d, 9);
   double Vd = volt(u, nd), Vg = volt(u, ng), Vs = volt(u, ns), Vb = volt(u, nb), Vdi = volt(u, ndi), Vsi = volt(u, nsi);
+  // parameters are fetched where they are first needed, not up front: 36 values held across the limiting code would not
+  // fit into the registers of a two-waves-per-SIMD kernel
   double type = par_of(d, M1_TYPE), vt = par_of(d, M1_VT), tPhi = par_of(d, M1_TPHI), tVbi = par_of(d, M1_TVBI);
-  double gamma = par_of(d, M1_GAMMA), lambda = par_of(d, M1_LAMBDA), Beta = par_of(d, M1_BETA);
-  double mf = par_of(d, M1_MFACTOR), gmin_m = par_of(d, M1_GMIN) / mf;
-  // this lane's junction: source side or drain side
-  const double isat = par_of(d, D ? M1_DSATCUR : M1_SSATCUR);
-  const double Cb = par_of(d, D ? M1_CBD : M1_CBS), Cbsw = par_of(d, D ? M1_CBDSW : M1_CBSSW);
-  const double f2 = par_of(d, D ? M1_F2D : M1_F2S), f3 = par_of(d, D ? M1_F3D : M1_F3S), f4 = par_of(d, D ? M1_F4D : M1_F4S);
+  double gamma = par_of(d, M1_GAMMA);
   CADNIP_TRACE_POINT(20);
   double w_gs, w_ds, w_bs, w_bd;
   m1_limit(d, u, type, vt, tPhi, tVbi, gamma, Vg, Vb, Vdi, Vsi, l0, l1, l2, l3, w_gs, w_ds, w_bs, w_bd);
@@ -713,12 +710,14 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
   D3 a = D3::seed(type * w_gs, 0), b = D3::seed(type * w_ds, 1), c = D3::seed(type * w_bs, 2);
   D3 dvbd = c - b, dvgd = a - b;
   const D3 vj = m1_sel(D, dvbd, c);
+  const double mf = par_of(d, M1_MFACTOR), gmin_m = par_of(d, M1_GMIN) / mf;
+  const double isat = par_of(d, D ? M1_DSATCUR : M1_SSATCUR);      // this lane's junction: source side or drain side
   const D3 cj = m1_junction(vj, vt, gmin_m, isat), co = m1_swap_pair(cj);
   const D3 cbs = m1_sel(D, co, cj), cbd = m1_sel(D, cj, co);
   CADNIP_TRACE_POINT(23);
   int mode;
   D3 dvon, vdsat, cdrain;
-  m1_channel(a, b, c, dvbd, dvgd, tPhi, tVbi, type, gamma, lambda, Beta, mode, dvon, vdsat, cdrain);
+  m1_channel(a, b, c, dvbd, dvgd, tPhi, tVbi, type, gamma, par_of(d, M1_LAMBDA), par_of(d, M1_BETA), mode, dvon, vdsat, cdrain);
   CADNIP_TRACE_POINT(24);
   const D3 cdreq = (mode >= 0 ? type : -type) * cdrain;
   const double dW_gs = (Vg - Vsi) - w_gs, dW_ds = (Vdi - Vsi) - w_ds, dW_bs = (Vb - Vsi) - w_bs;   // lim_rhs deltas
@@ -753,7 +752,8 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
   }
   CADNIP_TRACE_POINT(26);
   // depletion charge of this lane's junction (after the current rows: fewer values live at once), swapped like the current
-  const D3 qj = m1_qdep(vj, Cb, Cbsw, par_of(d, M1_TBULKPOT), par_of(d, M1_TDEPCAP), par_of(d, M1_MJ), par_of(d, M1_MJSW), f2, f3, f4);
+  const D3 qj = m1_qdep(vj, par_of(d, D ? M1_CBD : M1_CBS), par_of(d, D ? M1_CBDSW : M1_CBSSW), par_of(d, M1_TBULKPOT), par_of(d, M1_TDEPCAP),
+                        par_of(d, M1_MJ), par_of(d, M1_MJSW), par_of(d, D ? M1_F2D : M1_F2S), par_of(d, D ? M1_F3D : M1_F3S), par_of(d, D ? M1_F4D : M1_F4S));
   const D3 qo = m1_swap_pair(qj);
   const D3 qbs = m1_sel(D, qo, qj), qbd = m1_sel(D, qj, qo);
   CADNIP_TRACE_POINT(25);
