@@ -6,6 +6,6 @@ reference-shaped API (MNACircuit / dc / tran / CircuitSweep).  Device side: libc
 """
 from .circuit import Circuit, Param, Device  # noqa: F401
 from .structure import discover, pack_params, expand_breakpoints, Structure  # noqa: F401
-from . import mos1_params, bsource  # noqa: F401
+from . import mos1_params, bsource, netlist  # noqa: F401
 
 __all__ = ["Circuit", "Param", "Device", "discover", "pack_params", "expand_breakpoints", "Structure"]

@@ -85,8 +85,9 @@ def dff_circuit(mc_vto=None, mc_kp=None, meyer=False):
     c.V("VQ", "Q", "Q_tmp", dc=0.0)
     c.V("VNW", "VNW", "VDD", dc=0.0)
     c.V("VPW", "VPW", "VSS", dc=0.0)
-    c.V("VCLKN", "CLKN", "0", dc=0.0, wave=("pwl",) + CLKN_PWL, scale=amp)
-    c.V("VD", "D", "0", dc=0.0, wave=("pwl",) + D_PWL, scale=amp)
+    # DC value of a PWL source = its first point (src/spc/codegen.jl:2597), here scaled with the supply like the wave
+    c.V("VCLKN", "CLKN", "0", dc=Param("vdd", scale=CLKN_PWL[1][0] / 5.0), wave=("pwl",) + CLKN_PWL, scale=amp)
+    c.V("VD", "D", "0", dc=Param("vdd", scale=D_PWL[1][0] / 5.0), wave=("pwl",) + D_PWL, scale=amp)
     for (nm, d, g, s, b, W, L) in DFF_FETS:
         if meyer:
             base = NFET_06V0_MEYER if nm.startswith("tn") else PFET_06V0_MEYER

@@ -11,7 +11,7 @@ import numpy as np
 from .structure import Structure, TYPE_ID
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcadnip_hip.so")
+LIB_PATH = os.environ.get("CADNIP_HIP_LIB") or os.path.join(_HERE, "libcadnip_hip.so")   # same override as julia/CadnipHIP.jl
 
 OK, BADARG, SINGULAR, NONFINITE, HIPERROR, NOTREADY, NOCONV = range(7)
 STATUS_NAMES = {0: "CADNIP_OK", 1: "CADNIP_BADARG", 2: "CADNIP_SINGULAR", 3: "CADNIP_NONFINITE",

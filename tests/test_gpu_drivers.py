@@ -134,3 +134,22 @@ def test_dff_corner_sweep_small():
         assert abs(q[0]) < 0.05 and abs(q[2] - pt["vdd"]) < 0.05, (pt, q)
         assert min(abs(q[1]), abs(q[1] - pt["vdd"])) < 0.05, (pt, q)
     print(res.stats)
+
+
+def test_reference_dff_deck_end_to_end():
+    """The reference's DFF deck, read from the fixture text (tests/golden/, no hand transcription), through DC
+    initialisation and the fused transient kernel: the race-free logic pins of test/gf180_dff.jl:29-33."""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    deck = open(os.path.join(gold, "DFF_cap_all.cir")).read()
+    cell = open(os.path.join(gold, "gf180mcu_fd_sc_mcu7t5v0__dffnq_4.ngspice")).read()
+    circ, info = cj.netlist.read_spice(deck, models={"nfet_06v0": bm.NFET_06V0_MEYER, "pfet_06v0": bm.PFET_06V0_MEYER},
+                                       includes={"gf180mcu_fd_sc_mcu7t5v0__dffnq_4.ngspice": cell})
+    sim = api.BatchSimulator(api.MNACircuit(circ, {}, api.MNASpec(gmin=info["options"]["gmin"])))
+    st = sim.st
+    ts = np.array([150e-9, 250e-9, 700e-9])
+    out, per, stats = sim.tran((0.0, 7e-7), st.state_abstol(vntol=1e-6, iabstol=1e-9, chgtol=1e-6), 1e-4, ts, obs=[st.index_of("Q")], fused=1)
+    sim.close()
+    assert stats["n_failed"] == 0
+    q = out[0, :, 0]
+    assert abs(q[0]) < 0.05 and abs(q[1]) < 0.05 and abs(q[2] - 5.0) < 0.05, q
