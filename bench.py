@@ -162,6 +162,10 @@ def main():
                 # a fused launch runs up to 8 Newton rounds of every instance still active: count the iterations actually done
                 per_launch = ab["B_iter_per_instance"] * pstats["newton_iters"] / max(dom[1][1], 1)
                 roof["newton_iters_per_launch"] = round(pstats["newton_iters"] / max(dom[1][1], 1), 1)
+            if name.startswith("fused"):
+                roof["note"] = ("algorithmic bytes = SURVEY.md 8d's B_iter (slot writes, G/C/J, LU factors counted as memory traffic) x Newton "
+                                "iterations executed; the fused kernel keeps all of that in LDS and registers, so frac can exceed 1 and "
+                                "`traffic` (PMC HBM bytes) is far below it -- the kernel is VALU-issue / LDS-latency bound, see wave_time_shares")
             roof["algorithmic_bytes_per_launch"] = int(per_launch)
             roof["achieved"] = round(per_launch / avg_s / 1e9, 3)
             roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 5)
