@@ -35,6 +35,7 @@ namespace cadnip {
 typedef unsigned short u16;
 typedef unsigned long long u64;
 #define NOPOS 0xFFFFu
+#define F2_NCMAX 16   // largest core the in-register dense solve is unrolled for
 #define F2_TRASH 64   // per-instance trash words (one per lane) that absorb stamps into ground rows / columns
 
 // table sections (offsets in 32-bit words, every section 8-byte aligned)
@@ -64,7 +65,8 @@ struct F2Args {
   const unsigned* tab;       // packed tables in global memory
   int off[S_NSEC];
   int tab_len;               // 32-bit words (even)
-  int n, nnz, nnz_lu, n_pass, rounds, B;
+  int n, nnz, nnz_lu, rounds, B;   // nnz_lu: words of W before the rhs (sparse L\U entries + dense core block)
+  int n_pre, n_post, nc, dn0;       // passes before / after the dense core solve, core size, first word of the core block
   int* queue;                // next not-yet-resident instance (relative to gridDim.x * WPB); zeroed before every launch
   TranArgs t;
 };
@@ -176,6 +178,34 @@ struct FusedVecs {
   __device__ __forceinline__ void set_du(int, double) const {}   // du is rebuilt from u and beta when the kernel exits
   __device__ __forceinline__ double get_lw(int i) const { return lw[i]; }
 };
+
+// The core of the linear system: the Schur complement of the last NC pivots (accumulated in W by the entry program), one
+// row per lane, eliminated and solved in registers.  Pivot rows are broadcast with v_readlane; no LDS traffic and no fences
+// inside.  Static pivot order like the rest of the factorisation; a zero / non-finite pivot raises `bad`.
+template <int NC>
+__device__ __forceinline__ void dense_core_solve(double* W, int dn0, int yc0, int lane, int& bad) {
+  const int row = lane < NC ? lane : 0;
+  const double* S = W + dn0 + row * NC;
+  double A[NC], rp[NC], bc = W[yc0 + row];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) A[j] = S[j];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const double pkk = readlane_f64(A[k], k);
+    if (pkk == 0.0 || !isfinite(pkk)) bad = 1;
+    rp[k] = fast_div(1.0, pkk);
+    const double m = lane > k ? A[k] * rp[k] : 0.0;       // rows up to k keep their (final) U rows
+#pragma unroll
+    for (int j = k + 1; j < NC; ++j) A[j] = fma(-m, readlane_f64(A[j], k), A[j]);
+    bc = fma(-m, readlane_f64(bc, k), bc);
+  }
+#pragma unroll
+  for (int k = NC - 1; k >= 0; --k) {
+    const double xk = readlane_f64(bc * rp[k], k);         // lane k holds the reduced rhs of row k
+    bc = lane == k ? xk : (lane < k ? fma(-A[k], xk, bc) : bc);
+  }
+  if (lane < NC) W[yc0 + lane] = bc;
+}
 
 template <int WPB>
 __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
@@ -311,8 +341,9 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
     // fetched two passes ahead, lane descriptor and first term one pass ahead, so the chain inside a pass is
     // operand reads -> fma -> DPP sum -> [divide] -> write.
     int bad = 0;
-    if (f.n_pass > 0) {
-      u64 pd = passd[0], pd1 = passd[1];
+    auto run_passes = [&](const int p_first, const int p_count) {
+      if (p_count <= 0) return;
+      u64 pd = passd[p_first], pd1 = passd[p_first + 1];
       u64 D;
       unsigned T0;
       {
@@ -321,7 +352,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
         D = laned[lo + (lane < T ? lane : T - 1)];
         T0 = term[(unsigned)(D >> 32) & 0xFFFFu];
       }
-      for (int pi = 0; pi < f.n_pass; ++pi) {
+      for (int pi = p_first; pi < p_first + p_count; ++pi) {
         const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(pd >> 32));
         const int T = hi & 0x7F, maxlg = (hi >> 8) & 7, hasdiv = (hi >> 11) & 1, fence = (hi >> 12) & 1, multi = (hi >> 13) & 1;
         const bool act = lane < T;
@@ -359,7 +390,18 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
         if (fence) CADNIP_WAVE_SYNC();
         D = Dn; T0 = T0n; pd = pd1; pd1 = pd2;
       }
+    };
+    run_passes(0, f.n_pre);
+    CADNIP_TRACE_POINT(4);
+    if (f.nc > 0) {
+      const int yc0 = f.nnz_lu + n - f.nc;
+      if (f.nc == 8) dense_core_solve<8>(W, f.dn0, yc0, lane, bad);
+      else if (f.nc == 12) dense_core_solve<12>(W, f.dn0, yc0, lane, bad);
+      else dense_core_solve<F2_NCMAX>(W, f.dn0, yc0, lane, bad);
+      CADNIP_WAVE_SYNC();
     }
+    CADNIP_TRACE_POINT(5);
+    run_passes(f.n_pre, f.n_post);
     CADNIP_TRACE_POINT(3);
     // ---- Newton update + step controller (registers / LDS; HBM only for history and outputs)
     tran_update_body(a, vec, st, inst, lane, bad);
@@ -397,16 +439,197 @@ static inline u64 pack4(unsigned a, unsigned b, unsigned c, unsigned d) {
   return (u64)(a & 0xFFFFu) | ((u64)(b & 0xFFFFu) << 16) | ((u64)(c & 0xFFFFu) << 32) | ((u64)(d & 0xFFFFu) << 48);
 }
 
+// ---- the linear-solve program -------------------------------------------------------------------------------
+// Work array of one instance:  W = [ sparse L\U (all pattern entries outside the core block) | dense core NC x NC | rhs n | trash ].
+// The last NC pivots form the *core*: its Schur complement is accumulated by the entry program like everything else
+// and then eliminated by dense_core_solve in registers (NC = 0: no core, the entry program does it all).
+struct F2Program {
+  int nc = 0, lu_words = 0, dn0 = 0;       // core size, words before the rhs (sparse + dense), first dense word
+  std::vector<int> posW;                   // LU pattern position -> W offset
+  std::vector<u64> lanes, passes;          // lane descriptors, pass descriptors (pre-dense passes, then post-dense)
+  std::vector<unsigned> terms;
+  int n_pre = 0, n_post = 0;
+  double cost = 0;                         // issue-slot estimate used to choose nc
+};
+
+struct F2Ent { int pos, dg, lvl; std::vector<int> a, b; };
+
+// Levels -> passes of 64 lane descriptors.  An entry with nt terms gets a group of min(cap, pow2ceil(nt)) lanes (aligned,
+// so a DPP butterfly sums it); groups are packed widest first; cap is chosen per level to minimise passes*2 + iterations.
+static bool f2_emit_passes(std::vector<F2Ent>& ents, F2Program& G, int& n_passes) {
+  auto p2c = [](size_t x) { size_t r = 1; while (r < x) r *= 2; return r; };
+  std::stable_sort(ents.begin(), ents.end(), [](const F2Ent& p, const F2Ent& q) { return p.lvl < q.lvl; });
+  n_passes = 0;
+  for (size_t i = 0; i < ents.size();) {
+    size_t j = i;
+    while (j < ents.size() && ents[j].lvl == ents[i].lvl) ++j;
+    const size_t E = j - i;
+    size_t best_cost = (size_t)-1;
+    int best_cap = 1;
+    for (int cap = 16; cap >= 1; cap >>= 1) {
+      std::vector<size_t> L(E), ord(E);
+      size_t total = 0;
+      for (size_t e = 0; e < E; ++e) { L[e] = std::min((size_t)cap, p2c(std::max<size_t>(ents[i + e].a.size(), 1))); total += L[e]; ord[e] = e; }
+      std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return L[x] > L[y]; });
+      const size_t passes = (total + 63) / 64;
+      std::vector<size_t> it(passes, 1);
+      size_t off = 0;
+      for (size_t e : ord) { const size_t nt = ents[i + e].a.size(); it[off / 64] = std::max(it[off / 64], (nt + L[e] - 1) / L[e]); off += L[e]; }
+      size_t cost = 0;
+      for (size_t p = 0; p < passes; ++p) cost += 2 + it[p] - 1;
+      if (cost < best_cost) { best_cost = cost; best_cap = cap; }
+    }
+    std::vector<size_t> L(E), ord(E);
+    for (size_t e = 0; e < E; ++e) { L[e] = std::min((size_t)best_cap, p2c(std::max<size_t>(ents[i + e].a.size(), 1))); ord[e] = e; }
+    std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return L[x] > L[y]; });
+    const size_t base = G.lanes.size();
+    std::vector<int> lane_lg, lane_nt, lane_div;
+    for (size_t e : ord) {
+      const F2Ent& x = ents[i + e];
+      int lg = 0;
+      while (((size_t)1 << lg) < L[e]) ++lg;
+      for (size_t sub = 0; sub < L[e]; ++sub) {
+        const size_t t0 = G.terms.size();
+        size_t nt = 0;
+        for (size_t t = sub; t < x.a.size(); t += L[e], ++nt) G.terms.push_back((unsigned)x.a[t] | ((unsigned)x.b[t] << 16));
+        if (nt > 255 || t0 >= 65535) return false;
+        G.lanes.push_back(pack4(x.pos, x.dg < 0 ? NOPOS : x.dg, (unsigned)t0, (unsigned)(nt | ((unsigned)lg << 8) | ((sub == 0 ? 1u : 0u) << 12))));
+        lane_lg.push_back(lg); lane_nt.push_back((int)nt); lane_div.push_back(x.dg >= 0);
+      }
+    }
+    const size_t total = G.lanes.size() - base;
+    for (size_t off = 0; off < total; off += 64) {
+      const size_t T = std::min<size_t>(64, total - off);
+      unsigned maxlg = 0, hasdiv = 0, multi = 0;
+      for (size_t l = off; l < off + T; ++l) { maxlg = std::max(maxlg, (unsigned)lane_lg[l]); hasdiv |= (unsigned)lane_div[l]; multi |= lane_nt[l] > 1 ? 1u : 0u; }
+      const unsigned fence = off + 64 >= total ? 1u : 0u;
+      if (base + off >= ((size_t)1 << 31)) return false;
+      G.passes.push_back((u64)(base + off) | ((u64)(T | (maxlg << 8) | (hasdiv << 11) | (fence << 12) | (multi << 13)) << 32));
+      ++n_passes;
+    }
+    i = j;
+  }
+  return true;
+}
+
+// Entry program for core size nc, straight from the L\U pattern (permuted indices, rows sorted by column):
+//   pre  : every L\U entry outside the core block (left-looking recurrence, L entries divided by their pivot), the Schur
+//          updates of the core block by the leaf pivots, forward substitution as the recurrence of an extra column (for core
+//          rows: their leaf part);
+//   post : back substitution of the leaf rows, in place (the core rows of x are written by the dense solve).
+static bool f2_build_program(const LUProgram& P, int n, int nc, F2Program& G) {
+  G = F2Program();
+  G.nc = nc;
+  const int cs0 = n - nc;
+  std::vector<int> rowof(P.nnz_lu);
+  for (int i = 0; i < n; ++i) for (int p = P.lu_rowptr[i]; p < P.lu_rowptr[i + 1]; ++p) rowof[p] = i;
+  G.posW.assign(P.nnz_lu, -1);
+  int nsp = 0;
+  for (int p = 0; p < P.nnz_lu; ++p) if (!(rowof[p] >= cs0 && P.lu_col[p] >= cs0)) G.posW[p] = nsp++;
+  G.dn0 = nsp;
+  for (int p = 0; p < P.nnz_lu; ++p) if (G.posW[p] < 0) G.posW[p] = G.dn0 + (rowof[p] - cs0) * nc + (P.lu_col[p] - cs0);
+  G.lu_words = nsp + nc * nc;
+  const int y0 = G.lu_words;
+  auto find = [&](int i, int j) -> int {     // pattern position of (i, j) or -1
+    const int* b = &P.lu_col[P.lu_rowptr[i]]; const int* e = &P.lu_col[P.lu_rowptr[i + 1]];
+    const int* it = std::lower_bound(b, e, j);
+    return (it != e && *it == j) ? (int)(it - &P.lu_col[0]) : -1;
+  };
+  std::vector<int> lev(P.nnz_lu, -1);        // level at which a sparse entry is final (-1: as assembled)
+  std::vector<F2Ent> pre, post;
+  for (int i = 0; i < n; ++i)
+    for (int p = P.lu_rowptr[i]; p < P.lu_rowptr[i + 1]; ++p) {
+      const int j = P.lu_col[p];
+      if (i >= cs0 && j >= cs0) continue;
+      F2Ent x; x.pos = G.posW[p]; x.dg = -1; x.lvl = -1;
+      for (int pl = P.lu_rowptr[i]; pl < P.lu_diag[i]; ++pl) {
+        const int k = P.lu_col[pl];
+        if (k >= j) break;
+        const int pu = find(k, j);
+        if (pu < 0) continue;
+        x.a.push_back(G.posW[pl]); x.b.push_back(G.posW[pu]);
+        x.lvl = std::max(x.lvl, std::max(lev[pl], lev[pu]));
+      }
+      if (j < i) { x.dg = G.posW[P.lu_diag[j]]; x.lvl = std::max(x.lvl, lev[P.lu_diag[j]]); }
+      if (x.a.empty() && x.dg < 0) continue;
+      x.lvl += 1;
+      lev[p] = x.lvl;
+      pre.push_back(std::move(x));
+    }
+  for (int i = cs0; i < n; ++i)
+    for (int j = cs0; j < n; ++j) {
+      F2Ent x; x.pos = G.dn0 + (i - cs0) * nc + (j - cs0); x.dg = -1; x.lvl = -1;
+      for (int pl = P.lu_rowptr[i]; pl < P.lu_diag[i]; ++pl) {
+        const int k = P.lu_col[pl];
+        if (k >= cs0) break;
+        const int pu = find(k, j);
+        if (pu < 0) continue;
+        x.a.push_back(G.posW[pl]); x.b.push_back(G.posW[pu]);
+        x.lvl = std::max(x.lvl, std::max(lev[pl], lev[pu]));
+      }
+      if (x.a.empty()) continue;
+      x.lvl += 1;
+      pre.push_back(std::move(x));
+    }
+  std::vector<int> ylev(n, -1);
+  for (int i = 0; i < n; ++i) {
+    F2Ent x; x.pos = y0 + i; x.dg = -1; x.lvl = -1;
+    for (int pl = P.lu_rowptr[i]; pl < P.lu_diag[i]; ++pl) {
+      const int k = P.lu_col[pl];
+      if (k >= cs0) break;
+      x.a.push_back(G.posW[pl]); x.b.push_back(y0 + k);
+      x.lvl = std::max(x.lvl, std::max(lev[pl], ylev[k]));
+    }
+    if (x.a.empty()) continue;
+    x.lvl += 1;
+    ylev[i] = x.lvl;
+    pre.push_back(std::move(x));
+  }
+  std::vector<int> xlev(n, -1);
+  for (int i = cs0 - 1; i >= 0; --i) {
+    F2Ent x; x.pos = y0 + i; x.dg = G.posW[P.lu_diag[i]]; x.lvl = -1;
+    for (int pu = P.lu_diag[i] + 1; pu < P.lu_rowptr[i + 1]; ++pu) {
+      const int j = P.lu_col[pu];
+      x.a.push_back(G.posW[pu]); x.b.push_back(y0 + j);
+      if (j < cs0) x.lvl = std::max(x.lvl, xlev[j]);
+    }
+    x.lvl += 1;
+    xlev[i] = x.lvl;
+    post.push_back(std::move(x));
+  }
+  if (!f2_emit_passes(pre, G, G.n_pre) || !f2_emit_passes(post, G, G.n_post)) return false;
+  G.terms.push_back(0);   // a lane without terms still prefetches term[t0]
+  if (G.terms.size() >= 65535) return false;
+  // issue slots: ~150 per pass; the dense solve about 60 + 17 nc + 1.5 nc^2
+  G.cost = 150.0 * (G.n_pre + G.n_post) + (nc ? 60.0 + 17.0 * nc + 1.5 * nc * nc : 0.0);
+  return true;
+}
+
 static bool f2_prepare(CadnipHandle* h, F2Tables& T, const std::vector<int>& g_ptr, const std::vector<int>& g_slots, const std::vector<int>& c_ptr,
                        const std::vector<int>& c_slots, const std::vector<int>& b_ptr, const std::vector<int>& b_slots) {
   const LUProgram& P = h->lu;
-  const int n = h->n, nnz_lu = P.nnz_lu;
-  const int y0 = nnz_lu, trash0 = nnz_lu + n;                 // W offsets
-  if (trash0 + F2_TRASH >= 65535 || n >= 32767) return false;
+  const int n = h->n;
+  if (n >= 32767) return false;
+  // core size: the cheapest of {0, 8, 12, 16}; CADNIP_F2_NC forces one (diagnostic)
+  F2Program G;
+  {
+    bool any = false;
+    const char* force = getenv("CADNIP_F2_NC");
+    for (int nc : {0, 8, 12, F2_NCMAX}) {
+      if (nc > n || (force && atoi(force) != nc)) continue;
+      F2Program C;
+      if (!f2_build_program(P, n, nc, C)) continue;
+      if (!any || C.cost < G.cost) { G = std::move(C); any = true; }
+    }
+    if (!any) return false;
+  }
+  const int y0 = G.lu_words, trash0 = G.lu_words + n;                 // W offsets
+  if (trash0 + F2_TRASH >= 65535) return false;
+  h->f2_lu_words = G.lu_words; h->f2_nc = G.nc; h->f2_dn0 = G.dn0; h->f2_n_pre = G.n_pre; h->f2_n_post = G.n_post;
   std::vector<int> pinv(n), qinv(n);
   for (int k = 0; k < n; ++k) { pinv[P.rperm[k]] = k; qinv[P.cperm[k]] = k; }
   std::vector<int> dst(h->nnz, 0);
-  for (size_t k = 0; k < P.load_src.size(); ++k) dst[P.load_src[k]] = P.load_dst[k];
+  for (size_t k = 0; k < P.load_src.size(); ++k) dst[P.load_src[k]] = G.posW[P.load_dst[k]];
   // slot -> W offset.  A slot that no nz gathers (ground row / column) goes to the trash word of its lane.
   std::vector<int> gs(h->ns_g, -1), cpos(h->ns_c, -1), crow(h->ns_c, 0), ccol(h->ns_c, 0), br(h->ns_b, -1);
   for (int i = 0; i < n; ++i)
@@ -444,109 +667,9 @@ static bool f2_prepare(CadnipHandle* h, F2Tables& T, const std::vector<int>& g_p
     for (int i = 0; i < n; ++i) for (int e = h->h_rowptr[i]; e < h->h_rowptr[i + 1]; ++e) row_of[e] = i;
     for (auto& oe : order) { const int e = oe.second; T.add64(pack4(dst[e], y0 + pinv[row_of[e]], h->h_colidx[e], 0)); }
   }
-  // ---- unified entry program: factor entries, forward substitution as an extra column, back substitution in place
-  struct Ent { int pos, dg, lvl; std::vector<int> a, b; };
-  std::vector<Ent> ents;
-  std::vector<int> plev(nnz_lu, -1);
-  const int nF = (int)P.lev_ptr.size() - 1;
-  for (int L = 0; L < nF; ++L)
-    for (int e = P.lev_ptr[L]; e < P.lev_ptr[L + 1]; ++e) {
-      Ent x; x.pos = P.ent_pos[e]; x.dg = P.ent_diag[e]; x.lvl = L;
-      for (int t = P.ent_ptr[e]; t < P.ent_ptr[e + 1]; ++t) { x.a.push_back(P.term_a[t]); x.b.push_back(P.term_b[t]); }
-      plev[x.pos] = L;
-      ents.push_back(std::move(x));
-    }
-  int maxlev = nF - 1;
-  std::vector<int> ylev(n, -1);
-  for (int i = 0; i < n; ++i) {
-    Ent x; x.pos = y0 + i; x.dg = -1; x.lvl = -1;
-    for (int p = P.lu_rowptr[i]; p < P.lu_diag[i]; ++p) {
-      const int k = P.lu_col[p];
-      x.a.push_back(p); x.b.push_back(y0 + k);
-      x.lvl = std::max(x.lvl, std::max(plev[p], ylev[k]) + 1);
-    }
-    if (x.a.empty()) continue;
-    ylev[i] = x.lvl;
-    maxlev = std::max(maxlev, x.lvl);
-    ents.push_back(std::move(x));
-  }
-  std::vector<int> xlev(n, 0);
-  for (int i = n - 1; i >= 0; --i) {
-    Ent x; x.pos = y0 + i; x.dg = P.lu_diag[i]; x.lvl = maxlev + 1;
-    for (int p = P.lu_diag[i] + 1; p < P.lu_rowptr[i + 1]; ++p) {
-      const int j = P.lu_col[p];
-      x.a.push_back(p); x.b.push_back(y0 + j);
-      x.lvl = std::max(x.lvl, xlev[j] + 1);
-    }
-    xlev[i] = x.lvl;
-    ents.push_back(std::move(x));
-  }
-  std::stable_sort(ents.begin(), ents.end(), [](const Ent& p, const Ent& q) { return p.lvl < q.lvl; });
-  size_t n_terms = 0;
-  for (auto& e : ents) n_terms += e.a.size();
-  if (n_terms >= 65535) return false;
-  // Levels -> passes of 64 lane descriptors.  An entry with nt terms gets a group of min(cap, pow2ceil(nt)) lanes
-  // (aligned, so a DPP butterfly sums it); groups are packed widest first; cap is chosen per level to minimise
-  // passes*2 + dot-product iterations.
-  auto p2c = [](size_t x) { size_t r = 1; while (r < x) r *= 2; return r; };
-  std::vector<u64> pass_words, lane_words;
-  std::vector<unsigned> terms;
-  for (size_t i = 0; i < ents.size();) {
-    size_t j = i;
-    while (j < ents.size() && ents[j].lvl == ents[i].lvl) ++j;
-    const size_t E = j - i;
-    size_t best_cost = (size_t)-1;
-    int best_cap = 1;
-    for (int cap = 16; cap >= 1; cap >>= 1) {
-      std::vector<size_t> L(E);
-      size_t total = 0;
-      for (size_t e = 0; e < E; ++e) { L[e] = std::min((size_t)cap, p2c(std::max<size_t>(ents[i + e].a.size(), 1))); total += L[e]; }
-      std::vector<size_t> ord(E);
-      for (size_t e = 0; e < E; ++e) ord[e] = e;
-      std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return L[x] > L[y]; });
-      const size_t passes = (total + 63) / 64;
-      std::vector<size_t> it(passes, 1);
-      size_t off = 0;
-      for (size_t e : ord) { const size_t nt = ents[i + e].a.size(); it[off / 64] = std::max(it[off / 64], (nt + L[e] - 1) / L[e]); off += L[e]; }
-      size_t cost = 0;
-      for (size_t p = 0; p < passes; ++p) cost += 2 + it[p] - 1;
-      if (cost < best_cost) { best_cost = cost; best_cap = cap; }
-    }
-    std::vector<size_t> L(E), ord(E);
-    for (size_t e = 0; e < E; ++e) { L[e] = std::min((size_t)best_cap, p2c(std::max<size_t>(ents[i + e].a.size(), 1))); ord[e] = e; }
-    std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return L[x] > L[y]; });
-    const size_t base = lane_words.size();
-    std::vector<int> lane_lg, lane_nt, lane_div;
-    for (size_t e : ord) {
-      const Ent& x = ents[i + e];
-      int lg = 0;
-      while (((size_t)1 << lg) < L[e]) ++lg;
-      for (size_t sub = 0; sub < L[e]; ++sub) {
-        const size_t t0 = terms.size();
-        size_t nt = 0;
-        for (size_t t = sub; t < x.a.size(); t += L[e], ++nt) terms.push_back((unsigned)x.a[t] | ((unsigned)x.b[t] << 16));
-        if (nt > 255 || t0 >= 65535) return false;
-        lane_words.push_back(pack4(x.pos, x.dg < 0 ? NOPOS : x.dg, (unsigned)t0, (unsigned)(nt | ((unsigned)lg << 8) | ((sub == 0 ? 1u : 0u) << 12))));
-        lane_lg.push_back(lg); lane_nt.push_back((int)nt); lane_div.push_back(x.dg >= 0);
-      }
-    }
-    const size_t total = lane_words.size() - base;
-    for (size_t off = 0; off < total; off += 64) {
-      const size_t T = std::min<size_t>(64, total - off);
-      unsigned maxlg = 0, hasdiv = 0, multi = 0;
-      for (size_t l = off; l < off + T; ++l) { maxlg = std::max(maxlg, (unsigned)lane_lg[l]); hasdiv |= (unsigned)lane_div[l]; multi |= lane_nt[l] > 1 ? 1u : 0u; }
-      const unsigned fence = off + 64 >= total ? 1u : 0u;
-      if (base + off >= ((size_t)1 << 31)) return false;
-      pass_words.push_back((u64)(base + off) | ((u64)(T | (maxlg << 8) | (hasdiv << 11) | (fence << 12) | (multi << 13)) << 32));
-    }
-    i = j;
-  }
-  terms.push_back(0);   // a lane without terms still prefetches term[t0]
-  T.begin(S_ENT); for (u64 wv : lane_words) T.add64(wv);
-  std::vector<u64>& lev_words = pass_words;
-  T.begin(S_TERM); for (unsigned t : terms) T.add32(t);
-  h->f2_n_lev = (int)lev_words.size();
-  T.begin(S_LEV); for (u64 wv : lev_words) T.add64(wv);
+  T.begin(S_ENT); for (u64 wv : G.lanes) T.add64(wv);
+  T.begin(S_TERM); for (unsigned t : G.terms) T.add32(t);
+  T.begin(S_LEV); for (u64 wv : G.passes) T.add64(wv);
   T.add64(0); T.add64(0);   // two empty passes: the kernel reads pass descriptors two ahead
   std::vector<int> qoff(n);
   for (int j = 0; j < n; ++j) qoff[j] = y0 + qinv[j];
@@ -609,11 +732,11 @@ int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds) {
   f.tab = h->d_f2tab;
   for (int i = 0; i < S_NSEC; ++i) f.off[i] = h->f2off[i];
   f.tab_len = h->f2len;
-  f.n = h->n; f.nnz = h->nnz; f.nnz_lu = P.nnz_lu;
-  f.n_pass = h->f2_n_lev;
+  f.n = h->n; f.nnz = h->nnz; f.nnz_lu = h->f2_lu_words;
+  f.n_pre = h->f2_n_pre; f.n_post = h->f2_n_post; f.nc = h->f2_nc; f.dn0 = h->f2_dn0;
   f.rounds = rounds; f.B = h->B; f.t = t;
   const size_t tab_dbl = (size_t)h->f2len / 2;
-  const size_t per = (size_t)P.nnz_lu + 3 * (size_t)h->n + F2_TRASH;
+  const size_t per = (size_t)h->f2_lu_words + 3 * (size_t)h->n + F2_TRASH;
   const size_t lds_cap = 160 * 1024;
   if (h->n_cu <= 0) {
     int cu = 0;
@@ -632,7 +755,7 @@ int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds) {
   f.queue = h->d_f2queue;
   const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(lds_cap / shmem, (size_t)(32 / wpb)));
   int grid = std::min((h->B + wpb - 1) / wpb, h->n_cu * wg_per_cu);
-  if (getenv("CADNIP_F2_DEBUG")) fprintf(stderr, "[cadnip f2] B %d n_cu %d wpb %d grid %d shmem %zu rounds %d\n", h->B, h->n_cu, wpb, grid, shmem, rounds);
+  if (getenv("CADNIP_F2_DEBUG")) fprintf(stderr, "[cadnip f2] B %d n_cu %d wpb %d grid %d shmem %zu rounds %d nc %d passes %d+%d\n", h->B, h->n_cu, wpb, grid, shmem, rounds, h->f2_nc, h->f2_n_pre, h->f2_n_post);
 #define LAUNCH(W)                                                                                                      \
   do {                                                                                                                 \
     if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_fused2<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \

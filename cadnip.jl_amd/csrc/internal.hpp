@@ -88,7 +88,7 @@ struct CadnipHandle {
   unsigned int* d_f2tab = nullptr;
   int f2off[16] = {0};      // section offsets in 32-bit words
   int f2len = 0;            // 32-bit words
-  int f2_n_lev = 0;
+  int f2_lu_words = 0, f2_nc = 0, f2_dn0 = 0, f2_n_pre = 0, f2_n_post = 0;   // linear-solve program of the fused kernel
   std::vector<int> f2_nodes_off;   // per device block: offset (int16 units) of its node table inside the NODES section
   bool fused2_dirty = true;
   int* d_f2queue = nullptr;   // fused kernel: dynamic instance queue
