@@ -600,8 +600,8 @@ static bool f2_build_program(const LUProgram& P, int n, int nc, F2Program& G) {
   if (!f2_emit_passes(pre, G, G.n_pre) || !f2_emit_passes(post, G, G.n_post)) return false;
   G.terms.push_back(0);   // a lane without terms still prefetches term[t0]
   if (G.terms.size() >= 65535) return false;
-  // issue slots: ~150 per pass; the dense solve about 60 + 17 nc + 1.5 nc^2
-  G.cost = 150.0 * (G.n_pre + G.n_post) + (nc ? 60.0 + 17.0 * nc + 1.5 * nc * nc : 0.0);
+  // wave cycles measured on the DFF (tools/trace_fused2.py): ~950 per pass; dense solve 2.7 k at nc = 8, 4.3 k at nc = 12
+  G.cost = 950.0 * (G.n_pre + G.n_post) + (nc ? 1450.0 + 19.5 * nc * nc : 0.0);
   return true;
 }
 
