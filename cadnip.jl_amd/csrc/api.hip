@@ -319,6 +319,36 @@ int cadnip_host_lu_get(const CadnipHostLU* lu, int32_t which, int32_t* dst) {
   memcpy(dst, v->data(), v->size() * sizeof(int));
   return CADNIP_OK;
 }
+struct CadnipHostF2 { cadnip::F2Program g; std::vector<int> meta; };
+int cadnip_host_f2_build(const CadnipHostLU* lu, int32_t nc, CadnipHostF2** out) {
+  if (!lu || !out || nc < 0 || nc > lu->p.n) return CADNIP_BADARG;
+  CadnipHostF2* f = new CadnipHostF2();
+  if (!cadnip::f2_build_program(lu->p, lu->p.n, nc, f->g)) { delete f; return CADNIP_BADARG; }
+  f->meta = {f->g.nc, f->g.lu_words, f->g.dn0, f->g.n_pre, f->g.n_post};
+  *out = f;
+  return CADNIP_OK;
+}
+int32_t cadnip_host_f2_size(const CadnipHostF2* f, int32_t which) {
+  if (!f) return -1;
+  switch (which) {
+    case CADNIP_F2_POSW: return (int32_t)f->g.posW.size(); case CADNIP_F2_LANES: return (int32_t)f->g.lanes.size();
+    case CADNIP_F2_PASSES: return (int32_t)f->g.passes.size(); case CADNIP_F2_TERMS: return (int32_t)f->g.terms.size();
+    case CADNIP_F2_META: return (int32_t)f->meta.size();
+  }
+  return -1;
+}
+int cadnip_host_f2_get(const CadnipHostF2* f, int32_t which, void* dst) {
+  if (!f || !dst) return CADNIP_BADARG;
+  switch (which) {
+    case CADNIP_F2_POSW: memcpy(dst, f->g.posW.data(), f->g.posW.size() * 4); return CADNIP_OK;
+    case CADNIP_F2_LANES: memcpy(dst, f->g.lanes.data(), f->g.lanes.size() * 8); return CADNIP_OK;
+    case CADNIP_F2_PASSES: memcpy(dst, f->g.passes.data(), f->g.passes.size() * 8); return CADNIP_OK;
+    case CADNIP_F2_TERMS: memcpy(dst, f->g.terms.data(), f->g.terms.size() * 4); return CADNIP_OK;
+    case CADNIP_F2_META: memcpy(dst, f->meta.data(), f->meta.size() * 4); return CADNIP_OK;
+  }
+  return CADNIP_BADARG;
+}
+void cadnip_host_f2_free(CadnipHostF2* f) { delete f; }
 void cadnip_host_lu_free(CadnipHostLU* lu) { delete lu; }
 
 int cadnip_factor(CadnipHandle* h) {

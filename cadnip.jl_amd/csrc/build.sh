@@ -8,5 +8,5 @@ if [ "${1:-}" = "--trace" ]; then shift; OUT=../libcadnip_hip_trace.so; set -- -
 # -disable-machine-licm: the fused kernel runs two waves per SIMD (256 VGPRs); hoisting loop-invariant constants and
 # address arithmetic out of its round loop costs 80 more spilled VGPRs, each reloaded from scratch (HBM latency) at every use
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable -mllvm -disable-machine-licm"
-hipcc $FLAGS -shared -o $OUT kernels.hip api.hip driver.hip fused2.hip symbolic.cpp "$@"
+hipcc $FLAGS -shared -o $OUT kernels.hip api.hip driver.hip fused2.hip symbolic.cpp f2_program.cpp "$@"
 echo "built $(realpath $OUT)"

@@ -39,6 +39,24 @@ struct LUProgram {
   std::vector<int> fwd_rows, fwd_lev_ptr, bwd_rows, bwd_lev_ptr;
 };
 
+static inline unsigned long long pack4(unsigned a, unsigned b, unsigned c, unsigned d) {
+  return (unsigned long long)(a & 0xFFFFu) | ((unsigned long long)(b & 0xFFFFu) << 16) | ((unsigned long long)(c & 0xFFFFu) << 32) | ((unsigned long long)(d & 0xFFFFu) << 48);
+}
+
+// ---- linear-solve program of the fused kernel (f2_program.cpp) ----
+struct F2Program {
+  int nc = 0, lu_words = 0, dn0 = 0;       // core size, words before the rhs (sparse + dense), first dense word
+  std::vector<int> posW;                   // LU pattern position -> W offset
+  std::vector<unsigned long long> lanes, passes;          // lane descriptors, pass descriptors (pre-dense passes, then post-dense)
+  std::vector<unsigned> terms;
+  int n_pre = 0, n_post = 0;
+  double cost = 0;                         // issue-slot estimate used to choose nc
+};
+
+struct F2Ent { int pos, dg, lvl; std::vector<int> a, b; };
+
+bool f2_build_program(const LUProgram& P, int n, int nc, F2Program& G);
+
 struct DeviceBlock {
   int type, count, n_nodes, n_ipar, n_par;
   int g_base, c_base, b_base, n_g, n_c, n_b;

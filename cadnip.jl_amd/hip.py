@@ -25,6 +25,7 @@ EXPORTS = [
     "cadnip_tran_run", "cadnip_tran_state", "cadnip_dev_ptr", "cadnip_stream", "cadnip_set_u", "cadnip_get_u", "cadnip_get_flags",
     "cadnip_sync", "cadnip_debug_copy", "cadnip_profile_enable", "cadnip_profile_read", "cadnip_version",
     "cadnip_host_lu_analyze", "cadnip_host_lu_size", "cadnip_host_lu_get", "cadnip_host_lu_free",
+    "cadnip_host_f2_build", "cadnip_host_f2_size", "cadnip_host_f2_get", "cadnip_host_f2_free",
 ]
 
 
@@ -342,7 +343,10 @@ LU_ARRAYS = ("rperm", "cperm", "rowptr", "col", "diag", "load_src", "load_dst", 
              "term_a", "term_b", "lev_ptr", "fwd_rows", "fwd_lev_ptr", "bwd_rows", "bwd_lev_ptr")
 
 
-def host_lu_analyze(n, rowptr, colidx, vals, pivot_tol=1e-3, sample=False):
+F2_ARRAYS = (("posW", np.int32), ("lanes", np.uint64), ("passes", np.uint64), ("terms", np.uint32), ("meta", np.int32))
+
+
+def host_lu_analyze(n, rowptr, colidx, vals, pivot_tol=1e-3, sample=False, f2_nc=None):
     """Host-only symbolic phase (no GPU needed): returns the LU program as a dict of int32 arrays."""
     lib = load_library()
     rp = np.ascontiguousarray(rowptr, dtype=np.int32)
@@ -358,6 +362,21 @@ def host_lu_analyze(n, rowptr, colidx, vals, pivot_tol=1e-3, sample=False):
             a = np.zeros(max(sz, 1), dtype=np.int32)
             _check(lib.cadnip_host_lu_get(p, C.c_int32(k), _ip(a)), "cadnip_host_lu_get")
             out[nm] = a[:sz]
+        if f2_nc is not None:
+            # the fused kernel's entry program for this LU and core size (csrc/f2_program.cpp)
+            lib.cadnip_host_f2_free.restype = None
+            q = C.c_void_p()
+            _check(lib.cadnip_host_f2_build(p, C.c_int32(int(f2_nc)), C.byref(q)), "cadnip_host_f2_build")
+            try:
+                f2 = {}
+                for k, (nm, dt) in enumerate(F2_ARRAYS):
+                    sz = lib.cadnip_host_f2_size(q, C.c_int32(k))
+                    a = np.zeros(max(sz, 1), dtype=dt)
+                    _check(lib.cadnip_host_f2_get(q, C.c_int32(k), a.ctypes.data_as(C.c_void_p)), "cadnip_host_f2_get")
+                    f2[nm] = a[:sz]
+                out["f2"] = f2
+            finally:
+                lib.cadnip_host_f2_free(q)
     finally:
         lib.cadnip_host_lu_free(p)
     return out

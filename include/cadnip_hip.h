@@ -259,6 +259,16 @@ int32_t cadnip_host_lu_size(const CadnipHostLU* lu, int32_t which);
 int cadnip_host_lu_get(const CadnipHostLU* lu, int32_t which, int32_t* dst);
 void cadnip_host_lu_free(CadnipHostLU* lu);
 
+/* The fused kernel's linear-solve program for core size nc (0, 8, 12 or 16; csrc/f2_program.cpp), built from a host LU:
+ * arrays POSW (int32: LU pattern position -> work-array offset), LANES / PASSES (uint64 descriptors), TERMS (uint32) and
+ * META (int32: nc, lu_words, dn0, n_pre, n_post).  cadnip_host_f2_get copies raw bytes; _size returns the element count. */
+typedef struct CadnipHostF2 CadnipHostF2;
+typedef enum { CADNIP_F2_POSW = 0, CADNIP_F2_LANES, CADNIP_F2_PASSES, CADNIP_F2_TERMS, CADNIP_F2_META, CADNIP_F2_NARRAYS } CadnipF2Array;
+int cadnip_host_f2_build(const CadnipHostLU* lu, int32_t nc, CadnipHostF2** out);
+int32_t cadnip_host_f2_size(const CadnipHostF2* prog, int32_t which);
+int cadnip_host_f2_get(const CadnipHostF2* prog, int32_t which, void* dst);
+void cadnip_host_f2_free(CadnipHostF2* prog);
+
 #ifdef __cplusplus
 }
 #endif

@@ -340,3 +340,100 @@ def test_spice_deck_reader_elements_and_errors():
             cj.netlist.read_spice(bad, models={})
     with pytest.raises(FileNotFoundError):
         cj.netlist.read_spice('.include "missing.sp"')
+
+
+def _emulate_f2(P, n, csr_vals, rowptr, colidx, rhs):
+    """Execute the fused kernel's linear-solve program (csrc/f2_program.cpp) the way k_fused2 does: work array W =
+    [sparse L\\U | dense core | rhs | ...], passes of <= 64 lane descriptors (every read of a pass happens before any of its
+    writes, exactly one writer per word and pass), the in-register dense solve of the core between the two pass lists."""
+    f2 = P["f2"]
+    nc, lu_words, dn0, n_pre, n_post = [int(v) for v in f2["meta"]]
+    y0 = lu_words
+    W = np.zeros(lu_words + n + 64)
+    pinv = np.empty(n, dtype=int); pinv[P["rperm"]] = np.arange(n)
+    for k in range(len(P["load_src"])):
+        W[f2["posW"][P["load_dst"][k]]] += csr_vals[P["load_src"][k]]
+    W[y0 + pinv] = rhs
+
+    def run(first, count):
+        for pi in range(first, first + count):
+            pd = int(f2["passes"][pi])
+            base, hi = pd & 0xFFFFFFFF, pd >> 32
+            T, hasdiv, fence = hi & 0x7F, (hi >> 11) & 1, (hi >> 12) & 1
+            writes = {}
+            partial = {}
+            for l in range(T):
+                D = int(f2["lanes"][base + l])
+                pos, dg, t0, dhi = D & 0xFFFF, (D >> 16) & 0xFFFF, (D >> 32) & 0xFFFF, D >> 48
+                nt, lg, leader = dhi & 0xFF, (dhi >> 8) & 7, (dhi >> 12) & 1
+                part = 0.0
+                for t in range(nt):
+                    tm = int(f2["terms"][t0 + t])
+                    part += W[tm & 0xFFFF] * W[tm >> 16]
+                grp = l >> lg                      # aligned group of 2^lg lanes
+                key = (grp, lg)
+                partial[key] = partial.get(key, 0.0) + part
+                if leader:
+                    assert l % (1 << lg) == 0
+                    writes[key] = (pos, dg)
+            for key, (pos, dg) in writes.items():
+                acc = W[pos] - partial[key]
+                if hasdiv and dg != 0xFFFF:
+                    acc /= W[dg]
+                assert pos not in [p for k2, (p, _) in writes.items() if k2 != key]
+                writes[key] = (pos, acc)
+            for key, (pos, acc) in writes.items():
+                W[pos] = acc
+
+    run(0, n_pre)
+    if nc:
+        S = W[dn0:dn0 + nc * nc].reshape(nc, nc).copy()
+        b = W[y0 + n - nc:y0 + n].copy()
+        for k in range(nc):                        # no pivoting: static order, as on the GPU
+            for i in range(k + 1, nc):
+                m = S[i, k] / S[k, k]
+                S[i, k + 1:] -= m * S[k, k + 1:]
+                b[i] -= m * b[k]
+        for k in range(nc - 1, -1, -1):
+            b[k] /= S[k, k]
+            b[:k] -= S[:k, k] * b[k]
+        W[y0 + n - nc:y0 + n] = b
+    run(n_pre, n_post)
+    x = np.empty(n)
+    x[P["cperm"]] = W[y0:y0 + n]
+    return x, (n_pre, n_post)
+
+
+@pytest.mark.parametrize("nc", [0, 8, 12, 16])
+def test_fused_linear_solve_program_on_cpu(nc):
+    """The entry program the fused kernel executes (factorisation + forward substitution as an extra column, dense core,
+    back substitution), emulated pass by pass on the DFF Jacobian and on random MNA-like matrices."""
+    import scipy.sparse.linalg as spla
+    st, port = make_port(bm.dff_circuit(), {"vdd": 5.0})
+    rng = np.random.default_rng(11)
+    u = rng.random(st.n) * 5.0
+    G, Cm, b, lw = port.rebuild(u, 2.005e-7)
+    J = G + 1e9 * Cm
+    port.close()
+    cases = [(st.n, np.asarray(st.rowptr), np.asarray(st.colidx), J)]
+    for n in (20, 70):
+        A = sp.random(n, n, density=min(0.5, 4.0 / n), random_state=int(rng.integers(1 << 30)), format="lil")
+        for i in range(n):
+            A[i, i] = 4.0 + rng.random()
+            A[i, (i + 1) % n] = rng.random() - 0.5
+            A[(i + 3) % n, i] = rng.random() - 0.5
+        A = A.tocsr(); A.sort_indices()
+        cases.append((n, A.indptr, A.indices, A.data))
+    for n, rp, ci, vals in cases:
+        if nc > n:
+            continue
+        P = hip.host_lu_analyze(n, rp, ci, vals, f2_nc=nc)
+        rhs = rng.random(n) - 0.5
+        x, (n_pre, n_post) = _emulate_f2(P, n, vals, rp, ci, rhs)
+        A = sp.csr_matrix((vals, ci, rp), shape=(n, n))
+        ref = spla.spsolve(A.tocsc(), rhs)
+        bw = np.max(np.abs(A @ x - rhs) / (abs(A) @ np.abs(x) + np.abs(rhs) + 1e-300))
+        assert bw < 1e-9, (n, nc, bw)
+        assert np.max(np.abs(x - ref)) <= 1e-6 * max(1.0, np.max(np.abs(ref))), (n, nc)
+        if n == st.n:
+            assert n_pre + n_post <= (30 if nc == 0 else 19), (nc, n_pre, n_post)   # 29 passes without a core, 17-18 with
