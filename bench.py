@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--instances", type=int, default=4096, help="sweep instances per GPU (32 Vdd x instances/32 temps); 2048 are resident at a time, the rest queue in-kernel")
     ap.add_argument("--cpu-sample", type=int, default=160, help="corner points timed on the host for cpu_baseline")
     ap.add_argument("--fused", type=int, default=int(os.environ.get("CADNIP_FUSED", "2")),
-                    help="0 = one kernel per op (the drop-in ABI path), 1 = fused v1, 2 = fused v2 (default)")
+                    help="0 = one kernel per op (the kernels behind the callback ABI), non-zero = fused Newton kernel (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--calib-copy", type=int, default=0,
                     help="also run the 8 B/lane fp64 calibration copy of this many MiB (for rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE runs)")

@@ -168,6 +168,7 @@ int cadnip_set_params(CadnipHandle* h, int32_t block, const double* par_host) {
     }
     b.mos1_plain = plain;
   }
+  h->f2_blk_dirty = true;
   return CADNIP_OK;
 }
 

@@ -538,26 +538,34 @@ int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds) {
     for (int i = 0; i < S_NSEC; ++i) h->f2off[i] = T.off[i];
     h->f2len = (int)T.data.size();
     h->fused2_dirty = false;
+    h->f2_blk_dirty = true;
   }
   ProfScope ps(h, "fused2_newton");
   const LUProgram& P = h->lu;
   F2Args f;
-  F2Block hb[CADNIP_DEV_NTYPES];
-  f.n_blk = 0;
-  for (size_t bi = 0; bi < h->blocks.size() && f.n_blk < CADNIP_DEV_NTYPES; ++bi) {
-    auto& b = h->blocks[bi];
-    if (b.count == 0) continue;
-    hb[f.n_blk++] = F2Block{b.d_ipar, b.d_par, b.type, b.count, b.n_par, b.g_base, b.c_base, b.b_base, h->f2_nodes_off[bi], (b.mos1_plain && !getenv("CADNIP_NO_PAIR")) ? 1 : 0};
+  // device-block descriptors: rebuilt when the tables were, or when cadnip_set_params changed a block (sp_mos1 pairing)
+  if (h->f2_blk_dirty || !h->d_f2blk) {
+    F2Block hb[CADNIP_DEV_NTYPES];
+    int nb = 0;
+    for (size_t bi = 0; bi < h->blocks.size() && nb < CADNIP_DEV_NTYPES; ++bi) {
+      auto& b = h->blocks[bi];
+      if (b.count == 0) continue;
+      hb[nb++] = F2Block{b.d_ipar, b.d_par, b.type, b.count, b.n_par, b.g_base, b.c_base, b.b_base, h->f2_nodes_off[bi], b.mos1_plain ? 1 : 0};
+    }
+    // the heaviest device type first
+    for (int i = 0; i < nb; ++i)
+      for (int j = i + 1; j < nb; ++j)
+        if ((hb[j].type == CADNIP_DEV_MOS1) > (hb[i].type == CADNIP_DEV_MOS1)) { F2Block tmp = hb[i]; hb[i] = hb[j]; hb[j] = tmp; }
+    h->f2_rc_blk = -1;
+    for (int i = 0; i < nb; ++i)
+      if (hb[i].type == CADNIP_DEV_CAPACITOR || hb[i].type == CADNIP_DEV_RESISTOR) { h->f2_rc_blk = i; break; }
+    h->f2_n_blk = nb;
+    if (!h->d_f2blk) HIP_TRY(hipMalloc((void**)&h->d_f2blk, sizeof(hb)));
+    HIP_TRY(hipStreamSynchronize(h->stream));               // no launch in flight may still read the old descriptors
+    HIP_TRY(hipMemcpy(h->d_f2blk, hb, sizeof(F2Block) * (size_t)nb, hipMemcpyHostToDevice));
+    h->f2_blk_dirty = false;
   }
-  // the heaviest device type first
-  for (int i = 0; i < f.n_blk; ++i)
-    for (int j = i + 1; j < f.n_blk; ++j)
-      if ((hb[j].type == CADNIP_DEV_MOS1) > (hb[i].type == CADNIP_DEV_MOS1)) { F2Block tmp = hb[i]; hb[i] = hb[j]; hb[j] = tmp; }
-  f.rc_blk = -1;
-  for (int i = 0; i < f.n_blk; ++i)
-    if (hb[i].type == CADNIP_DEV_CAPACITOR || hb[i].type == CADNIP_DEV_RESISTOR) { f.rc_blk = i; break; }
-  if (!h->d_f2blk) HIP_TRY(hipMalloc((void**)&h->d_f2blk, sizeof(hb)));
-  HIP_TRY(hipMemcpyAsync(h->d_f2blk, hb, sizeof(F2Block) * (size_t)f.n_blk, hipMemcpyHostToDevice, h->stream));
+  f.n_blk = h->f2_n_blk; f.rc_blk = h->f2_rc_blk;
   f.blk = (const F2Block*)h->d_f2blk;
   f.wave = h->d_wave;
   f.tab = h->d_f2tab;

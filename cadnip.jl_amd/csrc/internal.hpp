@@ -111,6 +111,8 @@ struct CadnipHandle {
   bool fused2_dirty = true;
   int* d_f2queue = nullptr;   // fused kernel: dynamic instance queue
   void* d_f2blk = nullptr;    // fused kernel: device-block descriptors
+  bool f2_blk_dirty = true;
+  int f2_n_blk = 0, f2_rc_blk = -1;
   int n_cu = 0;
   // driver state (allocated lazily)
   struct Driver* drv = nullptr;
