@@ -187,7 +187,9 @@ class Handle:
     def set_params(self, packed):
         for k, arr in enumerate(packed):
             a = np.ascontiguousarray(arr, dtype=np.float64)
-            assert a.shape == (self.B, self.st.blocks[k].n_par, self.st.blocks[k].count), a.shape
+            want = (self.B, self.st.blocks[k].n_par, self.st.blocks[k].count)
+            if a.shape != want:
+                raise ValueError("parameter block %d has shape %r, the structure needs %r" % (k, a.shape, want))
             _check(self.lib.cadnip_set_params(self.h, C.c_int32(k), _dp(a)), "cadnip_set_params")
 
     def set_spec(self, mode=None, gmin=None, gshunt=None, srcFact=None):

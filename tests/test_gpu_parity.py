@@ -6,6 +6,7 @@ import scipy.sparse.linalg as spla
 
 import cadnip_jl_amd as cj
 from cadnip_jl_amd import hip
+from cadnip_jl_amd import api as api_mod
 from oracle import mna_ref as M
 from oracle.netlist_ref import make_builder
 from tests.circuits import ALL_STAMP
@@ -152,3 +153,65 @@ def test_singular_matrix_reports_status():
     with pytest.raises(hip.CadnipError):
         h.analyze()
     h.close()
+
+
+def test_abi_rejects_malformed_structures_and_calls():
+    """Host-side shape validation of the C ABI: what a wrong binding would pass must come back as CADNIP_BADARG /
+    CADNIP_NOTREADY, never reach a kernel."""
+    import copy
+    from tests.circuits import divider, rc_charge
+    st = cj.discover(divider(), {})
+    for mutate in ("node_oob", "slot_overflow", "rowptr_short", "zero_instances", "bad_type"):
+        s2 = copy.deepcopy(st)
+        B = 1
+        if mutate == "node_oob":
+            s2.blocks[1].nodes[0, 0] = st.n + 3
+        elif mutate == "slot_overflow":
+            s2.blocks[1].g_base = st.ns_g
+        elif mutate == "rowptr_short":
+            s2.rowptr = np.array(st.rowptr, copy=True); s2.rowptr[-1] = st.nnz + 5
+        elif mutate == "zero_instances":
+            B = 0
+        elif mutate == "bad_type":
+            s2.blocks[0].type = "R"; s2.blocks[0].n_par = 0
+            hip.TYPE_ID_BACKUP = dict(hip.TYPE_ID)
+            hip.TYPE_ID["R"] = 99
+        try:
+            with pytest.raises(hip.CadnipError) as ei:
+                hip.Handle(s2, B)
+            assert ei.value.code == hip.BADARG, mutate
+        finally:
+            if mutate == "bad_type":
+                hip.TYPE_ID.clear(); hip.TYPE_ID.update(hip.TYPE_ID_BACKUP)
+    # calls in the wrong order / with the wrong sizes
+    circ = rc_charge()
+    st = cj.discover(circ, {})
+    h = hip.Handle(st, 2)
+    h.set_params(cj.pack_params(st, circ, {}, 27.0, 2))
+    with pytest.raises(hip.CadnipError) as ei:            # LU before the symbolic phase
+        h.factor()
+    assert ei.value.code == hip.NOTREADY
+    with pytest.raises(hip.CadnipError) as ei:            # fused transient before the symbolic phase
+        h.tran_run(0.0, 1e-3, np.full(st.n, 1e-9), 1e-6, save_t=np.array([1e-3]), fused=1)
+    assert ei.value.code == hip.NOTREADY
+    with pytest.raises((hip.CadnipError, ValueError)):    # parameter block of the wrong shape
+        h.set_params([np.zeros((2, 1, 1))])
+    h.close()
+
+
+def test_transient_edge_cases():
+    """Empty save list, save points on both ends, a single instance and a batch whose size is not a multiple of the
+    workgroup's eight instances, all through the fused kernel."""
+    circ = cj.Circuit()
+    circ.V("v1", "vin", "0", dc=0.0, wave=("pwl", [0.0, 1e-9], [0.0, 5.0]))
+    circ.R("r1", "vin", "out", 1e3)
+    circ.C("c1", "out", "0", 1e-6)
+    for B in (1, 3, 11):
+        sim = api_mod.BatchSimulator(api_mod.MNACircuit(circ, {}), [{} for _ in range(B)])
+        st = sim.st
+        out, per, stats = sim.tran((0.0, 2e-3), np.full(st.n, 1e-9), 1e-6, np.array([0.0, 1e-3, 2e-3]), obs=[st.index_of("out")], fused=1)
+        assert stats["n_failed"] == 0 and out.shape == (B, 3, 1)
+        assert np.allclose(out[:, 1, 0], 5.0 * (1 - np.exp(-1.0)), rtol=1e-3) and np.allclose(out[:, 0, 0], out[0, 0, 0])
+        out2, per2, stats2 = sim.tran((0.0, 2e-3), np.full(st.n, 1e-9), 1e-6, np.array([]), obs=[st.index_of("out")], fused=1)
+        assert stats2["n_failed"] == 0 and out2.shape[1] == 0 and np.array_equal(per2[:, :3], per[:, :3])
+        sim.close()
