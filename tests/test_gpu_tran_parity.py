@@ -132,3 +132,36 @@ def test_fused_kernel_matches_per_op_path(name):
     tol = 1e-9 * scale + 10 * abstol if same_path else 100 * 1e-6 * scale
     assert np.max(np.abs(a - b)) <= tol, (name, same_path, np.max(np.abs(a - b)))
     assert abs(int(got[0][1][0]) - int(got[1][1][0])) <= max(3, 0.02 * got[0][1][0]), (name, got[0][1], got[1][1])
+
+
+def test_full_size_corner_sweep_properties():
+    """BASELINE.json config 4 at full size (32 Vdd x 32 temperature corners of the DFF transient, one resident batch)
+    checked through size-independent properties: every instance finishes; the race-free logic pins hold at every corner;
+    an instance's result does not depend on the batch it runs in (bitwise: nothing crosses instances, and the in-kernel
+    instance queue hands out whole instances); the sweep is invariant under permutation of the points."""
+    circ = bm.dff_circuit()
+    pts = list(bm.corner_grid(32, 32))
+    assert len(pts) == 1024
+    ts = np.array([150e-9, 250e-9, 700e-9])
+
+    def run(points):
+        sim = api.BatchSimulator(api.MNACircuit(circ, {"vdd": 5.0}), points)
+        st = sim.st
+        out, per, stats = sim.tran(bm.DFF_TSPAN, st.state_abstol(**ABSTOL), 1e-4, ts, obs=[st.index_of("Q"), st.index_of("Q_neg")], fused=1)
+        sim.close()
+        return out, per, stats
+
+    out, per, stats = run(pts)
+    assert stats["n_failed"] == 0 and np.all(per[:, 3] == 1)
+    vdd = np.array([p["vdd"] for p in pts])
+    assert np.all(np.abs(out[:, 0, 0]) < 0.05) and np.all(np.abs(out[:, 1, 0]) < 0.05) and np.all(np.abs(out[:, 2, 0] - vdd) < 0.05)
+    assert np.all(np.abs(out[:, 2, 1]) < 0.05)                       # Q_neg is the complement at 700 ns
+    assert stats["newton_iters"] == int(per[:, 0].sum())
+    # batch independence: 5 scattered corners alone == the same corners inside the 1024-batch, bit for bit
+    pick = [0, 31, 500, 777, 1023]
+    out_s, per_s, _ = run([pts[i] for i in pick])
+    assert np.array_equal(out_s, out[pick]) and np.array_equal(per_s, per[pick])
+    # permutation invariance
+    perm = np.random.default_rng(3).permutation(len(pts))
+    out_p, per_p, _ = run([pts[i] for i in perm])
+    assert np.array_equal(out_p, out[perm]) and np.array_equal(per_p[:, :4], per[perm][:, :4])
