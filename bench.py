@@ -104,7 +104,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     def one_step():
-        u0, conv, dcs = sim.dc(abstol=1e-9, mode="tranop")
+        u0, conv, dcs = sim.dc(abstol=1e-9, mode="tranop", fused=bool(args.fused))
         if not np.all(conv):
             raise RuntimeError("DC initialisation failed on rank %d" % rank)
         sim.h.set_spec(mode="tran")

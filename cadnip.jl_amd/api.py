@@ -295,18 +295,18 @@ class BatchSimulator:
         h.analyze_values(acc)
         self._analyzed = True
 
-    def dc(self, u0=None, abstol=1e-10, maxiters=100, mode="dcop"):
+    def dc(self, u0=None, abstol=1e-10, maxiters=100, mode="dcop", fused=False):
         self.h.set_spec(mode=mode)
         if not self._analyzed:
             self.analyze()
-        return self.h.dc_run(u0, abstol=abstol, maxiters=maxiters, use_pcnr=True, cold_start=u0 is None)
+        return self.h.dc_run(u0, abstol=abstol, maxiters=maxiters, use_pcnr=True, cold_start=u0 is None, fused=fused)
 
     def tran(self, tspan, abstol, reltol, saveat, **kw):
         st = self.st
         if not self._analyzed:
             self.analyze()
         # CedarTranOp: DC solve in :tranop mode at t0 (dcop.jl:160-212), abstol 1e-9
-        u0, conv, dcs = self.dc(abstol=1e-9, mode="tranop")
+        u0, conv, dcs = self.dc(abstol=1e-9, mode="tranop", fused=bool(kw.get("fused", False)))
         if not np.all(conv):
             raise RuntimeError("transient initialisation (CedarTranOp) failed for %d instance(s)" % int((~conv).sum()))
         breaks = expand_breakpoints(st.breakpoints, tspan)

@@ -188,7 +188,7 @@ int count_running(CadnipHandle* h, int* out) {
 }
 
 // one DC Newton run on the whole batch with the handle's current spec; returns per-instance status in drv->status
-int dc_newton(CadnipHandle* h, double abstol, int maxiters, int use_pcnr, int cold_start, long long* iters_total) {
+int dc_newton(CadnipHandle* h, double abstol, int maxiters, int use_pcnr, int cold_start, long long* iters_total, int fused = 0) {
   Driver* d = h->drv;
   DCArgs a{h->d_u, h->d_resid, h->d_delta, h->d_limit_w, h->d_limit_init, h->d_active, h->d_flags, d->status, d->dcstate, d->action, d->cnt,
            h->B, h->n, h->n_limits, (use_pcnr && h->n_limits > 0) ? 1 : 0, maxiters, abstol};
@@ -199,6 +199,27 @@ int dc_newton(CadnipHandle* h, double abstol, int maxiters, int use_pcnr, int co
   int saved_initjct = h->initjct;
   h->initjct = (cold_start && a.use_pcnr) ? 1 : 0;   // armed for the first stamping only (solve.jl:624,632)
   int rc = CADNIP_OK;
+  if (fused && h->analyzed && h->spec.gshunt == 0.0 && h->spec.srcFact >= 1.0) {
+    // the whole Newton loop of every instance in the fused kernel; the host only looks at the running count
+    TranArgs ta{};
+    ta.u = h->d_u; ta.limit_w = h->d_limit_w; ta.status = d->status; ta.cnt = d->cnt; ta.active = h->d_active; ta.flags = h->d_flags;
+    ta.B = h->B; ta.n = h->n; ta.n_limits = h->n_limits;
+    int first = h->initjct;
+    for (int launch = 0; launch < 4; ++launch) {
+      rc = launch_fused2_dc(h, ta, 2 * maxiters + 4, abstol, maxiters, a.use_pcnr, h->spec.mode, first, d->dcstate); if (rc) break;
+      first = 0;
+      int running = 0;
+      rc = count_running(h, &running); if (rc) break;
+      if (running == 0) break;
+    }
+    h->initjct = saved_initjct;
+    if (!rc && iters_total) {
+      std::vector<long long> cnt((size_t)h->B * 4);
+      HIP_TRY(hipMemcpy(cnt.data(), d->cnt, cnt.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      for (int i = 0; i < h->B; ++i) *iters_total += cnt[(size_t)i * 4];
+    }
+    return rc;
+  }
   for (int round = 0; round < 2 * maxiters + 4; ++round) {
     rc = launch_rebuild(h); if (rc) break;
     h->initjct = 0;
@@ -268,7 +289,7 @@ int cadnip_dc_run(CadnipHandle* h, const CadnipDCOpts* o, double* u_host, int32_
     TRY(cadnip_analyze(h, 0));
   }
   long long iters = 0;
-  TRY(dc_newton(h, o->abstol, o->maxiters, o->use_pcnr, o->cold_start, &iters));
+  TRY(dc_newton(h, o->abstol, o->maxiters, o->use_pcnr, o->cold_start, &iters, o->fused));
   std::vector<int> status(B);
   HIP_TRY(hipMemcpy(status.data(), d->status, B * sizeof(int), hipMemcpyDeviceToHost));
   int n_failed = 0;

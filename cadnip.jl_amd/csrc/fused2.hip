@@ -67,6 +67,8 @@ struct F2Args {
   int tab_len;               // 32-bit words (even)
   int n, nnz, nnz_lu, rounds, B;   // nnz_lu: words of W before the rhs (sparse L\U entries + dense core block)
   int n_pre, n_post, nc, dn0;       // passes before / after the dense core solve, core size, first word of the core block
+  // DC mode (k_fused2<WPB, true>): PCNR / plain Newton on G u = b (driver.hip: k_dc_check, k_dc_update)
+  double dc_abstol; int dc_maxiters, dc_pcnr, dc_mode, dc_initjct; int* dcstate;
   int* queue;                // next not-yet-resident instance (relative to gridDim.x * WPB); zeroed before every launch
   TranArgs t;
 };
@@ -207,7 +209,7 @@ __device__ __forceinline__ void dense_core_solve(double* W, int dn0, int yc0, in
   if (lane < NC) W[yc0 + lane] = bc;
 }
 
-template <int WPB>
+template <int WPB, bool DC>
 __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
   extern __shared__ double sm[];
   // w is the same for all lanes of a wave: say so (readfirstlane), or every address derived from it lives in VGPRs
@@ -247,8 +249,8 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
   StepState st;
   bool have = false;
   while (inst < f.B) {
-    st = load_state(a, inst);
-    make_uniform(st);
+    if (DC) st.status = __builtin_amdgcn_readfirstlane(a.status[inst]);
+    else { st = load_state(a, inst); make_uniform(st); }
     if (st.status == 0) { have = true; break; }
     int nx = 0;
     if (lane0 == 0) nx = atomicAdd(f.queue, 1);
@@ -259,10 +261,13 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
   double* betag = a.beta + (size_t)inst * n;
   // limit_w is read only by the PCNR corrector of the update: without it the stamps need not write it (each write is an
   // HBM store that later vector-memory waits would queue behind)
-  double* lw = a.use_pcnr ? a.limit_w + (size_t)inst * n : nullptr;
+  double* lw = (DC ? f.dc_pcnr : a.use_pcnr) ? a.limit_w + (size_t)inst * n : nullptr;
   const size_t vo = (size_t)inst * n;
   FusedVecs vec{us, betas, W, qinv, a.up + vo, a.u0 + vo, a.u1 + vo, a.u2 + vo, lw};
-  for (int i = lane0; i < n; i += 64) { us[i] = ug[i]; betas[i] = betag[i]; }
+  for (int i = lane0; i < n; i += 64) { us[i] = ug[i]; betas[i] = DC ? 0.0 : betag[i]; }
+  // DC state of this instance: settle flag of the PCNR loop (solve.jl:640-657), Newton solves done in this launch
+  int dc_state = 0, dc_iters = 0, dc_first = 0;
+  if (DC) { dc_state = __builtin_amdgcn_readfirstlane(f.dcstate[inst]); dc_first = f.dc_initjct; }
   double rc_val[2] = {0.0, 0.0};   // values of the first capacitor / resistor block: constant for the instance, kept in registers
   if (f.rc_blk >= 0) {
     const F2Block B = load_block(f.blk, f.rc_blk);
@@ -280,7 +285,9 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
     CADNIP_WAVE_SYNC();
     CADNIP_TRACE_POINT(0);
     // ---- stamp: accumulate J (at LU positions) and the C*beta - b part of the residual
-    const double tcur = st.tn, a0 = st.a0;
+    const double tcur = DC ? 0.0 : st.tn, a0 = DC ? 0.0 : st.a0;
+    const int dmode = DC ? f.dc_mode : 1, dinit = DC ? dc_first : 0;
+    dc_first = 0;                                       // initjct is armed for the first stamping only (solve.jl:624,632)
     for (int bi = 0; bi < f.n_blk; ++bi) {
       const F2Block B = load_block(f.blk, bi);
       const double* par = B.par + (size_t)inst * B.n_par * B.count;
@@ -303,14 +310,14 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
         for (int d0 = 0; d0 < B.count; d0 += 32) {
           const int dv = d0 + (lane >> 1);
           const bool valid = dv < B.count;
-          LdsCtx d{nodes + B.nodes_off, B.ipar, par, f.wave, B.count, valid ? dv : B.count - 1, tcur, 1, 0};
+          LdsCtx d{nodes + B.nodes_off, B.ipar, par, f.wave, B.count, valid ? dv : B.count - 1, tcur, dmode, dinit};
           AccumOutT<true> s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, d.dev, valid ? 0u : (unsigned)(f.nnz_lu + n + lane)};
           stamp_mos1_pair(d, us, s, lw, side, valid);
         }
         dev0 = B.count;
       }
       for (int dev = dev0; dev < B.count; dev += 64) {
-        LdsCtx d{nodes + B.nodes_off, B.ipar, par, f.wave, B.count, dev, tcur, 1, 0};
+        LdsCtx d{nodes + B.nodes_off, B.ipar, par, f.wave, B.count, dev, tcur, dmode, dinit};
         AccumOut s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev, 0u};
         dispatch_stamp2(B.type, d, us, s, lw);
       }
@@ -318,7 +325,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
     }
     CADNIP_WAVE_SYNC();
     CADNIP_TRACE_POINT(1);
-    vec.prefetch(a, lane);   // HBM operands of the update: in flight while the linear solve runs out of LDS
+    if (!DC) vec.prefetch(a, lane);   // HBM operands of the update: in flight while the linear solve runs out of LDS
     // ---- r += J*u  (J still unfactored in the LU array), eight entries per lane in flight
     for (int p0 = 0; p0 < f.nnz; p0 += 512) {
       u64 d[8];
@@ -335,6 +342,30 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
     }
     CADNIP_WAVE_SYNC();
     CADNIP_TRACE_POINT(2);
+    if (DC) {
+      // ---- k_dc_check (driver.hip) on F = G u - b, which is what the rhs words hold now
+      double s2 = 0.0;
+      int nonfinite = 0;
+      for (int i = lane; i < n; i += 64) { const double fv = W[f.nnz_lu + i]; if (!isfinite(fv)) nonfinite = 1; s2 += fv * fv; }
+      s2 = wave_sum(s2);
+      nonfinite = wave_any(nonfinite);
+      const bool pc = f.dc_pcnr && a.n_limits > 0;
+      int action = 0;
+      if (nonfinite) st.status = -1;
+      else if (sqrt(s2) < f.dc_abstol) {
+        if (!pc) st.status = 1;
+        else if (dc_state == 0) {                         // settle the limit slots, verify on the next stamping
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+          for (int i = n - a.n_limits + lane; i < n; i += 64) us[i] = lw[i];
+          dc_state = 1; action = 1;
+        } else st.status = 1;
+      } else dc_state = 0;
+      const long long done = a.cnt[(size_t)inst * 4] + dc_iters;
+      if (st.status == 0 && !action && done >= f.dc_maxiters) st.status = -3;
+      CADNIP_WAVE_SYNC();
+      if (st.status != 0) { --budget; break; }
+      if (action) continue;
+    }
     // ---- refactor + forward + backward substitution: one entry-wise program, executed pass by pass.  A pass gives
     // every lane one descriptor (entry, its share of the entry's terms, the width 2^lg of the entry's lane group);
     // a dependency level is one or more passes and ends with a fence.  Software pipeline: pass descriptors are
@@ -404,18 +435,37 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
     run_passes(f.n_pre, f.n_post);
     CADNIP_TRACE_POINT(3);
     // ---- Newton update + step controller (registers / LDS; HBM only for history and outputs)
-    tran_update_body(a, vec, st, inst, lane, bad);
-    make_uniform(st);
+    if (DC) {
+      // ---- k_dc_update: u -= delta, PCNR corrector u[lim] = limit_w (solve.jl:667-690)
+      for (int i = lane; i < n; i += 64) { const double dd = W[qinv[i]]; if (!isfinite(dd)) bad = 1; us[i] -= dd; }
+      bad = wave_any(bad);
+      CADNIP_WAVE_SYNC();
+      if (f.dc_pcnr && a.n_limits > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // limit_w was stored to HBM by other lanes of this wave
+        for (int i = n - a.n_limits + lane; i < n; i += 64) us[i] = lw[i];
+      }
+      dc_iters += 1;
+      if (bad) st.status = -2;
+    } else {
+      tran_update_body(a, vec, st, inst, lane, bad);
+      make_uniform(st);
+    }
     CADNIP_WAVE_SYNC();
     CADNIP_TRACE_POINT(16);
     if (st.status != 0) { --budget; break; }
   }
-  {
+  if (DC) {
+    for (int i = lane0; i < n; i += 64) ug[i] = us[i];
+    if (lane0 == 0) {
+      a.status[inst] = st.status; f.dcstate[inst] = dc_state; a.active[inst] = st.status == 0 ? 1 : 0;
+      a.cnt[(size_t)inst * 4] += dc_iters;
+    }
+  } else {
     double* dug = a.du + (size_t)inst * n;
     const double a0 = st.a0;
     for (int i = lane0; i < n; i += 64) { double x = us[i], b = betas[i]; ug[i] = x; betag[i] = b; dug[i] = a0 * x + b; }
+    store_state(a, inst, lane0, st);
   }
-  store_state(a, inst, lane0, st);
   CADNIP_WAVE_SYNC();
   if (st.status == 0) break;                // out of budget in the middle of this instance: the next launch resumes it
   int nx = 0;
@@ -516,7 +566,9 @@ static bool f2_prepare(CadnipHandle* h, F2Tables& T, const std::vector<int>& g_p
   return true;
 }
 
-int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds) {
+struct F2DcOpts { double abstol; int maxiters, use_pcnr, mode, initjct; int* dcstate; };
+
+static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F2DcOpts* dc) {
   if (!h->analyzed) return CADNIP_NOTREADY;
   if (h->spec.gshunt != 0.0 || h->spec.srcFact < 1.0) return CADNIP_BADARG;   // homotopies run on the per-op path
   if (!h->d_f2tab || h->fused2_dirty) {
@@ -540,7 +592,7 @@ int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds) {
     h->fused2_dirty = false;
     h->f2_blk_dirty = true;
   }
-  ProfScope ps(h, "fused2_newton");
+  ProfScope ps(h, dc ? "fused2_dc" : "fused2_newton");
   const LUProgram& P = h->lu;
   F2Args f;
   // device-block descriptors: rebuilt when the tables were, or when cadnip_set_params changed a block (sp_mos1 pairing)
@@ -574,6 +626,8 @@ int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds) {
   f.n = h->n; f.nnz = h->nnz; f.nnz_lu = h->f2_lu_words;
   f.n_pre = h->f2_n_pre; f.n_post = h->f2_n_post; f.nc = h->f2_nc; f.dn0 = h->f2_dn0;
   f.rounds = rounds; f.B = h->B; f.t = t;
+  f.dc_abstol = 0; f.dc_maxiters = 0; f.dc_pcnr = 0; f.dc_mode = 1; f.dc_initjct = 0; f.dcstate = nullptr;
+  if (dc) { f.dc_abstol = dc->abstol; f.dc_maxiters = dc->maxiters; f.dc_pcnr = dc->use_pcnr; f.dc_mode = dc->mode; f.dc_initjct = dc->initjct; f.dcstate = dc->dcstate; }
   const size_t tab_dbl = (size_t)h->f2len / 2;
   const size_t per = (size_t)h->f2_lu_words + 3 * (size_t)h->n + F2_TRASH;
   const size_t lds_cap = 160 * 1024;
@@ -595,15 +649,23 @@ int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds) {
   const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(lds_cap / shmem, (size_t)(32 / wpb)));
   int grid = std::min((h->B + wpb - 1) / wpb, h->n_cu * wg_per_cu);
   if (getenv("CADNIP_F2_DEBUG")) fprintf(stderr, "[cadnip f2] B %d n_cu %d wpb %d grid %d shmem %zu rounds %d nc %d passes %d+%d\n", h->B, h->n_cu, wpb, grid, shmem, rounds, h->f2_nc, h->f2_n_pre, h->f2_n_post);
-#define LAUNCH(W)                                                                                                      \
+#define LAUNCH(W, D)                                                                                                   \
   do {                                                                                                                 \
-    if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_fused2<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-    hipLaunchKernelGGL(k_fused2<W>, dim3(grid), dim3(64 * W), shmem, h->stream, f);                                    \
+    if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_fused2<W, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+    hipLaunchKernelGGL((k_fused2<W, D>), dim3(grid), dim3(64 * W), shmem, h->stream, f);                               \
   } while (0)
-  if (wpb == 8) LAUNCH(8); else if (wpb == 4) LAUNCH(4); else if (wpb == 2) LAUNCH(2); else LAUNCH(1);
+  if (dc) { if (wpb == 8) LAUNCH(8, true); else if (wpb == 4) LAUNCH(4, true); else if (wpb == 2) LAUNCH(2, true); else LAUNCH(1, true); }
+  else { if (wpb == 8) LAUNCH(8, false); else if (wpb == 4) LAUNCH(4, false); else if (wpb == 2) LAUNCH(2, false); else LAUNCH(1, false); }
 #undef LAUNCH
   HIP_TRY(hipGetLastError());
   return CADNIP_OK;
+}
+
+int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds) { return launch_fused2(h, t, rounds, nullptr); }
+
+int launch_fused2_dc(CadnipHandle* h, const TranArgs& t, int rounds, double abstol, int maxiters, int use_pcnr, int mode, int initjct, int* d_dcstate) {
+  F2DcOpts dc{abstol, maxiters, use_pcnr, mode, initjct, d_dcstate};
+  return launch_fused2(h, t, rounds, &dc);
 }
 
 #ifdef CADNIP_TRACE

@@ -140,6 +140,7 @@ int launch_calib_copy(CadnipHandle* h, long n, int reps);
 int launch_negate(CadnipHandle* h, double* d_x, long n);
 struct TranArgs;                                                          // tran_ctrl.hpp
 int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds); // fused2.hip
+int launch_fused2_dc(CadnipHandle* h, const TranArgs& t, int rounds, double abstol, int maxiters, int use_pcnr, int mode, int initjct, int* d_dcstate);
 struct ProfScope {
   CadnipHandle* h; int idx;
   ProfScope(CadnipHandle* h, const char* name);

@@ -186,6 +186,8 @@ typedef struct {
   int32_t use_pcnr;       /* PCNR corrector u[lim] = limit_w  solve.jl:682-688 */
   int32_t cold_start;     /* seed limit vars + initjct       solve.jl:615-625 */
   int32_t use_stepping;   /* gshunt / source stepping fallbacks solve.jl:909-925 */
+  int32_t fused;          /* non-zero: the first attempt (PCNR / Newton at the handle's spec) runs in the fused kernel
+                             (csrc/fused2.hip, DC mode); the fallback homotopies always use the per-op kernels */
 } CadnipDCOpts;
 
 typedef struct {

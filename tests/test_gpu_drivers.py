@@ -75,6 +75,25 @@ def test_behavioral_sources_dc_fixed_point():
     sim.close()
 
 
+@pytest.mark.parametrize("name", ["divider", "diode", "diode_chain", "inverter", "mos1_rd", "behavioral", "dff"])
+def test_fused_dc_matches_per_op_dc(name):
+    """The DC Newton loop inside the fused kernel (PCNR state machine, settle step, initjct on the cold start) against the
+    per-op kernels: same solution to 1e-9, Newton-solve counts within one of each other (summation order differs)."""
+    mk, params = tc.ALL_STAMP[name]
+    mode = "tranop" if name == "dff" else "dcop"
+    res = {}
+    for fused in (False, True):
+        sim = api.BatchSimulator(api.MNACircuit(mk(), params, api.MNASpec(mode=mode)), [dict(params) for _ in range(3)] if params else [{}] * 3)
+        u, conv, st = sim.dc(abstol=1e-9, maxiters=200, mode=mode, fused=fused)
+        res[fused] = (u, conv, st)
+        sim.close()
+    (u0, c0, s0), (u1, c1, s1) = res[False], res[True]
+    assert np.all(c0) and np.all(c1)
+    if name != "dff":   # the DFF's DC point is not unique (bistable latch): both are solutions, see test_dc_matches_oracle_pcnr
+        assert np.max(np.abs(u0 - u1) / np.maximum(np.abs(u0), 1.0)) < 1e-9, name
+    assert abs(s0["newton_iters"] - s1["newton_iters"]) <= 3, (name, s0["newton_iters"], s1["newton_iters"])
+
+
 def test_dc_sweep_divider_grid():
     # test/sweep.jl:299-312: I = -1/(R1+R2) over a 20x20 grid
     c = cj.Circuit()
