@@ -4,7 +4,7 @@ usage: python tools/make_pmc_summary.py <tag> <bench.json> <pmc.json from tools/
 """
 import json, sys
 
-K = 'void cadnip::k_fused2<8>(cadnip::F2Args)'
+K = 'void cadnip::k_fused2<8, false>(cadnip::F2Args)'
 CAL = 'cadnip::k_calib_copy_f64(double const*, double*, long)'
 
 
