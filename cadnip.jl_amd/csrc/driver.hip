@@ -7,8 +7,8 @@
 // the whole batch.  Each sweep instance walks its own step sequence (own t, h, order,
 // Newton count); its convergence test, error test, step-size choice, history rotation,
 // predictor and output interpolation are evaluated by one wave per instance in
-// k_tran_update, so desynchronised instances never round-trip over PCIe.  The host reads one
-// counter (instances still running) every few launches.
+// k_tran_update (per-op path) or inside the fused kernel (fused2.hip), so desynchronised instances never round-trip
+// over PCIe.  The host reads one counter (instances still running) every few launches.
 //
 // Integration method (identical in oracle/cpu_port.cpp, which is what the 1e-9 parity bar is
 // defined against -- SURVEY.md section 7 "hard parts"):
