@@ -118,6 +118,32 @@ def behavioral():
     return c
 
 
+def ring_oscillator():
+    """3-stage CMOS ring oscillator of the reference's sp_mos1 test (test/mna/vadistiller_integration.jl:45-60):
+    level-1 cards vto = -/+0.7, kp = 50u / 100u, W/L = 2u/1u and 1u/1u, Vdd = 3.3 V, 10 fF on every stage output."""
+    c = cj.Circuit("3-stage CMOS ring oscillator")
+    pm, nm = dict(type=-1, vto=-0.7, kp=50e-6), dict(type=1, vto=0.7, kp=100e-6)
+    c.V("Vdd", "vdd", "0", dc=3.3)
+    for k, (o, i) in enumerate((("out1", "in1"), ("out2", "out1"), ("in1", "out2")), 1):
+        c.MOS1("MP%d" % k, o, i, "vdd", "vdd", pm, w=2e-6, l=1e-6)
+        c.MOS1("MN%d" % k, o, i, "0", "0", nm, w=1e-6, l=1e-6)
+    c.C("C1", "out1", "0", 10e-15)
+    c.C("C2", "out2", "0", 10e-15)
+    c.C("C3", "in1", "0", 10e-15)
+    return c
+
+
+def ring_checks(v):
+    """The reference's assertions on V(out1) sampled at 500 points over the last 100 ns (vadistiller_integration.jl:668-690)."""
+    import numpy as np
+    lo, hi = float(np.min(v)), float(np.max(v))
+    mid = 0.5 * (lo + hi)
+    crossings = int(np.sum(((v[:-1] < mid) & (v[1:] >= mid)) | ((v[:-1] > mid) & (v[1:] <= mid))))
+    assert hi - lo > 2.0 and hi > 2.5 and lo < 0.8, (lo, hi)
+    assert crossings > 10, crossings
+    return lo, hi, crossings
+
+
 ALL_STAMP = {
     "divider": (divider, {}), "linear_zoo": (linear_zoo, {}), "diode": (diode_rectifier, {}),
     "diode_nolimit": (lambda: diode_rectifier(False), {}), "diode_chain": (diode_chain, {}),

@@ -172,3 +172,30 @@ def test_reference_dff_deck_end_to_end():
     assert stats["n_failed"] == 0
     q = out[0, :, 0]
     assert abs(q[0]) < 0.05 and abs(q[1]) < 0.05 and abs(q[2] - 5.0) < 0.05, q
+
+
+def test_ring_oscillator_fixture_gpu():
+    """test/mna/vadistiller_integration.jl:649-692 on the GPU (fused kernel), four supply corners at once: every
+    instance oscillates (the reference's swing / level / crossing-count assertions), and faster at higher supply."""
+    circ = tc.ring_oscillator()
+    circ.devices[0].params["dc"] = cj.Param("vdd")
+    pts = [{"vdd": v} for v in (2.7, 3.0, 3.3, 3.6)]   # higher supplies oscillate faster than 500 samples per 100 ns can count
+    sim = api.BatchSimulator(api.MNACircuit(circ, {"vdd": 3.3}), pts)
+    st = sim.st
+    sim.analyze()
+    u0 = np.zeros((len(pts), st.n))
+    for i, p in enumerate(pts):
+        u0[i, st.index_of("vdd")] = p["vdd"]
+        u0[i, st.index_of("out1")] = p["vdd"]
+    sim.h.set_u(u0)
+    sim.h.set_spec(mode="tran")
+    ts = np.linspace(100e-9, 200e-9, 500)
+    out, per, stats = sim.h.tran_run(0.0, 200e-9, st.state_abstol(vntol=1e-6, iabstol=1e-9, chgtol=1e-6), 1e-4, save_t=ts,
+                                     obs=[st.index_of("out1")], hmax=1e-9, fused=1)
+    sim.close()
+    assert stats["n_failed"] == 0
+    cross = []
+    for i, p in enumerate(pts):
+        v = out[i, :, 0] * (3.3 / p["vdd"])          # the reference's thresholds are for 3.3 V
+        cross.append(tc.ring_checks(v)[2])
+    assert cross == sorted(cross) and cross[-1] > cross[0], cross

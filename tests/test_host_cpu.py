@@ -437,3 +437,22 @@ def test_fused_linear_solve_program_on_cpu(nc):
         assert np.max(np.abs(x - ref)) <= 1e-6 * max(1.0, np.max(np.abs(ref))), (n, nc)
         if n == st.n:
             assert n_pre + n_post <= (30 if nc == 0 else 19), (nc, n_pre, n_post)   # 29 passes without a core, 17-18 with
+
+
+def test_cpu_port_ring_oscillator_fixture():
+    """test/mna/vadistiller_integration.jl:649-692: the 3-stage sp_mos1 ring oscillates -- swing > 2 V, max > 2.5 V,
+    min < 0.8 V, more than 10 mid-level crossings between 100 and 200 ns (dtmax = 1 ns).  The reference starts from
+    CedarUICOp (no DC point); here the start state is u = 0 with out1 at the rail: from the perfectly symmetric
+    all-zero state the three identical stages stay identical (the exact solution has no oscillation to find)."""
+    circ = tc.ring_oscillator()
+    st, port = make_port(circ, {}, 27.0, "tran")
+    analyze_port(st, port, 3.3)
+    u0 = np.zeros(st.n)
+    u0[st.index_of("vdd")] = 3.3
+    u0[st.index_of("out1")] = 3.3
+    ts = np.linspace(100e-9, 200e-9, 500)
+    out, _, rst, _ = port.tran(u0, 0.0, 200e-9, st.state_abstol(vntol=1e-6, iabstol=1e-9, chgtol=1e-6), 1e-4, save_t=ts,
+                               obs=[st.index_of("out1")], err_mask=st.differential_mask(), use_pcnr=False, hmax=1e-9)
+    assert rst["status"] == 1
+    tc.ring_checks(out[:, 0])
+    port.close()
