@@ -14,6 +14,7 @@ subset those tests use:
                    device macros as ``Xname d g s b nfet_06v0 W= L=`` -- resolved against ``models`` the same way
   B                behavioural source  V=expr / I=expr  (bsource.py)
   .INCLUDE .LIB    ``includes``: name -> text (a .LIB that is not supplied is skipped: model cards come from ``models``)
+  .MODEL           nmos / pmos (level 1 -> sp_mos1 card) and d cards; cards may also be passed in ``models``
   .PARAM .OPTION .TRAN .END ; continuation lines (+), comment lines (*), trailing comments (; or $)
 
 Values are numbers with SPICE suffixes (f p n u m k meg g t), ``{name}`` / bare names of ``.PARAM``s, or names listed
@@ -113,6 +114,20 @@ def read_spice(text, models=None, includes=None, sweep=(), title=""):
                 info["options"].update({k: parse_number(v) for k, v in kv.items()})
             elif hl == ".tran":
                 info["tran"] = tuple(parse_number(t) for t in toks[1:3])
+            elif hl == ".model":
+                # .model <name> nmos|pmos|d [level=1] key=value ...  (model cards, codegen.jl model registry)
+                pos, kv = _split_params([t.strip("()") for t in toks[1:] if t.strip("()")])
+                if len(pos) < 2:
+                    raise ValueError("malformed .model card: %r" % line)
+                kind_m = pos[1].lower()
+                card = {k: val(v) for k, v in kv.items() if k != "level"}
+                if kind_m in ("nmos", "pmos"):
+                    if float(kv.get("level", "1")) != 1.0:
+                        raise ValueError("only level-1 MOSFET cards (sp_mos1) have a GPU device: %r" % line)
+                    card["type"] = 1 if kind_m == "nmos" else -1
+                elif kind_m != "d":
+                    raise ValueError("unsupported .model type %r" % pos[1])
+                models[pos[0].lower()] = card
             elif hl in (".subckt", ".ends"):
                 raise ValueError("hierarchical decks are not supported by this reader: flatten %r first" % line)
             continue

@@ -335,6 +335,27 @@ def test_spice_deck_reader_elements_and_errors():
     assert d["B1"]["nodes"] == ["0", "out"] and d["B1"]["expr"] == "V(mid)*1e-3" and d["B2"]["type"] == "BV"
     assert "R99" not in d and info["tran"] == (1e-9, 1e-7)
     assert cj.netlist.parse_number("2.5MEG") == 2.5e6 and cj.netlist.parse_number("10pF") == pytest.approx(1e-11)
+    # .model cards: the ring oscillator deck of test/mna/vadistiller_integration.jl:45-60 in SPICE form == the table form
+    ring = """* 3-stage ring
+    .model pmos1 pmos level=1 vto=-0.7 kp=50e-6
+    .model nmos1 nmos level=1 vto=0.7 kp=100e-6
+    Vdd vdd 0 DC 3.3
+    MP1 out1 in1 vdd vdd pmos1 w=2e-6 l=1e-6
+    MN1 out1 in1 0 0 nmos1 w=1e-6 l=1e-6
+    MP2 out2 out1 vdd vdd pmos1 w=2e-6 l=1e-6
+    MN2 out2 out1 0 0 nmos1 w=1e-6 l=1e-6
+    MP3 in1 out2 vdd vdd pmos1 w=2e-6 l=1e-6
+    MN3 in1 out2 0 0 nmos1 w=1e-6 l=1e-6
+    C1 out1 0 10f
+    C2 out2 0 10f
+    C3 in1 0 10f
+    .END"""
+    rc, _ = cj.netlist.read_spice(ring)
+    ra, rb = rc.to_dicts({}), tc.ring_oscillator().to_dicts({})
+    assert [(x["type"], x["name"].lower(), x["nodes"]) for x in ra] == [(x["type"], x["name"].lower(), x["nodes"]) for x in rb]
+    assert all(x["model"] == pytest.approx(y["model"]) for x, y in zip(ra, rb) if x["type"] == "MOS1")
+    with pytest.raises(ValueError):
+        cj.netlist.read_spice(".model m1 nmos level=14")
     for bad in ("Q1 a b c npn", ".subckt x a b", "M1 d g s nfet"):
         with pytest.raises((ValueError, KeyError)):
             cj.netlist.read_spice(bad, models={})
