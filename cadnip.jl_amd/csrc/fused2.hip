@@ -36,6 +36,7 @@ typedef unsigned short u16;
 typedef unsigned long long u64;
 #define NOPOS 0xFFFFu
 #define F2_NCMAX 16   // largest core the in-register dense solve is unrolled for
+#define F2_JU 18      // J*u entries per lane and chunk
 #define F2_TRASH 64   // per-instance trash words (one per lane) that absorb stamps into ground rows / columns
 
 // table sections (offsets in 32-bit words, every section 8-byte aligned)
@@ -326,16 +327,17 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
     CADNIP_WAVE_SYNC();
     CADNIP_TRACE_POINT(1);
     if (!DC) vec.prefetch(a, lane);   // HBM operands of the update: in flight while the linear solve runs out of LDS
-    // ---- r += J*u  (J still unfactored in the LU array), eight entries per lane in flight
-    for (int p0 = 0; p0 < f.nnz; p0 += 512) {
-      u64 d[8];
-      double v[8];
+    // ---- r += J*u  (J still unfactored in the LU array).  F2_JU entries per lane in flight: all descriptor reads, then
+    // all operand reads, then all atomics -- three LDS round trips per chunk of 64 * F2_JU entries (one chunk on the DFF)
+    for (int p0 = 0; p0 < f.nnz; p0 += 64 * F2_JU) {
+      u64 d[F2_JU];
+      double v[F2_JU];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { const int p = p0 + q * 64 + lane; d[q] = nzd[p < f.nnz ? p : f.nnz - 1]; }
+      for (int q = 0; q < F2_JU; ++q) { const int p = p0 + q * 64 + lane; d[q] = nzd[p < f.nnz ? p : f.nnz - 1]; }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = W[(unsigned)d[q] & 0xFFFFu] * us[(unsigned)(d[q] >> 32) & 0xFFFFu];
+      for (int q = 0; q < F2_JU; ++q) v[q] = W[(unsigned)d[q] & 0xFFFFu] * us[(unsigned)(d[q] >> 32) & 0xFFFFu];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < F2_JU; ++q) {
         const bool ok = p0 + q * 64 + lane < f.nnz;
         atomicAdd(&W[ok ? ((unsigned)(d[q] >> 16) & 0xFFFFu) : (unsigned)(f.nnz_lu + n + lane)], ok ? v[q] : 0.0);
       }
