@@ -165,3 +165,28 @@ def test_full_size_corner_sweep_properties():
     perm = np.random.default_rng(3).permutation(len(pts))
     out_p, per_p, _ = run([pts[i] for i in perm])
     assert np.array_equal(out_p, out[perm]) and np.array_equal(per_p[:, :4], per[perm][:, :4])
+
+
+@pytest.mark.parametrize("B", [70, 300, 700])
+def test_inverter_sweep_batch_sizes(B):
+    """Batch sizes that select the 1-, 2- and 4-instance-per-workgroup variants of the fused kernel (and, with the small
+    LDS footprint of this circuit, several workgroups per CU): every instance equals its single-instance run bit for bit."""
+    circ = bm.inverter_circuit()
+    rng = np.random.default_rng(B)
+    pts = [{"vdd": float(v), "temp": float(t)} for v, t in zip(4.5 + rng.random(B), -40 + 165 * rng.random(B))]
+    ts = np.array([1.05e-7, 1.5e-7, 2.5e-7, 4e-7])     # input high at 150 and 400 ns, low at 250 ns
+
+    def run(points):
+        sim = api.BatchSimulator(api.MNACircuit(circ, {"vdd": 5.0}), points)
+        st = sim.st
+        out, per, stats = sim.tran((0.0, 4e-7), st.state_abstol(**ABSTOL), 1e-4, ts, obs=[st.index_of("Q")], fused=1)
+        sim.close()
+        assert stats["n_failed"] == 0
+        return out, per
+
+    out, per = run(pts)
+    for i in (0, B // 2, B - 1):
+        o1, p1 = run([pts[i]])
+        assert np.array_equal(o1[0], out[i]) and np.array_equal(p1[0], per[i]), i
+    vdd = np.array([p["vdd"] for p in pts])
+    assert np.all(np.abs(out[:, 1, 0]) < 0.05) and np.all(np.abs(out[:, 3, 0]) < 0.05) and np.all(np.abs(out[:, 2, 0] - vdd) < 0.05)
