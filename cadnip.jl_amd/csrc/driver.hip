@@ -199,7 +199,7 @@ int dc_newton(CadnipHandle* h, double abstol, int maxiters, int use_pcnr, int co
   int saved_initjct = h->initjct;
   h->initjct = (cold_start && a.use_pcnr) ? 1 : 0;   // armed for the first stamping only (solve.jl:624,632)
   int rc = CADNIP_OK;
-  if (fused && h->analyzed && h->spec.gshunt == 0.0 && h->spec.srcFact >= 1.0) {
+  if (fused && h->analyzed && h->spec.gshunt == 0.0 && h->spec.srcFact >= 1.0 && fused2_fits(h)) {
     // the whole Newton loop of every instance in the fused kernel; the host only looks at the running count
     TranArgs ta{};
     ta.u = h->d_u; ta.limit_w = h->d_limit_w; ta.status = d->status; ta.cnt = d->cnt; ta.active = h->d_active; ta.flags = h->d_flags;
@@ -411,6 +411,8 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
              h->B, h->n, h->n_limits, o->n_break, o->n_save, n_obs, n_err,
              o->t0, o->t1, o->reltol, h0, hmin, hmax, o->newton_tol > 0 ? o->newton_tol : 1e-3,
              o->max_newton > 0 ? o->max_newton : 10, o->max_order > 0 ? o->max_order : 2, o->use_pcnr};
+  if (!h->analyzed) return CADNIP_NOTREADY;              // the symbolic LU phase (cadnip_analyze*) comes first
+  const bool use_fused = o->fused && fused2_fits(h);     // a circuit too large for the LDS-resident kernel runs on the per-op kernels
   int saved_mode = h->spec.mode;
   h->spec.mode = 1;   // :tran
   hipLaunchKernelGGL(k_tran_init, dim3(h->B), dim3(64), 0, h->stream, a);
@@ -422,8 +424,8 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
   // Newton rounds between two looks at the running-instance count.  A fused launch loads the structure tables and each
   // instance's state once and ends when its slowest wave has done its rounds (measured, DFF sweep: 8 rounds per launch
   // 38.8 M iterations/s, 64: 43.2, 1024: 44.8, one launch for the whole transient: 45.2).
-  const int check_every = o->fused ? 1024 : 8;
-  if (o->fused) {
+  const int check_every = use_fused ? 1024 : 8;
+  if (use_fused) {
     // The host stays one launch ahead: launch k+1 is queued before the running-instance count of launch k is read,
     // so the GPU never waits for the host between launches.  Once every instance has finished, the one launch
     // already in the queue finds nothing to do (each wave reads its status and exits).
@@ -452,7 +454,7 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
     if (es != hipSuccess) { set_last_error("hipStreamSynchronize", es); return CADNIP_HIPERROR; }
     if (!rc && running > 0) rc = count_running(h, &running);
   }
-  while (!o->fused && running > 0 && launches < max_it) {
+  while (!use_fused && running > 0 && launches < max_it) {
     for (int c = 0; c < check_every; ++c) {
       rc = launch_rebuild(h); if (rc) break;
       rc = launch_residual(h, h->d_du); if (rc) break;

@@ -570,30 +570,44 @@ static bool f2_prepare(CadnipHandle* h, F2Tables& T, const std::vector<int>& g_p
 
 struct F2DcOpts { double abstol; int maxiters, use_pcnr, mode, initjct; int* dcstate; };
 
+// Build (or rebuild) the structure tables; CADNIP_BADARG if the circuit cannot be expressed in them (16-bit offsets)
+static int fused2_tables(CadnipHandle* h) {
+  if (!h->analyzed) return CADNIP_NOTREADY;
+  if (h->d_f2tab && !h->fused2_dirty) return CADNIP_OK;
+  // host copies of the gather lists are needed to invert them: read back once
+  std::vector<int> g_ptr(h->nnz + 1), c_ptr(h->nnz + 1), b_ptr(h->n + 1);
+  HIP_TRY(hipMemcpy(g_ptr.data(), h->d_g_ptr, g_ptr.size() * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(c_ptr.data(), h->d_c_ptr, c_ptr.size() * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(b_ptr.data(), h->d_b_ptr, b_ptr.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<int> g_slots(g_ptr.back()), c_slots(c_ptr.back()), b_slots(b_ptr.back());
+  if (!g_slots.empty()) HIP_TRY(hipMemcpy(g_slots.data(), h->d_g_slots, g_slots.size() * 4, hipMemcpyDeviceToHost));
+  if (!c_slots.empty()) HIP_TRY(hipMemcpy(c_slots.data(), h->d_c_slots, c_slots.size() * 4, hipMemcpyDeviceToHost));
+  if (!b_slots.empty()) HIP_TRY(hipMemcpy(b_slots.data(), h->d_b_slots, b_slots.size() * 4, hipMemcpyDeviceToHost));
+  F2Tables T;
+  if (!f2_prepare(h, T, g_ptr, g_slots, c_ptr, c_slots, b_ptr, b_slots)) return CADNIP_BADARG;
+  if (h->d_f2tab) (void)hipFree(h->d_f2tab);
+  h->d_f2tab = nullptr;
+  HIP_TRY(hipMalloc((void**)&h->d_f2tab, T.data.size() * sizeof(unsigned)));
+  HIP_TRY(hipMemcpy(h->d_f2tab, T.data.data(), T.data.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+  for (int i = 0; i < S_NSEC; ++i) h->f2off[i] = T.off[i];
+  h->f2len = (int)T.data.size();
+  h->fused2_dirty = false;
+  h->f2_blk_dirty = true;
+  return CADNIP_OK;
+}
+
+// Does one instance of this circuit (tables + work array) fit into a CU's LDS?  The drivers fall back to the per-op
+// kernels (still on the GPU) when it does not, or when the tables cannot address it.
+bool fused2_fits(CadnipHandle* h) {
+  if (fused2_tables(h) != CADNIP_OK) return false;
+  const size_t per = (size_t)h->f2_lu_words + 3 * (size_t)h->n + F2_TRASH;
+  return ((size_t)h->f2len / 2 + per) * 8 <= 160 * 1024;
+}
+
 static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F2DcOpts* dc) {
   if (!h->analyzed) return CADNIP_NOTREADY;
   if (h->spec.gshunt != 0.0 || h->spec.srcFact < 1.0) return CADNIP_BADARG;   // homotopies run on the per-op path
-  if (!h->d_f2tab || h->fused2_dirty) {
-    // host copies of the gather lists are needed to invert them: read back once
-    std::vector<int> g_ptr(h->nnz + 1), c_ptr(h->nnz + 1), b_ptr(h->n + 1);
-    HIP_TRY(hipMemcpy(g_ptr.data(), h->d_g_ptr, g_ptr.size() * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(c_ptr.data(), h->d_c_ptr, c_ptr.size() * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(b_ptr.data(), h->d_b_ptr, b_ptr.size() * 4, hipMemcpyDeviceToHost));
-    std::vector<int> g_slots(g_ptr.back()), c_slots(c_ptr.back()), b_slots(b_ptr.back());
-    if (!g_slots.empty()) HIP_TRY(hipMemcpy(g_slots.data(), h->d_g_slots, g_slots.size() * 4, hipMemcpyDeviceToHost));
-    if (!c_slots.empty()) HIP_TRY(hipMemcpy(c_slots.data(), h->d_c_slots, c_slots.size() * 4, hipMemcpyDeviceToHost));
-    if (!b_slots.empty()) HIP_TRY(hipMemcpy(b_slots.data(), h->d_b_slots, b_slots.size() * 4, hipMemcpyDeviceToHost));
-    F2Tables T;
-    if (!f2_prepare(h, T, g_ptr, g_slots, c_ptr, c_slots, b_ptr, b_slots)) return CADNIP_BADARG;
-    if (h->d_f2tab) (void)hipFree(h->d_f2tab);
-    h->d_f2tab = nullptr;
-    HIP_TRY(hipMalloc((void**)&h->d_f2tab, T.data.size() * sizeof(unsigned)));
-    HIP_TRY(hipMemcpy(h->d_f2tab, T.data.data(), T.data.size() * sizeof(unsigned), hipMemcpyHostToDevice));
-    for (int i = 0; i < S_NSEC; ++i) h->f2off[i] = T.off[i];
-    h->f2len = (int)T.data.size();
-    h->fused2_dirty = false;
-    h->f2_blk_dirty = true;
-  }
+  { int rc = fused2_tables(h); if (rc) return rc; }
   ProfScope ps(h, dc ? "fused2_dc" : "fused2_newton");
   const LUProgram& P = h->lu;
   F2Args f;

@@ -140,6 +140,7 @@ int launch_calib_copy(CadnipHandle* h, long n, int reps);
 int launch_negate(CadnipHandle* h, double* d_x, long n);
 struct TranArgs;                                                          // tran_ctrl.hpp
 int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds); // fused2.hip
+bool fused2_fits(CadnipHandle* h);                                        // false: circuit too large for the LDS-resident kernel
 int launch_fused2_dc(CadnipHandle* h, const TranArgs& t, int rounds, double abstol, int maxiters, int use_pcnr, int mode, int initjct, int* d_dcstate);
 struct ProfScope {
   CadnipHandle* h; int idx;

@@ -190,3 +190,20 @@ def test_inverter_sweep_batch_sizes(B):
         assert np.array_equal(o1[0], out[i]) and np.array_equal(p1[0], per[i]), i
     vdd = np.array([p["vdd"] for p in pts])
     assert np.all(np.abs(out[:, 1, 0]) < 0.05) and np.all(np.abs(out[:, 3, 0]) < 0.05) and np.all(np.abs(out[:, 2, 0] - vdd) < 0.05)
+
+
+def test_circuit_too_large_for_the_fused_kernel_runs_per_op():
+    """A 3000-section RC ladder (n = 3002) does not fit the LDS-resident kernel: asking for the fused path must still give
+    the per-op result (the driver routes it to the per-op kernels; nothing falls back to the CPU)."""
+    circ = _rc_ladder(3000)
+    res = {}
+    for fused in (0, 1):
+        sim = api.BatchSimulator(api.MNACircuit(circ, {}))
+        st = sim.st
+        obs = [st.index_of("n1"), st.index_of("n1500"), st.index_of("n3000")]
+        out, per, stats = sim.tran((0.0, 4e-6), np.full(st.n, 1e-9), 1e-5, np.array([2e-6, 4e-6]), obs=obs, fused=fused)
+        assert stats["n_failed"] == 0
+        res[fused] = (out, per)
+        sim.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert 0.0 < res[0][0][0, 1, 0] <= 1.0 + 1e-6
