@@ -59,6 +59,11 @@ typedef DevCtxT<int> DevCtx;
 
 // slot writers: S points at this instance's slot buffer; bases are per block
 struct SlotOut {
+  // DIRECT writers (fused kernel) take each device's residual contribution r = C du + G u - b straight from the device
+  // (Rn, by unknown index) instead of assembling it from b, C*beta and a J*u product; the slot writer never does.
+  static constexpr bool DIRECT = false;
+  __device__ __forceinline__ void Rn(int, double) const {}
+  __device__ __forceinline__ double du(int) const { return 0.0; }
   double* __restrict__ g;  // S + g_base
   double* __restrict__ c;  // S + ns_g + c_base
   double* __restrict__ b;  // S + ns_g + ns_c + b_base
@@ -149,16 +154,34 @@ template <class Out> __device__ inline void conductance4(const Out& s, int k0, d
 template <class Out> __device__ inline void capacitance4(const Out& s, int k0, double c) { const double v[4] = {c, -c, -c, c}; s.Cv(k0, v); }
 template <class Out> __device__ inline void branch4(const Out& s) { const double v[4] = {1.0, -1.0, 1.0, -1.0}; s.Gv(0, v); }
 
-template <class Ctx, class Out> __device__ inline void stamp_resistor(const Ctx& d, const double*, const Out& s, double*) { conductance4(s, 0, par_of(d, 0)); }
-template <class Ctx, class Out> __device__ inline void stamp_capacitor(const Ctx& d, const double*, const Out& s, double*) { capacitance4(s, 0, par_of(d, 0)); }
+// residual of a two-terminal branch current i flowing p -> n
+template <class Out> __device__ __forceinline__ void residual2(const Out& s, int p, int n, double i) { s.Rn(p, i); s.Rn(n, -i); }
+
+template <class Ctx, class Out> __device__ inline void stamp_resistor(const Ctx& d, const double* u, const Out& s, double*) {
+  const double g = par_of(d, 0);
+  conductance4(s, 0, g);
+  if constexpr (Out::DIRECT) { const int p = node_of(d, 0), n = node_of(d, 1); residual2(s, p, n, g * (volt(u, p) - volt(u, n))); }
+}
+template <class Ctx, class Out> __device__ inline void stamp_capacitor(const Ctx& d, const double*, const Out& s, double*) {
+  const double c = par_of(d, 0);
+  capacitance4(s, 0, c);
+  if constexpr (Out::DIRECT) { const int p = node_of(d, 0), n = node_of(d, 1); residual2(s, p, n, c * (s.du(p) - s.du(n))); }
+}
 template <class Ctx, class Out> __device__ inline void stamp_inductor(const Ctx& d, const double*, const Out& s, double*) { branch4(s); s.C(0, -par_of(d, 0)); }
-template <class Ctx, class Out> __device__ inline void stamp_vsource(const Ctx& d, const double*, const Out& s, double*) {
+template <class Ctx, class Out> __device__ inline void stamp_vsource(const Ctx& d, const double* u, const Out& s, double*) {
   branch4(s);
-  s.B(0, source_value(d, par_of(d, 0), par_of(d, 1)));
+  const double v = source_value(d, par_of(d, 0), par_of(d, 1));
+  s.B(0, v);
+  if constexpr (Out::DIRECT) {   // KCL rows carry the branch current, the branch row V(p) - V(n) - v
+    const int p = node_of(d, 0), n = node_of(d, 1), I = node_of(d, 2);
+    residual2(s, p, n, u[I]);
+    s.Rn(I, volt(u, p) - volt(u, n) - v);
+  }
 }
 template <class Ctx, class Out> __device__ inline void stamp_isource(const Ctx& d, const double*, const Out& s, double*) {
   double i = source_value(d, par_of(d, 0), par_of(d, 1));
   s.B(0, i); s.B(1, -i);
+  if constexpr (Out::DIRECT) residual2(s, node_of(d, 0), node_of(d, 1), -i);
 }
 template <class Ctx, class Out> __device__ inline void stamp_vcvs(const Ctx& d, const double*, const Out& s, double*) {
   double a = par_of(d, 0);
@@ -705,6 +728,10 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
   {   // g_lim rows (vasim.jl:3134-3136): two limit variables per lane
     const double gl[6] = {1.0, -1.0, 1.0, 1.0, -1.0, 1.0};
     s.Gv(6 * side, gl);
+    if constexpr (Out::DIRECT) {   // r_l = u_l - (V_p - V_n) for (g,s_int), (d_int,s_int) | (b,s_int), (b,d_int)
+      s.Rn(D ? l2 : l0, u[D ? l2 : l0] - ((D ? Vb : Vg) - Vsi));
+      s.Rn(D ? l3 : l1, u[D ? l3 : l1] - (D ? Vb - Vdi : Vdi - Vsi));
+    }
   }
   CADNIP_TRACE_POINT(22);
   D3 a = D3::seed(type * w_gs, 0), b = D3::seed(type * w_ds, 1), c = D3::seed(type * w_bs, 2);
@@ -740,6 +767,10 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
     const int br = 3 + side;
     s.Gv(12 + 6 * br, g);
     s.B(br, -Ieq);
+    if constexpr (Out::DIRECT) {   // the row's residual is the branch current itself plus the lim_rhs anchoring terms
+      const D3 I = m1_sel(D, I4, I3);
+      s.Rn(D ? ndi : nb, mf * I.v + (mf * type * I.p[0]) * dW_gs + (mf * type * I.p[1]) * dW_ds + (mf * type * I.p[2]) * dW_bs);
+    }
   }
   {   // row I(s_int): both lanes form it, each emits two of its four entries; the source-side lane owns the b entry
     const D3 I5 = -1.0 * (cdreq + type * cbs);
@@ -749,6 +780,8 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
     const double v2[2] = {D ? g[4] : g[1], D ? g[5] : g[3]};
     s.Gk(k2, v2);
     s.B(5, D ? 0.0 : -Ieq);
+    if constexpr (Out::DIRECT)
+      s.Rn(nsi, D ? 0.0 : mf * I5.v + (mf * type * I5.p[0]) * dW_gs + (mf * type * I5.p[1]) * dW_ds + (mf * type * I5.p[2]) * dW_bs);
   }
   CADNIP_TRACE_POINT(26);
   // depletion charge of this lane's junction (after the current rows: fewer values live at once), swapped like the current
@@ -764,6 +797,7 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
   // reactive rows: branch charges of g, b, d_int, s_int.  Meyer charges vanish with OxideCap == 0; the pair path is only
   // taken then (caller), so q_g = 0, q_b = type (qbs + qbd), q_dint = -type qbd, q_sint = -type qbs
   const D3 q0(0.0), q1 = type * qbs + type * qbd, q2 = -1.0 * (type * qbd), q3 = -1.0 * (type * qbs);
+  const int vdep = Out::DIRECT ? d.ipar[d.dev] : 0;       // bit r: reactive branch r uses a charge unknown
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int r = 2 * it + side;
@@ -778,6 +812,18 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
     bc += fa * dW_gs; bc += fb * dW_ds; bc += fc * dW_bs;
     s.B(6 + r, CS * bc);
     s.Cv(4 + 6 * r, dq);
+    if constexpr (Out::DIRECT) {
+      // branch node of reactive branch r: g, b, d_int, s_int.  Charge-state form (vasim.jl:3433-3472) when the branch was
+      // flagged voltage dependent: r_q = u_q - CS (q + lim terms), r_p += du_q / CS; else the linear form r_p += sum dq_k du_k.
+      const int np = r == 0 ? ng : r == 1 ? nb : r == 2 ? ndi : nsi;
+      if ((vdep >> r) & 1) {
+        const int nq = node_of(d, 10 + r);
+        s.Rn(nq, u[nq] - CS * (mf * q.v + fa * dW_gs + fb * dW_ds + fc * dW_bs));
+        s.Rn(np, s.du(nq) * (1.0 / CS));
+      } else {
+        s.Rn(np, dq[1] * s.du(ng) + dq[3] * s.du(nb) + dq[4] * s.du(ndi) + dq[5] * s.du(nsi));
+      }
+    }
   }
   CADNIP_TRACE_POINT(27);
 }

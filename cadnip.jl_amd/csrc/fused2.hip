@@ -40,7 +40,7 @@ typedef unsigned long long u64;
 #define F2_TRASH 64   // per-instance trash words (one per lane) that absorb stamps into ground rows / columns
 
 // table sections (offsets in 32-bit words, every section 8-byte aligned)
-enum { S_GPOS = 0, S_CDESC, S_BROW, S_NZ, S_ENT, S_TERM, S_LEV, S_QINV, S_NODES, S_NSEC };
+enum { S_GPOS = 0, S_CDESC, S_BROW, S_NZ, S_ENT, S_TERM, S_LEV, S_QINV, S_NODES, S_ROWOF, S_NSEC };
 
 struct F2Block {
   const int* ipar; const double* par;
@@ -76,13 +76,22 @@ struct F2Args {
 
 // stamp writer: accumulates into J (LU positions) and the residual; all targets are offsets into W.
 // GUARD: a lane whose `sink` is non-zero (no device behind it) sends every stamp to that trash word instead.
-template <bool GUARD>
+// DIRECT: the residual comes from the devices (Rn, devices.hpp) -- b stamps and the C*beta terms are dropped here and
+// the kernel skips its J*u product.
+template <bool GUARD, bool DIRECT_>
 struct AccumOutT {
+  static constexpr bool DIRECT = DIRECT_;
   double* W; const double* betas; double a0;
   const u16* gpos; const u64* cdesc; const u16* brow;   // already offset to this device block
   int count, dev;
   unsigned sink;
+  const double* us; const u16* rowof; unsigned trash;    // DIRECT: u, unknown index -> rhs word, this lane's trash word
   __device__ __forceinline__ unsigned tg(unsigned p) const { return GUARD && sink ? sink : p; }
+  __device__ __forceinline__ double du(int node) const { return node < 0 ? 0.0 : a0 * us[node] + betas[node]; }
+  __device__ __forceinline__ void Rn(int node, double v) const {
+    if (!DIRECT) return;
+    atomicAdd(&W[tg(node < 0 ? trash : (unsigned)rowof[node])], v);
+  }
   __device__ __forceinline__ void G(int k, double v) const {
     if (__builtin_constant_p(v) && v == 0.0) return;     // structurally zero stamps cost nothing
     atomicAdd(&W[tg(gpos[k * count + dev])], v);
@@ -91,10 +100,10 @@ struct AccumOutT {
     if (__builtin_constant_p(v) && v == 0.0) return;
     const u64 d = cdesc[k * count + dev];
     atomicAdd(&W[tg((unsigned)d & 0xFFFFu)], a0 * v);
-    atomicAdd(&W[tg((unsigned)(d >> 16) & 0xFFFFu)], v * betas[(unsigned)(d >> 32) & 0xFFFFu]);
+    if (!DIRECT) atomicAdd(&W[tg((unsigned)(d >> 16) & 0xFFFFu)], v * betas[(unsigned)(d >> 32) & 0xFFFFu]);
   }
   __device__ __forceinline__ void B(int k, double v) const {
-    if (__builtin_constant_p(v) && v == 0.0) return;
+    if (DIRECT || (__builtin_constant_p(v) && v == 0.0)) return;
     atomicAdd(&W[tg(brow[k * count + dev])], -v);
   }
   // batch forms: all table reads of the batch are issued before its first atomic, so a batch costs one LDS
@@ -118,16 +127,19 @@ struct AccumOutT {
     double bt[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) d[i] = cdesc[(k0 + i) * count + dev];
+    if (!DIRECT) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) bt[i] = betas[(unsigned)(d[i] >> 32) & 0xFFFFu];
+      for (int i = 0; i < N; ++i) bt[i] = betas[(unsigned)(d[i] >> 32) & 0xFFFFu];
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i)
       if (!(__builtin_constant_p(v[i]) && v[i] == 0.0)) {
         atomicAdd(&W[tg((unsigned)d[i] & 0xFFFFu)], a0 * v[i]);
-        atomicAdd(&W[tg((unsigned)(d[i] >> 16) & 0xFFFFu)], v[i] * bt[i]);
+        if (!DIRECT) atomicAdd(&W[tg((unsigned)(d[i] >> 16) & 0xFFFFu)], v[i] * bt[i]);
       }
   }
   template <int N> __device__ __forceinline__ void Bv(int k0, const double (&v)[N]) const {
+    if (DIRECT) return;
     unsigned p[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) p[i] = brow[(k0 + i) * count + dev];
@@ -135,7 +147,6 @@ struct AccumOutT {
     for (int i = 0; i < N; ++i) if (!(__builtin_constant_p(v[i]) && v[i] == 0.0)) atomicAdd(&W[tg(p[i])], -v[i]);
   }
 };
-typedef AccumOutT<false> AccumOut;
 
 typedef DevCtxT<short> LdsCtx;
 
@@ -210,7 +221,7 @@ __device__ __forceinline__ void dense_core_solve(double* W, int dn0, int yc0, in
   if (lane < NC) W[yc0 + lane] = bc;
 }
 
-template <int WPB, bool DC>
+template <int WPB, bool DC, bool DIRECT>
 __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
   extern __shared__ double sm[];
   // w is the same for all lanes of a wave: say so (readfirstlane), or every address derived from it lives in VGPRs
@@ -239,6 +250,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
   const u64* passd = (const u64*)(tab + f.off[S_LEV]);
   const u16* qinv = (const u16*)(tab + f.off[S_QINV]);
   const short* nodes = (const short*)(tab + f.off[S_NODES]);
+  const u16* rowof = (const u16*)(tab + f.off[S_ROWOF]);
 #ifdef CADNIP_TRACE
   if (blockIdx.x == 0 && tid == 0) g_trace_last = clock64();
 #endif
@@ -288,6 +300,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
     // ---- stamp: accumulate J (at LU positions) and the C*beta - b part of the residual
     const double tcur = DC ? 0.0 : st.tn, a0 = DC ? 0.0 : st.a0;
     const int dmode = DC ? f.dc_mode : 1, dinit = DC ? dc_first : 0;
+    const unsigned trash_w = (unsigned)(f.nnz_lu + n + lane);
     dc_first = 0;                                       // initjct is armed for the first stamping only (solve.jl:624,632)
     for (int bi = 0; bi < f.n_blk; ++bi) {
       const F2Block B = load_block(f.blk, bi);
@@ -299,8 +312,13 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
         for (int q = 0; q < 2; ++q) {
           const int dev = lane + 64 * q;
           if (dev < B.count) {
-            AccumOut s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev, 0u};
+            AccumOutT<false, DIRECT> s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev, 0u, us, rowof, trash_w};
             if (B.type == CADNIP_DEV_CAPACITOR) capacitance4(s, 0, rc_val[q]); else conductance4(s, 0, rc_val[q]);
+            if (DIRECT) {
+              const short* nd = nodes + B.nodes_off;
+              const int np = nd[dev], nn = nd[B.count + dev];
+              residual2(s, np, nn, B.type == CADNIP_DEV_CAPACITOR ? rc_val[q] * (s.du(np) - s.du(nn)) : rc_val[q] * (volt(us, np) - volt(us, nn)));
+            }
           }
         }
         dev0 = lane + 128;
@@ -312,14 +330,14 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
           const int dv = d0 + (lane >> 1);
           const bool valid = dv < B.count;
           LdsCtx d{nodes + B.nodes_off, B.ipar, par, f.wave, B.count, valid ? dv : B.count - 1, tcur, dmode, dinit};
-          AccumOutT<true> s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, d.dev, valid ? 0u : (unsigned)(f.nnz_lu + n + lane)};
+          AccumOutT<true, DIRECT> s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, d.dev, valid ? 0u : trash_w, us, rowof, trash_w};
           stamp_mos1_pair(d, us, s, lw, side, valid);
         }
         dev0 = B.count;
       }
       for (int dev = dev0; dev < B.count; dev += 64) {
         LdsCtx d{nodes + B.nodes_off, B.ipar, par, f.wave, B.count, dev, tcur, dmode, dinit};
-        AccumOut s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev, 0u};
+        AccumOutT<false, DIRECT> s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev, 0u, us, rowof, trash_w};
         dispatch_stamp2(B.type, d, us, s, lw);
       }
       CADNIP_TRACE_POINT(8 + bi);
@@ -329,7 +347,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
     if (!DC) vec.prefetch(a, lane);   // HBM operands of the update: in flight while the linear solve runs out of LDS
     // ---- r += J*u  (J still unfactored in the LU array).  F2_JU entries per lane in flight: all descriptor reads, then
     // all operand reads, then all atomics -- three LDS round trips per chunk of 64 * F2_JU entries (one chunk on the DFF)
-    for (int p0 = 0; p0 < f.nnz; p0 += 64 * F2_JU) {
+    for (int p0 = 0; !DIRECT && p0 < f.nnz; p0 += 64 * F2_JU) {
       u64 d[F2_JU];
       double v[F2_JU];
 #pragma unroll
@@ -557,6 +575,11 @@ static bool f2_prepare(CadnipHandle* h, F2Tables& T, const std::vector<int>& g_p
   std::vector<int> qoff(n);
   for (int j = 0; j < n; ++j) qoff[j] = y0 + qinv[j];
   T.begin(S_QINV); T.add16(qoff);
+  {
+    std::vector<int> rowoff(n);                       // unknown index -> rhs word of its row (direct residuals, devices.hpp Rn)
+    for (int i = 0; i < n; ++i) rowoff[i] = y0 + pinv[i];
+    T.begin(S_ROWOF); T.add16(rowoff);
+  }
   T.begin(S_NODES);
   h->f2_nodes_off.clear();
   {
@@ -628,6 +651,14 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
     for (int i = 0; i < nb; ++i)
       if (hb[i].type == CADNIP_DEV_CAPACITOR || hb[i].type == CADNIP_DEV_RESISTOR) { h->f2_rc_blk = i; break; }
     h->f2_n_blk = nb;
+    // direct residuals need every device type in the circuit to emit them (devices.hpp: R, C, V, I, paired sp_mos1)
+    h->f2_direct = !getenv("CADNIP_F2_NODIRECT");
+    for (int i = 0; i < nb; ++i) {
+      const int ty = hb[i].type;
+      const bool ok = ty == CADNIP_DEV_RESISTOR || ty == CADNIP_DEV_CAPACITOR || ty == CADNIP_DEV_VSOURCE || ty == CADNIP_DEV_ISOURCE ||
+                      (ty == CADNIP_DEV_MOS1 && hb[i].mos1_plain);
+      if (!ok) h->f2_direct = false;
+    }
     if (!h->d_f2blk) HIP_TRY(hipMalloc((void**)&h->d_f2blk, sizeof(hb)));
     HIP_TRY(hipStreamSynchronize(h->stream));               // no launch in flight may still read the old descriptors
     HIP_TRY(hipMemcpy(h->d_f2blk, hb, sizeof(F2Block) * (size_t)nb, hipMemcpyHostToDevice));
@@ -664,14 +695,16 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
   f.queue = h->d_f2queue;
   const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(lds_cap / shmem, (size_t)(32 / wpb)));
   int grid = std::min((h->B + wpb - 1) / wpb, h->n_cu * wg_per_cu);
-  if (getenv("CADNIP_F2_DEBUG")) fprintf(stderr, "[cadnip f2] B %d n_cu %d wpb %d grid %d shmem %zu rounds %d nc %d passes %d+%d\n", h->B, h->n_cu, wpb, grid, shmem, rounds, h->f2_nc, h->f2_n_pre, h->f2_n_post);
-#define LAUNCH(W, D)                                                                                                   \
+  if (getenv("CADNIP_F2_DEBUG")) fprintf(stderr, "[cadnip f2] B %d n_cu %d wpb %d grid %d shmem %zu rounds %d nc %d passes %d+%d direct %d\n", h->B, h->n_cu, wpb, grid, shmem, rounds, h->f2_nc, h->f2_n_pre, h->f2_n_post, (int)h->f2_direct);
+#define LAUNCH(W, D, R)                                                                                                \
   do {                                                                                                                 \
-    if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_fused2<W, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-    hipLaunchKernelGGL((k_fused2<W, D>), dim3(grid), dim3(64 * W), shmem, h->stream, f);                               \
+    if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_fused2<W, D, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+    hipLaunchKernelGGL((k_fused2<W, D, R>), dim3(grid), dim3(64 * W), shmem, h->stream, f);                            \
   } while (0)
-  if (dc) { if (wpb == 8) LAUNCH(8, true); else if (wpb == 4) LAUNCH(4, true); else if (wpb == 2) LAUNCH(2, true); else LAUNCH(1, true); }
-  else { if (wpb == 8) LAUNCH(8, false); else if (wpb == 4) LAUNCH(4, false); else if (wpb == 2) LAUNCH(2, false); else LAUNCH(1, false); }
+#define LAUNCH_W(D, R) do { if (wpb == 8) LAUNCH(8, D, R); else if (wpb == 4) LAUNCH(4, D, R); else if (wpb == 2) LAUNCH(2, D, R); else LAUNCH(1, D, R); } while (0)
+  if (dc) { if (h->f2_direct) LAUNCH_W(true, true); else LAUNCH_W(true, false); }
+  else { if (h->f2_direct) LAUNCH_W(false, true); else LAUNCH_W(false, false); }
+#undef LAUNCH_W
 #undef LAUNCH
   HIP_TRY(hipGetLastError());
   return CADNIP_OK;

@@ -113,6 +113,7 @@ struct CadnipHandle {
   void* d_f2blk = nullptr;    // fused kernel: device-block descriptors
   bool f2_blk_dirty = true;
   int f2_n_blk = 0, f2_rc_blk = -1;
+  bool f2_direct = false;     // every device type of the circuit emits its residual directly: no J*u pass
   int n_cu = 0;
   // driver state (allocated lazily)
   struct Driver* drv = nullptr;
