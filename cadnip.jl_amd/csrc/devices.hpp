@@ -167,37 +167,57 @@ template <class Ctx, class Out> __device__ inline void stamp_capacitor(const Ctx
   capacitance4(s, 0, c);
   if constexpr (Out::DIRECT) { const int p = node_of(d, 0), n = node_of(d, 1); residual2(s, p, n, c * (s.du(p) - s.du(n))); }
 }
-template <class Ctx, class Out> __device__ inline void stamp_inductor(const Ctx& d, const double*, const Out& s, double*) { branch4(s); s.C(0, -par_of(d, 0)); }
+// branch element with its own current unknown I between p and n: KCL rows carry u[I]; `vbranch` is what the branch row
+// equates V(p) - V(n) to
+template <class Out> __device__ __forceinline__ void residual_branch(const Out& s, const double* u, int p, int n, int I, double vbranch) {
+  residual2(s, p, n, u[I]);
+  s.Rn(I, volt(u, p) - volt(u, n) - vbranch);
+}
+template <class Ctx, class Out> __device__ inline void stamp_inductor(const Ctx& d, const double* u, const Out& s, double*) {
+  const double L = par_of(d, 0);
+  branch4(s); s.C(0, -L);
+  if constexpr (Out::DIRECT) { const int I = node_of(d, 2); residual_branch(s, u, node_of(d, 0), node_of(d, 1), I, L * s.du(I)); }
+}
 template <class Ctx, class Out> __device__ inline void stamp_vsource(const Ctx& d, const double* u, const Out& s, double*) {
   branch4(s);
   const double v = source_value(d, par_of(d, 0), par_of(d, 1));
   s.B(0, v);
-  if constexpr (Out::DIRECT) {   // KCL rows carry the branch current, the branch row V(p) - V(n) - v
-    const int p = node_of(d, 0), n = node_of(d, 1), I = node_of(d, 2);
-    residual2(s, p, n, u[I]);
-    s.Rn(I, volt(u, p) - volt(u, n) - v);
-  }
+  if constexpr (Out::DIRECT) residual_branch(s, u, node_of(d, 0), node_of(d, 1), node_of(d, 2), v);
 }
 template <class Ctx, class Out> __device__ inline void stamp_isource(const Ctx& d, const double*, const Out& s, double*) {
   double i = source_value(d, par_of(d, 0), par_of(d, 1));
   s.B(0, i); s.B(1, -i);
   if constexpr (Out::DIRECT) residual2(s, node_of(d, 0), node_of(d, 1), -i);
 }
-template <class Ctx, class Out> __device__ inline void stamp_vcvs(const Ctx& d, const double*, const Out& s, double*) {
+template <class Ctx, class Out> __device__ inline void stamp_vcvs(const Ctx& d, const double* u, const Out& s, double*) {
   double a = par_of(d, 0);
   s.G(0, 1.0); s.G(1, -1.0); s.G(2, 1.0); s.G(3, -1.0); s.G(4, -a); s.G(5, a);
+  if constexpr (Out::DIRECT)      // nodes op on ip in I: V(op) - V(on) = a (V(ip) - V(in))
+    residual_branch(s, u, node_of(d, 0), node_of(d, 1), node_of(d, 4), a * (volt(u, node_of(d, 2)) - volt(u, node_of(d, 3))));
 }
-template <class Ctx, class Out> __device__ inline void stamp_vccs(const Ctx& d, const double*, const Out& s, double*) {
+template <class Ctx, class Out> __device__ inline void stamp_vccs(const Ctx& d, const double* u, const Out& s, double*) {
   double gm = par_of(d, 0);
   s.G(0, -gm); s.G(1, gm); s.G(2, gm); s.G(3, -gm);
+  if constexpr (Out::DIRECT) residual2(s, node_of(d, 0), node_of(d, 1), -gm * (volt(u, node_of(d, 2)) - volt(u, node_of(d, 3))));
 }
-template <class Ctx, class Out> __device__ inline void stamp_ccvs(const Ctx& d, const double*, const Out& s, double*) {
+template <class Ctx, class Out> __device__ inline void stamp_ccvs(const Ctx& d, const double* u, const Out& s, double*) {
+  const double rm = par_of(d, 0);
   s.G(0, 1.0); s.G(1, -1.0); s.G(2, 1.0); s.G(3, -1.0);
-  s.G(4, 1.0); s.G(5, -1.0); s.G(6, 1.0); s.G(7, -1.0); s.G(8, -par_of(d, 0));
+  s.G(4, 1.0); s.G(5, -1.0); s.G(6, 1.0); s.G(7, -1.0); s.G(8, -rm);
+  if constexpr (Out::DIRECT) {   // nodes op on ip in Iin Iout: 0 V sense branch ip -> in, output branch V(op) - V(on) = rm I_in
+    const int Iin = node_of(d, 4);
+    residual_branch(s, u, node_of(d, 2), node_of(d, 3), Iin, 0.0);
+    residual_branch(s, u, node_of(d, 0), node_of(d, 1), node_of(d, 5), rm * u[Iin]);
+  }
 }
-template <class Ctx, class Out> __device__ inline void stamp_cccs(const Ctx& d, const double*, const Out& s, double*) {
+template <class Ctx, class Out> __device__ inline void stamp_cccs(const Ctx& d, const double* u, const Out& s, double*) {
   double a = par_of(d, 0);
   s.G(0, 1.0); s.G(1, -1.0); s.G(2, 1.0); s.G(3, -1.0); s.G(4, -a); s.G(5, a);
+  if constexpr (Out::DIRECT) {   // nodes op on ip in Iin: sense branch ip -> in; G(op,Iin) = -a, G(on,Iin) = +a
+    const int Iin = node_of(d, 4);
+    residual_branch(s, u, node_of(d, 2), node_of(d, 3), Iin, 0.0);
+    residual2(s, node_of(d, 0), node_of(d, 1), -a * u[Iin]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -246,11 +266,14 @@ template <class Ctx> __device__ inline double bsrc_value(const Ctx& d, const dou
 }
 template <class Ctx, class Out> __device__ inline void stamp_bvsource(const Ctx& d, const double* u, const Out& s, double*) {
   branch4(s);
-  s.B(0, bsrc_value(d, u));
+  const double v = bsrc_value(d, u);
+  s.B(0, v);
+  if constexpr (Out::DIRECT) residual_branch(s, u, node_of(d, 0), node_of(d, 1), node_of(d, 2), v);
 }
 template <class Ctx, class Out> __device__ inline void stamp_bisource(const Ctx& d, const double* u, const Out& s, double*) {
   const double i = bsrc_value(d, u);
   s.B(0, i); s.B(1, -i);
+  if constexpr (Out::DIRECT) residual2(s, node_of(d, 0), node_of(d, 1), -i);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -285,6 +308,7 @@ template <class Ctx, class Out> __device__ inline void stamp_diode(const Ctx& d,
     if (xarg > 80.0) { double e80 = exp(80.0); I0 = Is * (e80 * (1.0 + (xarg - 80.0)) - 1.0); Gd = Is / nVt * e80; }
     else { double e = exp(xarg); I0 = Is * (e - 1.0); Gd = Is / nVt * e; }
     Ieq = I0 - Gd * w;                         // anchored at w (devices.jl:1251-1258)
+    if constexpr (Out::DIRECT) s.Rn(l, vold - V0);   // limit row: u_l - (V(p) - V(n))
   } else {
     s.G(0, 0.0); s.G(1, 0.0); s.G(2, 0.0);
     double e = exp(V0 / nVt);
@@ -293,6 +317,7 @@ template <class Ctx, class Out> __device__ inline void stamp_diode(const Ctx& d,
   }
   conductance4(s, 3, Gd);
   s.B(0, -Ieq); s.B(1, Ieq);
+  if constexpr (Out::DIRECT) residual2(s, p, n, Gd * V0 + Ieq);   // = I0 + Gd (V0 - w): the companion model's current at V0
 }
 
 template <class Ctx, class Out> __device__ inline void stamp_diodecap(const Ctx& d, const double* u, const Out& s, double*) {
@@ -307,6 +332,7 @@ template <class Ctx, class Out> __device__ inline void stamp_diodecap(const Ctx&
   if (V0 < Vmax) C = Cj0 / pow(1 - V0 / Vj, m);
   else { double Ca = Cj0 / pow(1 - Vmax / Vj, m); double dC = Cj0 * m / Vj / pow(1 - Vmax / Vj, m + 1); C = Ca + dC * (V0 - Vmax); }
   capacitance4(s, 0, C);
+  if constexpr (Out::DIRECT) residual2(s, p, n, I0 + C * (s.du(p) - s.du(n)));
 }
 
 // SimpleMOSFET (devices.jl:1667-1749)
@@ -322,6 +348,12 @@ template <class Ctx, class Out> __device__ inline void stamp_simplemos(const Ctx
   s.B(0, -Ieq); s.B(1, Ieq);
   capacitance4(s, 0, Cgs);
   capacitance4(s, 4, Cgd);
+  if constexpr (Out::DIRECT) {   // channel current d -> s, capacitor currents g -> s and g -> d
+    const int nd = node_of(d, 0), ng = node_of(d, 1), ns = node_of(d, 2);
+    residual2(s, nd, ns, Ids);
+    residual2(s, ng, ns, Cgs * (s.du(ng) - s.du(ns)));
+    residual2(s, ng, nd, Cgd * (s.du(ng) - s.du(nd)));
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -656,8 +688,15 @@ template <class Ctx, class Out> __device__ inline void stamp_mos1(const Ctx& d, 
     Ieq = Ieq + (mf * type * Ir[br].p[1]) * dW_ds;
     Ieq = Ieq + (mf * type * Ir[br].p[2]) * dW_bs;
     Ib[br] = -Ieq;
+    if constexpr (Out::DIRECT) {   // the row's residual: the branch current plus the lim_rhs anchoring terms
+      const int nrow = br == 0 ? nd : br == 1 ? ng : br == 2 ? ns : br == 3 ? nb : br == 4 ? ndi : nsi;
+      s.Rn(nrow, mf * Iv[br] + (mf * type * Ir[br].p[0]) * dW_gs + (mf * type * Ir[br].p[1]) * dW_ds + (mf * type * Ir[br].p[2]) * dW_bs);
+    }
   }
   s.Bv(0, Ib);
+  if constexpr (Out::DIRECT) {     // limit rows: u_l - (V_p - V_n) for (g,s_int), (d_int,s_int), (b,s_int), (b,d_int)
+    s.Rn(l0, u[l0] - (Vg - Vsi)); s.Rn(l1, u[l1] - (Vdi - Vsi)); s.Rn(l2, u[l2] - (Vb - Vsi)); s.Rn(l3, u[l3] - (Vb - Vdi));
+  }
   CADNIP_TRACE_POINT(26);
   int vdep = d.ipar[d.dev];
   {
@@ -678,6 +717,16 @@ template <class Ctx, class Out> __device__ inline void stamp_mos1(const Ctx& d, 
     qb[r] = CS * bc;
     // linear form (vasim.jl:3474-3482), used when the branch was not flagged voltage dependent
     s.Cv(4 + 6 * r, dq);
+    if constexpr (Out::DIRECT) {
+      const int np = r == 0 ? ng : r == 1 ? nb : r == 2 ? ndi : nsi;
+      if ((vdep >> r) & 1) {
+        const int nq = node_of(d, 10 + r);
+        s.Rn(nq, u[nq] - CS * (mf * q[r].v + fa * dW_gs + fb * dW_ds + fc * dW_bs));
+        s.Rn(np, s.du(nq) * (1.0 / CS));
+      } else {
+        s.Rn(np, dq[1] * s.du(ng) + dq[3] * s.du(nb) + dq[4] * s.du(ndi) + dq[5] * s.du(nsi));
+      }
+    }
   }
   s.Bv(6, qb);
   (void)vdep;

@@ -651,14 +651,9 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
     for (int i = 0; i < nb; ++i)
       if (hb[i].type == CADNIP_DEV_CAPACITOR || hb[i].type == CADNIP_DEV_RESISTOR) { h->f2_rc_blk = i; break; }
     h->f2_n_blk = nb;
-    // direct residuals need every device type in the circuit to emit them (devices.hpp: R, C, V, I, paired sp_mos1)
+    // every device type emits its residual directly (devices.hpp, Rn); CADNIP_F2_NODIRECT=1 selects the assembled form
+    // r = J u + C beta - b instead (diagnostic: the two must agree)
     h->f2_direct = !getenv("CADNIP_F2_NODIRECT");
-    for (int i = 0; i < nb; ++i) {
-      const int ty = hb[i].type;
-      const bool ok = ty == CADNIP_DEV_RESISTOR || ty == CADNIP_DEV_CAPACITOR || ty == CADNIP_DEV_VSOURCE || ty == CADNIP_DEV_ISOURCE ||
-                      (ty == CADNIP_DEV_MOS1 && hb[i].mos1_plain);
-      if (!ok) h->f2_direct = false;
-    }
     if (!h->d_f2blk) HIP_TRY(hipMalloc((void**)&h->d_f2blk, sizeof(hb)));
     HIP_TRY(hipStreamSynchronize(h->stream));               // no launch in flight may still read the old descriptors
     HIP_TRY(hipMemcpy(h->d_f2blk, hb, sizeof(F2Block) * (size_t)nb, hipMemcpyHostToDevice));
