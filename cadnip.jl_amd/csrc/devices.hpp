@@ -178,16 +178,22 @@ template <class Ctx, class Out> __device__ inline void stamp_inductor(const Ctx&
   branch4(s); s.C(0, -L);
   if constexpr (Out::DIRECT) { const int I = node_of(d, 2); residual_branch(s, u, node_of(d, 0), node_of(d, 1), I, L * s.du(I)); }
 }
-template <class Ctx, class Out> __device__ inline void stamp_vsource(const Ctx& d, const double* u, const Out& s, double*) {
+// independent sources, split into value (a function of time only) and stamp so that a caller may keep the value
+// across the Newton rounds of one time point
+template <class Ctx, class Out> __device__ inline void stamp_vsource_value(const Ctx& d, const double* u, const Out& s, double v) {
   branch4(s);
-  const double v = source_value(d, par_of(d, 0), par_of(d, 1));
   s.B(0, v);
   if constexpr (Out::DIRECT) residual_branch(s, u, node_of(d, 0), node_of(d, 1), node_of(d, 2), v);
 }
-template <class Ctx, class Out> __device__ inline void stamp_isource(const Ctx& d, const double*, const Out& s, double*) {
-  double i = source_value(d, par_of(d, 0), par_of(d, 1));
+template <class Ctx, class Out> __device__ inline void stamp_isource_value(const Ctx& d, const Out& s, double i) {
   s.B(0, i); s.B(1, -i);
   if constexpr (Out::DIRECT) residual2(s, node_of(d, 0), node_of(d, 1), -i);
+}
+template <class Ctx, class Out> __device__ inline void stamp_vsource(const Ctx& d, const double* u, const Out& s, double*) {
+  stamp_vsource_value(d, u, s, source_value(d, par_of(d, 0), par_of(d, 1)));
+}
+template <class Ctx, class Out> __device__ inline void stamp_isource(const Ctx& d, const double*, const Out& s, double*) {
+  stamp_isource_value(d, s, source_value(d, par_of(d, 0), par_of(d, 1)));
 }
 template <class Ctx, class Out> __device__ inline void stamp_vcvs(const Ctx& d, const double* u, const Out& s, double*) {
   double a = par_of(d, 0);

@@ -62,6 +62,7 @@ __device__ __forceinline__ F2Block load_block(const F2Block* blk, int i) {
 struct F2Args {
   const F2Block* blk;        // [n_blk] in device memory
   int n_blk, rc_blk;         // rc_blk: index of the first capacitor / resistor block (-1 = none)
+  int src_blk;               // index of the first independent-source block (-1 = none)
   const double* wave;
   const unsigned* tab;       // packed tables in global memory
   int off[S_NSEC];
@@ -150,8 +151,25 @@ struct AccumOutT {
 
 typedef DevCtxT<short> LdsCtx;
 
-template <class Out>
+// LEAN: the circuit holds linear elements, independent sources and lane-paired sp_mos1 only (those are stamped by
+// stamp_mos1_pair in the kernel body).  The models left out are the register-hungry ones: with them compiled in, the
+// kernel no longer fits 256 VGPRs without spilling (33 spilled, -10 % on the DFF sweep).
+template <bool LEAN, class Out>
 __device__ __forceinline__ void dispatch_stamp2(int type, const LdsCtx& d, const double* u, const Out& s, double* lw) {
+  if constexpr (LEAN) {
+    switch (type) {
+      case CADNIP_DEV_RESISTOR: stamp_resistor(d, u, s, lw); break;
+      case CADNIP_DEV_CAPACITOR: stamp_capacitor(d, u, s, lw); break;
+      case CADNIP_DEV_INDUCTOR: stamp_inductor(d, u, s, lw); break;
+      case CADNIP_DEV_VSOURCE: stamp_vsource(d, u, s, lw); break;
+      case CADNIP_DEV_ISOURCE: stamp_isource(d, u, s, lw); break;
+      case CADNIP_DEV_VCVS: stamp_vcvs(d, u, s, lw); break;
+      case CADNIP_DEV_VCCS: stamp_vccs(d, u, s, lw); break;
+      case CADNIP_DEV_CCVS: stamp_ccvs(d, u, s, lw); break;
+      case CADNIP_DEV_CCCS: stamp_cccs(d, u, s, lw); break;
+    }
+    return;
+  }
   switch (type) {
     case CADNIP_DEV_RESISTOR: stamp_resistor(d, u, s, lw); break;
     case CADNIP_DEV_CAPACITOR: stamp_capacitor(d, u, s, lw); break;
@@ -221,8 +239,11 @@ __device__ __forceinline__ void dense_core_solve(double* W, int dn0, int yc0, in
   if (lane < NC) W[yc0 + lane] = bc;
 }
 
-template <int WPB, bool DC, bool DIRECT>
+// VAR: 0 = direct residuals, lean device set; 1 = direct residuals, every device type; 2 = assembled residual
+// r = J u + C beta - b (diagnostic, CADNIP_F2_NODIRECT=1), every device type
+template <int WPB, bool DC, int VAR>
 __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
+  constexpr bool DIRECT = VAR != 2, LEAN = VAR == 0;
   extern __shared__ double sm[];
   // w is the same for all lanes of a wave: say so (readfirstlane), or every address derived from it lives in VGPRs
   const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), n = f.n;
@@ -288,6 +309,9 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) { const int dev = lane0 + 64 * q; rc_val[q] = par[dev < B.count ? dev : 0]; }
   }
+  // values of the first independent-source block: functions of time only, kept over the Newton rounds of a time point
+  double src_val = 0.0, src_t = 0.0;
+  bool src_have = false;
   for (; budget > 0; --budget) {
     // Addresses derived from the lane id are loop invariant; hoisted out of the round loop they would have to live in
     // (and spill from) vector registers for the whole instance.  An opaque copy per round keeps them local.
@@ -323,6 +347,19 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
         }
         dev0 = lane + 128;
       }
+      if (bi == f.src_blk) {
+        const bool on = lane < B.count;
+        LdsCtx d{nodes + B.nodes_off, B.ipar, par, f.wave, B.count, on ? lane : 0, tcur, dmode, dinit};
+        if (DC || !src_have || tcur != src_t) {
+          src_val = source_value(d, par_of(d, 0), par_of(d, 1));
+          src_t = tcur; src_have = true;
+        }
+        if (on) {
+          AccumOutT<false, DIRECT> s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, lane, 0u, us, rowof, trash_w};
+          if (B.type == CADNIP_DEV_VSOURCE) stamp_vsource_value(d, us, s, src_val); else stamp_isource_value(d, s, src_val);
+        }
+        dev0 = lane + 64;
+      }
       if (B.type == CADNIP_DEV_MOS1 && B.mos1_plain) {
         // two lanes per MOSFET (devices.hpp: stamp_mos1_pair), 32 devices per wave pass
         const int side = lane & 1;
@@ -338,7 +375,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
       for (int dev = dev0; dev < B.count; dev += 64) {
         LdsCtx d{nodes + B.nodes_off, B.ipar, par, f.wave, B.count, dev, tcur, dmode, dinit};
         AccumOutT<false, DIRECT> s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev, 0u, us, rowof, trash_w};
-        dispatch_stamp2(B.type, d, us, s, lw);
+        dispatch_stamp2<LEAN>(B.type, d, us, s, lw);
       }
       CADNIP_TRACE_POINT(8 + bi);
     }
@@ -650,6 +687,16 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
     h->f2_rc_blk = -1;
     for (int i = 0; i < nb; ++i)
       if (hb[i].type == CADNIP_DEV_CAPACITOR || hb[i].type == CADNIP_DEV_RESISTOR) { h->f2_rc_blk = i; break; }
+    h->f2_src_blk = -1;
+    for (int i = 0; i < nb; ++i)
+      if (hb[i].type == CADNIP_DEV_VSOURCE || hb[i].type == CADNIP_DEV_ISOURCE) { h->f2_src_blk = i; break; }
+    h->f2_lean = true;
+    for (int i = 0; i < nb; ++i) {
+      const int ty = hb[i].type;
+      const bool heavy = ty == CADNIP_DEV_DIODE || ty == CADNIP_DEV_DIODECAP || ty == CADNIP_DEV_SIMPLEMOS || ty == CADNIP_DEV_BVSOURCE ||
+                         ty == CADNIP_DEV_BISOURCE || (ty == CADNIP_DEV_MOS1 && !hb[i].mos1_plain);
+      if (heavy) h->f2_lean = false;
+    }
     h->f2_n_blk = nb;
     // every device type emits its residual directly (devices.hpp, Rn); CADNIP_F2_NODIRECT=1 selects the assembled form
     // r = J u + C beta - b instead (diagnostic: the two must agree)
@@ -659,7 +706,7 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
     HIP_TRY(hipMemcpy(h->d_f2blk, hb, sizeof(F2Block) * (size_t)nb, hipMemcpyHostToDevice));
     h->f2_blk_dirty = false;
   }
-  f.n_blk = h->f2_n_blk; f.rc_blk = h->f2_rc_blk;
+  f.n_blk = h->f2_n_blk; f.rc_blk = h->f2_rc_blk; f.src_blk = h->f2_src_blk;
   f.blk = (const F2Block*)h->d_f2blk;
   f.wave = h->d_wave;
   f.tab = h->d_f2tab;
@@ -690,15 +737,16 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
   f.queue = h->d_f2queue;
   const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(lds_cap / shmem, (size_t)(32 / wpb)));
   int grid = std::min((h->B + wpb - 1) / wpb, h->n_cu * wg_per_cu);
-  if (getenv("CADNIP_F2_DEBUG")) fprintf(stderr, "[cadnip f2] B %d n_cu %d wpb %d grid %d shmem %zu rounds %d nc %d passes %d+%d direct %d\n", h->B, h->n_cu, wpb, grid, shmem, rounds, h->f2_nc, h->f2_n_pre, h->f2_n_post, (int)h->f2_direct);
+  if (getenv("CADNIP_F2_DEBUG")) fprintf(stderr, "[cadnip f2] B %d n_cu %d wpb %d grid %d shmem %zu rounds %d nc %d passes %d+%d variant %d\n", h->B, h->n_cu, wpb, grid, shmem, rounds, h->f2_nc, h->f2_n_pre, h->f2_n_post, !h->f2_direct ? 2 : h->f2_lean ? 0 : 1);
 #define LAUNCH(W, D, R)                                                                                                \
   do {                                                                                                                 \
     if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_fused2<W, D, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
     hipLaunchKernelGGL((k_fused2<W, D, R>), dim3(grid), dim3(64 * W), shmem, h->stream, f);                            \
   } while (0)
 #define LAUNCH_W(D, R) do { if (wpb == 8) LAUNCH(8, D, R); else if (wpb == 4) LAUNCH(4, D, R); else if (wpb == 2) LAUNCH(2, D, R); else LAUNCH(1, D, R); } while (0)
-  if (dc) { if (h->f2_direct) LAUNCH_W(true, true); else LAUNCH_W(true, false); }
-  else { if (h->f2_direct) LAUNCH_W(false, true); else LAUNCH_W(false, false); }
+  const int var = !h->f2_direct ? 2 : h->f2_lean ? 0 : 1;
+  if (dc) { if (var == 0) LAUNCH_W(true, 0); else if (var == 1) LAUNCH_W(true, 1); else LAUNCH_W(true, 2); }
+  else { if (var == 0) LAUNCH_W(false, 0); else if (var == 1) LAUNCH_W(false, 1); else LAUNCH_W(false, 2); }
 #undef LAUNCH_W
 #undef LAUNCH
   HIP_TRY(hipGetLastError());

@@ -113,7 +113,9 @@ struct CadnipHandle {
   void* d_f2blk = nullptr;    // fused kernel: device-block descriptors
   bool f2_blk_dirty = true;
   int f2_n_blk = 0, f2_rc_blk = -1;
-  bool f2_direct = false;     // every device type of the circuit emits its residual directly: no J*u pass
+  bool f2_direct = false;     // devices emit their residuals directly: no J*u pass (off: CADNIP_F2_NODIRECT=1)
+  bool f2_lean = false;       // only device types of the lean kernel variant (fused2.hip: dispatch_stamp2)
+  int f2_src_blk = -1;        // first independent-source block of the fused block list
   int n_cu = 0;
   // driver state (allocated lazily)
   struct Driver* drv = nullptr;

@@ -4,7 +4,6 @@ usage: python tools/make_pmc_summary.py <tag> <bench.json> <pmc.json from tools/
 """
 import json, sys
 
-K = 'void cadnip::k_fused2<8, false>(cadnip::F2Args)'
 CAL = 'cadnip::k_calib_copy_f64(double const*, double*, long)'
 
 
@@ -12,6 +11,8 @@ def main():
     tag, bench_fn, pmc_fn = sys.argv[1:4]
     d = json.load(open(pmc_fn))
     bench = json.load(open(bench_fn))
+    # the transient instantiation: k_fused2<WPB, DC=false, DIRECT>
+    K = next(k for k in d if 'k_fused2<' in k and ', false, ' in k)
     f, cal = d[K], d[CAL]
     fc = 1024 * 1024 / cal['FETCH_SIZE']['per_call']
     wc = 1024 * 1024 / cal['WRITE_SIZE']['per_call']
