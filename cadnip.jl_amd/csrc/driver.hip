@@ -85,6 +85,7 @@ __global__ void __launch_bounds__(64) k_tran_init(TranArgs a) {
   s.t = a.t0; s.h = a.h0; s.hprev = a.h0; s.hpp = a.h0; s.tn = a.t0; s.a0 = 0.0;
   s.nhist = 1; s.ord = 1; s.k = 0; s.status = 0; s.bp = bp; s.si = si;
   s.c_newton = s.c_accept = s.c_reject = s.c_fail = 0;
+  s.t_break = next_break(a, bp); s.t_save = next_save(a, si);
   GlobalVecs v(a, inst);
   prepare_step(a, v, s, tid, a.t0, a.h0, 1, a.h0, a.h0);
   store_state(a, inst, tid, s);

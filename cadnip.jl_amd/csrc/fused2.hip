@@ -191,15 +191,37 @@ __device__ __forceinline__ void dispatch_stamp2(int type, const LdsCtx& d, const
 
 // controller vector policy of the fused kernel (see tran_ctrl.hpp): u, beta and the Newton step in LDS
 struct FusedVecs {
-  static constexpr int KPF = 4;   // per-lane elements of u0 / up / atol / emask fetched ahead of the update (covers n <= 256)
+  // per-lane elements kept in registers (covers n <= 256): the history u0 / u1 / u2 and the predictor for the whole
+  // residence of the instance, the error weights from `prefetch` to the update.  Elements beyond stay in HBM.
+  static constexpr int KPF = 4;
   double *us, *betas; const double* W; const u16* qinv;
   double *up, *u0, *u1, *u2; const double* lw;
-  double pf_u0[KPF], pf_up[KPF], pf_at[KPF], pf_em[KPF];
+  double r_u0[KPF], r_u1[KPF], r_u2[KPF], r_up[KPF], pf_at[KPF], pf_em[KPF];
+  __device__ __forceinline__ void load_history(int n, int lane) {
+#pragma unroll
+    for (int k = 0; k < KPF; ++k) {
+      const int i = lane + 64 * k < n ? lane + 64 * k : 0;
+      r_u0[k] = u0[i]; r_u1[k] = u1[i]; r_u2[k] = u2[i]; r_up[k] = up[i];
+    }
+  }
+  __device__ __forceinline__ void store_history(int n, int lane) const {
+#pragma unroll
+    for (int k = 0; k < KPF; ++k) {
+      const int i = lane + 64 * k;
+      if (i < n) { u0[i] = r_u0[k]; u1[i] = r_u1[k]; u2[i] = r_u2[k]; up[i] = r_up[k]; }
+    }
+  }
+  __device__ __forceinline__ void history_to_memory(int n, int lane) const {
+#pragma unroll
+    for (int k = 0; k < KPF; ++k) { const int i = lane + 64 * k; if (i < n) { u0[i] = r_u0[k]; u1[i] = r_u1[k]; } }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // read back by other lanes of this wave (save_outputs)
+    __builtin_amdgcn_wave_barrier();
+  }
   __device__ __forceinline__ void prefetch(const TranArgs& a, int lane) {
 #pragma unroll
     for (int k = 0; k < KPF; ++k) {
       const int i = lane + 64 * k < a.n ? lane + 64 * k : 0;   // clamped, no select on the loaded value: nothing waits here
-      pf_u0[k] = u0[i]; pf_up[k] = up[i]; pf_at[k] = a.atol[i]; pf_em[k] = a.emask[i];
+      pf_at[k] = a.atol[i]; pf_em[k] = a.emask[i];
     }
   }
   __device__ __forceinline__ double get_delta(int i) const { return W[qinv[i]]; }
@@ -209,6 +231,17 @@ struct FusedVecs {
   __device__ __forceinline__ void set_beta(int i, double v) const { betas[i] = v; }
   __device__ __forceinline__ void set_du(int, double) const {}   // du is rebuilt from u and beta when the kernel exits
   __device__ __forceinline__ double get_lw(int i) const { return lw[i]; }
+  // k: compile-time ordinal of a register-held element, or -1 (tran_ctrl.hpp: each_elem)
+  __device__ __forceinline__ double h0(int i, int k) const { return k >= 0 ? r_u0[k] : u0[i]; }
+  __device__ __forceinline__ double h1(int i, int k) const { return k >= 0 ? r_u1[k] : u1[i]; }
+  __device__ __forceinline__ double h2(int i, int k) const { return k >= 0 ? r_u2[k] : u2[i]; }
+  __device__ __forceinline__ double hp(int i, int k) const { return k >= 0 ? r_up[k] : up[i]; }
+  __device__ __forceinline__ void set_h0(int i, int k, double v) { if (k >= 0) r_u0[k] = v; else u0[i] = v; }
+  __device__ __forceinline__ void set_h1(int i, int k, double v) { if (k >= 0) r_u1[k] = v; else u1[i] = v; }
+  __device__ __forceinline__ void set_h2(int i, int k, double v) { if (k >= 0) r_u2[k] = v; else u2[i] = v; }
+  __device__ __forceinline__ void set_hp(int i, int k, double v) { if (k >= 0) r_up[k] = v; else up[i] = v; }
+  __device__ __forceinline__ double atol_of(const TranArgs& a, int i, int k) const { return k >= 0 ? pf_at[k] : a.atol[i]; }
+  __device__ __forceinline__ double emask_of(const TranArgs& a, int i, int k) const { return k >= 0 ? pf_em[k] : a.emask[i]; }
 };
 
 // The core of the linear system: the Schur complement of the last NC pivots (accumulated in W by the entry program), one
@@ -298,6 +331,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
   double* lw = (DC ? f.dc_pcnr : a.use_pcnr) ? a.limit_w + (size_t)inst * n : nullptr;
   const size_t vo = (size_t)inst * n;
   FusedVecs vec{us, betas, W, qinv, a.up + vo, a.u0 + vo, a.u1 + vo, a.u2 + vo, lw};
+  if (!DC) vec.load_history(n, lane0);
   for (int i = lane0; i < n; i += 64) { us[i] = ug[i]; betas[i] = DC ? 0.0 : betag[i]; }
   // DC state of this instance: settle flag of the PCNR loop (solve.jl:640-657), Newton solves done in this launch
   int dc_state = 0, dc_iters = 0, dc_first = 0;
@@ -521,6 +555,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
     double* dug = a.du + (size_t)inst * n;
     const double a0 = st.a0;
     for (int i = lane0; i < n; i += 64) { double x = us[i], b = betas[i]; ug[i] = x; betag[i] = b; dug[i] = a0 * x + b; }
+    vec.store_history(n, lane0);
     store_state(a, inst, lane0, st);
   }
   CADNIP_WAVE_SYNC();

@@ -57,6 +57,9 @@ __device__ __forceinline__ double fast_div(double a, double b) {
 }
 
 // ------------------------------------------------------------------------------------------
+#ifndef CADNIP_TRACE_POINT
+#define CADNIP_TRACE_POINT(id) do {} while (0)
+#endif
 // transient controller
 // ------------------------------------------------------------------------------------------
 struct TranArgs {
@@ -74,7 +77,10 @@ struct StepState {
   double t, h, hprev, hpp, tn, a0;   // accepted time, step in flight, the two previous steps, t + h, BDF leading coefficient
   int nhist, ord, k, status, bp, si; // history depth, order, Newton counter, 0 running / 1 done / <0 failed, next breakpoint / save index
   int c_newton, c_accept, c_reject, c_fail;   // counter increments since load
+  double t_break, t_save;                     // breaks[bp] / save_t[si], +inf past the end: derived, refreshed when bp / si move
 };
+__device__ __forceinline__ double next_break(const TranArgs& a, int bp) { return bp < a.n_break ? a.breaks[bp] : __builtin_inf(); }
+__device__ __forceinline__ double next_save(const TranArgs& a, int si) { return si < a.n_save ? a.save_t[si] : __builtin_inf(); }
 
 // All lanes of the wave hold the same StepState; saying so (readfirstlane) lets it live in scalar registers, which
 // matters in the fused kernel where vector registers are the scarce resource.
@@ -83,7 +89,7 @@ __device__ __forceinline__ double uniform_f64(double v) {
 }
 __device__ __forceinline__ void make_uniform(StepState& s) {
   s.t = uniform_f64(s.t); s.h = uniform_f64(s.h); s.hprev = uniform_f64(s.hprev); s.hpp = uniform_f64(s.hpp);
-  s.tn = uniform_f64(s.tn); s.a0 = uniform_f64(s.a0);
+  s.tn = uniform_f64(s.tn); s.a0 = uniform_f64(s.a0); s.t_break = uniform_f64(s.t_break); s.t_save = uniform_f64(s.t_save);
   s.nhist = __builtin_amdgcn_readfirstlane(s.nhist); s.ord = __builtin_amdgcn_readfirstlane(s.ord); s.k = __builtin_amdgcn_readfirstlane(s.k);
   s.status = __builtin_amdgcn_readfirstlane(s.status); s.bp = __builtin_amdgcn_readfirstlane(s.bp); s.si = __builtin_amdgcn_readfirstlane(s.si);
   s.c_newton = __builtin_amdgcn_readfirstlane(s.c_newton); s.c_accept = __builtin_amdgcn_readfirstlane(s.c_accept);
@@ -95,6 +101,7 @@ __device__ inline StepState load_state(const TranArgs& a, int inst) {
   s.t = a.t[inst]; s.h = a.h[inst]; s.hprev = a.hprev[inst]; s.hpp = a.hpp[inst]; s.tn = a.tcur[inst]; s.a0 = a.gamma[inst];
   s.nhist = a.nhist[inst]; s.ord = a.order[inst]; s.k = a.k[inst]; s.status = a.status[inst]; s.bp = a.bp_idx[inst]; s.si = a.save_idx[inst];
   s.c_newton = s.c_accept = s.c_reject = s.c_fail = 0;
+  s.t_break = next_break(a, s.bp); s.t_save = next_save(a, s.si);
   return s;
 }
 __device__ inline void store_state(const TranArgs& a, int inst, int tid, const StepState& s) {
@@ -122,15 +129,39 @@ struct GlobalVecs {
   __device__ __forceinline__ void set_beta(int i, double v) const { beta[i] = v; }
   __device__ __forceinline__ void set_du(int i, double v) const { du[i] = v; }
   __device__ __forceinline__ double get_lw(int i) const { return lw[i]; }
+  // history (u at the last three accepted points), predictor, error weights.  `k` is the element's per-lane ordinal when
+  // the policy keeps the first KPF elements of each lane in registers (fused kernel), -1 otherwise: unused here.
+  __device__ __forceinline__ double h0(int i, int) const { return u0[i]; }
+  __device__ __forceinline__ double h1(int i, int) const { return u1[i]; }
+  __device__ __forceinline__ double h2(int i, int) const { return u2[i]; }
+  __device__ __forceinline__ double hp(int i, int) const { return up[i]; }
+  __device__ __forceinline__ void set_h0(int i, int, double v) { u0[i] = v; }
+  __device__ __forceinline__ void set_h1(int i, int, double v) { u1[i] = v; }
+  __device__ __forceinline__ void set_h2(int i, int, double v) { u2[i] = v; }
+  __device__ __forceinline__ void set_hp(int i, int, double v) { up[i] = v; }
+  __device__ __forceinline__ double atol_of(const TranArgs& a, int i, int) const { return a.atol[i]; }
+  __device__ __forceinline__ double emask_of(const TranArgs& a, int i, int) const { return a.emask[i]; }
+  __device__ __forceinline__ void history_to_memory(int, int) const {}   // u0 / u1 readable through the pointers: always
 };
+
+// f(i, k) for the elements i = tid, tid + 64, ... < n of one lane; k = the ordinal for the first V::KPF of them (a
+// compile-time constant after unrolling, so that V's per-lane register arrays are indexed statically), -1 beyond
+template <class V, class F>
+__device__ __forceinline__ void each_elem(int n, int tid, F&& f) {
+  if constexpr (V::KPF > 0) {
+#pragma unroll
+    for (int k = 0; k < V::KPF; ++k) { const int i = tid + 64 * k; if (i < n) f(i, k); }
+  }
+  for (int i = tid + 64 * V::KPF; i < n; i += 64) f(i, -1);
+}
 
 // Set up the step that starts at (t, history) with proposed size h: clip to the next stop,
 // pick order from the available history, extrapolate the predictor, BDF coefficients.
 template <class V>
-__device__ inline void prepare_step(const TranArgs& a, const V& v, StepState& s, int tid, double t, double h, int nhist, double hprev, double hpp) {
+__device__ inline void prepare_step(const TranArgs& a, V& v, StepState& s, int tid, double t, double h, int nhist, double hprev, double hpp) {
   const int n = a.n;
   double tstop = a.t1;
-  if (s.bp < a.n_break && a.breaks[s.bp] < tstop) tstop = a.breaks[s.bp];
+  if (s.t_break < tstop) tstop = s.t_break;
   double rem = tstop - t, tn;
   if (h >= rem * (1.0 - 1e-9)) { h = rem; tn = tstop; }
   else if (2.0 * h > rem) { h = 0.5 * rem; tn = t + h; }
@@ -139,17 +170,17 @@ __device__ inline void prepare_step(const TranArgs& a, const V& v, StepState& s,
   double a0;
   if (nhist <= 1) {
     ord = 1; a0 = 1.0 / h;
-    for (int i = tid; i < n; i += 64) { double p = v.u0[i]; v.up[i] = p; v.set_u(i, p); double b = -p / h; v.set_beta(i, b); v.set_du(i, a0 * p + b); }
+    each_elem<V>(n, tid, [&](int i, int k) { double p = v.h0(i, k); v.set_hp(i, k, p); v.set_u(i, p); double b = -p / h; v.set_beta(i, b); v.set_du(i, a0 * p + b); });
   } else if (nhist == 2 || a.max_order < 2) {
     ord = 1; a0 = 1.0 / h;
     double w = h / hprev;
-    for (int i = tid; i < n; i += 64) {
-      double x0 = v.u0[i];
-      double p = x0 + w * (x0 - v.u1[i]);
-      v.up[i] = p; v.set_u(i, p);
+    each_elem<V>(n, tid, [&](int i, int k) {
+      double x0 = v.h0(i, k);
+      double p = x0 + w * (x0 - v.h1(i, k));
+      v.set_hp(i, k, p); v.set_u(i, p);
       double b = -x0 / h;
       v.set_beta(i, b); v.set_du(i, a0 * p + b);
-    }
+    });
   } else {
     ord = 2;
     double w = h / hprev;
@@ -159,23 +190,26 @@ __device__ inline void prepare_step(const TranArgs& a, const V& v, StepState& s,
     double L0 = (x - x1) * (x - x2) / ((0.0 - x1) * (0.0 - x2));
     double L1 = (x - 0.0) * (x - x2) / ((x1 - 0.0) * (x1 - x2));
     double L2 = (x - 0.0) * (x - x1) / ((x2 - 0.0) * (x2 - x1));
-    for (int i = tid; i < n; i += 64) {
-      double x0 = v.u0[i], xm1 = v.u1[i];
-      double p = L0 * x0 + L1 * xm1 + L2 * v.u2[i];
-      v.up[i] = p; v.set_u(i, p);
+    each_elem<V>(n, tid, [&](int i, int k) {
+      double x0 = v.h0(i, k), xm1 = v.h1(i, k);
+      double p = L0 * x0 + L1 * xm1 + L2 * v.h2(i, k);
+      v.set_hp(i, k, p); v.set_u(i, p);
       double b = a1 * x0 + a2 * xm1;
       v.set_beta(i, b); v.set_du(i, a0 * p + b);
-    }
+    });
   }
   s.h = h; s.ord = ord; s.k = 0; s.tn = tn; s.a0 = a0;
 }
 
 template <class V>
-__device__ inline void save_outputs(const TranArgs& a, const V& v, StepState& s, int inst, int tid) {
+__device__ inline void save_outputs(const TranArgs& a, V& v, StepState& s, int inst, int tid) {
   const double told = s.t, tn = s.tn, hh = tn - told;
   int si = s.si;
-  while (si < a.n_save && a.save_t[si] <= tn * (1.0 + 1e-15)) {
-    double ts = a.save_t[si];
+  // observers read u0 / u1 at arbitrary unknowns: a policy that holds them in registers writes them out first (rare:
+  // once per save point)
+  if (s.t_save <= tn * (1.0 + 1e-15)) v.history_to_memory(a.n, tid);
+  while (s.t_save <= tn * (1.0 + 1e-15)) {
+    double ts = s.t_save;
     double* o = a.out + ((size_t)inst * a.n_save + si) * a.n_obs;
     if (s.nhist >= 2) {   // quadratic through (tn,unew) (told,u0) (told-hprev,u1)
       double x = ts - told, xa = hh, xc = -s.hprev;
@@ -188,6 +222,7 @@ __device__ inline void save_outputs(const TranArgs& a, const V& v, StepState& s,
       for (int j = tid; j < a.n_obs; j += 64) { int i = a.obs[j]; double x0 = v.u0[i]; o[j] = x0 + sc * (v.get_u(i) - x0); }
     }
     ++si;
+    s.t_save = next_save(a, si);
   }
   s.si = si;
 }
@@ -195,11 +230,12 @@ __device__ inline void save_outputs(const TranArgs& a, const V& v, StepState& s,
 // One Newton update + step controller for one sweep instance, executed by one 64-lane wave.  `bad` is the
 // wave-uniform "linear solve failed" flag of this round.  The caller guarantees s.status == 0.
 template <class V>
-__device__ inline void tran_update_body(const TranArgs& a, const V& v, StepState& s, int inst, int tid, int bad) {
+__device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, int inst, int tid, int bad) {
   const int n = a.n;
   const double h = s.h, hprev = s.hprev, hpp = s.hpp;
   double s1 = 0.0, s2 = 0.0;
-  auto elem = [&](int i, double x0, double at, double upv, double em) {
+  each_elem<V>(n, tid, [&](int i, int k) {
+    const double x0 = v.h0(i, k), at = v.atol_of(a, i, k), upv = v.hp(i, k), em = v.emask_of(a, i, k);
     double d = v.get_delta(i);
     double un = v.get_u(i) - d;
     if (!isfinite(d)) bad = 1;
@@ -209,16 +245,11 @@ __device__ inline void tran_update_body(const TranArgs& a, const V& v, StepState
     double w2 = fast_div(em, at + a.reltol * fmax(fabs(x0), fabs(un)));
     s2 += (e * w2) * (e * w2);
     v.set_u(i, un);
-  };
-  // the first V::KPF elements of each lane may have been prefetched into registers by the policy
-  if constexpr (V::KPF > 0) {
-#pragma unroll
-    for (int k = 0; k < V::KPF; ++k) { const int i = tid + 64 * k; if (i < n) elem(i, v.pf_u0[k], v.pf_at[k], v.pf_up[k], v.pf_em[k]); }
-  }
-  for (int i = tid + 64 * V::KPF; i < n; i += 64) elem(i, v.u0[i], a.atol[i], v.up[i], a.emask[i]);
+  });
   s1 = wave_sum(s1); s2 = wave_sum(s2);
   bad = wave_any(bad);
   const double dnorm = sqrt(s1 / n);
+  CADNIP_TRACE_POINT(30);
   s.c_newton += 1;
   const bool conv = !bad && dnorm < a.newton_tol;
   if (conv) {
@@ -235,9 +266,9 @@ __device__ inline void tran_update_body(const TranArgs& a, const V& v, StepState
     if (accept) {
       CADNIP_WAVE_SYNC();
       save_outputs(a, v, s, inst, tid);
-      for (int i = tid; i < n; i += 64) { double v1 = v.u1[i], v0 = v.u0[i]; v.u2[i] = v1; v.u1[i] = v0; v.u0[i] = v.get_u(i); }
+      each_elem<V>(n, tid, [&](int i, int k) { double v1 = v.h1(i, k), v0 = v.h0(i, k); v.set_h2(i, k, v1); v.set_h1(i, k, v0); v.set_h0(i, k, v.get_u(i)); });
       const double tn = s.tn;
-      bool landed = (s.bp < a.n_break && tn == a.breaks[s.bp]);
+      bool landed = tn == s.t_break;
       int nh_new = s.nhist + 1 > 3 ? 3 : s.nhist + 1;
       double hnext;
       if (tested) {
@@ -247,18 +278,21 @@ __device__ inline void tran_update_body(const TranArgs& a, const V& v, StepState
       } else hnext = 2.0 * h;
       if (landed) {
         ++s.bp;
+        s.t_break = next_break(a, s.bp);
         nh_new = 1;
         double tstop = a.t1;
-        if (s.bp < a.n_break && a.breaks[s.bp] < tstop) tstop = a.breaks[s.bp];
+        if (s.t_break < tstop) tstop = s.t_break;
         hnext = 0.1 * fmin(h, tstop - tn);
       }
       hnext = fmin(hnext, a.hmax);
       s.t = tn; s.hpp = hprev; s.hprev = h; s.nhist = nh_new;
       s.c_accept += 1;
+      CADNIP_TRACE_POINT(31);
       if (tn >= a.t1) { s.status = 1; return; }
       if (hnext < a.hmin) hnext = a.hmin;
       CADNIP_WAVE_SYNC();
       prepare_step(a, v, s, tid, tn, hnext, nh_new, s.hprev, s.hpp);
+      CADNIP_TRACE_POINT(32);
     } else {
       double fac = 0.9 * pow(errn, -1.0 / (s.ord + 1));
       fac = fmin(0.9, fmax(0.1, fac));
