@@ -97,12 +97,25 @@ __device__ __forceinline__ double volt(const double* u, int node) { return node 
 // ------------------------------------------------------------------------------------------
 // source waves (devices.jl:30-103, 155-203)
 // ------------------------------------------------------------------------------------------
-__device__ inline double pwl_at_time(const double* ts, const double* ys, int n, double t) {
+// `seg` (optional): the segment index i found by the previous call.  When t lies strictly inside that segment again
+// (time mostly advances in small steps) the search -- a chain of dependent memory reads -- is skipped; same result.
+__device__ inline double pwl_at_time(const double* ts, const double* ys, int n, double t, int* seg = nullptr) {
+  if (seg) {
+    const int i = *seg;
+    if (i >= 2 && i <= n) {
+      const double t_lo = ts[i - 2], t_hi = ts[i - 1], y_lo = ys[i - 2], y_hi = ys[i - 1];
+      if (t_lo < t && t < t_hi) {
+        if (y_lo == y_hi) return y_hi;
+        return y_lo + (t - t_lo) * ((y_hi - y_lo) / (t_hi - t_lo));
+      }
+    }
+  }
   // find_t_in_ts: searchsortedfirst, +1 on an exact hit (devices.jl:30-36); i is 1-based
   int lo = 0, hi = n;
   while (lo < hi) { int mid = (lo + hi) >> 1; if (ts[mid] < t) lo = mid + 1; else hi = mid; }
   int i = lo + 1;
   if (i <= n && ts[i - 1] == t) i += 1;
+  if (seg) *seg = i;
   if (i <= 1) return ys[0];
   if (i > n) return ys[n - 1];
   if (ys[i - 2] == ys[i - 1]) return ys[i - 1];
@@ -130,14 +143,14 @@ __device__ inline double sind_deg(double deg) {
 }
 
 // get_source_value (devices.jl:352-360): :dcop -> dc, otherwise tran(t)
-template <class Ctx> __device__ inline double source_value(const Ctx& d, double dc, double scale) {
+template <class Ctx> __device__ inline double source_value(const Ctx& d, double dc, double scale, int* seg = nullptr) {
   int kind = d.ipar[0 * d.count + d.dev];
   if (kind == 0 || d.mode == 0) return dc;
   int off = d.ipar[1 * d.count + d.dev];
   int len = d.ipar[2 * d.count + d.dev];
   const double* w = d.wave + off;
   double v;
-  if (kind == 1) v = pwl_at_time(w, w + len, len, d.t);
+  if (kind == 1) v = pwl_at_time(w, w + len, len, d.t, seg);
   else if (kind == 2) v = pulse_at_time(w[0], w[1], w[2], w[3], w[4], w[5], w[6], d.t);
   else {
     double vo = w[0], va = w[1], freq = w[2], td = w[3], theta = w[4], phase = w[5];

@@ -89,6 +89,7 @@ bool f2_build_program(const LUProgram& P, int n, int nc, F2Program& G) {
   G.dn0 = nsp;
   for (int p = 0; p < P.nnz_lu; ++p) if (G.posW[p] < 0) G.posW[p] = G.dn0 + (rowof[p] - cs0) * nc + (P.lu_col[p] - cs0);
   G.lu_words = nsp + nc * nc;
+  if ((G.lu_words + n) & 1) ++G.lu_words;   // pad: W = [LU | rhs n | trash] has an even word count (zeroed 16 bytes at a time)
   const int y0 = G.lu_words;
   auto find = [&](int i, int j) -> int {     // pattern position of (i, j) or -1
     const int* b = &P.lu_col[P.lu_rowptr[i]]; const int* e = &P.lu_col[P.lu_rowptr[i + 1]];

@@ -346,13 +346,14 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
   // values of the first independent-source block: functions of time only, kept over the Newton rounds of a time point
   double src_val = 0.0, src_t = 0.0;
   bool src_have = false;
+  int src_seg = 0;             // PWL segment of the last evaluation (devices.hpp: pwl_at_time)
   for (; budget > 0; --budget) {
     // Addresses derived from the lane id are loop invariant; hoisted out of the round loop they would have to live in
     // (and spill from) vector registers for the whole instance.  An opaque copy per round keeps them local.
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     CADNIP_TRACE_POINT(17);
-    for (int i = lane; i < nW; i += 64) W[i] = 0.0;
+    for (int i = lane; i < (nW >> 1); i += 64) ((double2*)W)[i] = make_double2(0.0, 0.0);   // nW is even (f2_program.cpp), W 16-byte aligned
     CADNIP_WAVE_SYNC();
     CADNIP_TRACE_POINT(0);
     // ---- stamp: accumulate J (at LU positions) and the C*beta - b part of the residual
@@ -385,7 +386,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
         const bool on = lane < B.count;
         LdsCtx d{nodes + B.nodes_off, B.ipar, par, f.wave, B.count, on ? lane : 0, tcur, dmode, dinit};
         if (DC || !src_have || tcur != src_t) {
-          src_val = source_value(d, par_of(d, 0), par_of(d, 1));
+          src_val = source_value(d, par_of(d, 0), par_of(d, 1), &src_seg);
           src_t = tcur; src_have = true;
         }
         if (on) {
@@ -680,6 +681,7 @@ static int fused2_tables(CadnipHandle* h) {
   if (!b_slots.empty()) HIP_TRY(hipMemcpy(b_slots.data(), h->d_b_slots, b_slots.size() * 4, hipMemcpyDeviceToHost));
   F2Tables T;
   if (!f2_prepare(h, T, g_ptr, g_slots, c_ptr, c_slots, b_ptr, b_slots)) return CADNIP_BADARG;
+  while (T.data.size() & 3) T.data.push_back(0);           // the per-wave work arrays behind the tables stay 16-byte aligned
   if (h->d_f2tab) (void)hipFree(h->d_f2tab);
   h->d_f2tab = nullptr;
   HIP_TRY(hipMalloc((void**)&h->d_f2tab, T.data.size() * sizeof(unsigned)));
