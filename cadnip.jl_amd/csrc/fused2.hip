@@ -305,6 +305,54 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
   const u16* qinv = (const u16*)(tab + f.off[S_QINV]);
   const short* nodes = (const short*)(tab + f.off[S_NODES]);
   const u16* rowof = (const u16*)(tab + f.off[S_ROWOF]);
+  // Pinned stamp targets (DIRECT variants): the first capacitor / resistor block (two devices per lane) and the first
+  // independent-source block (one per lane) are stamped from registers -- four matrix words, the residual words of
+  // their rows and their unknowns, as 16-bit offsets.  They depend on the circuit only, so they are read once per
+  // launch; a lane without a device points everything at its trash word / ground.
+  unsigned rc_gp[2][2] = {{0, 0}, {0, 0}}, rc_row[2] = {0, 0}, rc_nd[2] = {0, 0}, src_gp[2] = {0, 0}, src_row[2] = {0, 0}, src_nd[2] = {0, 0};
+  int rc_count = 0, rc_type = 0, src_count = 0, src_type = 0;
+  if constexpr (DIRECT) {
+    const unsigned tr = (unsigned)(f.nnz_lu + n + lane0);
+    auto row_of = [&](int node) -> unsigned { return node < 0 ? tr : (unsigned)rowof[node]; };
+    if (f.rc_blk >= 0) {
+      const F2Block B = load_block(f.blk, f.rc_blk);
+      rc_count = B.count; rc_type = B.type;
+      const short* nd = nodes + B.nodes_off;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int dev = lane0 + 64 * q;
+        unsigned p[4] = {tr, tr, tr, tr};
+        int np = -1, nn = -1;
+        if (dev < B.count) {
+          np = nd[dev]; nn = nd[B.count + dev];
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            p[k] = B.type == CADNIP_DEV_CAPACITOR ? (unsigned)cdesc[B.c_base + k * B.count + dev] & 0xFFFFu : (unsigned)gpos[B.g_base + k * B.count + dev];
+        }
+        rc_gp[q][0] = p[0] | p[1] << 16; rc_gp[q][1] = p[2] | p[3] << 16;
+        rc_row[q] = row_of(np) | row_of(nn) << 16;
+        rc_nd[q] = ((unsigned)np & 0xFFFFu) | ((unsigned)nn & 0xFFFFu) << 16;
+      }
+    }
+    if (f.src_blk >= 0) {
+      const F2Block B = load_block(f.blk, f.src_blk);
+      src_count = B.count; src_type = B.type;
+      const short* nd = nodes + B.nodes_off;
+      unsigned p[4] = {tr, tr, tr, tr};
+      int np = -1, nn = -1, ni = -1;
+      if (lane0 < B.count) {
+        np = nd[lane0]; nn = nd[B.count + lane0];
+        if (B.type == CADNIP_DEV_VSOURCE) {
+          ni = nd[2 * B.count + lane0];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) p[k] = (unsigned)gpos[B.g_base + k * B.count + lane0];
+        }
+      }
+      src_gp[0] = p[0] | p[1] << 16; src_gp[1] = p[2] | p[3] << 16;
+      src_row[0] = row_of(np) | row_of(nn) << 16; src_row[1] = row_of(ni);
+      src_nd[0] = ((unsigned)np & 0xFFFFu) | ((unsigned)nn & 0xFFFFu) << 16; src_nd[1] = (unsigned)ni & 0xFFFFu;
+    }
+  }
 #ifdef CADNIP_TRACE
   if (blockIdx.x == 0 && tid == 0) g_trace_last = clock64();
 #endif
@@ -361,11 +409,60 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
     const int dmode = DC ? f.dc_mode : 1, dinit = DC ? dc_first : 0;
     const unsigned trash_w = (unsigned)(f.nnz_lu + n + lane);
     dc_first = 0;                                       // initjct is armed for the first stamping only (solve.jl:624,632)
+    if constexpr (DIRECT) {
+      // ---- pinned blocks: no table reads, no block header -- operand reads, then the atomics
+      auto at = [&](unsigned nd16) -> double { const double x = us[nd16 == 0xFFFFu ? 0u : nd16]; return nd16 == 0xFFFFu ? 0.0 : x; };
+      auto dat = [&](unsigned nd16) -> double {
+        const unsigned i = nd16 == 0xFFFFu ? 0u : nd16;
+        const double x = a0 * us[i] + betas[i];
+        return nd16 == 0xFFFFu ? 0.0 : x;
+      };
+      if (f.rc_blk >= 0) {
+        const bool cap = rc_type == CADNIP_DEV_CAPACITOR;
+        double jv[2], cur[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const unsigned np = rc_nd[q] & 0xFFFFu, nn = rc_nd[q] >> 16;
+          const double xp = cap ? dat(np) : at(np), xn = cap ? dat(nn) : at(nn);
+          jv[q] = cap ? a0 * rc_val[q] : rc_val[q];
+          cur[q] = rc_val[q] * (xp - xn);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          atomicAdd(&W[rc_gp[q][0] & 0xFFFFu], jv[q]); atomicAdd(&W[rc_gp[q][0] >> 16], -jv[q]);
+          atomicAdd(&W[rc_gp[q][1] & 0xFFFFu], -jv[q]); atomicAdd(&W[rc_gp[q][1] >> 16], jv[q]);
+          atomicAdd(&W[rc_row[q] & 0xFFFFu], cur[q]); atomicAdd(&W[rc_row[q] >> 16], -cur[q]);
+        }
+      }
+      if (f.src_blk >= 0) {
+        if (DC || !src_have || tcur != src_t) {
+          const F2Block B = load_block(f.blk, f.src_blk);
+          const double* par = B.par + (size_t)inst * B.n_par * B.count;
+          LdsCtx d{nodes + B.nodes_off, B.ipar, par, f.wave, B.count, lane < B.count ? lane : 0, tcur, dmode, dinit};
+          src_val = source_value(d, par_of(d, 0), par_of(d, 1), &src_seg);
+          src_t = tcur; src_have = true;
+        }
+        if (src_type == CADNIP_DEV_VSOURCE) {
+          // branch rows / columns +-1 (devices.hpp: branch4); KCL rows carry u[I], the branch row V(p) - V(n) - v
+          const double ui = at(src_nd[1]), vd = at(src_nd[0] & 0xFFFFu) - at(src_nd[0] >> 16) - src_val;
+          atomicAdd(&W[src_gp[0] & 0xFFFFu], 1.0); atomicAdd(&W[src_gp[0] >> 16], -1.0);
+          atomicAdd(&W[src_gp[1] & 0xFFFFu], 1.0); atomicAdd(&W[src_gp[1] >> 16], -1.0);
+          atomicAdd(&W[src_row[0] & 0xFFFFu], ui); atomicAdd(&W[src_row[0] >> 16], -ui);
+          atomicAdd(&W[src_row[1]], vd);
+        } else {
+          atomicAdd(&W[src_row[0] & 0xFFFFu], -src_val); atomicAdd(&W[src_row[0] >> 16], src_val);
+        }
+      }
+      CADNIP_TRACE_POINT(13);
+    }
     for (int bi = 0; bi < f.n_blk; ++bi) {
+      if (DIRECT && ((bi == f.rc_blk && rc_count <= 128) || (bi == f.src_blk && src_count <= 64))) continue;   // all of it was pinned
       const F2Block B = load_block(f.blk, bi);
       const double* par = B.par + (size_t)inst * B.n_par * B.count;
       int dev0 = lane;
-      if (bi == f.rc_blk) {
+      if (DIRECT && bi == f.rc_blk) dev0 = lane + 128;
+      if (DIRECT && bi == f.src_blk) dev0 = lane + 64;
+      if (!DIRECT && bi == f.rc_blk) {
         // first capacitor / resistor block: its (round-invariant) values were fetched once per instance
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -382,7 +479,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
         }
         dev0 = lane + 128;
       }
-      if (bi == f.src_blk) {
+      if (!DIRECT && bi == f.src_blk) {
         const bool on = lane < B.count;
         LdsCtx d{nodes + B.nodes_off, B.ipar, par, f.wave, B.count, on ? lane : 0, tcur, dmode, dinit};
         if (DC || !src_have || tcur != src_t) {

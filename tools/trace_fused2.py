@@ -10,12 +10,12 @@ from cadnip_jl_amd import api, benchmarks as bm, hip
 from cadnip_jl_amd.structure import expand_breakpoints
 
 hip.LIB_PATH = os.path.join(os.path.dirname(hip.LIB_PATH), "libcadnip_hip_trace.so")
-NAMES = {17: "round top", 0: "load u/beta + zero", 8: "block0 (mos1)", 9: "block1", 10: "block2", 11: "block3", 12: "block4", 1: "stamp sync",
+NAMES = {17: "round top", 0: "load u/beta + zero", 8: "block0 (mos1)", 9: "block1", 10: "block2", 11: "block3", 12: "block4", 13: "pinned R/C + source blocks", 1: "stamp sync",
          2: "r += J*u", 3: "passes after the core", 4: "passes before the core", 5: "dense core solve", 6: "backward", 7: "delta write", 16: "update/controller",
          20: " mos1: loads", 21: " mos1: limiting", 22: " mos1: g_lim stamps", 23: " mos1: junction currents", 24: " mos1: drain current",
          25: " mos1: depletion charges", 26: " mos1: current stamps", 27: " mos1: charge stamps",
          30: " update: norms", 31: " update: accept (outputs, history)", 32: " update: next step (predictor)"}
-ORDER = [17, 0, 20, 21, 22, 23, 24, 25, 26, 27, 8, 9, 10, 11, 12, 1, 2, 4, 5, 3, 30, 31, 32, 16]
+ORDER = [17, 0, 13, 20, 21, 22, 23, 24, 25, 26, 27, 8, 9, 10, 11, 12, 1, 2, 4, 5, 3, 30, 31, 32, 16]
 
 
 def main():
