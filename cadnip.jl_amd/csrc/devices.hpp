@@ -788,6 +788,11 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
   // fit into the registers of a two-waves-per-SIMD kernel
   double type = par_of(d, M1_TYPE), vt = par_of(d, M1_VT), tPhi = par_of(d, M1_TPHI), tVbi = par_of(d, M1_TVBI);
   double gamma = par_of(d, M1_GAMMA);
+  // second group, needed after the limiting code: requested now so that the memory latency (the parameter blocks of the
+  // resident instances exceed the L2) passes behind the limiting arithmetic
+  const double mf = par_of(d, M1_MFACTOR), gmin_p = par_of(d, M1_GMIN), isat = par_of(d, D ? M1_DSATCUR : M1_SSATCUR);
+  const double lambda = par_of(d, M1_LAMBDA), Beta = par_of(d, M1_BETA);
+  __builtin_amdgcn_sched_barrier(0);
   CADNIP_TRACE_POINT(20);
   double w_gs, w_ds, w_bs, w_bd;
   m1_limit(d, u, type, vt, tPhi, tVbi, gamma, Vg, Vb, Vdi, Vsi, l0, l1, l2, l3, w_gs, w_ds, w_bs, w_bd);
@@ -805,14 +810,17 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
   D3 a = D3::seed(type * w_gs, 0), b = D3::seed(type * w_ds, 1), c = D3::seed(type * w_bs, 2);
   D3 dvbd = c - b, dvgd = a - b;
   const D3 vj = m1_sel(D, dvbd, c);
-  const double mf = par_of(d, M1_MFACTOR), gmin_m = par_of(d, M1_GMIN) / mf;
-  const double isat = par_of(d, D ? M1_DSATCUR : M1_SSATCUR);      // this lane's junction: source side or drain side
+  const double gmin_m = gmin_p / mf;                               // isat: this lane's junction, source side or drain side
+  // third group (depletion charge of this lane's junction), in flight during the junction and channel arithmetic
+  const double q_cb = par_of(d, D ? M1_CBD : M1_CBS), q_cbsw = par_of(d, D ? M1_CBDSW : M1_CBSSW), q_pot = par_of(d, M1_TBULKPOT), q_dep = par_of(d, M1_TDEPCAP);
+  const double q_mj = par_of(d, M1_MJ), q_mjsw = par_of(d, M1_MJSW), q_f2 = par_of(d, D ? M1_F2D : M1_F2S), q_f3 = par_of(d, D ? M1_F3D : M1_F3S), q_f4 = par_of(d, D ? M1_F4D : M1_F4S);
+  __builtin_amdgcn_sched_barrier(0);
   const D3 cj = m1_junction(vj, vt, gmin_m, isat), co = m1_swap_pair(cj);
   const D3 cbs = m1_sel(D, co, cj), cbd = m1_sel(D, cj, co);
   CADNIP_TRACE_POINT(23);
   int mode;
   D3 dvon, vdsat, cdrain;
-  m1_channel(a, b, c, dvbd, dvgd, tPhi, tVbi, type, gamma, par_of(d, M1_LAMBDA), par_of(d, M1_BETA), mode, dvon, vdsat, cdrain);
+  m1_channel(a, b, c, dvbd, dvgd, tPhi, tVbi, type, gamma, lambda, Beta, mode, dvon, vdsat, cdrain);
   CADNIP_TRACE_POINT(24);
   const D3 cdreq = (mode >= 0 ? type : -type) * cdrain;
   const double dW_gs = (Vg - Vsi) - w_gs, dW_ds = (Vdi - Vsi) - w_ds, dW_bs = (Vb - Vsi) - w_bs;   // lim_rhs deltas
@@ -853,8 +861,7 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
   }
   CADNIP_TRACE_POINT(26);
   // depletion charge of this lane's junction (after the current rows: fewer values live at once), swapped like the current
-  const D3 qj = m1_qdep(vj, par_of(d, D ? M1_CBD : M1_CBS), par_of(d, D ? M1_CBDSW : M1_CBSSW), par_of(d, M1_TBULKPOT), par_of(d, M1_TDEPCAP),
-                        par_of(d, M1_MJ), par_of(d, M1_MJSW), par_of(d, D ? M1_F2D : M1_F2S), par_of(d, D ? M1_F3D : M1_F3S), par_of(d, D ? M1_F4D : M1_F4S));
+  const D3 qj = m1_qdep(vj, q_cb, q_cbsw, q_pot, q_dep, q_mj, q_mjsw, q_f2, q_f3, q_f4);
   const D3 qo = m1_swap_pair(qj);
   const D3 qbs = m1_sel(D, qo, qj), qbd = m1_sel(D, qj, qo);
   CADNIP_TRACE_POINT(25);
