@@ -792,6 +792,7 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
   // resident instances exceed the L2) passes behind the limiting arithmetic
   const double mf = par_of(d, M1_MFACTOR), gmin_p = par_of(d, M1_GMIN), isat = par_of(d, D ? M1_DSATCUR : M1_SSATCUR);
   const double lambda = par_of(d, M1_LAMBDA), Beta = par_of(d, M1_BETA);
+  const int vdep = Out::DIRECT ? d.ipar[d.dev] : 0;       // bit r: reactive branch r uses a charge unknown
   __builtin_amdgcn_sched_barrier(0);
   CADNIP_TRACE_POINT(20);
   double w_gs, w_ds, w_bs, w_bd;
@@ -872,7 +873,6 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
   // reactive rows: branch charges of g, b, d_int, s_int.  Meyer charges vanish with OxideCap == 0; the pair path is only
   // taken then (caller), so q_g = 0, q_b = type (qbs + qbd), q_dint = -type qbd, q_sint = -type qbs
   const D3 q0(0.0), q1 = type * qbs + type * qbd, q2 = -1.0 * (type * qbd), q3 = -1.0 * (type * qbs);
-  const int vdep = Out::DIRECT ? d.ipar[d.dev] : 0;       // bit r: reactive branch r uses a charge unknown
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int r = 2 * it + side;
@@ -880,13 +880,17 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
     const double fa = mf * type * q.p[0], fb = mf * type * q.p[1], fc = mf * type * q.p[2];
     const double dq[6] = {0.0, fa, 0.0, fc, fb, -(fa + fb + fc)};
     const double gq[7] = {1.0, -CS * dq[0], -CS * dq[1], -CS * dq[2], -CS * dq[3], -CS * dq[4], -CS * dq[5]};
-    s.Gv(48 + 7 * r, gq);
+    // Only one of the two forms of a branch lands in the matrix: the slots of the other one lead to trash words (no
+    // charge unknown / no linear entries in the pattern).  The direct-residual variants know which (vdep) and leave the
+    // dead half out; q_g = 0 here, so branch 0 stamps nothing at all.
+    const bool cs_form = !Out::DIRECT || ((vdep >> r) & 1), lin_form = !Out::DIRECT || (!((vdep >> r) & 1) && r != 0);
+    if (cs_form) s.Gv(48 + 7 * r, gq);
     double bc = mf * q.v;
 #pragma unroll
     for (int k = 0; k < 6; ++k) bc -= dq[k] * Vk[k];
     bc += fa * dW_gs; bc += fb * dW_ds; bc += fc * dW_bs;
     s.B(6 + r, CS * bc);
-    s.Cv(4 + 6 * r, dq);
+    if (lin_form) s.Cv(4 + 6 * r, dq);
     if constexpr (Out::DIRECT) {
       // branch node of reactive branch r: g, b, d_int, s_int.  Charge-state form (vasim.jl:3433-3472) when the branch was
       // flagged voltage dependent: r_q = u_q - CS (q + lim terms), r_p += du_q / CS; else the linear form r_p += sum dq_k du_k.
@@ -895,7 +899,7 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
         const int nq = node_of(d, 10 + r);
         s.Rn(nq, u[nq] - CS * (mf * q.v + fa * dW_gs + fb * dW_ds + fc * dW_bs));
         s.Rn(np, s.du(nq) * (1.0 / CS));
-      } else {
+      } else if (r != 0) {
         s.Rn(np, dq[1] * s.du(ng) + dq[3] * s.du(nb) + dq[4] * s.du(ndi) + dq[5] * s.du(nsi));
       }
     }
