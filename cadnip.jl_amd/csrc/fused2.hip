@@ -75,6 +75,34 @@ struct F2Args {
   TranArgs t;
 };
 
+// Scalar registers are the scarce resource next to vector registers: the argument block alone is > 120 dwords, and a
+// kernel argument stays live (i.e. spilled to vector lanes, reloaded with v_readlane) from the entry block to its last
+// use.  Pointers that are needed only when an instance is picked up, handed back or writes outputs are therefore not
+// taken from `f` but fetched from the kernarg segment where they are used (scalar loads, constant cache); the opaque
+// copy of the segment pointer keeps those loads from being hoisted back to the top.
+typedef const __attribute__((address_space(4))) F2Args* F2ArgsK;
+__device__ __forceinline__ F2ArgsK kargs() {
+  F2ArgsK p = (F2ArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+// per-instance controller state arrays (member names as in TranArgs: load_state / store_state take either)
+struct TranStateView {
+  double *t, *h, *hprev, *hpp, *tcur, *gamma;
+  int *nhist, *order, *k, *status, *bp_idx, *save_idx, *active;
+  long long* cnt;
+  const double *breaks, *save_t;
+  int n_break, n_save;
+};
+__device__ __forceinline__ TranStateView state_view() {
+  const F2ArgsK p = kargs();
+  TranStateView v;
+  v.t = p->t.t; v.h = p->t.h; v.hprev = p->t.hprev; v.hpp = p->t.hpp; v.tcur = p->t.tcur; v.gamma = p->t.gamma;
+  v.nhist = p->t.nhist; v.order = p->t.order; v.k = p->t.k; v.status = p->t.status; v.bp_idx = p->t.bp_idx; v.save_idx = p->t.save_idx;
+  v.active = p->t.active; v.cnt = p->t.cnt; v.breaks = p->t.breaks; v.save_t = p->t.save_t; v.n_break = p->t.n_break; v.n_save = p->t.n_save;
+  return v;
+}
+
 // stamp writer: accumulates into J (LU positions) and the residual; all targets are offsets into W.
 // GUARD: a lane whose `sink` is non-zero (no device behind it) sends every stamp to that trash word instead.
 // DIRECT: the residual comes from the devices (Rn, devices.hpp) -- b stamps and the C*beta terms are dropped here and
@@ -195,9 +223,17 @@ struct FusedVecs {
   // residence of the instance, the error weights from `prefetch` to the update.  Elements beyond stay in HBM.
   static constexpr int KPF = 4;
   double *us, *betas; const double* W; const u16* qinv;
-  double *up, *u0, *u1, *u2; const double* lw;
+  size_t vo;                   // this instance's offset into the per-unknown vectors; their bases come from the kernarg segment
+  const double* lw;
   double r_u0[KPF], r_u1[KPF], r_u2[KPF], r_up[KPF], pf_at[KPF], pf_em[KPF];
+  __device__ __forceinline__ double* p_u0() const { return kargs()->t.u0 + vo; }
+  __device__ __forceinline__ double* p_u1() const { return kargs()->t.u1 + vo; }
+  __device__ __forceinline__ double* p_u2() const { return kargs()->t.u2 + vo; }
+  __device__ __forceinline__ double* p_up() const { return kargs()->t.up + vo; }
+  __device__ __forceinline__ double mem_u0(int i) const { return p_u0()[i]; }
+  __device__ __forceinline__ double mem_u1(int i) const { return p_u1()[i]; }
   __device__ __forceinline__ void load_history(int n, int lane) {
+    const double *u0 = p_u0(), *u1 = p_u1(), *u2 = p_u2(), *up = p_up();
 #pragma unroll
     for (int k = 0; k < KPF; ++k) {
       const int i = lane + 64 * k < n ? lane + 64 * k : 0;
@@ -205,6 +241,7 @@ struct FusedVecs {
     }
   }
   __device__ __forceinline__ void store_history(int n, int lane) const {
+    double *u0 = p_u0(), *u1 = p_u1(), *u2 = p_u2(), *up = p_up();
 #pragma unroll
     for (int k = 0; k < KPF; ++k) {
       const int i = lane + 64 * k;
@@ -212,6 +249,7 @@ struct FusedVecs {
     }
   }
   __device__ __forceinline__ void history_to_memory(int n, int lane) const {
+    double *u0 = p_u0(), *u1 = p_u1();
 #pragma unroll
     for (int k = 0; k < KPF; ++k) { const int i = lane + 64 * k; if (i < n) { u0[i] = r_u0[k]; u1[i] = r_u1[k]; } }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // read back by other lanes of this wave (save_outputs)
@@ -232,14 +270,14 @@ struct FusedVecs {
   __device__ __forceinline__ void set_du(int, double) const {}   // du is rebuilt from u and beta when the kernel exits
   __device__ __forceinline__ double get_lw(int i) const { return lw[i]; }
   // k: compile-time ordinal of a register-held element, or -1 (tran_ctrl.hpp: each_elem)
-  __device__ __forceinline__ double h0(int i, int k) const { return k >= 0 ? r_u0[k] : u0[i]; }
-  __device__ __forceinline__ double h1(int i, int k) const { return k >= 0 ? r_u1[k] : u1[i]; }
-  __device__ __forceinline__ double h2(int i, int k) const { return k >= 0 ? r_u2[k] : u2[i]; }
-  __device__ __forceinline__ double hp(int i, int k) const { return k >= 0 ? r_up[k] : up[i]; }
-  __device__ __forceinline__ void set_h0(int i, int k, double v) { if (k >= 0) r_u0[k] = v; else u0[i] = v; }
-  __device__ __forceinline__ void set_h1(int i, int k, double v) { if (k >= 0) r_u1[k] = v; else u1[i] = v; }
-  __device__ __forceinline__ void set_h2(int i, int k, double v) { if (k >= 0) r_u2[k] = v; else u2[i] = v; }
-  __device__ __forceinline__ void set_hp(int i, int k, double v) { if (k >= 0) r_up[k] = v; else up[i] = v; }
+  __device__ __forceinline__ double h0(int i, int k) const { return k >= 0 ? r_u0[k] : p_u0()[i]; }
+  __device__ __forceinline__ double h1(int i, int k) const { return k >= 0 ? r_u1[k] : p_u1()[i]; }
+  __device__ __forceinline__ double h2(int i, int k) const { return k >= 0 ? r_u2[k] : p_u2()[i]; }
+  __device__ __forceinline__ double hp(int i, int k) const { return k >= 0 ? r_up[k] : p_up()[i]; }
+  __device__ __forceinline__ void set_h0(int i, int k, double v) { if (k >= 0) r_u0[k] = v; else p_u0()[i] = v; }
+  __device__ __forceinline__ void set_h1(int i, int k, double v) { if (k >= 0) r_u1[k] = v; else p_u1()[i] = v; }
+  __device__ __forceinline__ void set_h2(int i, int k, double v) { if (k >= 0) r_u2[k] = v; else p_u2()[i] = v; }
+  __device__ __forceinline__ void set_hp(int i, int k, double v) { if (k >= 0) r_up[k] = v; else p_up()[i] = v; }
   __device__ __forceinline__ double atol_of(const TranArgs& a, int i, int k) const { return k >= 0 ? pf_at[k] : a.atol[i]; }
   __device__ __forceinline__ double emask_of(const TranArgs& a, int i, int k) const { return k >= 0 ? pf_em[k] : a.emask[i]; }
 };
@@ -364,26 +402,29 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
   StepState st;
   bool have = false;
   while (inst < f.B) {
-    if (DC) st.status = __builtin_amdgcn_readfirstlane(a.status[inst]);
-    else { st = load_state(a, inst); make_uniform(st); }
+    const TranStateView sv = state_view();
+    if (DC) st.status = __builtin_amdgcn_readfirstlane(sv.status[inst]);
+    else { st = load_state(sv, inst); make_uniform(st); }
     if (st.status == 0) { have = true; break; }
     int nx = 0;
-    if (lane0 == 0) nx = atomicAdd(f.queue, 1);
+    if (lane0 == 0) nx = atomicAdd(kargs()->queue, 1);
     inst = (int)gridDim.x * WPB + __builtin_amdgcn_readfirstlane(nx);
   }
   if (!have || budget <= 0) break;
-  double* ug = a.u + (size_t)inst * n;
-  double* betag = a.beta + (size_t)inst * n;
+  const size_t vo = (size_t)inst * n;
   // limit_w is read only by the PCNR corrector of the update: without it the stamps need not write it (each write is an
   // HBM store that later vector-memory waits would queue behind)
-  double* lw = (DC ? f.dc_pcnr : a.use_pcnr) ? a.limit_w + (size_t)inst * n : nullptr;
-  const size_t vo = (size_t)inst * n;
-  FusedVecs vec{us, betas, W, qinv, a.up + vo, a.u0 + vo, a.u1 + vo, a.u2 + vo, lw};
+  double* lw = (DC ? f.dc_pcnr : a.use_pcnr) ? kargs()->t.limit_w + vo : nullptr;
+  FusedVecs vec{us, betas, W, qinv, vo, lw};
   if (!DC) vec.load_history(n, lane0);
-  for (int i = lane0; i < n; i += 64) { us[i] = ug[i]; betas[i] = DC ? 0.0 : betag[i]; }
+  {
+    const F2ArgsK ka = kargs();
+    const double *ug = ka->t.u + vo, *betag = ka->t.beta + vo;
+    for (int i = lane0; i < n; i += 64) { us[i] = ug[i]; betas[i] = DC ? 0.0 : betag[i]; }
+  }
   // DC state of this instance: settle flag of the PCNR loop (solve.jl:640-657), Newton solves done in this launch
   int dc_state = 0, dc_iters = 0, dc_first = 0;
-  if (DC) { dc_state = __builtin_amdgcn_readfirstlane(f.dcstate[inst]); dc_first = f.dc_initjct; }
+  if (DC) { dc_state = __builtin_amdgcn_readfirstlane(kargs()->dcstate[inst]); dc_first = f.dc_initjct; }
   double rc_val[2] = {0.0, 0.0};   // values of the first capacitor / resistor block: constant for the instance, kept in registers
   if (f.rc_blk >= 0) {
     const F2Block B = load_block(f.blk, f.rc_blk);
@@ -549,7 +590,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
           dc_state = 1; action = 1;
         } else st.status = 1;
       } else dc_state = 0;
-      const long long done = a.cnt[(size_t)inst * 4] + dc_iters;
+      const long long done = kargs()->t.cnt[(size_t)inst * 4] + dc_iters;
       if (st.status == 0 && !action && done >= f.dc_maxiters) st.status = -3;
       CADNIP_WAVE_SYNC();
       if (st.status != 0) { --budget; break; }
@@ -643,23 +684,27 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
     CADNIP_TRACE_POINT(16);
     if (st.status != 0) { --budget; break; }
   }
-  if (DC) {
-    for (int i = lane0; i < n; i += 64) ug[i] = us[i];
-    if (lane0 == 0) {
-      a.status[inst] = st.status; f.dcstate[inst] = dc_state; a.active[inst] = st.status == 0 ? 1 : 0;
-      a.cnt[(size_t)inst * 4] += dc_iters;
+  {
+    const F2ArgsK ka = kargs();
+    double* ug = ka->t.u + vo;
+    if (DC) {
+      for (int i = lane0; i < n; i += 64) ug[i] = us[i];
+      if (lane0 == 0) {
+        ka->t.status[inst] = st.status; ka->dcstate[inst] = dc_state; ka->t.active[inst] = st.status == 0 ? 1 : 0;
+        ka->t.cnt[(size_t)inst * 4] += dc_iters;
+      }
+    } else {
+      double *betag = ka->t.beta + vo, *dug = ka->t.du + vo;
+      const double a0 = st.a0;
+      for (int i = lane0; i < n; i += 64) { double x = us[i], b = betas[i]; ug[i] = x; betag[i] = b; dug[i] = a0 * x + b; }
+      vec.store_history(n, lane0);
+      store_state(state_view(), inst, lane0, st);
     }
-  } else {
-    double* dug = a.du + (size_t)inst * n;
-    const double a0 = st.a0;
-    for (int i = lane0; i < n; i += 64) { double x = us[i], b = betas[i]; ug[i] = x; betag[i] = b; dug[i] = a0 * x + b; }
-    vec.store_history(n, lane0);
-    store_state(a, inst, lane0, st);
   }
   CADNIP_WAVE_SYNC();
   if (st.status == 0) break;                // out of budget in the middle of this instance: the next launch resumes it
   int nx = 0;
-  if (lane0 == 0) nx = atomicAdd(f.queue, 1);
+  if (lane0 == 0) nx = atomicAdd(kargs()->queue, 1);
   inst = (int)gridDim.x * WPB + __builtin_amdgcn_readfirstlane(nx);
   }
 }

@@ -79,8 +79,8 @@ struct StepState {
   int c_newton, c_accept, c_reject, c_fail;   // counter increments since load
   double t_break, t_save;                     // breaks[bp] / save_t[si], +inf past the end: derived, refreshed when bp / si move
 };
-__device__ __forceinline__ double next_break(const TranArgs& a, int bp) { return bp < a.n_break ? a.breaks[bp] : __builtin_inf(); }
-__device__ __forceinline__ double next_save(const TranArgs& a, int si) { return si < a.n_save ? a.save_t[si] : __builtin_inf(); }
+template <class A> __device__ __forceinline__ double next_break(const A& a, int bp) { return bp < a.n_break ? a.breaks[bp] : __builtin_inf(); }
+template <class A> __device__ __forceinline__ double next_save(const A& a, int si) { return si < a.n_save ? a.save_t[si] : __builtin_inf(); }
 
 // All lanes of the wave hold the same StepState; saying so (readfirstlane) lets it live in scalar registers, which
 // matters in the fused kernel where vector registers are the scarce resource.
@@ -96,7 +96,8 @@ __device__ __forceinline__ void make_uniform(StepState& s) {
   s.c_reject = __builtin_amdgcn_readfirstlane(s.c_reject); s.c_fail = __builtin_amdgcn_readfirstlane(s.c_fail);
 }
 
-__device__ inline StepState load_state(const TranArgs& a, int inst) {
+// A: TranArgs, or a view with the same member names (the fused kernel fetches these rarely used pointers on demand)
+template <class A> __device__ inline StepState load_state(const A& a, int inst) {
   StepState s;
   s.t = a.t[inst]; s.h = a.h[inst]; s.hprev = a.hprev[inst]; s.hpp = a.hpp[inst]; s.tn = a.tcur[inst]; s.a0 = a.gamma[inst];
   s.nhist = a.nhist[inst]; s.ord = a.order[inst]; s.k = a.k[inst]; s.status = a.status[inst]; s.bp = a.bp_idx[inst]; s.si = a.save_idx[inst];
@@ -104,7 +105,7 @@ __device__ inline StepState load_state(const TranArgs& a, int inst) {
   s.t_break = next_break(a, s.bp); s.t_save = next_save(a, s.si);
   return s;
 }
-__device__ inline void store_state(const TranArgs& a, int inst, int tid, const StepState& s) {
+template <class A> __device__ inline void store_state(const A& a, int inst, int tid, const StepState& s) {
   if (tid != 0) return;
   a.t[inst] = s.t; a.h[inst] = s.h; a.hprev[inst] = s.hprev; a.hpp[inst] = s.hpp; a.tcur[inst] = s.tn; a.gamma[inst] = s.a0;
   a.nhist[inst] = s.nhist; a.order[inst] = s.ord; a.k[inst] = s.k; a.status[inst] = s.status; a.bp_idx[inst] = s.bp; a.save_idx[inst] = s.si;
@@ -141,7 +142,9 @@ struct GlobalVecs {
   __device__ __forceinline__ void set_hp(int i, int, double v) { up[i] = v; }
   __device__ __forceinline__ double atol_of(const TranArgs& a, int i, int) const { return a.atol[i]; }
   __device__ __forceinline__ double emask_of(const TranArgs& a, int i, int) const { return a.emask[i]; }
-  __device__ __forceinline__ void history_to_memory(int, int) const {}   // u0 / u1 readable through the pointers: always
+  __device__ __forceinline__ void history_to_memory(int, int) const {}   // u0 / u1 are in memory: always
+  __device__ __forceinline__ double mem_u0(int i) const { return u0[i]; }   // any unknown's u0 / u1 (valid after history_to_memory)
+  __device__ __forceinline__ double mem_u1(int i) const { return u1[i]; }
 };
 
 // f(i, k) for the elements i = tid, tid + 64, ... < n of one lane; k = the ordinal for the first V::KPF of them (a
@@ -216,10 +219,10 @@ __device__ inline void save_outputs(const TranArgs& a, V& v, StepState& s, int i
       double La = (x - 0.0) * (x - xc) / ((xa - 0.0) * (xa - xc));
       double Lb = (x - xa) * (x - xc) / ((0.0 - xa) * (0.0 - xc));
       double Lc = (x - xa) * (x - 0.0) / ((xc - xa) * (xc - 0.0));
-      for (int j = tid; j < a.n_obs; j += 64) { int i = a.obs[j]; o[j] = La * v.get_u(i) + Lb * v.u0[i] + Lc * v.u1[i]; }
+      for (int j = tid; j < a.n_obs; j += 64) { int i = a.obs[j]; o[j] = La * v.get_u(i) + Lb * v.mem_u0(i) + Lc * v.mem_u1(i); }
     } else {
       double sc = (ts - told) / hh;
-      for (int j = tid; j < a.n_obs; j += 64) { int i = a.obs[j]; double x0 = v.u0[i]; o[j] = x0 + sc * (v.get_u(i) - x0); }
+      for (int j = tid; j < a.n_obs; j += 64) { int i = a.obs[j]; double x0 = v.mem_u0(i); o[j] = x0 + sc * (v.get_u(i) - x0); }
     }
     ++si;
     s.t_save = next_save(a, si);
