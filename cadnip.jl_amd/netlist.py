@@ -15,11 +15,16 @@ subset those tests use:
   B                behavioural source  V=expr / I=expr  (bsource.py)
   .INCLUDE .LIB    ``includes``: name -> text (a .LIB that is not supplied is skipped: model cards come from ``models``)
   .MODEL           nmos / pmos (level 1 -> sp_mos1 card) and d cards; cards may also be passed in ``models``
+  X                ``Xname nets... subckt [k=v]``: a call of a ``.SUBCKT`` defined in the deck (or an include) is expanded
+  .SUBCKT .ENDS    hierarchical definitions, flattened with the reference's ``prefix_name`` naming; .GLOBAL nets
   .PARAM .OPTION .TRAN .END ; continuation lines (+), comment lines (*), trailing comments (; or $)
 
-Values are numbers with SPICE suffixes (f p n u m k meg g t), ``{name}`` / bare names of ``.PARAM``s, or names listed
-in ``sweep`` -- those become ``Param`` references so that the deck can be swept on the GPU.
+Values are numbers with SPICE suffixes (f p n u m k meg g t), ``{expr}`` / ``'expr'`` expressions over ``.PARAM``s and
+subcircuit parameters (+ - * / ** and one-line functions), or names listed in ``sweep`` -- those become ``Param``
+references (they may pass affinely through expressions) so that the deck can be swept on the GPU.
 """
+import ast
+import math
 import re
 
 from .circuit import Circuit, Param
@@ -55,6 +60,8 @@ def _logical_lines(text, includes):
         out.append(line)
     res = []
     for line in out:
+        # an expression is one token: drop the blanks inside {...} and '...'
+        line = re.sub(r"\{[^}]*\}|'[^']*'", lambda m: re.sub(r"\s+", "", m.group(0)), line)
         head = line.split()[0].lower()
         if head in (".include", ".inc", ".lib"):
             name = line.split(None, 1)[1].strip().split()[0].strip("\"'")
@@ -81,46 +88,212 @@ def _split_params(tokens):
     return pos, kv
 
 
+class _Affine:
+    """value = scale * sweep[name] + offset: what a ``Param`` can carry through +, -, * const, / const."""
+
+    def __init__(self, name, scale=1.0, offset=0.0):
+        self.name, self.scale, self.offset = name, scale, offset
+
+    @staticmethod
+    def of(x):
+        if isinstance(x, Param):
+            return _Affine(x.name, x.scale, x.offset)
+        return x
+
+    def to_param(self):
+        return Param(self.name, scale=self.scale, offset=self.offset)
+
+
+def _arith(op, a, b):
+    import operator
+    fa, fb = isinstance(a, _Affine), isinstance(b, _Affine)
+    if not fa and not fb:
+        return {"+": operator.add, "-": operator.sub, "*": operator.mul, "/": operator.truediv, "**": operator.pow}[op](a, b)
+    if op in "+-":
+        sgn = 1.0 if op == "+" else -1.0
+        if fa and fb:
+            if a.name != b.name:
+                raise ValueError("expression mixes the sweep parameters %r and %r" % (a.name, b.name))
+            return _Affine(a.name, a.scale + sgn * b.scale, a.offset + sgn * b.offset)
+        if fa:
+            return _Affine(a.name, a.scale, a.offset + sgn * b)
+        return _Affine(b.name, sgn * b.scale, a + sgn * b.offset)
+    if op == "*" and not (fa and fb):
+        k, x = (b, a) if fa else (a, b)
+        return _Affine(x.name, x.scale * k, x.offset * k)
+    if op == "/" and fa and not fb:
+        return _Affine(a.name, a.scale / b, a.offset / b)
+    raise ValueError("expression is not affine in the sweep parameter")
+
+
+_FUNCS = {"sqrt": math.sqrt, "exp": math.exp, "ln": math.log, "log": math.log, "log10": math.log10, "abs": abs, "min": min, "max": max,
+          "pow": pow, "sin": math.sin, "cos": math.cos, "tan": math.tan, "atan": math.atan, "floor": math.floor, "ceil": math.ceil,
+          "int": lambda x: float(int(x))}
+
+
+def eval_expr(text, lookup):
+    """``{...}`` / ``'...'`` parameter expression: numbers with SPICE suffixes, names (``lookup(name)`` -> float or Param),
+    + - * / ** (also ^), parentheses and the usual one-line functions.  A sweep parameter may appear affinely."""
+    src = re.sub(r"(?<![\w.])((?:\d+\.?\d*|\.\d+)(?:e[+-]?\d+)?(?:meg|mil|[tgkmunpfa])?)(?![\w.])",
+                 lambda m: repr(parse_number(m.group(1))), text.strip().lower().replace("^", "**"))
+    try:
+        tree = ast.parse(src, mode="eval")
+    except SyntaxError as e:
+        raise ValueError("cannot parse expression %r" % text) from e
+
+    def ev(nd):
+        if isinstance(nd, ast.Expression):
+            return ev(nd.body)
+        if isinstance(nd, ast.Constant) and isinstance(nd.value, (int, float)):
+            return float(nd.value)
+        if isinstance(nd, ast.Name):
+            return _Affine.of(lookup(nd.id))
+        if isinstance(nd, ast.UnaryOp) and isinstance(nd.op, (ast.USub, ast.UAdd)):
+            v = ev(nd.operand)
+            return v if isinstance(nd.op, ast.UAdd) else _arith("*", -1.0, v)
+        if isinstance(nd, ast.BinOp):
+            op = {ast.Add: "+", ast.Sub: "-", ast.Mult: "*", ast.Div: "/", ast.Pow: "**"}.get(type(nd.op))
+            if op is None:
+                raise ValueError("unsupported operator in %r" % text)
+            return _arith(op, ev(nd.left), ev(nd.right))
+        if isinstance(nd, ast.Call) and isinstance(nd.func, ast.Name) and nd.func.id in _FUNCS:
+            args = [ev(a) for a in nd.args]
+            if any(isinstance(a, _Affine) for a in args):
+                raise ValueError("function of a sweep parameter in %r" % text)
+            return float(_FUNCS[nd.func.id](*args))
+        raise ValueError("unsupported construct in expression %r" % text)
+
+    v = ev(tree)
+    return v.to_param() if isinstance(v, _Affine) else float(v)
+
+
+_GROUND = ("0", "gnd", "gnd!")
+
+
 def read_spice(text, models=None, includes=None, sweep=(), title=""):
     """Parse a deck.  ``models``: model / macro name -> card dict (MOSFETs: an sp_mos1 card with ``type``; diodes:
-    ``is``, ``n``).  Returns ``(circuit, info)``; ``info`` holds ``options``, ``tran`` (tstep, tstop) and ``params``."""
+    ``is``, ``n``).  Returns ``(circuit, info)``; ``info`` holds ``options``, ``tran`` (tstep, tstop) and ``params``.
+
+    Hierarchy: ``.SUBCKT name ports... [PARAMS:] k=v`` ... ``.ENDS`` definitions are expanded at every ``X`` call into
+    the flat device table, with the reference's naming: instance ``m1`` inside ``x1`` inside ``xu1`` becomes
+    ``xu1_x1_m1``, an internal net ``n`` becomes ``xu1_x1_n`` (codegen.jl:745-757); ports, ground and ``.GLOBAL`` nets
+    keep their outer names.  Call parameters are evaluated in the caller's scope and override the definition's
+    defaults; a body sees its own parameters first, then the enclosing scopes."""
     models = {k.lower(): v for k, v in (models or {}).items()}
     lines = _logical_lines(text, includes or {})
     info = {"options": {}, "tran": None, "params": {}}
     sweep = set(sweep)
+    globals_ = set()
+    subckts = {}
 
-    def val(tok):
-        t = tok.strip().strip("{}'")
-        if t in sweep:
-            return Param(t)
-        if t.lower() in info["params"]:
-            return info["params"][t.lower()]
-        return parse_number(t)
+    # ---- pass 1: lift .SUBCKT bodies out of the line list
+    top, stack = [], []
+    for line in lines:
+        hl = line.split()[0].lower()
+        if hl == ".subckt":
+            toks = line.replace(",", " ").split()
+            pos, kv = _split_params([t for t in toks[2:] if t.lower() != "params:"])
+            stack.append({"name": toks[1].lower(), "ports": pos, "defaults": kv, "body": []})
+        elif hl == ".ends":
+            if not stack:
+                raise ValueError(".ENDS without .SUBCKT")
+            sc = stack.pop()
+            if stack:
+                raise ValueError("nested .SUBCKT definitions are not supported (%s inside %s)" % (sc["name"], stack[-1]["name"]))
+            subckts[sc["name"]] = sc
+        elif stack:
+            stack[-1]["body"].append(line)
+        else:
+            top.append(line)
+    if stack:
+        raise ValueError(".SUBCKT %s is not closed by .ENDS" % stack[-1]["name"])
 
     sources, others = [], []
-    for line in lines:
+
+    class Scope:
+        def __init__(self, prefix="", nmap=None, params=None, parent=None):
+            self.prefix, self.nmap, self.params, self.parent = prefix, nmap or {}, params if params is not None else {}, parent
+
+        def lookup(self, name):
+            sc = self
+            while sc is not None:
+                if name in sc.params:
+                    return sc.params[name]
+                sc = sc.parent
+            if name in sweep_l:
+                return Param(sweep_l[name])
+            raise KeyError("unknown parameter %r" % name)
+
+        def val(self, tok):
+            t = tok.strip()
+            if t in sweep:
+                return Param(t)
+            if t[:1] in "{'" and t[-1:] in "}'":
+                return eval_expr(t[1:-1], self.lookup)
+            try:
+                return parse_number(t)
+            except ValueError:
+                return eval_expr(t, self.lookup)
+
+        def node(self, n):
+            if n.lower() in _GROUND or n.lower() in globals_:
+                return n
+            if n in self.nmap:
+                return self.nmap[n]
+            return self.prefix + "_" + n if self.prefix else n
+
+        def name(self, n):
+            return self.prefix + "_" + n if self.prefix else n
+
+    sweep_l = {k.lower(): k for k in sweep}
+
+    def bexpr(expr, sc):
+        """Rename the nets inside V(...) and fold parameter names into numbers."""
+        def vsub(m):
+            return "V(" + ",".join(sc.node(a.strip()) for a in m.group(1).split(",")) + ")"
+        out = re.sub(r"\b[vV]\(([^)]*)\)", vsub, expr)
+        if sc.prefix or sc.params or info["params"]:
+            def psub(m):
+                w = m.group(0)
+                if m.end() < len(out) and out[m.end():m.end() + 1] == "(":
+                    return w
+                try:
+                    v = sc.lookup(w.lower())
+                except KeyError:
+                    return w
+                if isinstance(v, Param):
+                    raise ValueError("behavioural source uses the sweep parameter %r" % w)
+                return repr(float(v))
+            parts = re.split(r"(V\([^)]*\))", out)
+            out = "".join(p if p.startswith("V(") else re.sub(r"(?<![\w.])[A-Za-z_]\w*", psub, p) for p in parts)
+        return out
+
+    def handle(line, sc, depth):
         toks = line.replace(",", " ").split()
         head = toks[0]
         hl = head.lower()
         if hl.startswith("."):
-            if hl == ".end":
-                break
             if hl == ".param":
                 _, kv = _split_params(toks[1:])
                 for k, v in kv.items():
-                    info["params"][k] = val(v)
+                    sc.params[k] = sc.val(v)
+            elif sc.prefix:
+                if hl not in (".model",):
+                    raise ValueError("%s is not allowed inside a .SUBCKT body" % head)
             elif hl in (".option", ".options"):
                 _, kv = _split_params(toks[1:])
                 info["options"].update({k: parse_number(v) for k, v in kv.items()})
             elif hl == ".tran":
                 info["tran"] = tuple(parse_number(t) for t in toks[1:3])
-            elif hl == ".model":
+            elif hl == ".global":
+                globals_.update(t.lower() for t in toks[1:])
+            if hl == ".model":
                 # .model <name> nmos|pmos|d [level=1] key=value ...  (model cards, codegen.jl model registry)
                 pos, kv = _split_params([t.strip("()") for t in toks[1:] if t.strip("()")])
                 if len(pos) < 2:
                     raise ValueError("malformed .model card: %r" % line)
                 kind_m = pos[1].lower()
-                card = {k: val(v) for k, v in kv.items() if k != "level"}
+                card = {k: sc.val(v) for k, v in kv.items() if k != "level"}
                 if kind_m in ("nmos", "pmos"):
                     if float(kv.get("level", "1")) != 1.0:
                         raise ValueError("only level-1 MOSFET cards (sp_mos1) have a GPU device: %r" % line)
@@ -128,17 +301,18 @@ def read_spice(text, models=None, includes=None, sweep=(), title=""):
                 elif kind_m != "d":
                     raise ValueError("unsupported .model type %r" % pos[1])
                 models[pos[0].lower()] = card
-            elif hl in (".subckt", ".ends"):
-                raise ValueError("hierarchical decks are not supported by this reader: flatten %r first" % line)
-            continue
+            return
         kind = hl[0]
+        name = sc.name(head)
         if kind in "vi":
-            p, n = toks[1], toks[2]
+            p, n = sc.node(toks[1]), sc.node(toks[2])
             rest = re.sub(r"\s*\(\s*", "(", re.sub(r"\s*\)", ")", " ".join(toks[3:])))
             wave, dc = None, 0.0
             m = re.search(r"\b(pwl|pulse|sin)\(([^)]*)\)", rest, re.I)
             if m:
-                args = [parse_number(a) for a in m.group(2).split()]
+                args = [sc.val(a) for a in m.group(2).split()]
+                if any(isinstance(a, Param) for a in args):
+                    raise ValueError("waveform arguments cannot be swept (scale the source instead): %r" % line)
                 fn = m.group(1).lower()
                 if fn == "pwl":
                     wave = ("pwl", args[0::2], args[1::2])
@@ -153,35 +327,58 @@ def read_spice(text, models=None, includes=None, sweep=(), title=""):
                 rest = rest[:m.start()] + rest[m.end():]
             rt = [t for t in rest.split() if t.lower() != "dc"]
             if rt:
-                dc = val(rt[0])
-            (sources if kind == "v" else others).append((kind.upper(), head, (p, n), {"dc": dc, "wave": wave}))
+                dc = sc.val(rt[0])
+            (sources if kind == "v" else others).append((kind.upper(), name, (p, n), {"dc": dc, "wave": wave}))
         elif kind in "rcl":
-            others.append((kind.upper(), head, (toks[1], toks[2]), {"value": val(toks[3])}))
+            others.append((kind.upper(), name, (sc.node(toks[1]), sc.node(toks[2])), {"value": sc.val(toks[3])}))
         elif kind in "eg":
-            others.append((kind.upper(), head, tuple(toks[1:5]), {"value": val(toks[5])}))
+            others.append((kind.upper(), name, tuple(sc.node(t) for t in toks[1:5]), {"value": sc.val(toks[5])}))
         elif kind == "d":
             card = models.get(toks[3].lower())
             if card is None:
                 raise KeyError("diode model %r is not in `models`" % toks[3])
-            others.append(("D", head, (toks[1], toks[2]), {"card": card}))
+            others.append(("D", name, (sc.node(toks[1]), sc.node(toks[2])), {"card": card}))
         elif kind in "mx":
             pos, kv = _split_params(toks[1:])
+            sub = subckts.get(pos[-1].lower()) if kind == "x" and pos else None
+            if sub is not None:
+                if depth > 32:
+                    raise ValueError("subcircuit recursion through %s" % sub["name"])
+                if len(pos) - 1 != len(sub["ports"]):
+                    raise ValueError("%s: %d nets for the %d ports of %s" % (head, len(pos) - 1, len(sub["ports"]), sub["name"]))
+                unknown = [k for k in kv if k not in sub["defaults"] and k != "m"]
+                if unknown:
+                    raise ValueError("%s: %s has no parameter %s" % (head, sub["name"], ", ".join(unknown)))
+                pars = {k: sc.val(v) for k, v in kv.items()}                 # call values: the caller's scope
+                inner = Scope(name, dict(zip(sub["ports"], (sc.node(t) for t in pos[:-1]))), pars, sc)
+                for k, v in sub["defaults"].items():                         # defaults may refer to earlier parameters
+                    if k not in pars:
+                        pars[k] = inner.val(v)
+                for body_line in sub["body"]:
+                    handle(body_line, inner, depth + 1)
+                return
             if len(pos) != 5:
-                raise ValueError("only 4-terminal MOSFET instances / macros are supported: %r" % line)
+                raise ValueError("only 4-terminal MOSFET instances / macros and .SUBCKT calls are supported: %r" % line)
             card = models.get(pos[4].lower())
             if card is None:
-                raise KeyError("MOSFET model / macro %r is not in `models`" % pos[4])
-            inst = {k: val(v) for k, v in kv.items() if k != "m"}
-            others.append(("MOS1", head, tuple(pos[:4]), {"card": card, "inst": inst, "m": val(kv["m"]) if "m" in kv else 1.0}))
+                raise KeyError("MOSFET model / macro / subcircuit %r is not defined" % pos[4])
+            inst = {k: sc.val(v) for k, v in kv.items() if k != "m"}
+            others.append(("MOS1", name, tuple(sc.node(t) for t in pos[:4]), {"card": card, "inst": inst, "m": sc.val(kv["m"]) if "m" in kv else 1.0}))
         elif kind == "b":
             body = line.split(None, 3)[3]
             m = re.match(r"\s*([vi])\s*=\s*(.*)$", body, re.I)
             if not m:
                 raise ValueError("behavioural source needs V=expr or I=expr: %r" % line)
-            expr = m.group(2).strip().strip("{}'")
-            others.append(("BV" if m.group(1).lower() == "v" else "BI", head, (toks[1], toks[2]), {"expr": expr}))
+            expr = bexpr(m.group(2).strip().strip("{}'"), sc)
+            others.append(("BV" if m.group(1).lower() == "v" else "BI", name, (sc.node(toks[1]), sc.node(toks[2])), {"expr": expr}))
         else:
             raise ValueError("unsupported element %r" % line)
+
+    root = Scope("", {}, info["params"], None)
+    for line in top:
+        if line.split()[0].lower() == ".end":
+            break
+        handle(line, root, 0)
 
     c = Circuit(title)
     for ty, name, nodes, a in sources + others:

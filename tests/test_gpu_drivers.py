@@ -199,3 +199,42 @@ def test_ring_oscillator_fixture_gpu():
         v = out[i, :, 0] * (3.3 / p["vdd"])          # the reference's thresholds are for 3.3 V
         cross.append(tc.ring_checks(v)[2])
     assert cross == sorted(cross) and cross[-1] > cross[0], cross
+
+
+def test_hierarchical_deck_runs_like_the_flat_table_gpu():
+    """A .SUBCKT deck (one inverter stage per call, its load capacitor inside the cell) through the deck reader and the
+    fused kernel: same waveform, bit for bit, as the hand-built table of the same ring (tests/circuits.py)."""
+    deck = """* 3-stage ring from a stage cell
+    .model pmos1 pmos level=1 vto=-0.7 kp=50e-6
+    .model nmos1 nmos level=1 vto=0.7 kp=100e-6
+    .subckt stage in out vdd cl=10f
+    MP out in vdd vdd pmos1 w=2e-6 l=1e-6
+    MN out in 0 0 nmos1 w=1e-6 l=1e-6
+    C out 0 {cl}
+    .ends
+    Vdd vdd 0 DC 3.3
+    X1 in1 out1 vdd stage
+    X2 out1 out2 vdd stage
+    X3 out2 in1 vdd stage cl='2*5f'
+    .end
+    """
+    hier, _ = cj.netlist.read_spice(deck)
+    assert [d.name for d in hier.devices] == ["Vdd", "X1_MP", "X1_MN", "X1_C", "X2_MP", "X2_MN", "X2_C", "X3_MP", "X3_MN", "X3_C"]
+    outs = []
+    for circ in (hier, tc.ring_oscillator()):
+        sim = api.BatchSimulator(api.MNACircuit(circ, {}), [{}, {}])
+        st = sim.st
+        sim.analyze()
+        u0 = np.zeros((2, st.n))
+        u0[:, st.index_of("vdd")] = 3.3
+        u0[:, st.index_of("out1")] = 3.3
+        sim.h.set_u(u0)
+        sim.h.set_spec(mode="tran")
+        ts = np.linspace(100e-9, 200e-9, 500)
+        out, per, stats = sim.h.tran_run(0.0, 200e-9, st.state_abstol(vntol=1e-6, iabstol=1e-9, chgtol=1e-6), 1e-4, save_t=ts,
+                                         obs=[st.index_of("out1")], hmax=1e-9, fused=1)
+        sim.close()
+        assert stats["n_failed"] == 0
+        outs.append(out)
+    tc.ring_checks(outs[0][0, :, 0])
+    assert np.array_equal(outs[0], outs[1])

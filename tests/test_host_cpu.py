@@ -477,3 +477,86 @@ def test_cpu_port_ring_oscillator_fixture():
     assert rst["status"] == 1
     tc.ring_checks(out[:, 0])
     port.close()
+
+
+def test_spice_deck_reader_flattens_subcircuits():
+    """.SUBCKT hierarchy -> flat device table with the reference's naming (instance m1 in x1 in xu1 -> xu1_x1_m1, internal net n
+    -> xu1_x1_n; src/spc/codegen.jl:745-757, 1708-1715): the hierarchical deck and its hand-flattened twin give the same
+    table, structure and sweep behaviour."""
+    hier = """* buffer chain from inverter cells
+    .param wbase=1u
+    .global vdd
+    .model nch nmos level=1 vto=0.7 kp=100e-6
+    .model pch pmos level=1 vto=-0.7 kp=50e-6
+    .subckt inv in out wn=1u ratio=2
+    .param wp={wn*ratio}
+    MP out in vdd vdd pch w={wp} l=1e-6
+    MN out in 0 0 nch w={wn} l=1e-6
+    Cl out 0 {2f*ratio}
+    .ends
+    .subckt buf a y PARAMS: w=1u
+    Xi1 a mid inv wn={w}
+    Xi2 mid y inv wn={2*w} ratio=3
+    Rleak mid 0 1meg
+    .ends inv
+    Vdd vdd 0 DC supply
+    Vin in 0 DC 0 PULSE(0 3.3 1n 1n 1n 5n 20n)
+    Xb1 in n1 buf w={wbase}
+    Xb2 n1 out buf w='wbase*1.5'
+    Bmon mon 0 V=V(n1)-V(out)
+    Rs out 0 {supply*1k + 500}
+    .end
+    """
+    flat = """* the same, flattened by hand
+    .model nch nmos level=1 vto=0.7 kp=100e-6
+    .model pch pmos level=1 vto=-0.7 kp=50e-6
+    Vdd vdd 0 DC supply
+    Vin in 0 DC 0 PULSE(0 3.3 1n 1n 1n 5n 20n)
+    MXb1_Xi1_MP Xb1_mid in vdd vdd pch w=2e-6 l=1e-6
+    MXb1_Xi1_MN Xb1_mid in 0 0 nch w=1e-6 l=1e-6
+    CXb1_Xi1_Cl Xb1_mid 0 4f
+    MXb1_Xi2_MP n1 Xb1_mid vdd vdd pch w=6e-6 l=1e-6
+    MXb1_Xi2_MN n1 Xb1_mid 0 0 nch w=2e-6 l=1e-6
+    CXb1_Xi2_Cl n1 0 6f
+    RXb1_Rleak Xb1_mid 0 1meg
+    MXb2_Xi1_MP Xb2_mid n1 vdd vdd pch w=3e-6 l=1e-6
+    MXb2_Xi1_MN Xb2_mid n1 0 0 nch w=1.5e-6 l=1e-6
+    CXb2_Xi1_Cl Xb2_mid 0 4f
+    MXb2_Xi2_MP out Xb2_mid vdd vdd pch w=9e-6 l=1e-6
+    MXb2_Xi2_MN out Xb2_mid 0 0 nch w=3e-6 l=1e-6
+    CXb2_Xi2_Cl out 0 6f
+    RXb2_Rleak Xb2_mid 0 1meg
+    Bmon mon 0 V=V(n1)-V(out)
+    Rs out 0 3800
+    .end
+    """
+    ch, _ = cj.netlist.read_spice(hier, sweep=("supply",))
+    cf, _ = cj.netlist.read_spice(flat, sweep=("supply",))
+    gh, gf = ch.to_dicts({"supply": 3.3}), cf.to_dicts({"supply": 3.3})
+    # the flat deck's element names carry the SPICE type letter in front; everything else must agree
+    assert [d["name"] for d in gh] == [d["name"][1:] if "_" in d["name"] else d["name"] for d in gf]
+    for a, b in zip(gh, gf):
+        assert a["type"] == b["type"] and a["nodes"] == b["nodes"], (a, b)
+        for k in a:
+            if k in ("name", "type", "nodes"):
+                continue
+            if isinstance(a[k], dict):
+                assert a[k] == pytest.approx(b[k]), (a["name"], k)
+            elif isinstance(a[k], float):
+                assert a[k] == pytest.approx(b[k], rel=1e-14), (a["name"], k)
+            else:
+                assert a[k] == b[k], (a["name"], k)
+    sa, sb = cj.discover(ch, {"supply": 3.3}), cj.discover(cf, {"supply": 3.3})
+    assert sa.n == sb.n and sa.nnz == sb.nnz and sa.node_names == sb.node_names and np.array_equal(sa.colidx, sb.colidx)
+    # the sweep parameter went through an affine expression
+    rs = [d for d in ch.to_dicts({"supply": 2.0}) if d["name"] == "Rs"][0]
+    assert rs["r"] == pytest.approx(2500.0)
+    # error behaviour
+    for bad, exc in ((".subckt a p\nR1 p 0 1\n.ends\nX1 n1 n2 a\n", ValueError),            # port count
+                     (".subckt a p\nR1 p 0 1\n.ends\nX1 n1 a rr=2\n", ValueError),           # unknown call parameter
+                     (".subckt a p\nX1 p a\n.ends\nX1 n1 a\n", ValueError),                  # recursion
+                     (".subckt a p\nR1 p 0 {nope}\n.ends\nX1 n1 a\n", KeyError),             # unknown name in an expression
+                     ("R1 a 0 {supply*supply}\n", ValueError)):                                 # not affine in the sweep parameter
+        with pytest.raises(exc):
+            cj.netlist.read_spice(bad, sweep=("supply",))
+    assert cj.netlist.eval_expr("2*(1k+500)/3 + sqrt(16) - 2^3", lambda n: 0.0) == pytest.approx(996.0)
