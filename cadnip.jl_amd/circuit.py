@@ -96,6 +96,12 @@ class Circuit:
         mp.update(instance)
         return self._add("MOS1", name, (d, g, s, b), {"m": m}, model=mp)
 
+    def VA(self, name, module, nodes, m=1.0, **params):
+        """Instance of a Verilog-A module that is compiled into the library (cadnip.jl_amd/va: ``va.registry()``);
+        ``nodes`` in port order, ``params`` the given module parameters, ``m`` the multiplicity ($mfactor)."""
+        mp = {k.lower(): v for k, v in params.items()}
+        return self._add("VA:" + module, name, tuple(nodes), {"m": m}, model=mp)
+
     # neutral form used by tests to feed the oracle's builder (oracle/netlist_ref.py)
     def to_dicts(self, params=None):
         """Plain-dict form of the table.  With ``params`` every Param is evaluated to a number;

@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 #include "internal.hpp"
+#include "va_generated.hpp"   // CADNIP_VA_SHAPES: the generated Verilog-A modules this library was built with
 
 using namespace cadnip;
 
@@ -109,6 +110,18 @@ int cadnip_create(const CadnipStructure* s, int32_t n_instances, int32_t device,
       }
     }
     if (b.type == CADNIP_DEV_MOS1 && (b.n_par != CADNIP_MOS1_NPAR || b.n_nodes != 14)) { cadnip_destroy(h); return CADNIP_BADARG; }
+    if (b.type == CADNIP_DEV_VA) {
+      // one generated module per block; its shape must be the one the library was generated with (va_generated.hpp)
+      bool ok = b.n_ipar >= 2 && b.count > 0;
+      const int id = ok ? sb.ipar[0] : -1;
+      ok = ok && id >= 0 && id < CADNIP_VA_NMODELS;
+      for (int d = 0; ok && d < b.count; ++d) ok = sb.ipar[d] == id;
+      if (ok) {
+        const auto& sh = CADNIP_VA_SHAPES[id];
+        ok = b.n_nodes == sh.n_nodes && b.n_g == sh.n_g && b.n_c == sh.n_c && b.n_b == sh.n_b && b.n_par == sh.n_par;
+      }
+      if (!ok) { cadnip_destroy(h); return CADNIP_BADARG; }
+    }
     b.h_nodes.assign(sb.nodes, sb.nodes + (size_t)b.n_nodes * b.count);
     TRY(dev_upload(&b.d_nodes, sb.nodes, (size_t)b.n_nodes * b.count));
     TRY(dev_upload(&b.d_ipar, sb.ipar, (size_t)(b.n_ipar > 0 ? b.n_ipar : 1) * b.count));

@@ -908,3 +908,5 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
 }
 
 }  // namespace cadnip
+
+#include "va_runtime.hpp"

@@ -37,6 +37,7 @@ typedef unsigned long long u64;
 #define NOPOS 0xFFFFu
 #define F2_NCMAX 16   // largest core the in-register dense solve is unrolled for
 #define F2_JU 18      // J*u entries per lane and chunk
+#define F2_MAX_BLOCKS 32   // device blocks of one circuit (one per built-in type, one per Verilog-A module); more: per-op path
 #define F2_TRASH 64   // per-instance trash words (one per lane) that absorb stamps into ground rows / columns
 
 // table sections (offsets in 32-bit words, every section 8-byte aligned)
@@ -214,6 +215,7 @@ __device__ __forceinline__ void dispatch_stamp2(int type, const LdsCtx& d, const
     case CADNIP_DEV_MOS1: stamp_mos1(d, u, s, lw); break;
     case CADNIP_DEV_BVSOURCE: stamp_bvsource(d, u, s, lw); break;
     case CADNIP_DEV_BISOURCE: stamp_bisource(d, u, s, lw); break;
+    case CADNIP_DEV_VA: stamp_va(d, u, s, lw); break;
   }
 }
 
@@ -839,6 +841,9 @@ static int fused2_tables(CadnipHandle* h) {
 // kernels (still on the GPU) when it does not, or when the tables cannot address it.
 bool fused2_fits(CadnipHandle* h) {
   if (fused2_tables(h) != CADNIP_OK) return false;
+  int nb = 0;
+  for (auto& b : h->blocks) nb += b.count > 0;
+  if (nb > F2_MAX_BLOCKS) return false;
   const size_t per = (size_t)h->f2_lu_words + 3 * (size_t)h->n + F2_TRASH;
   return ((size_t)h->f2len / 2 + per) * 8 <= 160 * 1024;
 }
@@ -852,9 +857,9 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
   F2Args f;
   // device-block descriptors: rebuilt when the tables were, or when cadnip_set_params changed a block (sp_mos1 pairing)
   if (h->f2_blk_dirty || !h->d_f2blk) {
-    F2Block hb[CADNIP_DEV_NTYPES];
+    F2Block hb[F2_MAX_BLOCKS];
     int nb = 0;
-    for (size_t bi = 0; bi < h->blocks.size() && nb < CADNIP_DEV_NTYPES; ++bi) {
+    for (size_t bi = 0; bi < h->blocks.size() && nb < F2_MAX_BLOCKS; ++bi) {
       auto& b = h->blocks[bi];
       if (b.count == 0) continue;
       hb[nb++] = F2Block{b.d_ipar, b.d_par, b.type, b.count, b.n_par, b.g_base, b.c_base, b.b_base, h->f2_nodes_off[bi], b.mos1_plain ? 1 : 0};
@@ -873,7 +878,7 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
     for (int i = 0; i < nb; ++i) {
       const int ty = hb[i].type;
       const bool heavy = ty == CADNIP_DEV_DIODE || ty == CADNIP_DEV_DIODECAP || ty == CADNIP_DEV_SIMPLEMOS || ty == CADNIP_DEV_BVSOURCE ||
-                         ty == CADNIP_DEV_BISOURCE || (ty == CADNIP_DEV_MOS1 && !hb[i].mos1_plain);
+                         ty == CADNIP_DEV_BISOURCE || ty == CADNIP_DEV_VA || (ty == CADNIP_DEV_MOS1 && !hb[i].mos1_plain);
       if (heavy) h->f2_lean = false;
     }
     h->f2_n_blk = nb;

@@ -73,6 +73,7 @@ __global__ void __launch_bounds__(256) k_stamp(StampArgs a) {
   else if (TYPE == CADNIP_DEV_MOS1) stamp_mos1(d, u, s, lw);
   else if (TYPE == CADNIP_DEV_BVSOURCE) stamp_bvsource(d, u, s, lw);
   else if (TYPE == CADNIP_DEV_BISOURCE) stamp_bisource(d, u, s, lw);
+  else if (TYPE == CADNIP_DEV_VA) stamp_va(d, u, s, lw);
 }
 
 template <int TYPE>
@@ -276,6 +277,7 @@ int launch_rebuild(CadnipHandle* h) {
       CASE(CADNIP_DEV_CCVS, "stamp_ccvs") CASE(CADNIP_DEV_CCCS, "stamp_cccs") CASE(CADNIP_DEV_DIODE, "stamp_diode")
       CASE(CADNIP_DEV_DIODECAP, "stamp_diodecap") CASE(CADNIP_DEV_SIMPLEMOS, "stamp_simplemos")
       CASE(CADNIP_DEV_MOS1, "stamp_mos1") CASE(CADNIP_DEV_BVSOURCE, "stamp_bvsource") CASE(CADNIP_DEV_BISOURCE, "stamp_bisource")
+      CASE(CADNIP_DEV_VA, "stamp_va")
 #undef CASE
       default: return CADNIP_BADARG;
     }

@@ -1,0 +1,118 @@
+// va_runtime.hpp -- what the generated Verilog-A stamp functions (va_generated.hpp, written by cadnip.jl_amd/va/hipgen.py)
+// are built from: elementary functions on Dual<N> / double, and the branch stamp of the reference's generated stamp!
+// (/root/reference/src/vasim.jl:3319-3521; charge-state formulation :3433-3472, constant capacitance :3474-3482).
+// Included at the end of devices.hpp.
+#pragma once
+
+namespace cadnip {
+
+template <class X> __device__ __forceinline__ double va_val(X x) { return (double)x; }
+template <int N> __device__ __forceinline__ double va_val(const Dual<N>& x) { return x.v; }
+template <class X> __device__ __forceinline__ bool va_true(X x) { return va_val(x) != 0.0; }
+
+// f(a) with derivative df: chain rule over the partials
+template <int N> __device__ __forceinline__ Dual<N> va_chain(const Dual<N>& a, double f, double df) {
+  Dual<N> r; r.v = f;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.p[i] = a.p[i] * df;
+  return r;
+}
+#define VA_UNARY(name, fexpr, dfexpr)                                                                     \
+  __device__ __forceinline__ double va_##name(double x) { return fexpr; }                                 \
+  template <int N> __device__ __forceinline__ Dual<N> va_##name(const Dual<N>& a) {                        \
+    const double x = a.v; const double f = fexpr; (void)f; return va_chain(a, f, dfexpr); }
+VA_UNARY(exp, exp(x), f)
+VA_UNARY(ln, log(x), 1.0 / x)
+VA_UNARY(log, log10(x), 1.0 / (x * 2.302585092994046))
+VA_UNARY(sqrt, sqrt(x), 0.5 / f)
+VA_UNARY(tanh, tanh(x), 1.0 - f * f)
+VA_UNARY(sinh, sinh(x), cosh(x))
+VA_UNARY(cosh, cosh(x), sinh(x))
+VA_UNARY(sin, sin(x), cos(x))
+VA_UNARY(cos, cos(x), -sin(x))
+VA_UNARY(atan, atan(x), 1.0 / (1.0 + x * x))
+// limexp: exp below 80, its tangent above (the usual SPICE continuation)
+VA_UNARY(limexp, (x < 80.0 ? exp(x) : exp(80.0) * (1.0 + x - 80.0)), (x < 80.0 ? f : exp(80.0)))
+#undef VA_UNARY
+__device__ __forceinline__ double va_abs(double x) { return fabs(x); }
+template <int N> __device__ __forceinline__ Dual<N> va_abs(const Dual<N>& a) { return a.v >= 0.0 ? a : -a; }
+
+// two-argument functions: every double / dual combination
+__device__ __forceinline__ double va_pow(double a, double b) { return pow(a, b); }
+template <int N> __device__ __forceinline__ Dual<N> va_pow(const Dual<N>& a, double b) {
+  const double f = pow(a.v, b);
+  return va_chain(a, f, b == 0.0 ? 0.0 : b * pow(a.v, b - 1.0));
+}
+template <int N> __device__ __forceinline__ Dual<N> va_pow(double a, const Dual<N>& b) {
+  const double f = pow(a, b.v);
+  return va_chain(b, f, f * log(a));
+}
+template <int N> __device__ __forceinline__ Dual<N> va_pow(const Dual<N>& a, const Dual<N>& b) {
+  const double f = pow(a.v, b.v), da = b.v == 0.0 ? 0.0 : b.v * pow(a.v, b.v - 1.0), db = f * log(a.v);
+  Dual<N> r; r.v = f;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.p[i] = a.p[i] * da + (b.p[i] != 0.0 ? b.p[i] * db : 0.0);
+  return r;
+}
+// min / max select by value and carry the selected operand's partials (ForwardDiff semantics); ties take the first
+__device__ __forceinline__ double va_max(double a, double b) { return b > a ? b : a; }
+__device__ __forceinline__ double va_min(double a, double b) { return b < a ? b : a; }
+template <int N> __device__ __forceinline__ Dual<N> va_max(const Dual<N>& a, const Dual<N>& b) { return b.v > a.v ? b : a; }
+template <int N> __device__ __forceinline__ Dual<N> va_min(const Dual<N>& a, const Dual<N>& b) { return b.v < a.v ? b : a; }
+template <int N> __device__ __forceinline__ Dual<N> va_max(const Dual<N>& a, double b) { return b > a.v ? Dual<N>(b) : a; }
+template <int N> __device__ __forceinline__ Dual<N> va_max(double a, const Dual<N>& b) { return b.v > a ? b : Dual<N>(a); }
+template <int N> __device__ __forceinline__ Dual<N> va_min(const Dual<N>& a, double b) { return b < a.v ? Dual<N>(b) : a; }
+template <int N> __device__ __forceinline__ Dual<N> va_min(double a, const Dual<N>& b) { return b.v < a ? b : Dual<N>(a); }
+
+// One branch (p, n) of a generated module: I = resistive current (value + d/dV_k), Q = charge (value + d/dV_k), both
+// already scaled by the multiplicity factor.  Slot layout: VAModule.shape / .program (cadnip.jl_amd/va/frontend.py).
+// Both reactive forms are written; the circuit's pattern holds the one the host's voltage-dependence detection chose, the
+// other's slots are never gathered (per-op path) / lead to trash words (fused path).  `pl`, `nl`: local node index or -1.
+template <int N, int B, bool REACTIVE, class Ctx, class Out>
+__device__ __forceinline__ void va_emit_branch(const Ctx& d, const double* u, const Out& s, const double (&Vf)[N], const int* nd, int b, int pl, int nl,
+                                               const Dual<N>& I, const Dual<N>& Q, bool vdep) {
+  const double CS = CADNIP_CHARGE_SCALE;
+  double Ieq = I.v;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    s.G(2 * N * b + 2 * k, I.p[k]);
+    s.G(2 * N * b + 2 * k + 1, -I.p[k]);
+    Ieq += -I.p[k] * Vf[k];
+  }
+  if (REACTIVE) {
+    s.C(2 * b, 1.0 / CS);
+    s.C(2 * b + 1, -1.0 / CS);
+    s.G(2 * N * B + (N + 1) * b, 1.0);
+    double bq = Q.v;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      s.G(2 * N * B + (N + 1) * b + 1 + k, -CS * Q.p[k]);
+      bq -= Q.p[k] * Vf[k];
+      s.C(2 * B + 2 * N * b + 2 * k, Q.p[k]);
+      s.C(2 * B + 2 * N * b + 2 * k + 1, -Q.p[k]);
+    }
+    s.B(3 * b + 2, CS * bq);
+  }
+  s.B(3 * b, -Ieq);
+  s.B(3 * b + 1, Ieq);
+  if constexpr (Out::DIRECT) {   // the branch's share of r = C du + G u - b, straight from I and Q
+    double r = I.v;
+    if (REACTIVE) {
+      if (vdep) {
+        const int nq = nd[N + b];
+        s.Rn(nq, u[nq] - CS * Q.v);
+        r += s.du(nq) * (1.0 / CS);
+      } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) r += Q.p[k] * s.du(nd[k]);
+      }
+    }
+    s.Rn(pl < 0 ? -1 : nd[pl], r);
+    s.Rn(nl < 0 ? -1 : nd[nl], -r);
+  }
+}
+
+}  // namespace cadnip
+
+#define CADNIP_VA_DEVICE_CODE
+#include "va_generated.hpp"

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from .structure import Structure, TYPE_ID
+from .structure import Structure, TYPE_ID, type_id
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CADNIP_HIP_LIB") or os.path.join(_HERE, "libcadnip_hip.so")   # same override as julia/CadnipHIP.jl
@@ -143,7 +143,7 @@ class Handle:
             ipar = np.ascontiguousarray(blk.ipar, dtype=np.int32)
             self._keep += [nodes, ipar]
             b = blocks[k]
-            b.type, b.count = TYPE_ID[blk.type], blk.count
+            b.type, b.count = type_id(blk.type), blk.count
             b.n_nodes, b.nodes = nodes.shape[0], _ip(nodes)
             b.n_ipar, b.ipar = ipar.shape[0], _ip(ipar)
             b.n_par = blk.n_par

@@ -24,12 +24,25 @@ import numpy as np
 
 from . import bsource
 from . import mos1_params as m1
+from . import va
 from .circuit import Circuit, resolve
 
 # device type ids: keep in sync with CadnipDeviceType in include/cadnip_hip.h
 TYPE_ID = {"R": 0, "C": 1, "L": 2, "V": 3, "I": 4, "E": 5, "G": 6, "H": 7, "F": 8,
            "D": 9, "DCAP": 10, "SMOS": 11, "MOS1": 12, "BV": 13, "BI": 14}
+TYPE_ID_VA = 15          # CADNIP_DEV_VA: every "VA:<module>" block (the module is ipar row 0)
 WAVE_DC, WAVE_PWL, WAVE_PULSE, WAVE_SIN = 0, 1, 2, 3
+
+
+def type_id(ty):
+    return TYPE_ID_VA if ty.startswith("VA:") else TYPE_ID[ty]
+
+
+def shape_of(ty):
+    """(n_local_nodes, n_g, n_c, n_b, n_par, n_ipar) of a device type; generated Verilog-A modules bring their own."""
+    if ty.startswith("VA:"):
+        return va.get(ty[3:])[1].shape()
+    return SHAPE[ty]
 
 # (n_local_nodes, n_g, n_c, n_b, n_par, n_ipar) per type
 SHAPE = {
@@ -351,6 +364,89 @@ def detect_mos1_vdep(circuit: Circuit, params: Dict[str, float], seed: int = 0xD
     return tuple(is_vdep)
 
 
+def detect_va_vdep(circuit: Circuit, params: Dict[str, float], seed: int = 0xDEADBEEF):
+    """Per Verilog-A module in the circuit: which reactive branches use a charge unknown.  Emulates the reference's
+    detection run (build_with_detection, solve.jl:1793-1822) pass by pass: five builder passes, the first at x = 0, pass
+    k > 0 at ``x = 2 (rand(known_size) - 0.5)`` where ``known_size`` is the system size after the previous pass (charge
+    unknowns allocated so far included); every VA stamp! restarts the detection position counter (vasim.jl:3926), so all
+    instances -- of all modules -- share one cache indexed by reactive-branch *position*, and a position compares
+    consecutive evaluations whichever device they belong to (detect_or_cached!, contrib.jl:214-257).  A flag, once set,
+    stays.  The structure is the one of the last pass.  Probe points come from numpy's generator (the reference uses
+    Julia's MersenneTwister); sp_mos1 instances in the same circuit keep their own detection (detect_mos1_vdep)."""
+    devs = [d for d in circuit.devices if d.type.startswith("VA:")]
+    if not devs:
+        return {}
+    # unknown numbering of the builder: nodes by first use (external nets in instance order, internal nodes as their
+    # instance is stamped); the counts of the other unknown kinds fix where x ends
+    A = _Alloc()
+    n_cur = n_lim = n_m1q = 0
+    m1v = detect_mos1_vdep(circuit, params)
+    internal = {}
+    for d in circuit.devices:
+        for nm in d.nodes:
+            A.node(nm)
+        ty = d.type
+        if ty in ("L", "V", "BV", "E", "F"):
+            n_cur += 1
+        elif ty == "H":
+            n_cur += 2
+        elif ty in ("BV", "BI"):
+            for tok in bsource.compile_expr(d.params["expr"]):
+                if tok[0] == "v":
+                    A.node(tok[1]); A.node(tok[2])
+        elif ty == "D" and bool(d.params.get("limit", True)):
+            n_lim += 1
+        elif ty == "MOS1":
+            given = {k: resolve(v, params) for k, v in d.model.items()}
+            sc_d, sc_s = m1.short_circuits(given)
+            if not sc_d:
+                A.node("%s_sp_mos1_d_int" % d.name)
+            if not sc_s:
+                A.node("%s_sp_mos1_s_int" % d.name)
+            n_lim += 4
+            n_m1q += sum(m1v)
+        elif ty.startswith("VA:"):
+            mod = va.get(ty[3:])[1]
+            internal[d.name] = [A.node("%s_%s_%s" % (d.name, mod.name, nm)) for nm in mod.nodes[len(mod.ports):]]
+    n_nodes = len(A.node_names)
+    rng = np.random.default_rng(seed)
+    is_vdep, Qs, Vs = [], [], []
+    n_q_prev = 0
+    last = {}
+    for p in range(5):
+        x = np.zeros(n_nodes) if p == 0 else (rng.random(n_nodes + n_cur + n_m1q + n_q_prev + n_lim) - 0.5) * 2.0
+        n_q = 0
+        for d in devs:
+            mod = va.get(d.type[3:])[1]
+            par = va.host_eval.defaults(mod, {k: float(np.asarray(resolve(v, params)).flat[0]) for k, v in d.model.items()})
+            idx = [A.node(nm) for nm in d.nodes] + internal[d.name]
+            V = [0.0 if t == GND else float(x[t[1]]) for t in idx]
+            mf = float(np.asarray(resolve(d.params["m"], params)).flat[0])
+            vals = va.host_eval.evaluate(mod, V, par, 27.0 + 273.15, mf, 1e-12)
+            flags, pos = [], 0
+            for b, (pn, nn) in enumerate(mod.branches):
+                if not mod.reactive[b]:
+                    flags.append(False)
+                    continue
+                Vb = (V[pn] if pn >= 0 else 0.0) - (V[nn] if nn >= 0 else 0.0)
+                Q = mf * vals[b][1]
+                if pos >= len(Qs):
+                    is_vdep.append(False); Qs.append(Q); Vs.append(Vb)
+                else:
+                    if abs(Vb) > 1e-6 and abs(Vs[pos]) > 1e-6:
+                        Cc, Cs = Q / Vb, Qs[pos] / Vs[pos]
+                        diff, mx = abs(Cc - Cs), max(abs(Cc), abs(Cs))
+                        if diff > 1e-15 and (mx < 1e-30 or diff / mx > 1e-6):
+                            is_vdep[pos] = True
+                    Qs[pos], Vs[pos] = Q, Vb
+                flags.append(is_vdep[pos])
+                n_q += int(is_vdep[pos])
+                pos += 1
+            last[d.name] = tuple(flags)
+        n_q_prev = n_q
+    return last
+
+
 def discover(circuit: Circuit, params: Dict[str, float]) -> Structure:
     """Structure of ``circuit`` for parameter set ``params`` (first sweep instance; every
     instance of a batch must share it)."""
@@ -360,6 +456,7 @@ def discover(circuit: Circuit, params: Dict[str, float]) -> Structure:
     order: List[str] = []
     breakpoints = []
     vdep = detect_mos1_vdep(circuit, params)
+    va_vdep = detect_va_vdep(circuit, params)
     pending_bsrc = []   # (ipar list, tokens): programs are encoded once every node has its index
     recs = []   # (stream, seq-order implicit, type, dev_in_block, local_slot, row_typed, col_typed)
     for di, dev in enumerate(circuit.devices):
@@ -418,6 +515,19 @@ def discover(circuit: Circuit, params: Dict[str, float]) -> Structure:
             nodes += qs
             ipar = [sum((1 << r) for r in range(4) if vdep[r])]
             prog = mos1_program(vdep)
+        if ty.startswith("VA:"):
+            mid, mod = va.get(ty[3:])
+            if len(dev.nodes) != len(mod.ports):
+                raise ValueError("%s: %d nets for the %d ports of %s" % (dev.name, len(dev.nodes), len(mod.ports), mod.name))
+            # internal nodes, then one charge unknown per voltage-dependent reactive branch, allocated in branch order as
+            # the branches are stamped (vasim.jl:3533-3564, 3433-3472)
+            nodes += [A.node("%s_%s_%s" % (dev.name, mod.name, nm)) for nm in mod.nodes[len(mod.ports):]]
+            vd = va_vdep[dev.name]
+            for b, (p, n) in enumerate(mod.branches):
+                nm = "%s_%s_Q_%s_%s" % (dev.name, mod.name, mod.nodes[p] if p >= 0 else "0", mod.nodes[n] if n >= 0 else "0")
+                nodes.append(A.charge(nm) if (mod.reactive[b] and vd[b]) else GND)
+            ipar = [mid, sum((1 << b) for b in range(len(mod.branches)) if mod.reactive[b] and vd[b])]
+            prog = mod.program(vd)
         d_in_block = len(per_type[ty])
         per_type[ty].append((di, nodes, ipar))
         for (stream, k, rl, cl) in prog:
@@ -443,7 +553,7 @@ def discover(circuit: Circuit, params: Dict[str, float]) -> Structure:
     for ty in order:
         items = per_type[ty]
         cnt = len(items)
-        nl, ng, nc, nb, npar, nip = SHAPE[ty]
+        nl, ng, nc, nb, npar, nip = shape_of(ty)
         nodes = np.full((nl, cnt), -1, dtype=np.int32)
         ipar = np.zeros((max(nip, 1), cnt), dtype=np.int32)
         for j, (di, nd, ip) in enumerate(items):
@@ -553,5 +663,14 @@ def pack_params(st: Structure, circuit: Circuit, params: Dict[str, np.ndarray], 
                 given = {k: resolve(v, params) for k, v in dev.model.items()}
                 der, _ = m1.derive(given, temp_c, tnom_c, gmin, mfactor=g("m"))
                 arr[:, :, j] = der.T if der.shape[1] == B else np.repeat(der.T, B, axis=0)
+            elif ty.startswith("VA:"):
+                mod = va.get(ty[3:])[1]
+                par = va.host_eval.defaults(mod, {k: resolve(v, params) for k, v in dev.model.items()})
+                for k, nm in enumerate(mod.params):
+                    arr[:, k, j] = par[nm]
+                np_ = len(mod.params)
+                arr[:, np_, j] = np.asarray(temp_c, dtype=float) + 273.15     # $temperature
+                arr[:, np_ + 1, j] = g("m")                                     # $mfactor
+                arr[:, np_ + 2, j] = gmin                                       # $simparam("gmin")
         out.append(np.ascontiguousarray(arr))
     return out

@@ -1,0 +1,206 @@
+"""Verilog-A module -> HIP stamp function for gfx950 (the device half of SURVEY.md section 8f-3).
+
+Counterpart of the reference's ``generate_mna_stamp_method_nterm`` (/root/reference/src/vasim.jl:2993-3985): the module
+body becomes straight-line C++ over forward-mode duals ``Dual<N>`` (value + one partial per module node, devices.hpp);
+``ddt()`` splits an expression into a resistive and a reactive (charge) part, tracked statically here instead of by a
+second dual tag (contrib.jl:356-375).  Expressions that cannot depend on a voltage stay plain ``double``.  The branch
+stamps themselves (Jacobian rows, equivalent currents, charge-state or constant-capacitance form, direct residuals)
+are the hand-written ``va_emit_branch`` in devices.hpp.
+
+    python -m cadnip_jl_amd.va.hipgen  model1.va model2.va ...  > csrc/va_generated.hpp      (csrc/build.sh does this)
+"""
+import sys
+
+from .frontend import VAError, parse_module
+
+K_OVER_Q = 1.380649e-23 / 1.602176634e-19
+
+
+def _lit(x):
+    r = repr(float(x))
+    return r if ("." in r or "e" in r or "inf" in r or "nan" in r) else r + ".0"
+
+
+class _Gen:
+    def __init__(self, m):
+        self.m = m
+        self.lines = []
+
+    def T(self, code, is_t):
+        return code if is_t else "T(%s)" % code
+
+    # expression -> (resistive code, it is a dual, reactive code or None)
+    def g(self, e):
+        m, k = self.m, e[0]
+        if k == "num":
+            return _lit(e[1]), False, None
+        if k == "var":
+            if e[1] in m.params:
+                return "p_" + e[1], False, None
+            return "v_" + e[1], m.var_is_dual[e[1]], ("v_%s_q" % e[1]) if m.var_is_reactive[e[1]] else None
+        if k == "V":
+            a, b = m.node_index(e[1]), m.node_index(e[2])
+            if a >= 0 and b >= 0:
+                return "(V%d - V%d)" % (a, b), True, None
+            if a >= 0:
+                return "V%d" % a, True, None
+            return "(-V%d)" % b, True, None
+        if k == "ddt":
+            c, t, _ = self.g(e[1])
+            return "0.0", False, self.T(c, t)
+        if k == "un":
+            c, t, q = self.g(e[2])
+            if e[1] == "!":
+                return "(!va_true(%s))" % c, False, None
+            return "(-%s)" % c, t, ("(-%s)" % q) if q else None
+        if k == "cond":
+            cc = self.g(e[1])[0]
+            a, ta, qa = self.g(e[2])
+            b, tb, qb = self.g(e[3])
+            t = ta or tb
+            r = "(va_true(%s) ? %s : %s)" % (cc, self.T(a, ta) if t else a, self.T(b, tb) if t else b)
+            q = None
+            if qa or qb:
+                q = "(va_true(%s) ? %s : %s)" % (cc, qa or "T(0.0)", qb or "T(0.0)")
+            return r, t, q
+        if k == "call":
+            args = [self.g(a) for a in e[2]]
+            return "va_%s(%s)" % (e[1], ", ".join(a[0] for a in args)), any(a[1] for a in args), None
+        if k == "sys":
+            if e[1] == "$temperature":
+                return "sys_temp", False, None
+            if e[1] == "$mfactor":
+                return "sys_mf", False, None
+            if e[1] == "$vt":
+                if e[2]:
+                    c, t, _ = self.g(e[2][0])
+                    return "(%s * %s)" % (_lit(K_OVER_Q), c), t, None
+                return "(%s * sys_temp)" % _lit(K_OVER_Q), False, None
+            if e[2] and e[2][0] == ("str", "gmin"):
+                return "sys_gmin", False, None
+            if len(e[2]) > 1:
+                return self.g(e[2][1])
+            raise VAError("$simparam(%r) has no value on the device" % (e[2][0][1] if e[2] else ""))
+        op = e[1]
+        l, tl, ql = self.g(e[2])
+        r, tr, qr = self.g(e[3])
+        if op in ("+", "-"):
+            q = None
+            if ql and qr:
+                q = "(%s %s %s)" % (ql, op, qr)
+            elif ql:
+                q = ql
+            elif qr:
+                q = qr if op == "+" else "(-%s)" % qr
+            return "(%s %s %s)" % (l, op, r), tl or tr, q
+        if op == "*":
+            q = ("(%s * %s)" % (ql, r)) if ql else ("(%s * %s)" % (l, qr)) if qr else None
+            return "(%s * %s)" % (l, r), tl or tr, q
+        if op == "/":
+            return "(%s / %s)" % (l, r), tl or tr, ("(%s / %s)" % (ql, r)) if ql else None
+        if op in ("&&", "||"):
+            return "(va_true(%s) %s va_true(%s))" % (l, op, r), False, None
+        return "(va_val(%s) %s va_val(%s))" % (l, op, r), False, None
+
+    def stmts(self, body, ind):
+        m, pad = self.m, "  " * ind
+        for s in body:
+            if s[0] == "assign":
+                c, t, q = self.g(s[2])
+                self.lines.append("%sv_%s = %s;" % (pad, s[1], c))
+                if m.var_is_reactive[s[1]]:
+                    self.lines.append("%sv_%s_q = %s;" % (pad, s[1], q or "T(0.0)"))
+            elif s[0] == "contrib":
+                b = m.branches.index((m.node_index(s[1]), m.node_index(s[2])))
+                c, t, q = self.g(s[3])
+                self.lines.append("%sbr%d_r = br%d_r + %s;" % (pad, b, b, c))
+                if q:
+                    self.lines.append("%sbr%d_q = br%d_q + %s;" % (pad, b, b, q))
+            elif s[0] == "block":
+                self.stmts(s[1], ind)
+            elif s[0] == "if":
+                self.lines.append("%sif (va_true(%s)) {" % (pad, self.g(s[1])[0]))
+                self.stmts([s[2]], ind + 1)
+                if s[3] != ("block", []):
+                    self.lines.append("%s} else {" % pad)
+                    self.stmts([s[3]], ind + 1)
+                self.lines.append("%s}" % pad)
+
+
+def generate_function(m):
+    N, B, NP = m.n_nodes, len(m.branches), len(m.params)
+    g = _Gen(m)
+    L = g.lines
+    L.append("// module %s: nodes (%s), %d parameter(s), branches %s" % (
+        m.name, ", ".join(m.nodes), NP, ", ".join("(%s,%s)%s" % (m.nodes[p] if p >= 0 else "gnd", m.nodes[n] if n >= 0 else "gnd",
+                                                               " reactive" if r else "") for (p, n), r in zip(m.branches, m.reactive))))
+    L.append("template <class Ctx, class Out>")
+    L.append("__device__ inline void stamp_va_%s(const Ctx& d, const double* u, const Out& s, double*) {" % m.name)
+    L.append("  constexpr int N = %d, B = %d;" % (N, B))
+    L.append("  typedef Dual<N> T;")
+    L.append("  int nd[N + B];")
+    L.append("#pragma unroll")
+    L.append("  for (int k = 0; k < N + B; ++k) nd[k] = node_of(d, k);")
+    L.append("  double Vf[N];")
+    L.append("#pragma unroll")
+    L.append("  for (int k = 0; k < N; ++k) Vf[k] = volt(u, nd[k]);")
+    for k in range(N):
+        L.append("  const T V%d = T::seed(Vf[%d], %d);   // V(%s)" % (k, k, k, m.nodes[k]))
+    for i, p in enumerate(m.params):
+        L.append("  const double p_%s = par_of(d, %d);" % (p, i))
+    L.append("  const double sys_temp = par_of(d, %d), sys_mf = par_of(d, %d), sys_gmin = par_of(d, %d);" % (NP, NP + 1, NP + 2))
+    L.append("  (void)sys_temp; (void)sys_gmin;")
+    for v in m.locals_:
+        L.append("  %s v_%s = 0.0;" % ("T" if m.var_is_dual[v] else "double", v))
+        if m.var_is_reactive[v]:
+            L.append("  T v_%s_q = 0.0;" % v)
+    for b in range(B):
+        L.append("  T br%d_r = 0.0, br%d_q = 0.0;" % (b, b))
+    g.stmts(m.body, 1)
+    L.append("  const int vdep = d.ipar[1 * d.count + d.dev];   // bit b: branch b uses a charge unknown")
+    for b, ((p, n), r) in enumerate(zip(m.branches, m.reactive)):
+        L.append("  va_emit_branch<N, B, %s>(d, u, s, Vf, nd, %d, %d, %d, sys_mf * br%d_r, sys_mf * br%d_q, ((vdep >> %d) & 1) != 0);"
+                 % ("true" if r else "false", b, p, n, b, b, b))
+    L.append("}")
+    return "\n".join(L)
+
+
+def generate_header(modules):
+    """The whole va_generated.hpp: one function per module, the dispatcher and the host-side shape table."""
+    out = ["// GENERATED by cadnip.jl_amd/va/hipgen.py from the Verilog-A sources listed below -- do not edit.",
+           "// Included by devices.hpp (device code) and api.hip (shape table).", "#pragma once", ""]
+    out.append("#ifdef CADNIP_VA_DEVICE_CODE   // set by va_runtime.hpp (device translation units); api.hip takes the shape table only")
+    out.append("namespace cadnip {")
+    for m in modules:
+        out.append(generate_function(m))
+        out.append("")
+    out.append("// model id = position in the list the generator was given (ipar row 0 of a CADNIP_DEV_VA block)")
+    out.append("template <class Ctx, class Out>")
+    out.append("__device__ inline void stamp_va(const Ctx& d, const double* u, const Out& s, double* lw) {")
+    out.append("  switch (d.ipar[0 * d.count + d.dev]) {")
+    for i, m in enumerate(modules):
+        out.append("    case %d: stamp_va_%s(d, u, s, lw); break;" % (i, m.name))
+    out.append("    default: break;")
+    out.append("  }")
+    out.append("}")
+    out.append("}  // namespace cadnip")
+    out.append("#endif")
+    out.append("")
+    out.append("// n_nodes (local unknowns), n_g, n_c, n_b, n_par, n_ipar per generated model: what cadnip_create checks a block against")
+    out.append("#define CADNIP_VA_NMODELS %d" % len(modules))
+    out.append("static const struct { const char* name; int n_nodes, n_g, n_c, n_b, n_par, n_ipar; } CADNIP_VA_SHAPES[%d] = {" % max(1, len(modules)))
+    for m in modules:
+        out.append('  {"%s", %d, %d, %d, %d, %d, %d},' % ((m.name,) + m.shape()))
+    if not modules:
+        out.append('  {"", 0, 0, 0, 0, 0, 0},')
+    out.append("};")
+    return "\n".join(out) + "\n"
+
+
+def main(argv):
+    mods = [parse_module(open(fn).read()) for fn in argv]
+    sys.stdout.write(generate_header(mods))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -60,7 +60,11 @@ typedef enum {
                                 (setup+temp hoisted, mos1.va:695-897) values; ipar: flags       */
   CADNIP_DEV_BVSOURCE = 13,  /* devices.jl:1079-1102 BehavioralVoltageSource  nodes p,n,I   par: scale   ipar: program off,len */
   CADNIP_DEV_BISOURCE = 14,  /* devices.jl:1118-1131 BehavioralCurrentSource  nodes p,n     par: scale   ipar: program off,len */
-  CADNIP_DEV_NTYPES = 15
+  CADNIP_DEV_VA = 15,        /* generated Verilog-A module (src/vasim.jl:2993-3985 generate_mna_stamp_method_nterm): nodes = ports, internal
+                              * nodes, one charge unknown per branch (-1 = none); par = module parameters, temperature [K], mfactor,
+                              * gmin; ipar: model id (position in the list the library was generated from), voltage-dependent-charge
+                              * bit mask.  One block per module; slot layout: cadnip.jl_amd/va/frontend.py */
+  CADNIP_DEV_NTYPES = 16
 } CadnipDeviceType;
 
 #define CADNIP_MOS1_NPAR 36

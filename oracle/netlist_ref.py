@@ -14,6 +14,7 @@ Wave fields: ``wave = ("pwl", ts, ys) | ("pulse", v1, v2, td, tr, tf, pw, per) |
 from . import devices_ref as D
 from .mna_ref import MNAContext, ZERO_VECTOR
 from .va_mos1_ref import Mos1Model, stamp_mos1
+from .va_ref import stamp_va
 
 
 def _num(v, params):
@@ -117,6 +118,12 @@ def make_builder(devices):
                 mp = {k: _num(v, params) for k, v in dev["model"].items()}
                 stamp_mos1(ctx, Mos1Model(**mp), nodes[0], nodes[1], nodes[2], nodes[3], x, spec, name,
                            mfactor=g("m", 1.0))
+            elif ty.startswith("VA:"):
+                # a generated Verilog-A module: the syntax tree and the parameter defaults come from the product's front end
+                from cadnip_jl_amd import va
+                mod = va.get(ty[3:])[1]
+                par = va.host_eval.defaults(mod, {k: _num(v, params) for k, v in dev["model"].items()})
+                stamp_va(ctx, mod, nodes, x, par, spec, name, mfactor=g("m", 1.0))
             else:
                 raise ValueError("unknown device type %r" % ty)
         return ctx

@@ -133,6 +133,23 @@ def ring_oscillator():
     return c
 
 
+def va_zoo():
+    """Every Verilog-A module that is compiled into the library (cadnip.jl_amd/va/models): a resistor / diode (internal
+    node, voltage-dependent charge) / capacitor (constant capacitance) chain and a CMOS inverter from va_sqmos."""
+    c = cj.Circuit("generated Verilog-A modules")
+    c.V("Vin", "in", "0", dc=0.9, wave=("sin", 0.9, 0.4, 2e6, 0.0, 0.0, 0.0))
+    c.V("Vdd", "vdd", "0", dc=1.8)
+    c.VA("XR1", "va_resistor", ("in", "a"), r=2e3)
+    c.VA("XD1", "va_diode", ("a", "k"), rs=25.0, cj0=2e-12, tt=5e-9)
+    c.VA("XR2", "va_resistor", ("k", "0"), r=1e3, m=2.0)
+    c.VA("XC1", "va_capacitor", ("k", "0"), c=3e-12)
+    c.VA("XD2", "va_diode", ("0", "k"), **{"is": 5e-14})
+    c.VA("XMN", "va_sqmos", ("out", "a", "0", "0"), type=1.0, w=2e-6)
+    c.VA("XMP", "va_sqmos", ("out", "a", "vdd", "vdd"), type=-1.0, vto=0.7, kp=40e-6, w=4e-6)
+    c.VA("XCL", "va_capacitor", ("out", "0"), c=20e-15)
+    return c
+
+
 def ring_checks(v):
     """The reference's assertions on V(out1) sampled at 500 points over the last 100 ns (vadistiller_integration.jl:668-690)."""
     import numpy as np
@@ -148,5 +165,6 @@ ALL_STAMP = {
     "divider": (divider, {}), "linear_zoo": (linear_zoo, {}), "diode": (diode_rectifier, {}),
     "diode_nolimit": (lambda: diode_rectifier(False), {}), "diode_chain": (diode_chain, {}),
     "nonlinear_zoo": (nonlinear_zoo, {}), "behavioral": (behavioral, {}), "inverter": (inverter_dc, {}), "mos1_rd": (mos1_rd, {}),
+    "va_zoo": (va_zoo, {}),
     "dff": (bm.dff_circuit, {"vdd": 5.0}), "dff_meyer": (lambda: bm.dff_circuit(meyer=True), {"vdd": 5.0}),
 }
