@@ -1,0 +1,97 @@
+"""Generated Verilog-A modules on the GPU: DC and transient behaviour of the stamp functions
+that cadnip.jl_amd/va/hipgen.py emits, beyond the per-stamp parity of tests/test_gpu_parity.py[va_zoo]."""
+import numpy as np
+import pytest
+
+import cadnip_jl_amd as cj
+from cadnip_jl_amd import api
+from tests import circuits as tc
+from tests.test_gpu_drivers import _oracle_dc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_va_dc_matches_oracle(fused):
+    """Plain Newton on G u = b (solve.jl:599-698 without limit variables) over the generated modules: same solution as
+    the oracle's interpreter-driven Newton to 1e-9, same number of Newton solves on the per-op path."""
+    circ = tc.va_zoo()
+    uo, oko, ito = _oracle_dc(circ, {}, "dcop")
+    sim = api.BatchSimulator(api.MNACircuit(circ, {}, api.MNASpec(mode="dcop")), [{}, {}])
+    u, conv, st = sim.dc(abstol=1e-10, maxiters=100, fused=fused)
+    sim.close()
+    assert oko and np.all(conv)
+    assert np.max(np.abs(u[0] - uo) / np.maximum(np.abs(uo), 1.0)) < 1e-9
+    assert np.array_equal(u[0], u[1])
+    if not fused:
+        assert st["newton_iters"] == 2 * ito
+
+
+def test_va_linear_modules_equal_builtin_devices():
+    """va_resistor / va_capacitor are the same physics as the built-in R / C (devices.jl:498-534): an RC ladder made of
+    either gives the same transient -- identical step sequence, waveforms to 1e-9 -- as long as the capacitors are
+    stamped as constant capacitances.  With unequal capacitor values the reference's position-shared detection cache
+    (contrib.jl:214-257; consecutive instances compare their Q/V) flags them voltage dependent, the ladder gets charge
+    unknowns, and the two formulations agree to the integration tolerance instead."""
+    def ladder(kind, equal_c=True):
+        c = cj.Circuit()
+        c.V("v1", "n0", "0", dc=0.0, wave=("pulse", 0.0, 1.0, 1e-7, 1e-8, 1e-8, 4e-7, 1e-6))
+        for k in range(6):
+            a, b = "n%d" % k, "n%d" % (k + 1)
+            if kind == "va":
+                c.VA("xr%d" % k, "va_resistor", (a, b), r=1e3 * (1 + k))
+                c.VA("xc%d" % k, "va_capacitor", (b, "0"), c=1e-11 if equal_c else 1e-11 / (1 + k))
+            else:
+                c.R("r%d" % k, a, b, 1e3 * (1 + k))
+                c.C("c%d" % k, b, "0", 1e-11 if equal_c else 1e-11 / (1 + k))
+        return c
+
+    ts = np.array([1.5e-7, 3e-7, 6e-7, 1e-6])
+    res = {}
+    for kind in ("builtin", "va"):
+        for fused in (0, 1):
+            sim = api.BatchSimulator(api.MNACircuit(ladder(kind), {}))
+            st = sim.st
+            out, per, stats = sim.tran((0.0, 1e-6), np.full(st.n, 1e-9), 1e-6, ts, obs=[st.index_of("n%d" % k) for k in (1, 3, 6)], fused=fused)
+            sim.close()
+            assert stats["n_failed"] == 0
+            res[kind, fused] = (out[0], tuple(per[0][:3]))
+    for fused in (0, 1):
+        assert res["va", fused][1] == res["builtin", fused][1], (fused, res["va", fused][1], res["builtin", fused][1])
+        assert np.max(np.abs(res["va", fused][0] - res["builtin", fused][0])) < 1e-9
+    assert np.max(np.abs(res["va", 1][0] - res["va", 0][0])) < 1e-7
+    assert cj.discover(ladder("va"), {}).n_charges == 0 and cj.discover(ladder("va", False), {}).n_charges == 6
+    outs = []
+    for kind in ("builtin", "va"):
+        sim = api.BatchSimulator(api.MNACircuit(ladder(kind, False), {}))
+        st = sim.st
+        out, per, stats = sim.tran((0.0, 1e-6), st.state_abstol(vntol=1e-9, iabstol=1e-12, chgtol=1e-9), 1e-6, ts,
+                                   obs=[st.index_of("n%d" % k) for k in (1, 3, 6)], fused=1)
+        sim.close()
+        assert stats["n_failed"] == 0
+        outs.append(out[0])
+    assert np.max(np.abs(outs[0] - outs[1])) < 1e-4    # two formulations, each within its local-error budget
+
+
+def test_va_transient_fused_matches_per_op_and_conserves_charge():
+    """The nonlinear modules (diode with internal node and a voltage-dependent charge, square-law MOSFETs with junction
+    charges) under a 2 MHz sine: fused kernel (direct residuals from va_emit_branch) against the per-op kernels."""
+    circ = tc.va_zoo()
+    ts = np.linspace(1e-7, 1e-6, 10)
+    got = {}
+    for fused in (0, 1):
+        sim = api.BatchSimulator(api.MNACircuit(circ, {}), [{}, {}, {}])
+        st = sim.st
+        u, conv, _ = sim.dc(abstol=1e-9, mode="tranop", fused=bool(fused))
+        assert np.all(conv)
+        out, per, stats = sim.tran((0.0, 1e-6), st.state_abstol(vntol=1e-7, iabstol=1e-10, chgtol=1e-7), 1e-5, ts,
+                                   obs=[st.index_of(nm) for nm in ("a", "k", "out")], fused=fused)
+        sim.close()
+        assert stats["n_failed"] == 0, stats
+        assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
+        got[fused] = (out[0], per[0])
+    a, b = got[0][0], got[1][0]
+    assert np.max(np.abs(a - b)) < 1e-4 * max(1.0, float(np.max(np.abs(a)))), np.max(np.abs(a - b))
+    assert abs(int(got[0][1][0]) - int(got[1][1][0])) <= max(3, 0.03 * got[0][1][0]), (got[0][1], got[1][1])
+    # the inverter output swings with the input (0.5 .. 1.3 V around the switching point)
+    assert np.ptp(a[:, 2]) > 0.5
