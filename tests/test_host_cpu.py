@@ -560,3 +560,68 @@ def test_spice_deck_reader_flattens_subcircuits():
         with pytest.raises(exc):
             cj.netlist.read_spice(bad, sweep=("supply",))
     assert cj.netlist.eval_expr("2*(1k+500)/3 + sqrt(16) - 2^3", lambda n: 0.0) == pytest.approx(996.0)
+
+
+def test_verilog_a_front_end_and_generator():
+    """cadnip.jl_amd/va: parsing, the static analysis the generators rely on (branches in first-use order, which locals are
+    duals, which carry a ddt() part), host-side evaluation, the emitted HIP text, and the constructs that must be refused."""
+    from cadnip_jl_amd import va
+    from cadnip_jl_amd.va import hipgen
+    src = """
+    `include "disciplines.vams"
+    module tst(a, b, c);
+      inout a, b, c; electrical a, b, c, x;      // x: internal node
+      parameter real g = 1m from (0:inf);
+      parameter real cq = 2p;
+      parameter real k = 2.0 * g;                 /* default from an earlier parameter */
+      real v, i, q, w;
+      analog begin
+        v = V(a, x);  w = cq * 3.0;
+        if (v > 0.5) i = g * v * v; else i = k * v;
+        q = w * v * (1.0 + 0.1 * v);
+        I(a, x) <+ i + ddt(q);
+        I(x, b) <+ V(x, b) * g;
+        I(c) <+ 1u * tanh(V(c)) - ddt(w * V(c, a));
+        I(a, x) <+ $simparam("gmin", 1e-12) * V(a, x);
+      end
+    endmodule
+    """
+    m = va.parse_module(src)
+    assert (m.name, m.ports, m.nodes) == ("tst", ["a", "b", "c"], ["a", "b", "c", "x"]) and list(m.params) == ["g", "cq", "k"]
+    assert m.branches == [(0, 3), (3, 1), (2, -1)] and m.reactive == [True, False, True]
+    assert m.var_is_dual == {"v": True, "i": True, "q": True, "w": False} and not any(m.var_is_reactive.values())
+    assert m.shape() == (4 + 3, 2 * 4 * 3 + 5 * 3, 2 * 3 + 2 * 4 * 3, 9, 3 + 3, 2)
+    par = va.host_eval.defaults(m, {"G": 2e-3})
+    assert par == {"g": 2e-3, "cq": 2e-12, "k": 4e-3}
+    with pytest.raises(va.VAError):
+        va.host_eval.defaults(m, {"nope": 1.0})
+    (i0, q0), (i1, q1), (i2, q2) = va.host_eval.evaluate(m, [1.0, 0.2, -0.3, 0.25], par, gmin=1e-12)
+    assert i0 == pytest.approx(2e-3 * 0.75 ** 2 + 1e-12 * 0.75) and q0 == pytest.approx(6e-12 * 0.75 * 1.075)
+    assert i1 == pytest.approx(0.05 * 2e-3) and q1 == 0.0
+    assert i2 == pytest.approx(1e-6 * np.tanh(-0.3)) and q2 == pytest.approx(-6e-12 * (-1.3))
+    text = hipgen.generate_function(m)
+    assert "stamp_va_tst" in text and "constexpr int N = 4, B = 3;" in text
+    assert "double v_w = 0.0;" in text and "T v_q = 0.0;" in text            # w never sees a voltage: stays a double
+    assert "va_emit_branch<N, B, true>(d, u, s, Vf, nd, 0, 0, 3," in text and "va_emit_branch<N, B, true>(d, u, s, Vf, nd, 2, 2, -1," in text
+    hdr = hipgen.generate_header([m])
+    assert '{"tst", 7, 39, 30, 9, 6, 2}' in hdr and "case 0: stamp_va_tst(d, u, s, lw); break;" in hdr
+    # a local that carries ddt(): the reactive part follows it through assignments, sums and scaling
+    m2 = va.parse_module("module r(p, n); electrical p, n; parameter real c = 1p; real t1, t2;"
+                         " analog begin t1 = ddt(c * V(p, n)); t2 = 2.0 * t1 + V(p, n) * 1m; I(p, n) <+ -t2 / 4.0; end endmodule")
+    assert m2.var_is_reactive == {"t1": True, "t2": True} and m2.reactive == [True]
+    (ir, qr), = va.host_eval.evaluate(m2, [0.8, 0.0], {"c": 1e-12})
+    assert ir == pytest.approx(-0.8e-3 / 4.0) and qr == pytest.approx(-2.0 * 0.8e-12 / 4.0)
+    # the modules that ship in the library parse, and their ids are their positions
+    reg = va.registry()
+    assert [reg[n][0] for n in ("va_resistor", "va_capacitor", "va_diode", "va_sqmos")] == [0, 1, 2, 3]
+    # refused, never approximated
+    for bad in ("module x(a); electrical a; analog V(a) <+ 1.0; endmodule",                       # potential contribution
+                'module x(a); electrical a; real v; analog begin v = $limit(V(a), "pnjlim", 1, 2); I(a) <+ v; end endmodule',
+                "module x(a); electrical a; analog I(a) <+ ddt(V(a)) * ddt(V(a)); endmodule",     # product of two ddt()
+                "module x(a); electrical a; analog I(a) <+ exp(ddt(V(a))); endmodule",            # ddt inside a function
+                "module x(a); electrical a; analog I(a) <+ undeclared * V(a); endmodule",
+                "module x(a); electrical a; analog I(a, b) <+ V(a); endmodule",                    # unknown net
+                "module x(a); electrical a; analog @(initial_step) I(a) <+ 1; endmodule",
+                "module x(a); analog I(a) <+ 1; endmodule"):                                       # port not electrical
+        with pytest.raises(va.VAError):
+            va.parse_module(bad)
