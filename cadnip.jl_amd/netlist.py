@@ -15,7 +15,8 @@ subset those tests use:
   B                behavioural source  V=expr / I=expr  (bsource.py)
   .INCLUDE .LIB    ``includes``: name -> text (a .LIB that is not supplied is skipped: model cards come from ``models``)
   .MODEL           nmos / pmos (level 1 -> sp_mos1 card) and d cards; cards may also be passed in ``models``
-  X                ``Xname nets... subckt [k=v]``: a call of a ``.SUBCKT`` defined in the deck (or an include) is expanded
+  X                ``Xname nets... subckt [k=v]``: a call of a ``.SUBCKT`` defined in the deck (or an include) is expanded;
+                   ``Xname nets... module [k=v]``: an instance of a Verilog-A module compiled into the library (va/)
   .SUBCKT .ENDS    hierarchical definitions, flattened with the reference's ``prefix_name`` naming; .GLOBAL nets
   .PARAM .OPTION .TRAN .END ; continuation lines (+), comment lines (*), trailing comments (; or $)
 
@@ -209,6 +210,8 @@ def read_spice(text, models=None, includes=None, sweep=(), title=""):
         raise ValueError(".SUBCKT %s is not closed by .ENDS" % stack[-1]["name"])
 
     sources, others = [], []
+    from . import va
+    va_modules = {nm.lower(): m for nm, (_, m) in va.registry().items()}
 
     class Scope:
         def __init__(self, prefix="", nmap=None, params=None, parent=None):
@@ -357,8 +360,16 @@ def read_spice(text, models=None, includes=None, sweep=(), title=""):
                 for body_line in sub["body"]:
                     handle(body_line, inner, depth + 1)
                 return
+            if kind == "x" and pos and pos[-1].lower() in va_modules:
+                # instance of a Verilog-A module that is compiled into the library (cadnip.jl_amd/va)
+                mod = va_modules[pos[-1].lower()]
+                if len(pos) - 1 != len(mod.ports):
+                    raise ValueError("%s: %d nets for the %d ports of %s" % (head, len(pos) - 1, len(mod.ports), mod.name))
+                inst = {k: sc.val(v) for k, v in kv.items() if k != "m"}
+                others.append(("VA", name, tuple(sc.node(t) for t in pos[:-1]), {"module": mod.name, "inst": inst, "m": sc.val(kv["m"]) if "m" in kv else 1.0}))
+                return
             if len(pos) != 5:
-                raise ValueError("only 4-terminal MOSFET instances / macros and .SUBCKT calls are supported: %r" % line)
+                raise ValueError("only 4-terminal MOSFET instances / macros, Verilog-A modules and .SUBCKT calls are supported: %r" % line)
             card = models.get(pos[4].lower())
             if card is None:
                 raise KeyError("MOSFET model / macro / subcircuit %r is not defined" % pos[4])
@@ -400,6 +411,8 @@ def read_spice(text, models=None, includes=None, sweep=(), title=""):
             c.D(name, nodes[0], nodes[1], Is=a["card"].get("is", 1e-14), n_=a["card"].get("n", 1.0))
         elif ty == "MOS1":
             c.MOS1(name, nodes[0], nodes[1], nodes[2], nodes[3], a["card"], m=a["m"], **a["inst"])
+        elif ty == "VA":
+            c.VA(name, a["module"], nodes, m=a["m"], **a["inst"])
         elif ty == "BV":
             c.BV(name, nodes[0], nodes[1], a["expr"])
         elif ty == "BI":

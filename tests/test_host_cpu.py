@@ -560,6 +560,17 @@ def test_spice_deck_reader_flattens_subcircuits():
         with pytest.raises(exc):
             cj.netlist.read_spice(bad, sweep=("supply",))
     assert cj.netlist.eval_expr("2*(1k+500)/3 + sqrt(16) - 2^3", lambda n: 0.0) == pytest.approx(996.0)
+    # X cards naming a Verilog-A module of the library become VA instances, also from inside a .SUBCKT
+    vd, _ = cj.netlist.read_spice(""".subckt clamp a k rser=25
+    Xd a k va_diode rs={rser} cj0=2p
+    Xr k 0 va_resistor r=1k m=2
+    .ends
+    V1 in 0 DC 1
+    X1 in out clamp rser=50
+    """)
+    got = vd.to_dicts({})
+    assert [(d["type"], d["name"], d["nodes"]) for d in got] == [("V", "V1", ["in", "0"]), ("VA:va_diode", "X1_Xd", ["in", "out"]), ("VA:va_resistor", "X1_Xr", ["out", "0"])]
+    assert got[1]["model"] == {"rs": 50.0, "cj0": pytest.approx(2e-12)} and got[2]["m"] == 2.0 and cj.discover(vd, {}).n == 5
 
 
 def test_verilog_a_front_end_and_generator():
