@@ -6,6 +6,9 @@
 
 namespace cadnip {
 
+// what $temperature, $mfactor and $simparam("gmin" | "initjct") read
+struct VaSys { double temp, mf, gmin, initjct; };
+
 template <class X> __device__ __forceinline__ double va_val(X x) { return (double)x; }
 template <int N> __device__ __forceinline__ double va_val(const Dual<N>& x) { return x.v; }
 template <class X> __device__ __forceinline__ bool va_true(X x) { return va_val(x) != 0.0; }
@@ -64,15 +67,34 @@ template <int N> __device__ __forceinline__ Dual<N> va_max(double a, const Dual<
 template <int N> __device__ __forceinline__ Dual<N> va_min(const Dual<N>& a, double b) { return b < a.v ? Dual<N>(b) : a; }
 template <int N> __device__ __forceinline__ Dual<N> va_min(double a, const Dual<N>& b) { return b.v < a ? b : Dual<N>(a); }
 
+// A $limit call site (vasim.jl:1316-1330): value w, the probe's node partials kept ("undamped"), unit partial in the site's
+// own slot so that the companion model can be re-anchored at w (lim_rhs).
+template <int W> __device__ __forceinline__ Dual<W> va_site(const Dual<W>& probe, double w, int slot) {
+  Dual<W> r = probe;
+  r.v = w;
+  r.p[slot] = 1.0;
+  return r;
+}
+// rows of the limit unknown l of probe branch (p, n): u_l - (V_p - V_n) = 0 (the hoisted preamble, vasim.jl:3110-3138)
+template <int N, int B, class Out> __device__ __forceinline__ void va_emit_limit_rows(const Out& s, int l) {
+  const int g0 = 2 * N * B + (N + 1) * B + 3 * l;
+  s.G(g0, 1.0);
+  s.G(g0 + 1, -1.0);
+  s.G(g0 + 2, 1.0);
+}
+
 // One branch (p, n) of a generated module: I = resistive current (value + d/dV_k), Q = charge (value + d/dV_k), both
 // already scaled by the multiplicity factor.  Slot layout: VAModule.shape / .program (cadnip.jl_amd/va/frontend.py).
 // Both reactive forms are written; the circuit's pattern holds the one the host's voltage-dependence detection chose, the
 // other's slots are never gathered (per-op path) / lead to trash words (fused path).  `pl`, `nl`: local node index or -1.
-template <int N, int B, bool REACTIVE, class Ctx, class Out>
-__device__ __forceinline__ void va_emit_branch(const Ctx& d, const double* u, const Out& s, const double (&Vf)[N], const int* nd, int b, int pl, int nl,
-                                               const Dual<N>& I, const Dual<N>& Q, bool vdep) {
+// `ld[j]` = V(probe_j) - w_j of $limit site j: the partials N + j of I and Q re-anchor the companion model at w.
+template <int N, int S, int B, bool REACTIVE, class Ctx, class Out>
+__device__ __forceinline__ void va_emit_branch(const Ctx& d, const double* u, const Out& s, const double (&Vf)[N], const double* ld, const int* nd, int b, int pl,
+                                               int nl, const Dual<N + S>& I, const Dual<N + S>& Q, bool vdep) {
   const double CS = CADNIP_CHARGE_SCALE;
-  double Ieq = I.v;
+  double Ieq = I.v, Ilim = 0.0, Qlim = 0.0;
+#pragma unroll
+  for (int j = 0; j < S; ++j) { Ilim += I.p[N + j] * ld[j]; Qlim += Q.p[N + j] * ld[j]; }
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     s.G(2 * N * b + 2 * k, I.p[k]);
@@ -91,16 +113,18 @@ __device__ __forceinline__ void va_emit_branch(const Ctx& d, const double* u, co
       s.C(2 * B + 2 * N * b + 2 * k, Q.p[k]);
       s.C(2 * B + 2 * N * b + 2 * k + 1, -Q.p[k]);
     }
+    bq += Qlim;                       // same summation order as the reference: value, node terms, then the lim_rhs terms
     s.B(3 * b + 2, CS * bq);
   }
+  Ieq += Ilim;
   s.B(3 * b, -Ieq);
   s.B(3 * b + 1, Ieq);
   if constexpr (Out::DIRECT) {   // the branch's share of r = C du + G u - b, straight from I and Q
-    double r = I.v;
+    double r = I.v + Ilim;
     if (REACTIVE) {
       if (vdep) {
         const int nq = nd[N + b];
-        s.Rn(nq, u[nq] - CS * Q.v);
+        s.Rn(nq, u[nq] - CS * (Q.v + Qlim));
         r += s.du(nq) * (1.0 / CS);
       } else {
 #pragma unroll

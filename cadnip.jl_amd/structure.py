@@ -408,21 +408,54 @@ def detect_va_vdep(circuit: Circuit, params: Dict[str, float], seed: int = 0xDEA
         elif ty.startswith("VA:"):
             mod = va.get(ty[3:])[1]
             internal[d.name] = [A.node("%s_%s_%s" % (d.name, mod.name, nm)) for nm in mod.nodes[len(mod.ports):]]
+            n_lim += len(mod.limit_branches)
     n_nodes = len(A.node_names)
     rng = np.random.default_rng(seed)
     is_vdep, Qs, Vs = [], [], []
     n_q_prev = 0
     last = {}
     for p in range(5):
-        x = np.zeros(n_nodes) if p == 0 else (rng.random(n_nodes + n_cur + n_m1q + n_q_prev + n_lim) - 0.5) * 2.0
-        n_q = 0
-        for d in devs:
-            mod = va.get(d.type[3:])[1]
+        x = np.zeros(0) if p == 0 else (rng.random(n_nodes + n_cur + n_m1q + n_q_prev + n_lim) - 0.5) * 2.0
+
+        def xat(i):      # 0-based read, tolerant of a short x (vasim.jl:3123-3133)
+            return float(x[i]) if 0 <= i < len(x) else 0.0
+        # the builder allocates as it goes: an index resolved in the middle of a pass uses the counts reached so far
+        # (context.jl:577-581), which is where a $limit preamble finds its `vold`
+        seen_nodes, cur_sf, q_sf, lim_sf = set(), 0, 0, 0
+        for d in circuit.devices:
+            ty = d.type
+            for nm in d.nodes:
+                if nm not in ("0", "gnd", "gnd!"):
+                    seen_nodes.add(nm)
+            if ty in ("L", "V", "BV", "E", "F"):
+                cur_sf += 1
+            elif ty == "H":
+                cur_sf += 2
+            elif ty == "D" and bool(d.params.get("limit", True)):
+                lim_sf += 1
+            elif ty == "MOS1":
+                given = {k: resolve(v, params) for k, v in d.model.items()}
+                sc_d, sc_s = m1.short_circuits(given)
+                seen_nodes.update(nm for nm, sc in (("%s_sp_mos1_d_int" % d.name, sc_d), ("%s_sp_mos1_s_int" % d.name, sc_s)) if not sc)
+                lim_sf += 4
+                q_sf += sum(m1v)
+            if ty in ("BV", "BI"):
+                for tok in bsource.compile_expr(d.params["expr"]):
+                    if tok[0] == "v":
+                        seen_nodes.update(nm for nm in (tok[1], tok[2]) if nm not in ("0", "gnd", "gnd!"))
+            if not ty.startswith("VA:"):
+                continue
+            mod = va.get(ty[3:])[1]
             par = va.host_eval.defaults(mod, {k: float(np.asarray(resolve(v, params)).flat[0]) for k, v in d.model.items()})
             idx = [A.node(nm) for nm in d.nodes] + internal[d.name]
-            V = [0.0 if t == GND else float(x[t[1]]) for t in idx]
+            seen_nodes.update(A.node_names[t[1]] for t in internal[d.name])
+            V = [0.0 if t == GND else xat(t[1]) for t in idx]
+            vold = []
+            for l in range(len(mod.limit_branches)):
+                lim_sf += 1
+                vold.append(xat(len(seen_nodes) + cur_sf + q_sf + lim_sf - 1))
             mf = float(np.asarray(resolve(d.params["m"], params)).flat[0])
-            vals = va.host_eval.evaluate(mod, V, par, 27.0 + 273.15, mf, 1e-12)
+            vals = va.host_eval.evaluate(mod, V, par, 27.0 + 273.15, mf, 1e-12, vold=vold)
             flags, pos = [], 0
             for b, (pn, nn) in enumerate(mod.branches):
                 if not mod.reactive[b]:
@@ -440,10 +473,10 @@ def detect_va_vdep(circuit: Circuit, params: Dict[str, float], seed: int = 0xDEA
                             is_vdep[pos] = True
                     Qs[pos], Vs[pos] = Q, Vb
                 flags.append(is_vdep[pos])
-                n_q += int(is_vdep[pos])
+                q_sf += int(is_vdep[pos])
                 pos += 1
             last[d.name] = tuple(flags)
-        n_q_prev = n_q
+        n_q_prev = q_sf - n_m1q
     return last
 
 
@@ -526,6 +559,8 @@ def discover(circuit: Circuit, params: Dict[str, float]) -> Structure:
             for b, (p, n) in enumerate(mod.branches):
                 nm = "%s_%s_Q_%s_%s" % (dev.name, mod.name, mod.nodes[p] if p >= 0 else "0", mod.nodes[n] if n >= 0 else "0")
                 nodes.append(A.charge(nm) if (mod.reactive[b] and vd[b]) else GND)
+            for (p, n) in mod.limit_branches:      # one limit unknown per $limit probe branch, init 0 (vasim.jl:3110-3138)
+                nodes.append(A.limit("%s_%s_lim_%s_%s" % (dev.name, mod.name, mod.nodes[p] if p >= 0 else "0", mod.nodes[n] if n >= 0 else "0"), 0.0))
             ipar = [mid, sum((1 << b) for b in range(len(mod.branches)) if mod.reactive[b] and vd[b])]
             prog = mod.program(vd)
         d_in_block = len(per_type[ty])

@@ -14,10 +14,13 @@ Supported::
       x = expr;   I(a,b) <+ expr;   I(a) <+ expr;   if (c) stmt [else stmt];   begin ... end
     expressions: + - * / unary- ! comparison && || ?:  numbers with scale factors (T G M K k m u n p f a)
       V(a,b) V(a)  ddt(e)  exp ln log sqrt pow abs min max limexp tanh sinh cosh sin cos atan
-      $vt [$vt(T)]  $temperature  $mfactor  $simparam("gmin"[, default])
+      $vt [$vt(T)]  $temperature  $mfactor  $simparam("gmin"|"initjct"[, default])
+    analog function real NAME; input a, b; real x; begin ... NAME = expr; end endfunction      // pure functions of their inputs
+    $limit(V(p,n), NAME, args...)      // PCNR limiting with the user function NAME(vnew, vold, args...) (vasim.jl:1258-1330);
+                                       // top level of the analog block only, as in the reference
 
-Not supported (an error, never a silent approximation): ``$limit``, potential contributions ``V() <+``, named branches,
-``@(...)`` events, loops, user functions, ``idt``, noise sources.
+Not supported (an error, never a silent approximation): potential contributions ``V() <+``, named branches,
+``@(...)`` events, loops, ``idt``, noise sources, the string form of ``$limit``.
 """
 import re
 from dataclasses import dataclass, field
@@ -67,6 +70,9 @@ class VAModule:
     reactive: List[bool] = field(default_factory=list)                # per branch: its contributions carry ddt()
     var_is_dual: Dict[str, bool] = field(default_factory=dict)        # local depends on a voltage
     var_is_reactive: Dict[str, bool] = field(default_factory=dict)    # local carries a ddt() part
+    functions: Dict[str, tuple] = field(default_factory=dict)         # analog functions: name -> (inputs, locals, body)
+    limit_branches: List[Tuple[int, int]] = field(default_factory=list)   # probe branches of the $limit sites, first-use order
+    limit_sites: List[int] = field(default_factory=list)              # per $limit call site (evaluation order): its limit branch
     source: str = ""
 
     @property
@@ -77,22 +83,34 @@ class VAModule:
     def n_internal(self):
         return len(self.nodes) - len(self.ports)
 
+    @property
+    def n_sites(self):
+        return len(self.limit_sites)
+
     # ---- stamp layout (structure.py / hipgen.py / oracle agree on it) ------------------------------------------
-    # local unknowns: nodes 0..N-1, then one charge unknown per branch (ground when the branch has none)
+    # local unknowns: nodes 0..N-1, then one charge unknown per branch (ground when the branch has none), then one limit
+    # unknown per $limit probe branch;  g_lim rows (l,l) (l,p) (l,n) of limit branch l -> G slots 2N B + (N+1) B + 3 l + {0,1,2}
     # G slots: branch b, node k:  (p,k) -> 2N b + 2k, (n,k) -> 2N b + 2k + 1;  charge row of branch b: (q,q) -> 2N B + (N+1) b,
     #          (q,k) -> 2N B + (N+1) b + 1 + k
     # C slots: charge columns (p,q) -> 2b, (n,q) -> 2b + 1;  linear form (p,k) -> 2B + 2N b + 2k, (n,k) -> ... + 1
     # b slots: branch b: p -> 3b, n -> 3b + 1, charge row -> 3b + 2
     def shape(self):
-        N, B = self.n_nodes, len(self.branches)
+        N, B, L = self.n_nodes, len(self.branches), len(self.limit_branches)
         n_par = len(self.params) + 3        # + temperature [K], mfactor, gmin
-        return (N + B, 2 * N * B + (N + 1) * B, 2 * B + 2 * N * B, 3 * B, n_par, 2)
+        return (N + B + L, 2 * N * B + (N + 1) * B + 3 * L, 2 * B + 2 * N * B, 3 * B, n_par, 2)
 
     def program(self, vdep):
         """(stream, local slot, local row, local col) in the reference's stamp order (vasim.jl:3374-3521): per branch the
         resistive Jacobian, then the reactive part in charge-state or linear form, then the equivalent currents."""
         N, B = self.n_nodes, len(self.branches)
         prog = []
+        for l, (p, n) in enumerate(self.limit_branches):     # the hoisted $limit preamble (vasim.jl:3110-3138)
+            ul, g0 = N + B + l, 2 * N * B + (N + 1) * B + 3 * l
+            prog.append(("G", g0, ul, ul))
+            if p >= 0:
+                prog.append(("G", g0 + 1, ul, p))
+            if n >= 0:
+                prog.append(("G", g0 + 2, ul, n))
         for b, (p, n) in enumerate(self.branches):
             for k in range(N):
                 if p >= 0:
@@ -127,6 +145,7 @@ class _Parser:
     def __init__(self, text):
         self.toks = tokenize(text)
         self.i = 0
+        self.functions = {}
 
     def peek(self, k=0):
         return self.toks[self.i + k]
@@ -219,6 +238,23 @@ class _Parser:
             e = self.expr()
             self.expect(")")
             return ("ddt", e)
+        if v == "$limit":
+            self.expect("(")
+            if self.next()[1] != "V":
+                raise VAError("$limit: the first argument must be a potential probe V(p[,n])")
+            self.expect("(")
+            a = self.ident()
+            b = self.ident() if self.accept(",") else None
+            self.expect(")")
+            self.expect(",")
+            if self.peek()[0] == "str":
+                raise VAError("$limit: the string form of the limiter is not supported; name an analog function")
+            fn = self.ident()
+            args = []
+            while self.accept(","):
+                args.append(self.expr())
+            self.expect(")")
+            return ("limit", a, b, fn, args, [-1])
         if v.startswith("$"):
             args = []
             if self.accept("("):
@@ -230,13 +266,17 @@ class _Parser:
                 raise VAError("system function %s is not supported" % v)
             return ("sys", v, args)
         if self.peek()[1] == "(":
-            if v not in FUNCS:
+            if v not in FUNCS and v not in self.functions:
                 raise VAError("function %s is not supported" % v)
             self.next()
             args = []
             while not self.accept(")"):
                 args.append(self.expr())
                 self.accept(",")
+            if v in self.functions:
+                if len(args) != len(self.functions[v][0]):
+                    raise VAError("%s takes %d argument(s)" % (v, len(self.functions[v][0])))
+                return ("ucall", v, args)
             if len(args) != FUNCS[v]:
                 raise VAError("%s takes %d argument(s)" % (v, FUNCS[v]))
             return ("call", v, args)
@@ -320,6 +360,24 @@ class _Parser:
                     if self.accept(";"):
                         break
                     self.expect(",")
+            elif t == "analog" and self.peek(1)[1] == "function":
+                self.next(); self.next()
+                if self.peek()[1] in ("real", "integer"):
+                    self.next()
+                fname = self.ident()
+                self.expect(";")
+                f_in, f_loc = [], []
+                while self.peek()[1] in ("input", "real", "integer"):
+                    tgt = f_in if self.next()[1] == "input" else f_loc
+                    while True:
+                        tgt.append(self.ident())
+                        if self.accept(";"):
+                            break
+                        self.expect(",")
+                self.functions[fname] = (f_in, [x for x in f_loc if x not in f_in], None)   # visible to its own body (recursion is refused below)
+                fbody = self.stmt()
+                self.expect("endfunction")
+                self.functions[fname] = (f_in, [x for x in f_loc if x not in f_in], fbody[1] if fbody[0] == "block" else [fbody])
             elif t == "analog":
                 self.next()
                 if body is not None:
@@ -335,7 +393,7 @@ class _Parser:
             if p not in nets:
                 raise VAError("port %s of %s is not declared electrical" % (p, name))
         nodes = list(ports) + [x for x in nets if x not in ports]
-        return VAModule(name, ports, nodes, params, locals_, body[1] if body[0] == "block" else [body])
+        return VAModule(name, ports, nodes, params, locals_, body[1] if body[0] == "block" else [body], functions=dict(self.functions))
 
 
 def _walk(stmts):
@@ -359,19 +417,81 @@ def _analyse(m: VAModule):
 
     names = set(m.params) | set(m.locals_)
 
-    def check(e):
+    def check(e, names=names, in_func=False):
         k = e[0]
         if k == "var" and e[1] not in names:
             raise VAError("%s: %s is neither a parameter nor a declared variable" % (m.name, e[1]))
+        if k in ("V", "ddt", "limit") and in_func:
+            raise VAError("%s: %s inside an analog function" % (m.name, {"V": "V()", "ddt": "ddt()", "limit": "$limit"}[k]))
         if k == "V":
             node(e[1]); node(e[2])
+        if k == "limit":
+            node(e[1]); node(e[2])
+            if e[3] not in m.functions:
+                raise VAError("%s: $limit: unknown limiter function %s" % (m.name, e[3]))
+            if len(m.functions[e[3]][0]) != 2 + len(e[4]):
+                raise VAError("%s: $limit: %s takes (vnew, vold, ...) = %d arguments" % (m.name, e[3], len(m.functions[e[3]][0])))
+            for a in e[4]:
+                check(a, names, in_func)
+            return
         for sub in e[1:]:
             if isinstance(sub, tuple):
-                check(sub)
+                check(sub, names, in_func)
             elif isinstance(sub, list):
                 for a in sub:
                     if isinstance(a, tuple):
-                        check(a)
+                        check(a, names, in_func)
+
+    # ---- analog functions: pure, non-recursive (a function sees the ones defined before it)
+    seen = set()
+    for fname, (f_in, f_loc, f_body) in m.functions.items():
+        fnames = set(f_in) | set(f_loc) | {fname}
+
+        def fcheck(e):
+            if e[0] == "ucall" and e[1] not in seen:
+                raise VAError("%s: %s calls %s, which is not defined before it" % (m.name, fname, e[1]))
+            for sub in e[1:]:
+                for a in (sub if isinstance(sub, list) else [sub]):
+                    if isinstance(a, tuple) and a and isinstance(a[0], str):
+                        fcheck(a)
+        for s in _walk(f_body):
+            if s[0] == "assign":
+                if s[1] not in fnames:
+                    raise VAError("%s: %s assigns %s, which it does not declare" % (m.name, fname, s[1]))
+                check(s[2], fnames, True); fcheck(s[2])
+            elif s[0] == "if":
+                check(s[1], fnames, True); fcheck(s[1])
+            elif s[0] == "contrib":
+                raise VAError("%s: contribution inside the analog function %s" % (m.name, fname))
+        seen.add(fname)
+
+    # ---- $limit call sites: numbered in source order; top level of the analog block only (vasim.jl:1278-1279)
+    def sites(e, allowed):
+        if e[0] == "limit":
+            if not allowed:
+                raise VAError("%s: $limit under a runtime conditional is unsupported" % m.name)
+            br = (node(e[1]), node(e[2]))
+            if br not in m.limit_branches:
+                m.limit_branches.append(br)
+            e[5][0] = len(m.limit_sites)
+            m.limit_sites.append(m.limit_branches.index(br))
+        for sub in e[1:]:
+            for a in (sub if isinstance(sub, list) else [sub]):
+                if isinstance(a, tuple) and a and isinstance(a[0], str):
+                    sites(a, allowed)
+
+    def site_walk(stmts, allowed):
+        for s in stmts:
+            if s[0] == "assign":
+                sites(s[2], allowed)
+            elif s[0] == "contrib":
+                sites(s[3], allowed)
+            elif s[0] == "block":
+                site_walk(s[1], allowed)
+            elif s[0] == "if":
+                sites(s[1], False)
+                site_walk([s[2], s[3]], False)
+    site_walk(m.body, True)
 
     for s in _walk(m.body):
         if s[0] == "assign":
@@ -396,7 +516,7 @@ def _analyse(m: VAModule):
 
     def is_dual(e):
         k = e[0]
-        if k == "V":
+        if k in ("V", "limit"):
             return True
         if k == "var":
             return dual.get(e[1], False)
@@ -431,9 +551,11 @@ def _analyse(m: VAModule):
             if is_react(e[1]):
                 raise VAError("%s: ddt() inside a condition" % m.name)
             return is_react(e[2]) or is_react(e[3])
-        if k in ("call", "sys"):
+        if k in ("call", "sys", "ucall"):
             if any(isinstance(a, tuple) and a[0] != "str" and is_react(a) for a in e[2]):
                 raise VAError("%s: ddt() inside a function argument" % m.name)
+        if k == "limit" and any(is_react(a) for a in e[4]):
+            raise VAError("%s: ddt() inside a $limit argument" % m.name)
         return False
 
     changed = True

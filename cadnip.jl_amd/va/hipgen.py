@@ -22,12 +22,18 @@ def _lit(x):
 
 
 class _Gen:
-    def __init__(self, m):
+    def __init__(self, m, func=None):
         self.m = m
         self.lines = []
+        self.pre = []          # definitions of $limit sites: emitted in front of the statement that uses them
+        self.func = func       # name of the analog function being generated: every variable has the template type X
+        self.tname = "X" if func else "T"
 
     def T(self, code, is_t):
-        return code if is_t else "T(%s)" % code
+        return code if is_t else "%s(%s)" % (self.tname, code)
+
+    def fname(self, f):
+        return "vaf_%s_%s" % (self.m.name, f)
 
     # expression -> (resistive code, it is a dual, reactive code or None)
     def g(self, e):
@@ -35,9 +41,30 @@ class _Gen:
         if k == "num":
             return _lit(e[1]), False, None
         if k == "var":
+            if self.func:
+                return "f_" + e[1], True, None
             if e[1] in m.params:
                 return "p_" + e[1], False, None
             return "v_" + e[1], m.var_is_dual[e[1]], ("v_%s_q" % e[1]) if m.var_is_reactive[e[1]] else None
+        if k == "ucall":
+            args = [self.g(a) for a in e[2]]
+            t = any(a[1] for a in args)
+            if self.func:
+                return "%s<X>(%s, sys)" % (self.fname(e[1]), ", ".join(self.T(a[0], a[1]) for a in args)), True, None
+            if t:
+                return "%s<T>(%s, sys)" % (self.fname(e[1]), ", ".join(self.T(a[0], a[1]) for a in args)), True, None
+            return "%s<double>(%s, sys)" % (self.fname(e[1]), ", ".join(a[0] for a in args)), False, None
+        if k == "limit":
+            # vasim.jl:1258-1330: w = limiter(vnew, vold, args...) on values; the site's dual is anchored at w, keeps the
+            # probe's node partials and owns partial N + j
+            j, lb = e[5][0], m.limit_sites[e[5][0]]
+            probe = self.g(("V", e[1], e[2]))[0]
+            args = ", ".join(["va_val(%s)" % probe, "vold%d" % lb] + ["va_val(%s)" % self.g(a)[0] for a in e[4]])
+            self.pre.append("const double lim_w%d = %s<double>(%s, sys);" % (j, self.fname(e[3]), args))
+            self.pre.append("if (lw) lw[nd[N + B + %d]] = lim_w%d;" % (lb, j))
+            self.pre.append("ld[%d] = va_val(%s) - lim_w%d;" % (j, probe, j))
+            self.pre.append("const T site%d = va_site(%s, lim_w%d, N + %d);" % (j, probe, j, j))
+            return "site%d" % j, True, None
         if k == "V":
             a, b = m.node_index(e[1]), m.node_index(e[2])
             if a >= 0 and b >= 0:
@@ -68,16 +95,18 @@ class _Gen:
             return "va_%s(%s)" % (e[1], ", ".join(a[0] for a in args)), any(a[1] for a in args), None
         if k == "sys":
             if e[1] == "$temperature":
-                return "sys_temp", False, None
+                return "sys.temp", False, None
             if e[1] == "$mfactor":
-                return "sys_mf", False, None
+                return "sys.mf", False, None
             if e[1] == "$vt":
                 if e[2]:
                     c, t, _ = self.g(e[2][0])
                     return "(%s * %s)" % (_lit(K_OVER_Q), c), t, None
-                return "(%s * sys_temp)" % _lit(K_OVER_Q), False, None
+                return "(%s * sys.temp)" % _lit(K_OVER_Q), False, None
             if e[2] and e[2][0] == ("str", "gmin"):
-                return "sys_gmin", False, None
+                return "sys.gmin", False, None
+            if e[2] and e[2][0] == ("str", "initjct"):
+                return "sys.initjct", False, None
             if len(e[2]) > 1:
                 return self.g(e[2][1])
             raise VAError("$simparam(%r) has no value on the device" % (e[2][0][1] if e[2] else ""))
@@ -107,12 +136,17 @@ class _Gen:
         for s in body:
             if s[0] == "assign":
                 c, t, q = self.g(s[2])
+                self.flush(pad)
+                if self.func:
+                    self.lines.append("%sf_%s = %s;" % (pad, s[1], c))
+                    continue
                 self.lines.append("%sv_%s = %s;" % (pad, s[1], c))
                 if m.var_is_reactive[s[1]]:
                     self.lines.append("%sv_%s_q = %s;" % (pad, s[1], q or "T(0.0)"))
             elif s[0] == "contrib":
                 b = m.branches.index((m.node_index(s[1]), m.node_index(s[2])))
                 c, t, q = self.g(s[3])
+                self.flush(pad)
                 self.lines.append("%sbr%d_r = br%d_r + %s;" % (pad, b, b, c))
                 if q:
                     self.lines.append("%sbr%d_q = br%d_q + %s;" % (pad, b, b, q))
@@ -127,20 +161,48 @@ class _Gen:
                 self.lines.append("%s}" % pad)
 
 
+def _flush(self, pad):
+    for l in self.pre:
+        self.lines.append(pad + l)
+    self.pre = []
+
+
+_Gen.flush = _flush
+
+
+def generate_analog_functions(m):
+    """``template <class X> X vaf_<module>_<name>(X inputs..., const VaSys& sys)`` per analog function: instantiated
+    with double ($limit limiters, voltage-independent calls) and with the module's dual type."""
+    out = []
+    for fname, (f_in, f_loc, f_body) in m.functions.items():
+        g = _Gen(m, func=fname)
+        out.append("template <class X>")
+        out.append("__device__ inline X vaf_%s_%s(%s) {" % (m.name, fname, ", ".join(["X f_%s" % a for a in f_in] + ["const VaSys& sys"])))
+        for v in f_loc + [fname]:
+            out.append("  X f_%s = 0.0;" % v)
+        g.stmts(f_body, 1)
+        out.extend(g.lines)
+        out.append("  return f_%s;" % fname)
+        out.append("}")
+    return "\n".join(out)
+
+
 def generate_function(m):
-    N, B, NP = m.n_nodes, len(m.branches), len(m.params)
+    N, B, NP, S, NL = m.n_nodes, len(m.branches), len(m.params), m.n_sites, len(m.limit_branches)
     g = _Gen(m)
     L = g.lines
+    if m.functions:
+        L.append(generate_analog_functions(m))
     L.append("// module %s: nodes (%s), %d parameter(s), branches %s" % (
         m.name, ", ".join(m.nodes), NP, ", ".join("(%s,%s)%s" % (m.nodes[p] if p >= 0 else "gnd", m.nodes[n] if n >= 0 else "gnd",
                                                                " reactive" if r else "") for (p, n), r in zip(m.branches, m.reactive))))
     L.append("template <class Ctx, class Out>")
-    L.append("__device__ inline void stamp_va_%s(const Ctx& d, const double* u, const Out& s, double*) {" % m.name)
-    L.append("  constexpr int N = %d, B = %d;" % (N, B))
-    L.append("  typedef Dual<N> T;")
-    L.append("  int nd[N + B];")
+    L.append("__device__ inline void stamp_va_%s(const Ctx& d, const double* u, const Out& s, double* lw) {" % m.name)
+    L.append("  constexpr int N = %d, B = %d, S = %d, NL = %d;   // nodes, branches, $limit sites, limit unknowns" % (N, B, S, NL))
+    L.append("  typedef Dual<N + S> T;")
+    L.append("  int nd[N + B + NL];")
     L.append("#pragma unroll")
-    L.append("  for (int k = 0; k < N + B; ++k) nd[k] = node_of(d, k);")
+    L.append("  for (int k = 0; k < N + B + NL; ++k) nd[k] = node_of(d, k);")
     L.append("  double Vf[N];")
     L.append("#pragma unroll")
     L.append("  for (int k = 0; k < N; ++k) Vf[k] = volt(u, nd[k]);")
@@ -148,8 +210,12 @@ def generate_function(m):
         L.append("  const T V%d = T::seed(Vf[%d], %d);   // V(%s)" % (k, k, k, m.nodes[k]))
     for i, p in enumerate(m.params):
         L.append("  const double p_%s = par_of(d, %d);" % (p, i))
-    L.append("  const double sys_temp = par_of(d, %d), sys_mf = par_of(d, %d), sys_gmin = par_of(d, %d);" % (NP, NP + 1, NP + 2))
-    L.append("  (void)sys_temp; (void)sys_gmin;")
+    L.append("  const VaSys sys{par_of(d, %d), par_of(d, %d), par_of(d, %d), d.initjct ? 1.0 : 0.0};   // $temperature, $mfactor, gmin, initjct" % (NP, NP + 1, NP + 2))
+    L.append("  double ld[S > 0 ? S : 1] = {0.0};    // per $limit site: V(probe) - w, the lim_rhs delta (vasim.jl:2957-2966)")
+    for lb, (p, n) in enumerate(m.limit_branches):
+        L.append("  const double vold%d = u[nd[N + B + %d]];   // limit unknown of probe branch (%s,%s)" % (
+            lb, lb, m.nodes[p] if p >= 0 else "gnd", m.nodes[n] if n >= 0 else "gnd"))
+        L.append("  va_emit_limit_rows<N, B>(s, %d);" % lb)
     for v in m.locals_:
         L.append("  %s v_%s = 0.0;" % ("T" if m.var_is_dual[v] else "double", v))
         if m.var_is_reactive[v]:
@@ -159,8 +225,11 @@ def generate_function(m):
     g.stmts(m.body, 1)
     L.append("  const int vdep = d.ipar[1 * d.count + d.dev];   // bit b: branch b uses a charge unknown")
     for b, ((p, n), r) in enumerate(zip(m.branches, m.reactive)):
-        L.append("  va_emit_branch<N, B, %s>(d, u, s, Vf, nd, %d, %d, %d, sys_mf * br%d_r, sys_mf * br%d_q, ((vdep >> %d) & 1) != 0);"
+        L.append("  va_emit_branch<N, S, B, %s>(d, u, s, Vf, ld, nd, %d, %d, %d, sys.mf * br%d_r, sys.mf * br%d_q, ((vdep >> %d) & 1) != 0);"
                  % ("true" if r else "false", b, p, n, b, b, b))
+    for lb, (p, n) in enumerate(m.limit_branches):
+        L.append("  if constexpr (Out::DIRECT) s.Rn(nd[N + B + %d], vold%d - (%s));   // limit row: u_l - V(probe)" % (
+            lb, lb, " - ".join(["Vf[%d]" % p if p >= 0 else "0.0", "Vf[%d]" % n if n >= 0 else "0.0"])))
     L.append("}")
     return "\n".join(L)
 

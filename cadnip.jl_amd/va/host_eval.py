@@ -36,18 +36,38 @@ def _q(x):
     return x.q if isinstance(x, _Pair) else 0.0
 
 
-def evaluate(m, V, par, temp_k=300.15, mfactor=1.0, gmin=1e-12):
+def evaluate(m, V, par, temp_k=300.15, mfactor=1.0, gmin=1e-12, vold=None, initjct=0):
     """Branch values of module ``m`` at node voltages ``V`` (list over m.nodes): ``[(I_b, q_b)]`` per branch, before the
-    multiplicity factor.  ``par``: parameter name -> number (all of them; see ``defaults``)."""
+    multiplicity factor.  ``par``: parameter name -> number (all of them; see ``defaults``); ``vold``: the value of the
+    limit unknown of every $limit probe branch (zeros when omitted)."""
     env = {v: 0.0 for v in m.locals_}
     acc = [_Pair(0.0, 0.0) for _ in m.branches]
+    vold = list(vold) if vold is not None else [0.0] * len(m.limit_branches)
+    scope = [None]          # the analog function being evaluated: its variables shadow everything
+
+    def call(fname, args):
+        f_in, f_loc, f_body = m.functions[fname]
+        saved = scope[0]
+        scope[0] = dict({v: 0.0 for v in f_loc}, **dict(zip(f_in, args)), **{fname: 0.0})
+        fenv = scope[0]
+        run(f_body)
+        scope[0] = saved
+        return fenv[fname]
 
     def ev(e):
         k = e[0]
         if k == "num":
             return e[1]
         if k == "var":
+            if scope[0] is not None:
+                return scope[0][e[1]]
             return par[e[1]] if e[1] in par else env[e[1]]
+        if k == "ucall":
+            return call(e[1], [ev(a) for a in e[2]])
+        if k == "limit":
+            a, b = m.node_index(e[1]), m.node_index(e[2])
+            vnew = (V[a] if a >= 0 else 0.0) - (V[b] if b >= 0 else 0.0)
+            return call(e[3], [vnew, vold[m.limit_sites[e[5][0]]]] + [ev(x) for x in e[4]])
         if k == "V":
             a, b = m.node_index(e[1]), m.node_index(e[2])
             return (V[a] if a >= 0 else 0.0) - (V[b] if b >= 0 else 0.0)
@@ -71,6 +91,8 @@ def evaluate(m, V, par, temp_k=300.15, mfactor=1.0, gmin=1e-12):
                 return mfactor
             if e[2] and e[2][0] == ("str", "gmin"):
                 return gmin
+            if e[2] and e[2][0] == ("str", "initjct"):
+                return float(initjct)
             if len(e[2]) > 1:
                 return ev(e[2][1])
             raise VAError("$simparam(%r) has no value here" % (e[2][0][1] if e[2] else ""))
@@ -94,7 +116,7 @@ def evaluate(m, V, par, temp_k=300.15, mfactor=1.0, gmin=1e-12):
     def run(stmts):
         for s in stmts:
             if s[0] == "assign":
-                env[s[1]] = ev(s[2])
+                (scope[0] if scope[0] is not None else env)[s[1]] = ev(s[2])
             elif s[0] == "contrib":
                 b = m.branches.index((m.node_index(s[1]), m.node_index(s[2])))
                 x = ev(s[3])

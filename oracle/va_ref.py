@@ -5,7 +5,8 @@ front end parses: node voltages are seeded as ``Dual{JacobianTag}`` (one partial
 analog block is evaluated on them with ``ddt`` producing ``Dual{ContributionTag}`` pairs (contrib.jl:356-375), and every
 branch (p, n) is stamped as in :3319-3521 -- G[p,k] += dI/dV_k, G[n,k] -= ..., equivalent currents into b, and the
 reactive part either through a charge unknown (:3433-3472) or as constant capacitances (:3474-3482), chosen by
-``ctx.detect_or_cached`` (contrib.jl:214-257).  No ``$limit`` sites (the front end rejects them).
+``ctx.detect_or_cached`` (contrib.jl:214-257).  ``$limit`` sites follow vasim.jl:1258-1330 (site dual anchored at the
+limiter's value, own partial slot), the hoisted limit preamble :3110-3138 and the lim_rhs terms :2957-2966.
 
 The syntax tree comes from the product's parser (cadnip.jl_amd/va/frontend.py); the arithmetic, the dual numbers
 (oracle/dual.py) and the stamping are the oracle's own.  Pure-Python: meant for small cases.
@@ -64,17 +65,37 @@ FUNCS = {
 }
 
 
-def evaluate(mod, Vd, par, temp_k, mfactor, gmin):
-    """Branch contributions of ``mod`` on dual node voltages ``Vd``: one Dual / CDual / float per branch."""
+def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False):
+    """Branch contributions of ``mod`` on dual node voltages ``Vd``: one Dual / CDual / float per branch.
+    ``limit_site(j, vnew_dual, fn)`` implements a $limit call site (stamp_va)."""
     env = {v: 0.0 for v in mod.locals_}
     acc = [0.0 for _ in mod.branches]
+    scope = [None]
+
+    def call(fname, args):
+        f_in, f_loc, f_body = mod.functions[fname]
+        saved = scope[0]
+        fenv = dict({v: 0.0 for v in f_loc}, **dict(zip(f_in, args)), **{fname: 0.0})
+        scope[0] = fenv
+        run(f_body)
+        scope[0] = saved
+        return fenv[fname]
 
     def ev(e):
         k = e[0]
         if k == "num":
             return e[1]
         if k == "var":
+            if scope[0] is not None:
+                return scope[0][e[1]]
             return par[e[1]] if e[1] in par else env[e[1]]
+        if k == "ucall":
+            return call(e[1], [ev(a) for a in e[2]])
+        if k == "limit":
+            a, b = mod.node_index(e[1]), mod.node_index(e[2])
+            vnew = (Vd[a] if a >= 0 else 0.0) - (Vd[b] if b >= 0 else 0.0)
+            user = [ev(x) for x in e[4]]
+            return limit_site(e[5][0], vnew, lambda vn, vo: call(e[3], [vn, vo] + user))
         if k == "V":
             a, b = mod.node_index(e[1]), mod.node_index(e[2])
             return (Vd[a] if a >= 0 else 0.0) - (Vd[b] if b >= 0 else 0.0)
@@ -96,6 +117,8 @@ def evaluate(mod, Vd, par, temp_k, mfactor, gmin):
                 return mfactor
             if e[2] and e[2][0] == ("str", "gmin"):
                 return gmin
+            if e[2] and e[2][0] == ("str", "initjct"):
+                return 1.0 if initjct else 0.0
             return ev(e[2][1])
         op, l, r = e[1], ev(e[2]), ev(e[3])
         if op == "+":
@@ -113,7 +136,7 @@ def evaluate(mod, Vd, par, temp_k, mfactor, gmin):
     def run(stmts):
         for s in stmts:
             if s[0] == "assign":
-                env[s[1]] = ev(s[2])
+                (scope[0] if scope[0] is not None else env)[s[1]] = ev(s[2])
             elif s[0] == "contrib":
                 b = mod.branches.index((mod.node_index(s[1]), mod.node_index(s[2])))
                 acc[b] = acc[b] + ev(s[3])
@@ -128,13 +151,40 @@ def evaluate(mod, Vd, par, temp_k, mfactor, gmin):
 
 def stamp_va(ctx, mod, ext_nodes, x, par, spec, instance, mfactor=1.0, gmin=None):
     """The generated stamp! body for one instance of ``mod`` (vasim.jl:3886-3963)."""
-    N = len(mod.nodes)
+    N, S = len(mod.nodes), mod.n_sites
+    W = N + S
     node = list(ext_nodes) + [ctx.alloc_internal_node("%s_%s_%s" % (instance, mod.name, nm)) for nm in mod.nodes[len(mod.ports):]]
+    # $limit preamble (vasim.jl:3110-3138): one limit unknown per probe branch, its tracking row u_l - (V_p - V_n) = 0
+    lidx, vold = [], []
+    for (pl, nl) in mod.limit_branches:
+        p_node, n_node = (node[pl] if pl >= 0 else 0), (node[nl] if nl >= 0 else 0)
+        li = ctx.alloc_limit("%s_%s_lim_%s_%s" % (instance, mod.name, mod.nodes[pl] if pl >= 0 else "0", mod.nodes[nl] if nl >= 0 else "0"),
+                             p_node, n_node, init=0.0)
+        lidx.append(li)
+        vold.append(x_at(x, ctx.resolve_index(li)))
+        ctx.stamp_G(li, li, 1.0)
+        ctx.stamp_G(li, p_node, -1.0)
+        ctx.stamp_G(li, n_node, 1.0)
     Vf = [x_at(x, nd) for nd in node]
     ctx.reset_detection_counter()                                                  # vasim.jl:3926
-    Vd = [Dual.seed(Vf[k], k, N) for k in range(N)]                                # vasim.jl:3617-3626
+    Vd = [Dual.seed(Vf[k], k, W) for k in range(N)]                                # vasim.jl:3617-3626
+    limw = [0.0] * S
+
+    def limit_site(j, vnew, fn):                                                   # vasim.jl:1258-1330
+        lb = mod.limit_sites[j]
+        w = val(fn(val(vnew), vold[lb]))
+        limw[j] = w
+        ctx.record_limit_w(lidx[lb], w)
+        seed = np.zeros(W)
+        seed[N + j] = 1.0
+        return vnew - val(vnew) + w + Dual(0.0, seed)
+
+    def lim_delta(j):                                                              # limit_rhs_terms vasim.jl:2957-2966
+        pl, nl = mod.limit_branches[mod.limit_sites[j]]
+        return (Vf[pl] if pl >= 0 else 0.0) - (Vf[nl] if nl >= 0 else 0.0) - limw[j]
+
     temp_k = float(getattr(spec, "temp", 27.0)) + 273.15
-    Ibr = evaluate(mod, Vd, par, temp_k, mfactor, spec.gmin if gmin is None else gmin)
+    Ibr = evaluate(mod, Vd, par, temp_k, mfactor, spec.gmin if gmin is None else gmin, limit_site, ctx.initjct)
     for b, (pl, nl) in enumerate(mod.branches):
         p_node = node[pl] if pl >= 0 else 0
         n_node = node[nl] if nl >= 0 else 0
@@ -146,8 +196,8 @@ def stamp_va(ctx, mod, ext_nodes, x, par, spec, instance, mfactor=1.0, gmin=None
         # "determined by TYPE, not value" (vasim.jl:3388-3391): a branch whose contributions carry ddt() is reactive even
         # when this evaluation took a path without it
         has_reactive = has_reactive or mod.reactive[b]
-        I_val, dI = val(I_resist), partials(I_resist, N)
-        q_val, dq = val(I_react), partials(I_react, N)
+        I_val, dI = val(I_resist), partials(I_resist, W)
+        q_val, dq = val(I_react), partials(I_react, W)
         for k in range(N):
             k_node = node[k]
             if p_node != 0 and k_node != 0:
@@ -170,6 +220,8 @@ def stamp_va(ctx, mod, ext_nodes, x, par, spec, instance, mfactor=1.0, gmin=None
                 b_con = q_val
                 for k in range(N):
                     b_con -= dq[k] * Vf[k]
+                for j in range(S):
+                    b_con += dq[N + j] * lim_delta(j)
                 ctx.stamp_b(qi, CHARGE_SCALE * b_con)
             else:
                 for k in range(N):
@@ -181,6 +233,8 @@ def stamp_va(ctx, mod, ext_nodes, x, par, spec, instance, mfactor=1.0, gmin=None
         Ieq = I_val
         for k in range(N):
             Ieq = Ieq + (-dI[k] * Vf[k])
+        for j in range(S):
+            Ieq = Ieq + dI[N + j] * lim_delta(j)
         if p_node != 0:
             ctx.stamp_b(p_node, -Ieq)
         if n_node != 0:

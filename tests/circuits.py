@@ -150,6 +150,22 @@ def va_zoo():
     return c
 
 
+def va_limited():
+    """$limit sites: the generated limited diode (va_dlim: user pnjlim through $limit, limit unknown, lim_rhs terms) as a
+    half-wave rectifier and a two-diode clamp.  (No built-in limited diode beside it: the reference's own `limit!` reads
+    x[li] unguarded and would throw during the detection passes once a junction charge shifts the limit indices,
+    devices.jl:1213-1217.)"""
+    c = cj.Circuit("generated Verilog-A module with $limit")
+    c.V("Vs", "in", "0", dc=2.0, wave=("sin", 0.3, 2.0, 1e6, 0.0, 0.0, 0.0))
+    c.VA("XD1", "va_dlim", ("in", "out"), cj=2e-12)
+    c.R("RL", "out", "0", 1e3)
+    c.C("CL", "out", "0", 1e-9)
+    c.VA("XR", "va_resistor", ("in", "x"), r=500.0)
+    c.VA("XD2", "va_dlim", ("x", "0"), **{"is": 2e-14, "n": 1.5})
+    c.VA("XD3", "va_dlim", ("0", "x"))
+    return c
+
+
 def ring_checks(v):
     """The reference's assertions on V(out1) sampled at 500 points over the last 100 ns (vadistiller_integration.jl:668-690)."""
     import numpy as np
@@ -165,6 +181,6 @@ ALL_STAMP = {
     "divider": (divider, {}), "linear_zoo": (linear_zoo, {}), "diode": (diode_rectifier, {}),
     "diode_nolimit": (lambda: diode_rectifier(False), {}), "diode_chain": (diode_chain, {}),
     "nonlinear_zoo": (nonlinear_zoo, {}), "behavioral": (behavioral, {}), "inverter": (inverter_dc, {}), "mos1_rd": (mos1_rd, {}),
-    "va_zoo": (va_zoo, {}),
+    "va_zoo": (va_zoo, {}), "va_limited": (va_limited, {}),
     "dff": (bm.dff_circuit, {"vdd": 5.0}), "dff_meyer": (lambda: bm.dff_circuit(meyer=True), {"vdd": 5.0}),
 }

@@ -95,3 +95,57 @@ def test_va_transient_fused_matches_per_op_and_conserves_charge():
     assert abs(int(got[0][1][0]) - int(got[1][1][0])) <= max(3, 0.03 * got[0][1][0]), (got[0][1], got[1][1])
     # the inverter output swings with the input (0.5 .. 1.3 V around the switching point)
     assert np.ptp(a[:, 2]) > 0.5
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_va_limit_sites_dc_pcnr_matches_oracle_and_builtin_diode(fused):
+    """$limit through the PCNR loop (solve.jl:599-698): the generated limited diode reaches the oracle's solution with the
+    same number of Newton solves (per-op path), and the same operating point as the built-in limited Diode."""
+    circ = tc.va_limited()
+    uo, oko, ito = _oracle_dc(circ, {}, "dcop")
+    sim = api.BatchSimulator(api.MNACircuit(circ, {}, api.MNASpec(mode="dcop")), [{}, {}])
+    u, conv, st = sim.dc(abstol=1e-10, maxiters=100, fused=fused)
+    names = sim.st
+    sim.close()
+    assert oko and np.all(conv)
+    assert np.max(np.abs(u[0] - uo) / np.maximum(np.abs(uo), 1.0)) < 1e-9
+    if not fused:
+        assert st["newton_iters"] == 2 * ito
+    # rectifier V -> diode -> 1k: va_dlim against the built-in Diode (devices.jl:1370-1428), same physics
+    out = []
+    for kind in ("va", "builtin"):
+        c = cj.Circuit()
+        c.V("v", "in", "0", dc=2.0)
+        if kind == "va":
+            c.VA("xd", "va_dlim", ("in", "out"))
+        else:
+            c.D("d", "in", "out", Is=1e-14, Vt=0.026, n_=1.0)
+        c.R("r", "out", "0", 1e3)
+        sim = api.BatchSimulator(api.MNACircuit(c, {}, api.MNASpec(mode="dcop")))
+        uu, cv, _ = sim.dc(abstol=1e-10, maxiters=100, fused=fused)
+        assert cv[0]
+        out.append(uu[0, sim.st.index_of("out")])
+        sim.close()
+    assert abs(out[0] - out[1]) < 1e-9 and 1.2 < out[0] < 1.4
+
+
+def test_va_limit_sites_transient_fused_matches_per_op():
+    """Rectifier and clamp from the limited module under a 1 MHz sine: fused kernel (direct residuals incl. the limit
+    rows and lim_rhs terms) against the per-op kernels, PCNR corrector on."""
+    circ = tc.va_limited()
+    ts = np.linspace(2e-7, 2e-6, 10)
+    got = {}
+    for fused in (0, 1):
+        sim = api.BatchSimulator(api.MNACircuit(circ, {}), [{}, {}])
+        st = sim.st
+        u, conv, _ = sim.dc(abstol=1e-9, mode="tranop", fused=bool(fused))
+        assert np.all(conv)
+        out, per, stats = sim.tran((0.0, 2e-6), st.state_abstol(vntol=1e-7, iabstol=1e-10, chgtol=1e-7), 1e-5, ts,
+                                   obs=[st.index_of(nm) for nm in ("out", "x")], fused=fused)
+        sim.close()
+        assert stats["n_failed"] == 0, stats
+        assert np.array_equal(out[0], out[1])
+        got[fused] = (out[0], per[0])
+    a, b = got[0][0], got[1][0]
+    assert np.max(np.abs(a - b)) < 1e-4 * max(1.0, float(np.max(np.abs(a)))), np.max(np.abs(a - b))
+    assert np.max(a[:, 0]) > 1.0 and np.max(np.abs(a[:, 1])) < 1.1          # rectified output; clamp holds |x| near a diode drop

@@ -611,9 +611,9 @@ def test_verilog_a_front_end_and_generator():
     assert i1 == pytest.approx(0.05 * 2e-3) and q1 == 0.0
     assert i2 == pytest.approx(1e-6 * np.tanh(-0.3)) and q2 == pytest.approx(-6e-12 * (-1.3))
     text = hipgen.generate_function(m)
-    assert "stamp_va_tst" in text and "constexpr int N = 4, B = 3;" in text
+    assert "stamp_va_tst" in text and "constexpr int N = 4, B = 3, S = 0, NL = 0;" in text
     assert "double v_w = 0.0;" in text and "T v_q = 0.0;" in text            # w never sees a voltage: stays a double
-    assert "va_emit_branch<N, B, true>(d, u, s, Vf, nd, 0, 0, 3," in text and "va_emit_branch<N, B, true>(d, u, s, Vf, nd, 2, 2, -1," in text
+    assert "va_emit_branch<N, S, B, true>(d, u, s, Vf, ld, nd, 0, 0, 3," in text and "va_emit_branch<N, S, B, true>(d, u, s, Vf, ld, nd, 2, 2, -1," in text
     hdr = hipgen.generate_header([m])
     assert '{"tst", 7, 39, 30, 9, 6, 2}' in hdr and "case 0: stamp_va_tst(d, u, s, lw); break;" in hdr
     # a local that carries ddt(): the reactive part follows it through assignments, sums and scaling
@@ -624,10 +624,31 @@ def test_verilog_a_front_end_and_generator():
     assert ir == pytest.approx(-0.8e-3 / 4.0) and qr == pytest.approx(-2.0 * 0.8e-12 / 4.0)
     # the modules that ship in the library parse, and their ids are their positions
     reg = va.registry()
-    assert [reg[n][0] for n in ("va_resistor", "va_capacitor", "va_diode", "va_sqmos")] == [0, 1, 2, 3]
+    assert [reg[n][0] for n in ("va_resistor", "va_capacitor", "va_diode", "va_sqmos", "va_dlim")] == [0, 1, 2, 3, 4]
+    # analog functions and $limit sites (vasim.jl:1258-1330): one limit unknown per probe branch, one dual slot per site
+    m3 = va.parse_module("""module lim(a, c, e); electrical a, c, e;
+      analog function real clip; input vnew, vold, k; real t; begin t = vnew; if (vnew > vold + k) t = vold + k; clip = t; end endfunction
+      analog function real twice; input x; begin twice = 2.0 * clip(x, 0.0, 1.0); end endfunction
+      real v1, v2, v3;
+      analog begin
+        v1 = $limit(V(a, c), clip, 0.1);  v2 = $limit(V(e), clip, 0.2);  v3 = $limit(V(a, c), clip, 0.3);
+        I(a, c) <+ 1m * v1 * v3 + twice(V(e));  I(e) <+ 2m * v2;
+      end endmodule""")
+    assert m3.limit_branches == [(0, 1), (2, -1)] and m3.limit_sites == [0, 1, 0] and list(m3.functions) == ["clip", "twice"]
+    assert m3.shape() == (3 + 2 + 2, 2 * 3 * 2 + 4 * 2 + 3 * 2, 2 * 2 + 2 * 3 * 2, 6, 3, 2)
+    assert m3.program([False, False])[:5] == [("G", 20, 5, 5), ("G", 21, 5, 0), ("G", 22, 5, 1), ("G", 23, 6, 6), ("G", 24, 6, 2)]
+    (ia, _), (ie, _) = va.host_eval.evaluate(m3, [1.0, 0.2, 0.7], {}, vold=[0.5, 0.1])
+    assert ia == pytest.approx(1e-3 * 0.6 * 0.8 + 2.0 * 0.7) and ie == pytest.approx(2e-3 * 0.3)      # clipped at vold + k; twice() clips at 1.0
+    t3 = hipgen.generate_function(m3)
+    assert "vaf_lim_clip<double>(va_val((V0 - V1)), vold0, va_val(0.3), sys)" in t3 and "const T site2 = va_site((V0 - V1), lim_w2, N + 2);" in t3
+    assert "typedef Dual<N + S> T;" in t3 and "S = 3, NL = 2" in t3 and "vaf_lim_twice<T>(V2, sys)" in t3
     # refused, never approximated
     for bad in ("module x(a); electrical a; analog V(a) <+ 1.0; endmodule",                       # potential contribution
-                'module x(a); electrical a; real v; analog begin v = $limit(V(a), "pnjlim", 1, 2); I(a) <+ v; end endmodule',
+                'module x(a); electrical a; real v; analog begin v = $limit(V(a), "pnjlim", 1, 2); I(a) <+ v; end endmodule',   # string form
+                "module x(a); electrical a; real v; analog begin v = $limit(V(a), nofn, 1.0); I(a) <+ v; end endmodule",
+                "module x(a); electrical a; analog function real f; input p, q; begin f = p; end endfunction real v;"
+                " analog begin if (V(a) > 0) v = $limit(V(a), f); I(a) <+ v; end endmodule",        # $limit under a conditional
+                "module x(a); electrical a; analog function real f; input p; begin f = f(p); end endfunction analog I(a) <+ f(V(a)); endmodule",
                 "module x(a); electrical a; analog I(a) <+ ddt(V(a)) * ddt(V(a)); endmodule",     # product of two ddt()
                 "module x(a); electrical a; analog I(a) <+ exp(ddt(V(a))); endmodule",            # ddt inside a function
                 "module x(a); electrical a; analog I(a) <+ undeclared * V(a); endmodule",
