@@ -207,3 +207,32 @@ def test_circuit_too_large_for_the_fused_kernel_runs_per_op():
         sim.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert 0.0 < res[0][0][0, 1, 0] <= 1.0 + 1e-6
+
+
+def test_dff_monte_carlo_variant_matches_port():
+    """SURVEY.md 8d config 4, Monte-Carlo variant: threshold shift ~ N(0, 0.02^2) V and kp factor ~ N(1, 0.03^2) per
+    instance from numpy.random.default_rng(0xDEADBEEF), every instance at nominal supply.  All 64 samples finish with
+    the race-free logic pins; three of them are checked against the CPU port at the 1e-9 bar."""
+    circ = bm.dff_circuit(mc_vto="dvto", mc_kp="kpf")
+    rng = np.random.default_rng(0xDEADBEEF)
+    pts = [{"vdd": 5.0, "dvto": float(a), "kpf": float(b)} for a, b in zip(rng.normal(0.0, 0.02, 64), rng.normal(1.0, 0.03, 64))]
+    sim = api.BatchSimulator(api.MNACircuit(circ, {"vdd": 5.0, "dvto": 0.0, "kpf": 1.0}), pts)
+    st = sim.st
+    sim.analyze()
+    u0, conv, _ = sim.dc(abstol=1e-9, mode="tranop")
+    assert np.all(conv)
+    ts = np.array([150e-9, 250e-9, 700e-9])
+    obs = [st.index_of("Q"), st.index_of("Q_neg")]
+    sim.h.set_spec(mode="tran")
+    breaks = expand_breakpoints(st.breakpoints, bm.DFF_TSPAN)
+    out, per, stats = sim.h.tran_run(0.0, 7e-7, st.state_abstol(**ABSTOL), 1e-4, breaks=breaks, save_t=ts, obs=obs, fused=1)
+    vs = sim.vscale()
+    sim.close()
+    assert stats["n_failed"] == 0
+    assert np.all(np.abs(out[:, 0, 0]) < 0.05) and np.all(np.abs(out[:, 1, 0]) < 0.05) and np.all(np.abs(out[:, 2, 0] - 5.0) < 0.05)
+    assert len({int(x) for x in per[:, 0]}) > 8          # the samples really differ: different Newton counts
+    for i in (0, 17, 63):
+        ref, rst = _port_run(circ, pts[i], 27.0, u0[i], ts, obs, vs)
+        assert rst["status"] == 1
+        assert abs(per[i, 0] - rst["newton_iters"]) <= 0.01 * rst["newton_iters"], (i, per[i], rst)
+        assert np.max(np.abs(out[i] - ref) / np.maximum(np.abs(ref), 1.0)) <= REL_TOL, i
