@@ -909,10 +909,12 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
     HIP_TRY(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, h->device));
     h->n_cu = cu > 0 ? cu : 256;
   }
-  // waves (= instances) per workgroup: 8 (two waves per SIMD) when they fit into LDS and the batch gives at least half of
-  // the CUs such a workgroup; else 4, 2, 1
+  // waves (= instances) per workgroup: 8 (two waves per SIMD) when they fit into LDS; fewer when the whole batch is then
+  // still resident in one generation with a workgroup on every CU -- a wave runs about 20 % faster with half as many
+  // neighbours on its CU (1024 instances: 4 per workgroup on 256 CUs, 57.7 M iterations/s, against 48.1 M as 8 x 128)
   int wpb = 8;
-  while (wpb > 1 && ((tab_dbl + wpb * per) * 8 > lds_cap || (h->B + wpb - 1) / wpb < h->n_cu / 2)) wpb >>= 1;
+  if (const char* e = getenv("CADNIP_F2_WPB")) wpb = atoi(e) >= 8 ? 8 : atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 1;   // diagnostic: cap the waves per workgroup
+  while (wpb > 1 && ((tab_dbl + wpb * per) * 8 > lds_cap || h->n_cu * (wpb / 2) >= h->B)) wpb >>= 1;
   size_t shmem = (tab_dbl + wpb * per) * 8;
   if (shmem > lds_cap) return CADNIP_BADARG;
   // resident workgroups only: the instances beyond them are handed out by the in-kernel queue as waves become free
