@@ -95,6 +95,14 @@ def _nonlinear_tran():
     return c
 
 
+def _many_sources(c, n_src=69):
+    """+ 69 small DC sources, each loaded by a resistor into the ladder's first node."""
+    for k in range(n_src):
+        c.V("vs%d" % k, "s%d" % (k + 1), "0", dc=0.01 * (k + 1))
+        c.R("rs%d" % k, "s%d" % (k + 1), "n1", 1e6)
+    return c
+
+
 FUSED_CASES = {
     # name: (circuit factory, params, tspan, saveat, observed unknowns, abstol)
     "rc": (tc.rc_charge, {}, (0.0, 3e-3), [1e-4, 1e-3, 3e-3], ["out"], 1e-9),
@@ -105,6 +113,9 @@ FUSED_CASES = {
     "inverter": (bm.inverter_circuit, {"vdd": 5.0}, (0.0, 4e-7), [5e-8, 1.05e-7, 1.5e-7, 2.05e-7, 4e-7], ["Q"], 1e-9),
     "meyer_inverter_rd": (_meyer_inverter, {}, (0.0, 2e-8), [3e-9, 8e-9, 1.3e-8, 2e-8], ["out"], 1e-9),
     "rc_ladder": (_rc_ladder, {}, (0.0, 2e-5), [2e-6, 5e-6, 1e-5, 2e-5], ["n1", "n40", "n80"], 1e-9),
+    # n = 302 > 256: the history elements beyond the register-resident 4 per lane stay in HBM; 300 capacitors > the 128 the
+    # pinned descriptors cover; 70 sources > the 64 of the pinned source block
+    "rc_ladder_300": (lambda: _many_sources(_rc_ladder(300)), {}, (0.0, 2e-5), [2e-6, 5e-6, 1e-5, 2e-5], ["n1", "n150", "n300", "s69"], 1e-9),
 }
 
 
