@@ -3,17 +3,18 @@
 
 One "step" = one complete tran! of the per-GPU sweep batch: CedarTranOp-style DC initialisation
 (:tranop, PCNR Newton) + the 0-700 ns transient of every resident sweep instance, results gathered.
-Per-GPU work is fixed (weak scaling): each rank integrates ``--instances`` corner points (default the
-32 Vdd x 32 temp grid = 1024 of BASELINE.json config 4); with N ranks the temp axis is refined to
-32*N values over the same range and split into contiguous blocks, so N GPUs
-process N x 1024 independent transients.  The only collective is the final gather of the result
+Per-GPU work is fixed (weak scaling): each rank integrates ``--instances`` corner points (default 4096:
+BASELINE.json config 4's 32-value Vdd axis x 128 temperatures, so that the 2048 instances a GPU holds at a time
+are followed by a second generation from the in-kernel queue); with N ranks the temp axis is refined N-fold over
+the same range and split into contiguous blocks, so N GPUs process N x 4096 independent
+transients.  The only collective is the final gather of the result
 blocks (RCCL all_gather), inside the timed region.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     : dominant kernel, algorithmic bytes per launch / its measured average
                  launch duration (HIP events on the launching stream), vs 8 TB/s HBM3E peak
-  cpu_baseline : the oracle's C++ port (oracle/cpu_port.cpp, 1 host core) on a bounded sample of the
-                 same workload (rank 0, N = 1 only).
+  cpu_baseline : the oracle's C++ port (oracle/cpu_port.cpp) on a bounded sample of the same workload, one port per
+                 corner point on 16 host threads; `value_1_core` is the single-thread rate (rank 0, N = 1 only).
 """
 import argparse
 import json
