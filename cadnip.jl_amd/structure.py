@@ -407,7 +407,16 @@ def detect_va_vdep(circuit: Circuit, params: Dict[str, float], seed: int = 0xDEA
             n_m1q += sum(m1v)
         elif ty.startswith("VA:"):
             mod = va.get(ty[3:])[1]
-            internal[d.name] = [A.node("%s_%s_%s" % (d.name, mod.name, nm)) for nm in mod.nodes[len(mod.ports):]]
+            alias = mod.aliases(va.host_eval.defaults(mod, {k: float(np.asarray(resolve(v, params)).flat[0]) for k, v in d.model.items()}))
+            ext = [A.node(nm) for nm in d.nodes]
+            loc = list(ext) + [None] * mod.n_internal
+            for k in range(len(mod.ports), mod.n_nodes):
+                if k not in alias:
+                    loc[k] = A.node("%s_%s_%s" % (d.name, mod.name, mod.nodes[k]))
+            for k in range(len(mod.ports), mod.n_nodes):
+                if k in alias:
+                    loc[k] = loc[alias[k]]
+            internal[d.name] = loc[len(mod.ports):]
             n_lim += len(mod.limit_branches)
     n_nodes = len(A.node_names)
     rng = np.random.default_rng(seed)
@@ -448,7 +457,7 @@ def detect_va_vdep(circuit: Circuit, params: Dict[str, float], seed: int = 0xDEA
             mod = va.get(ty[3:])[1]
             par = va.host_eval.defaults(mod, {k: float(np.asarray(resolve(v, params)).flat[0]) for k, v in d.model.items()})
             idx = [A.node(nm) for nm in d.nodes] + internal[d.name]
-            seen_nodes.update(A.node_names[t[1]] for t in internal[d.name])
+            seen_nodes.update(A.node_names[t[1]] for t in internal[d.name] if t != GND)
             V = [0.0 if t == GND else xat(t[1]) for t in idx]
             vold = []
             for l in range(len(mod.limit_branches)):
@@ -554,7 +563,12 @@ def discover(circuit: Circuit, params: Dict[str, float]) -> Structure:
                 raise ValueError("%s: %d nets for the %d ports of %s" % (dev.name, len(dev.nodes), len(mod.ports), mod.name))
             # internal nodes, then one charge unknown per voltage-dependent reactive branch, allocated in branch order as
             # the branches are stamped (vasim.jl:3533-3564, 3433-3472)
-            nodes += [A.node("%s_%s_%s" % (dev.name, mod.name, nm)) for nm in mod.nodes[len(mod.ports):]]
+            alias = mod.aliases(va.host_eval.defaults(mod, {k: float(np.asarray(resolve(v, params)).flat[0]) for k, v in dev.model.items()}))
+            for k in range(len(mod.ports), mod.n_nodes):     # a collapsed internal node is its neighbour's unknown (vasim.jl:3533-3564)
+                nodes.append(nodes[alias[k]] if k in alias and alias[k] < k else None if k in alias else A.node("%s_%s_%s" % (dev.name, mod.name, mod.nodes[k])))
+            for k in range(len(mod.ports), mod.n_nodes):     # ... also when the neighbour is a later internal node
+                if nodes[k] is None:
+                    nodes[k] = nodes[alias[k]]
             vd = va_vdep[dev.name]
             for b, (p, n) in enumerate(mod.branches):
                 nm = "%s_%s_Q_%s_%s" % (dev.name, mod.name, mod.nodes[p] if p >= 0 else "0", mod.nodes[n] if n >= 0 else "0")

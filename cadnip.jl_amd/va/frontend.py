@@ -19,7 +19,10 @@ Supported::
     $limit(V(p,n), NAME, args...)      // PCNR limiting with the user function NAME(vnew, vold, args...) (vasim.jl:1258-1330);
                                        // top level of the analog block only, as in the reference
 
-Not supported (an error, never a silent approximation): potential contributions ``V() <+``, named branches,
+    if (static condition) V(a,b) <+ 0; else I(a,b) <+ ...      // node collapse: the internal node of the pair is aliased
+                                       // to the other one for instances whose parameters make the condition true
+
+Not supported (an error, never a silent approximation): other potential contributions ``V() <+ expr``, named branches,
 ``@(...)`` events, loops, ``idt``, noise sources, the string form of ``$limit``.
 """
 import re
@@ -73,6 +76,7 @@ class VAModule:
     functions: Dict[str, tuple] = field(default_factory=dict)         # analog functions: name -> (inputs, locals, body)
     limit_branches: List[Tuple[int, int]] = field(default_factory=list)   # probe branches of the $limit sites, first-use order
     limit_sites: List[int] = field(default_factory=list)              # per $limit call site (evaluation order): its limit branch
+    shorts: List[tuple] = field(default_factory=list)                 # V(a,b) <+ 0: (a, b, [(static condition, wanted truth)])
     source: str = ""
 
     @property
@@ -86,6 +90,31 @@ class VAModule:
     @property
     def n_sites(self):
         return len(self.limit_sites)
+
+    def aliases(self, par):
+        """Node collapse of one instance: internal node index -> the node it is merged into, for the ``V(a,b) <+ 0``
+        statements whose (parameter-only) conditions hold with the parameter values ``par``."""
+        from .host_eval import static_eval
+        out = {}
+        np_ = len(self.ports)
+
+        def root(i):
+            while i in out:
+                i = out[i]
+            return i
+        for a, b, guards in self.shorts:
+            if all(bool(static_eval(c, par)) == want for c, want in guards):
+                a, b = root(a), root(b)
+                if a == b:
+                    continue
+                if a >= np_:
+                    out[a] = b
+                elif b >= np_:
+                    out[b] = a
+                else:
+                    raise VAError("%s: V(%s,%s) <+ 0 between two terminals needs a branch current (not supported)"
+                                  % (self.name, self.nodes[a], self.nodes[b]))
+        return {k: root(k) for k in out}
 
     # ---- stamp layout (structure.py / hipgen.py / oracle agree on it) ------------------------------------------
     # local unknowns: nodes 0..N-1, then one charge unknown per branch (ground when the branch has none), then one limit
@@ -305,11 +334,15 @@ class _Parser:
             b = self.ident() if self.accept(",") else None
             self.expect(")")
             if self.peek()[1] == "<+":
-                if acc == "V":
-                    raise VAError("potential contributions V(...) <+ are not supported")
                 self.next()
                 e = self.expr()
                 self.expect(";")
+                if acc == "V":
+                    # the one potential contribution compact models use: V(a,b) <+ 0 collapses an internal node onto its
+                    # neighbour when a series resistance is zero (vasim.jl:2313-2395, 3533-3564)
+                    if e != ("num", 0.0):
+                        raise VAError("potential contributions other than V(a,b) <+ 0 (node collapse) are not supported")
+                    return ("short", a, b)
                 return ("contrib", a, b, e)
             raise VAError("expected <+ after %s(%s...)" % (acc, a))
         name = self.ident()
@@ -464,6 +497,34 @@ def _analyse(m: VAModule):
             elif s[0] == "contrib":
                 raise VAError("%s: contribution inside the analog function %s" % (m.name, fname))
         seen.add(fname)
+
+    # ---- V(a,b) <+ 0: collected with the conditions that guard them, which must be decidable from the parameters
+    def is_static(e):
+        k = e[0]
+        if k in ("V", "ddt", "limit", "ucall"):
+            return False
+        if k == "var":
+            return e[1] in m.params
+        if k == "sys":
+            return e[1] != "$simparam" or not (e[2] and e[2][0] == ("str", "initjct"))
+        return all(is_static(a) for sub in e[1:] for a in (sub if isinstance(sub, list) else [sub]) if isinstance(a, tuple) and a and isinstance(a[0], str) and a[0] != "str")
+
+    def short_walk(stmts, guards):
+        for s in stmts:
+            if s[0] == "short":
+                a, b = node(s[1]), node(s[2])
+                if a < 0 or b < 0 or a == b:
+                    raise VAError("%s: V(%s,%s) <+ 0 must join two distinct nets of the module" % (m.name, s[1], s[2]))
+                for c, _ in guards:
+                    if not is_static(c):
+                        raise VAError("%s: V(%s,%s) <+ 0 under a condition that is not decided by the parameters" % (m.name, s[1], s[2]))
+                m.shorts.append((a, b, list(guards)))
+            elif s[0] == "block":
+                short_walk(s[1], guards)
+            elif s[0] == "if":
+                short_walk([s[2]], guards + [(s[1], True)])
+                short_walk([s[3]], guards + [(s[1], False)])
+    short_walk(m.body, [])
 
     # ---- $limit call sites: numbered in source order; top level of the analog block only (vasim.jl:1278-1279)
     def sites(e, allowed):

@@ -150,6 +150,8 @@ class _Gen:
                 self.lines.append("%sbr%d_r = br%d_r + %s;" % (pad, b, b, c))
                 if q:
                     self.lines.append("%sbr%d_q = br%d_q + %s;" % (pad, b, b, q))
+            elif s[0] == "short":
+                self.lines.append("%s// V(%s,%s) <+ 0: the two nets are one unknown for this instance (collapsed at structure discovery)" % (pad, s[1], s[2]))
             elif s[0] == "block":
                 self.stmts(s[1], ind)
             elif s[0] == "if":

@@ -130,6 +130,36 @@ def evaluate(m, V, par, temp_k=300.15, mfactor=1.0, gmin=1e-12, vold=None, initj
     return [(a.r, a.q) for a in acc]
 
 
+def static_eval(e, par, temp_k=300.15, mfactor=1.0, gmin=1e-12):
+    """Value of an expression over parameters and numbers only (conditions that guard a node collapse)."""
+    k = e[0]
+    if k == "num":
+        return e[1]
+    if k == "var":
+        return par[e[1]]
+    if k == "un":
+        return -static_eval(e[2], par) if e[1] == "-" else float(not static_eval(e[2], par))
+    if k == "cond":
+        return static_eval(e[2], par) if static_eval(e[1], par) else static_eval(e[3], par)
+    if k == "call":
+        return _F[e[1]](*[static_eval(a, par) for a in e[2]])
+    if k == "sys":
+        if e[1] == "$temperature":
+            return temp_k
+        if e[1] == "$vt":
+            return K_BOLTZ * (static_eval(e[2][0], par) if e[2] else temp_k) / Q_ELEM
+        if e[1] == "$mfactor":
+            return mfactor
+        if e[2] and e[2][0] == ("str", "gmin"):
+            return gmin
+        return static_eval(e[2][1], par)
+    op, l, r = e[1], static_eval(e[2], par), static_eval(e[3], par)
+    if op in "+-*/":
+        return l + r if op == "+" else l - r if op == "-" else l * r if op == "*" else l / r
+    return float({"==": l == r, "!=": l != r, "<": l < r, ">": l > r, "<=": l <= r, ">=": l >= r,
+                  "&&": bool(l) and bool(r), "||": bool(l) or bool(r)}[op])
+
+
 def defaults(m, given=None):
     """All parameter values of an instance: ``given`` overrides, the rest from the declarations (which may refer to
     earlier parameters)."""

@@ -144,6 +144,7 @@ def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False
                 run(s[1])
             elif s[0] == "if":
                 run([s[2]] if val(ev(s[1])) else [s[3]])
+            # "short" (V(a,b) <+ 0): structural, nothing to evaluate
 
     run(mod.body)
     return acc
@@ -153,7 +154,15 @@ def stamp_va(ctx, mod, ext_nodes, x, par, spec, instance, mfactor=1.0, gmin=None
     """The generated stamp! body for one instance of ``mod`` (vasim.jl:3886-3963)."""
     N, S = len(mod.nodes), mod.n_sites
     W = N + S
-    node = list(ext_nodes) + [ctx.alloc_internal_node("%s_%s_%s" % (instance, mod.name, nm)) for nm in mod.nodes[len(mod.ports):]]
+    # internal node allocation with short-circuit aliasing (vasim.jl:3533-3564): V(a,b) <+ 0 under a parameter condition
+    alias = mod.aliases(par)
+    node = list(ext_nodes) + [None] * (N - len(mod.ports))
+    for k in range(len(mod.ports), N):
+        if k not in alias:
+            node[k] = ctx.alloc_internal_node("%s_%s_%s" % (instance, mod.name, mod.nodes[k]))
+    for k in range(len(mod.ports), N):
+        if k in alias:
+            node[k] = node[alias[k]]
     # $limit preamble (vasim.jl:3110-3138): one limit unknown per probe branch, its tracking row u_l - (V_p - V_n) = 0
     lidx, vold = [], []
     for (pl, nl) in mod.limit_branches:

@@ -143,7 +143,7 @@ def va_zoo():
     c.VA("XD1", "va_diode", ("a", "k"), rs=25.0, cj0=2e-12, tt=5e-9)
     c.VA("XR2", "va_resistor", ("k", "0"), r=1e3, m=2.0)
     c.VA("XC1", "va_capacitor", ("k", "0"), c=3e-12)
-    c.VA("XD2", "va_diode", ("0", "k"), **{"is": 5e-14})
+    c.VA("XD2", "va_diode", ("0", "k"), **{"is": 5e-14, "rs": 0.0})       # rs = 0: V(a,ai) <+ 0 collapses the internal node
     c.VA("XMN", "va_sqmos", ("out", "in", "0", "0"), type=1.0, w=2e-6)
     c.VA("XMP", "va_sqmos", ("out", "in", "vdd", "vdd"), type=-1.0, vto=0.7, kp=40e-6, w=4e-6)
     c.VA("XCL", "va_capacitor", ("out", "0"), c=20e-15)

@@ -642,8 +642,17 @@ def test_verilog_a_front_end_and_generator():
     t3 = hipgen.generate_function(m3)
     assert "vaf_lim_clip<double>(va_val((V0 - V1)), vold0, va_val(0.3), sys)" in t3 and "const T site2 = va_site((V0 - V1), lim_w2, N + 2);" in t3
     assert "typedef Dual<N + S> T;" in t3 and "S = 3, NL = 2" in t3 and "vaf_lim_twice<T>(V2, sys)" in t3
+    # node collapse: V(a,b) <+ 0 under a parameter-only condition aliases the internal node for the instances it holds for
+    md = va.get("va_diode")[1]
+    assert md.shorts and md.aliases(va.host_eval.defaults(md, {"rs": 0.0})) == {2: 0} and md.aliases(va.host_eval.defaults(md, {})) == {}
+    c1, c2 = cj.Circuit(), cj.Circuit()
+    for cc, rs in ((c1, 0.0), (c2, 5.0)):
+        cc.V("v", "a", "0", dc=1.0)
+        cc.VA("x", "va_diode", ("a", "0"), rs=rs)
+    assert cj.discover(c1, {}).node_names == ["a"] and cj.discover(c2, {}).node_names == ["a", "x_va_diode_ai"]
     # refused, never approximated
-    for bad in ("module x(a); electrical a; analog V(a) <+ 1.0; endmodule",                       # potential contribution
+    for bad in ("module x(a); electrical a; analog V(a) <+ 1.0; endmodule",                       # potential contribution other than <+ 0
+                "module x(a, b); electrical a, b; analog if (V(a) > 0) V(a, b) <+ 0; endmodule",  # collapse under a voltage condition
                 'module x(a); electrical a; real v; analog begin v = $limit(V(a), "pnjlim", 1, 2); I(a) <+ v; end endmodule',   # string form
                 "module x(a); electrical a; real v; analog begin v = $limit(V(a), nofn, 1.0); I(a) <+ v; end endmodule",
                 "module x(a); electrical a; analog function real f; input p, q; begin f = p; end endfunction real v;"
