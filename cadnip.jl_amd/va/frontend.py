@@ -22,7 +22,9 @@ Supported::
     if (static condition) V(a,b) <+ 0; else I(a,b) <+ ...      // node collapse: the internal node of the pair is aliased
                                        // to the other one for instances whose parameters make the condition true
 
-Not supported (an error, never a silent approximation): other potential contributions ``V() <+ expr``, named branches,
+    branch (a,b) name;   V(name)  I(name) <+ ...                 // named branches
+
+Not supported (an error, never a silent approximation): other potential contributions ``V() <+ expr``,
 ``@(...)`` events, loops, ``idt``, noise sources, the string form of ``$limit``.
 """
 import re
@@ -175,6 +177,7 @@ class _Parser:
         self.toks = tokenize(text)
         self.i = 0
         self.functions = {}
+        self.named = {}         # branch (a,b) name;
 
     def peek(self, k=0):
         return self.toks[self.i + k]
@@ -256,9 +259,7 @@ class _Parser:
             raise VAError("unexpected %r in an expression" % v)
         if v == "V" and self.peek()[1] == "(":
             self.next()
-            a = self.ident()
-            b = self.ident() if self.accept(",") else None
-            self.expect(")")
+            a, b = self.probe_nets()
             return ("V", a, b)
         if v == "I" and self.peek()[1] == "(":
             raise VAError("branch current probes I(...) inside expressions are not supported")
@@ -272,9 +273,7 @@ class _Parser:
             if self.next()[1] != "V":
                 raise VAError("$limit: the first argument must be a potential probe V(p[,n])")
             self.expect("(")
-            a = self.ident()
-            b = self.ident() if self.accept(",") else None
-            self.expect(")")
+            a, b = self.probe_nets()
             self.expect(",")
             if self.peek()[0] == "str":
                 raise VAError("$limit: the string form of the limiter is not supported; name an analog function")
@@ -311,6 +310,15 @@ class _Parser:
             return ("call", v, args)
         return ("var", v)
 
+    def probe_nets(self):
+        """``a[, b])`` after ``V(`` / ``I(``; a single name may be a declared branch (``branch (a,b) name;``)."""
+        a = self.ident()
+        b = self.ident() if self.accept(",") else None
+        self.expect(")")
+        if b is None and a in self.named:
+            return self.named[a]
+        return a, b
+
     # ---- statements --------------------------------------------------------------------------------------------------
     def stmt(self):
         if self.accept("begin"):
@@ -330,9 +338,7 @@ class _Parser:
         if self.peek()[1] in ("I", "V") and self.peek(1)[1] == "(":
             acc = self.next()[1]
             self.next()
-            a = self.ident()
-            b = self.ident() if self.accept(",") else None
-            self.expect(")")
+            a, b = self.probe_nets()
             if self.peek()[1] == "<+":
                 self.next()
                 e = self.expr()
@@ -416,8 +422,17 @@ class _Parser:
                 if body is not None:
                     raise VAError("more than one analog block")
                 body = self.stmt()
-            elif t in ("branch", "analog function", "function"):
-                raise VAError("%s declarations are not supported" % t)
+            elif t == "branch":
+                self.next()
+                self.expect("(")
+                ba = self.ident()
+                bb = self.ident() if self.accept(",") else None
+                self.expect(")")
+                while True:
+                    self.named[self.ident()] = (ba, bb)
+                    if self.accept(";"):
+                        break
+                    self.expect(",")
             else:
                 raise VAError("unexpected %r in module %s" % (t, name))
         if body is None:

@@ -642,6 +642,11 @@ def test_verilog_a_front_end_and_generator():
     t3 = hipgen.generate_function(m3)
     assert "vaf_lim_clip<double>(va_val((V0 - V1)), vold0, va_val(0.3), sys)" in t3 and "const T site2 = va_site((V0 - V1), lim_w2, N + 2);" in t3
     assert "typedef Dual<N + S> T;" in t3 and "S = 3, NL = 2" in t3 and "vaf_lim_twice<T>(V2, sys)" in t3
+    # named branches are plain aliases of their net pair
+    m4 = va.parse_module("module nb(a, b); electrical a, b; branch (a, b) ab, again; branch (b) bg; parameter real g = 1m;"
+                         " analog begin I(ab) <+ g * V(again); I(bg) <+ 2.0 * g * V(bg); end endmodule")
+    assert m4.branches == [(0, 1), (1, -1)]
+    assert va.host_eval.evaluate(m4, [1.0, 0.25], {"g": 1e-3}) == [(pytest.approx(0.75e-3), 0.0), (pytest.approx(0.5e-3), 0.0)]
     # node collapse: V(a,b) <+ 0 under a parameter-only condition aliases the internal node for the instances it holds for
     md = va.get("va_diode")[1]
     assert md.shorts and md.aliases(va.host_eval.defaults(md, {"rs": 0.0})) == {2: 0} and md.aliases(va.host_eval.defaults(md, {})) == {}
