@@ -8,7 +8,7 @@ from . import host_eval
 
 MODEL_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models")
 # the modules compiled into libcadnip_hip.so, in model-id order (csrc/build.sh passes the same list to hipgen.py)
-MODEL_FILES = ("va_resistor.va", "va_capacitor.va", "va_diode.va", "va_sqmos.va", "va_dlim.va")
+MODEL_FILES = ("va_resistor.va", "va_capacitor.va", "va_diode.va", "va_sqmos.va", "va_dlim.va", "va_mos1l.va")
 
 _cache = {}
 

@@ -166,6 +166,33 @@ def va_limited():
     return c
 
 
+VA_NCARD = dict(type=1.0, vto=0.7, kp=100e-6, gamma=0.45, phi=0.7, cbd=1e-15, cbs=1e-15, pb=0.8, **{"lambda": 0.03})
+VA_PCARD = dict(type=-1.0, vto=-0.8, kp=50e-6, gamma=0.45, phi=0.7, cbd=1e-15, cbs=1e-15, pb=0.8, **{"lambda": 0.04})
+
+
+def va_mos_inverter(builtin=False, rd=0.0):
+    """CMOS inverter + pass transistor from the generated level-1 MOSFET (va_mos1l: three $limit sites, two junction
+    charges, series resistances that collapse when zero) -- or, with ``builtin``, the same netlist from the hand-written
+    sp_mos1 device with the same card (benchmarks.py NFET_06V0 / PFET_06V0)."""
+    c = cj.Circuit("level-1 MOSFETs: generated vs hand-written")
+    c.V("Vdd", "vdd", "0", dc=5.0)
+    c.V("Vin", "in", "0", dc=1.2, wave=("pwl", [0.0, 2e-9, 4e-9, 12e-9, 14e-9], [1.2, 1.2, 4.0, 4.0, 0.5]))
+    fets = (("mn", ("out", "in", "0", "0"), "n", 3.6e-7, 6e-7), ("mp", ("out", "in", "vdd", "vdd"), "p", 4.95e-7, 5e-7),
+            ("mt", ("y", "vdd", "out", "0"), "n", 3.6e-7, 6e-7))
+    for name, nodes, pol, w, l in fets:
+        if builtin:
+            card = dict(bm.NFET_06V0 if pol == "n" else bm.PFET_06V0)
+            if rd:
+                card.update(rd=rd, rs=rd)
+            c.MOS1(name, nodes[0], nodes[1], nodes[2], nodes[3], card, w=w, l=l)
+        else:
+            c.VA(name, "va_mos1l", nodes, w=w, l=l, rd=rd, rs=rd, **(VA_NCARD if pol == "n" else VA_PCARD))
+    c.C("cl", "out", "0", 5e-15)
+    c.C("cy", "y", "0", 2e-15)
+    c.R("ry", "y", "0", 1e6)
+    return c
+
+
 def ring_checks(v):
     """The reference's assertions on V(out1) sampled at 500 points over the last 100 ns (vadistiller_integration.jl:668-690)."""
     import numpy as np
@@ -181,6 +208,7 @@ ALL_STAMP = {
     "divider": (divider, {}), "linear_zoo": (linear_zoo, {}), "diode": (diode_rectifier, {}),
     "diode_nolimit": (lambda: diode_rectifier(False), {}), "diode_chain": (diode_chain, {}),
     "nonlinear_zoo": (nonlinear_zoo, {}), "behavioral": (behavioral, {}), "inverter": (inverter_dc, {}), "mos1_rd": (mos1_rd, {}),
-    "va_zoo": (va_zoo, {}), "va_limited": (va_limited, {}),
+    "va_zoo": (va_zoo, {}), "va_limited": (va_limited, {}), "va_mos_inverter": (va_mos_inverter, {}),
+    "va_mos_inverter_rd": (lambda: va_mos_inverter(rd=40.0), {}),
     "dff": (bm.dff_circuit, {"vdd": 5.0}), "dff_meyer": (lambda: bm.dff_circuit(meyer=True), {"vdd": 5.0}),
 }

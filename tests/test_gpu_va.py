@@ -149,3 +149,37 @@ def test_va_limit_sites_transient_fused_matches_per_op():
     a, b = got[0][0], got[1][0]
     assert np.max(np.abs(a - b)) < 1e-4 * max(1.0, float(np.max(np.abs(a)))), np.max(np.abs(a - b))
     assert np.max(a[:, 0]) > 1.0 and np.max(np.abs(a[:, 1])) < 1.1          # rectified output; clamp holds |x| near a diode drop
+
+
+@pytest.mark.parametrize("rd", [0.0, 40.0])
+def test_generated_level1_mosfet_against_the_hand_written_device(rd):
+    """va_mos1l (generated: $limit sites, junction charges, collapsing series resistances) against sp_mos1 (hand written
+    from the reference's mos1.va) with the same card at 27 C: same DC operating points over an input sweep and the same
+    switching waveform -- two independent implementations of the level-1 equations on the GPU."""
+    res = {}
+    for kind in ("va", "builtin"):
+        circ = tc.va_mos_inverter(builtin=(kind == "builtin"), rd=rd)
+        circ.devices[1].params["dc"] = cj.Param("vin")
+        pts = [{"vin": v} for v in (0.0, 1.0, 2.0, 2.4, 2.8, 3.5, 5.0)]
+        sim = api.BatchSimulator(api.MNACircuit(circ, {"vin": 1.2}, api.MNASpec(mode="dcop")), pts)
+        u, conv, _ = sim.dc(abstol=1e-13, maxiters=200)       # residual norm in A: 1e-13 A over ~1e-4 S is ~1e-9 V
+        assert np.all(conv), (kind, conv)
+        st = sim.st
+        res[kind, "dc"] = u[:, [st.index_of("out"), st.index_of("y"), st.index_of("I_Vdd")]]
+        sim.close()
+        circ = tc.va_mos_inverter(builtin=(kind == "builtin"), rd=rd)
+        sim = api.BatchSimulator(api.MNACircuit(circ, {}), [{}])
+        st = sim.st
+        u, conv, _ = sim.dc(abstol=1e-9, mode="tranop")
+        assert np.all(conv)
+        ts = np.linspace(1e-9, 2e-8, 20)
+        out, per, stats = sim.tran((0.0, 2e-8), st.state_abstol(vntol=1e-7, iabstol=1e-10, chgtol=1e-7), 1e-5, ts,
+                                   obs=[st.index_of("out"), st.index_of("y")], fused=1)
+        sim.close()
+        assert stats["n_failed"] == 0, (kind, stats)
+        res[kind, "tran"] = out[0]
+    dc_a, dc_b = res["va", "dc"], res["builtin", "dc"]
+    assert np.max(np.abs(dc_a[:, :2] - dc_b[:, :2])) < 1e-7, np.max(np.abs(dc_a - dc_b))      # node voltages
+    assert np.max(np.abs(dc_a[:, 2] - dc_b[:, 2])) < 1e-11                                    # supply current
+    assert dc_a[0, 0] > 4.9 and dc_a[-1, 0] < 0.1                                             # it is an inverter
+    assert np.max(np.abs(res["va", "tran"] - res["builtin", "tran"])) < 2e-4
