@@ -73,8 +73,9 @@ def _card(base, **over):
     return c
 
 
-def dff_circuit(mc_vto=None, mc_kp=None, meyer=False):
-    """gf180 DFF (dffnq_4) test bench.  Sweepable parameter ``vdd`` (default 5 V) scales the
+def dff_circuit(mc_vto=None, mc_kp=None, meyer=False, generated=False):
+    """gf180 DFF (dffnq_4) test bench.  ``generated``: the MOSFETs are instances of the generated Verilog-A level-1
+    module ``va_mos1l`` (cadnip.jl_amd/va/models) instead of the hand-written sp_mos1 device -- same cards, same netlist.  Sweepable parameter ``vdd`` (default 5 V) scales the
     supply and the PWL stimulus amplitude together.  ``mc_vto`` / ``mc_kp`` (optional Param names)
     add Monte-Carlo shifts: vto += type * params[mc_vto], kp *= params[mc_kp].  ``meyer`` selects
     the Meyer-charge card variant (see the card comment above)."""
@@ -98,7 +99,10 @@ def dff_circuit(mc_vto=None, mc_kp=None, meyer=False):
             card["vto"] = Param(mc_vto, scale=float(base["type"]), offset=base["vto"])
         if mc_kp is not None:
             card["kp"] = Param(mc_kp, scale=base["kp"])
-        c.MOS1("X_" + nm, d, g, s, b, card, w=W, l=L)
+        if generated:
+            c.VA("X_" + nm, "va_mos1l", (d, g, s, b), w=W, l=L, **{k: (float(v) if not isinstance(v, Param) else v) for k, v in card.items()})
+        else:
+            c.MOS1("X_" + nm, d, g, s, b, card, w=W, l=L)
     c.C("CQ", "Q_tmp", "0", 1.7205e-13)
     if not meyer:
         for (nm, d, g, s, b, W, L) in DFF_FETS:

@@ -358,7 +358,9 @@ int cadnip_dc_run(CadnipHandle* h, const CadnipDCOpts* o, double* u_host, int32_
       }
       h->spec = spec0;
       n_failed = ok ? 0 : (int)B;
-      if (ok) std::fill(status.begin(), status.end(), 1);
+      // the homotopies move the whole batch together: all instances arrive, or none (the flags of the last partial
+      // solve, at a reduced source factor, say nothing about the real problem)
+      std::fill(status.begin(), status.end(), ok ? 1 : 0);
     } else std::fill(status.begin(), status.end(), 1);
   }
   HIP_TRY(hipMemcpy(u_host, h->d_u, B * n * sizeof(double), hipMemcpyDeviceToHost));
