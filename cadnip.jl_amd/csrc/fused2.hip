@@ -341,7 +341,10 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
   const u64* nzd = (const u64*)(tab + f.off[S_NZ]);
   const u64* laned = (const u64*)(tab + f.off[S_ENT]);
   const unsigned* term = tab + f.off[S_TERM];
-  const u64* passd = (const u64*)(tab + f.off[S_LEV]);
+  // pass descriptors are wave-uniform: read them with scalar loads from the table's copy in global memory (constant
+  // cache) instead of an LDS read plus two v_readfirstlane per pass
+  typedef const __attribute__((address_space(4))) u64* PassPtr;
+  const PassPtr passd = (PassPtr)(const u64*)(f.tab + f.off[S_LEV]);
   const u16* qinv = (const u16*)(tab + f.off[S_QINV]);
   const short* nodes = (const short*)(tab + f.off[S_NODES]);
   const u16* rowof = (const u16*)(tab + f.off[S_ROWOF]);
