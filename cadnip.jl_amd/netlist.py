@@ -312,6 +312,8 @@ def read_spice(text, models=None, includes=None, sweep=(), title=""):
             rest = re.sub(r"\s*\(\s*", "(", re.sub(r"\s*\)", ")", " ".join(toks[3:])))
             wave, dc = None, 0.0
             m = re.search(r"\b(pwl|pulse|sin)\(([^)]*)\)", rest, re.I)
+            if not m:      # the same functions without parentheses: the rest of the card is the argument list
+                m = re.search(r"\b(pwl|pulse|sin)\s+(.*)$", rest, re.I)
             if m:
                 args = [sc.val(a) for a in m.group(2).split()]
                 if any(isinstance(a, Param) for a in args):

@@ -212,3 +212,60 @@ def test_dff_with_the_generated_mosfet_model():
     k150, k250, k700 = (int(np.argmin(np.abs(ts - t))) for t in (150e-9, 250e-9, 700e-9))
     vdd = np.array([p["vdd"] for p in pts])
     assert np.all(np.abs(q[True][:, k150]) < 0.05) and np.all(np.abs(q[True][:, k250]) < 0.05) and np.all(np.abs(q[True][:, k700] - vdd) < 0.05)
+
+
+RING9_DECK = """* 9-stage ring oscillator, every MOSFET an instance of the generated level-1 module (BASELINE.json config 5's shape:
+* hierarchical deck, in-kernel dual-number stamping; the PSP103 cards of the original are third-party and not used)
+.param vsup=1.8
+.subckt nmos d g s b w=1u l=1u
+xm d g s b va_mos1l type=1 vto=0.45 kp=120u gamma=0.3 phi=0.7 lambda=0.05 cbd=2f cbs=2f w={w} l={l}
+.ends
+.subckt pmos d g s b w=1u l=1u
+xm d g s b va_mos1l type=-1 vto=-0.45 kp=60u gamma=0.3 phi=0.7 lambda=0.05 cbd=2f cbs=2f w={w} l={l}
+.ends
+.subckt inverter in out vdd vss w=1u l=1u pfact=2
+xmp out in vdd vdd pmos w={w*pfact} l={l}
+xmn out in vss vss nmos w={w} l={l}
+xcg in vss va_capacitor c={3.45e-3*w*l*(1+pfact)}
+.ends
+i0 0 1 dc 0 pulse 0 10u 1n 1n 1n 1n
+xu1 1 2 vdd 0 inverter w={10u} l={1u}
+xu2 2 3 vdd 0 inverter w={10u} l={1u}
+xu3 3 4 vdd 0 inverter w={10u} l={1u}
+xu4 4 5 vdd 0 inverter w={10u} l={1u}
+xu5 5 6 vdd 0 inverter w={10u} l={1u}
+xu6 6 7 vdd 0 inverter w={10u} l={1u}
+xu7 7 8 vdd 0 inverter w={10u} l={1u}
+xu8 8 9 vdd 0 inverter w={10u} l={1u}
+xu9 9 1 vdd 0 inverter w={10u} l={1u}
+vdd vdd 0 vsup
+.end
+"""
+
+
+def test_ring9_from_a_hierarchical_deck_with_generated_models():
+    """Deck reader (.SUBCKT three levels deep, parameter expressions) -> 18 instances of the generated MOSFET module and 9
+    generated capacitors -> DC point and 150 ns transient in the fused kernel with dtmax = 50 ps, four supply corners at
+    once.  The ring oscillates rail to rail and faster at higher supply (cf. test/mna/vadistiller_integration.jl:649-692)."""
+    circ, _ = cj.netlist.read_spice(RING9_DECK, sweep=("vsup",))
+    assert len(circ.devices) == 2 + 9 * 3 and circ.devices[-1].name == "xu9_xcg" and circ.devices[2].type == "VA:va_mos1l"
+    pts = [{"vsup": v} for v in (1.2, 1.5, 1.8, 2.1)]
+    sim = api.BatchSimulator(api.MNACircuit(circ, {"vsup": 1.8}), pts)
+    st = sim.st
+    sim.analyze()
+    u, conv, _ = sim.dc(abstol=1e-10, mode="tranop", fused=True)
+    assert np.all(conv)
+    ts = np.linspace(50e-9, 150e-9, 1000)
+    sim.h.set_spec(mode="tran")
+    from cadnip_jl_amd.structure import expand_breakpoints
+    out, per, stats = sim.h.tran_run(0.0, 150e-9, st.state_abstol(vntol=1e-6, iabstol=1e-9, chgtol=1e-6), 1e-4,
+                                     breaks=expand_breakpoints(st.breakpoints, (0.0, 150e-9)), save_t=ts, obs=[st.index_of("5")], hmax=50e-12, fused=1)
+    sim.close()
+    assert stats["n_failed"] == 0, stats
+    cross = []
+    for i, p in enumerate(pts):
+        v = out[i, :, 0]
+        assert v.max() > 0.9 * p["vsup"] and v.min() < 0.1 * p["vsup"], (p, v.min(), v.max())
+        mid = 0.5 * p["vsup"]
+        cross.append(int(np.sum((v[:-1] < mid) & (v[1:] >= mid))))
+    assert cross[0] >= 3 and cross == sorted(cross) and cross[-1] > cross[0], cross

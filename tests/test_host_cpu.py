@@ -334,6 +334,8 @@ def test_spice_deck_reader_elements_and_errors():
     assert d["R1"]["r"] == 2000.0 and d["R2"]["r"] == 750.0 and d["C1"]["c"] == pytest.approx(1e-11) and d["G1"]["gm"] == 1e6
     assert d["B1"]["nodes"] == ["0", "out"] and d["B1"]["expr"] == "V(mid)*1e-3" and d["B2"]["type"] == "BV"
     assert "R99" not in d and info["tran"] == (1e-9, 1e-7)
+    kick, _ = cj.netlist.read_spice("i0 0 1 dc 0 pulse 0 10u 1n 1n 1n 1n\nr1 1 0 1k\n")       # waveform without parentheses
+    assert kick.to_dicts({})[0]["wave"] == ("pulse", 0.0, 1e-5, 1e-9, 1e-9, 1e-9, 1e-9, 0.0) and kick.to_dicts({})[0]["dc"] == 0.0
     assert cj.netlist.parse_number("2.5MEG") == 2.5e6 and cj.netlist.parse_number("10pF") == pytest.approx(1e-11)
     # .model cards: the ring oscillator deck of test/mna/vadistiller_integration.jl:45-60 in SPICE form == the table form
     ring = """* 3-stage ring
