@@ -165,8 +165,9 @@ __global__ void __launch_bounds__(64) k_dc_update(DCArgs a) {
   if (status == 0 && a.action[inst] == 0) {
     double* u = a.u + (size_t)inst * n;
     const double* d = a.delta + (size_t)inst * n;
-    int bad = (a.flags[inst] & 1);
-    for (int i = tid; i < n; i += 64) { double dd = d[i]; if (!isfinite(dd)) bad = 1; u[i] -= dd; }
+    int bad = (a.flags[inst] & 1);     // the refactorisation met a zero / non-finite pivot: leave u alone (the host may re-pivot)
+    if (!bad)
+      for (int i = tid; i < n; i += 64) { double dd = d[i]; if (!isfinite(dd)) bad = 1; u[i] -= dd; }
     bad = wave_any(bad);
     if (a.use_pcnr && a.n_limits > 0) {
       const double* lw = a.limit_w + (size_t)inst * n;
@@ -221,6 +222,7 @@ int dc_newton(CadnipHandle* h, double abstol, int maxiters, int use_pcnr, int co
     }
     return rc;
   }
+  int prev_running = h->B, repivots = 0;
   for (int round = 0; round < 2 * maxiters + 4; ++round) {
     rc = launch_rebuild(h); if (rc) break;
     h->initjct = 0;
@@ -230,6 +232,33 @@ int dc_newton(CadnipHandle* h, double abstol, int maxiters, int use_pcnr, int co
     hipLaunchKernelGGL(k_dc_update, dim3(h->B), dim3(64), 0, h->stream, a);
     int running = 0;
     rc = count_running(h, &running); if (rc) break;
+    if (running < prev_running && repivots < 2) {
+      // Some instance stopped.  If its refactorisation hit a zero pivot, the static pivot order does not fit this operating
+      // point: choose a new one on the Jacobian at hand and let the instance repeat the iteration -- what KLU does when
+      // klu_refactor fails and the caller falls back to klu_factor (solve.jl:667-670 keeps the symbolic object only as
+      // long as refactoring works).  The new order serves every instance from here on.
+      std::vector<int> stat((size_t)h->B);
+      HIP_TRY(hipMemcpy(stat.data(), d->status, stat.size() * sizeof(int), hipMemcpyDeviceToHost));
+      int victim = -1;
+      for (int i = 0; i < h->B && victim < 0; ++i) if (stat[i] == -2) victim = i;
+      if (victim >= 0) {
+        ++repivots;
+        std::vector<int> act((size_t)h->B);
+        for (int i = 0; i < h->B; ++i) act[i] = (stat[i] == 0 || stat[i] == -2) ? 1 : 0;
+        HIP_TRY(hipMemcpy(h->d_active, act.data(), act.size() * sizeof(int), hipMemcpyHostToDevice));
+        rc = launch_jacobian(h); if (rc) break;                 // J = G + gamma C of this round (G, C are still the round's stamps)
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (cadnip_analyze(h, victim) == CADNIP_OK) {
+          for (int i = 0; i < h->B; ++i) if (stat[i] == -2) stat[i] = 0;
+          HIP_TRY(hipMemcpy(d->status, stat.data(), stat.size() * sizeof(int), hipMemcpyHostToDevice));
+          rc = count_running(h, &running); if (rc) break;
+        } else {
+          for (int i = 0; i < h->B; ++i) act[i] = stat[i] == 0 ? 1 : 0;
+          HIP_TRY(hipMemcpy(h->d_active, act.data(), act.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
+      }
+    }
+    prev_running = running;
     if (running == 0) break;
   }
   h->initjct = saved_initjct;

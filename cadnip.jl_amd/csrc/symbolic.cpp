@@ -25,6 +25,9 @@
 
 namespace cadnip {
 
+static const int LU_EXHAUSTIVE_MAX = 4096;   // unknowns up to which every remaining entry is a pivot candidate
+static const int LU_SEARCH_ROWS = 12;        // beyond: candidates come from this many shortest rows
+
 static int lu_analyze_mode(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, const std::vector<double>& vals,
                            double pivot_tol, bool magnitudes, LUProgram& out, std::string& err);
 
@@ -61,12 +64,31 @@ static int lu_analyze_mode(int n, const std::vector<int>& rowptr, const std::vec
   out.cperm.assign(n, -1);
   std::vector<double> colmax(n);
   std::vector<int> colmax_stamp(n, -1);
+  // Exhaustive Markowitz search costs O(n * nnz): fine for the circuits the fused kernel takes (the DFF: 235 unknowns),
+  // minutes at 76 k unknowns (a 16 x 16 multiplier).  Large systems search the LU_SEARCH_ROWS shortest remaining rows
+  // only (rows are kept ordered by their current length), the classic restricted Markowitz strategy; the pivot rule inside
+  // the searched rows is the same.
+  const bool restricted = n > LU_EXHAUSTIVE_MAX;
+  std::set<std::pair<int, int>> by_len;      // (current row length, row) of the rows not yet eliminated
+  if (restricted) for (int i = 0; i < n; ++i) by_len.insert({(int)rows[i].size(), i});
+  std::vector<int> cand;
   for (int k = 0; k < n; ++k) {
     long best_cost = -1;
     int bi = -1, bj = -1;
     bool bdiag = false;
     double brel = 0;
-    for (int i = 0; i < n; ++i) {
+    cand.clear();
+    if (restricted) {
+      // the shortest rows; keep going while nothing acceptable was found (threshold test) -- done below by widening
+      for (auto it = by_len.begin(); it != by_len.end() && (int)cand.size() < LU_SEARCH_ROWS; ++it) cand.push_back(it->second);
+    }
+    const int n_scan = restricted ? (int)cand.size() : n;
+    for (int ci = 0; ci < n_scan || (restricted && bi < 0 && ci < (int)by_len.size()); ++ci) {
+      if (restricted && ci >= (int)cand.size()) {      // widen: nothing passed the threshold among the shortest rows
+        cand.clear();
+        for (auto& pr : by_len) cand.push_back(pr.second);
+      }
+      const int i = restricted ? cand[ci] : ci;
       if (rdone[i]) continue;
       long r = (long)rows[i].size();
       for (auto& kv : rows[i]) {
@@ -100,6 +122,10 @@ static int lu_analyze_mode(int n, const std::vector<int>& rowptr, const std::vec
     for (int i : cols[bj]) if (i != bi) lrows.push_back(i);
     for (auto& kv : rows[bi]) Urow[k].push_back(kv.first);
     Lcol[k] = lrows;
+    if (restricted) {
+      by_len.erase({(int)rows[bi].size(), bi});
+      for (int i : lrows) by_len.erase({(int)rows[i].size(), i});
+    }
     for (int i : lrows) {
       double f = rows[i][bj] / piv;
       for (auto& kv : rows[bi]) {
@@ -111,6 +137,7 @@ static int lu_analyze_mode(int n, const std::vector<int>& rowptr, const std::vec
         else it->second -= f * kv.second;
       }
       rows[i].erase(bj);
+      if (restricted) by_len.insert({(int)rows[i].size(), i});
     }
     for (auto& kv : rows[bi]) cols[kv.first].erase(bi);
     cols[bj].clear();

@@ -673,3 +673,23 @@ def test_verilog_a_front_end_and_generator():
                 "module x(a); analog I(a) <+ 1; endmodule"):                                       # port not electrical
         with pytest.raises(va.VAError):
             va.parse_module(bad)
+
+
+def test_c6288_deck_flattens_and_orders_at_scale():
+    """Deck reader and host symbolic phase on a single large circuit (c6288: three levels of .SUBCKT, .GLOBAL supplies,
+    10 112 MOSFETs): device count, unknown layout, and the restricted Markowitz order (symbolic.cpp: beyond 4 096 unknowns
+    only the shortest rows are searched) keeps the fill below 20 % on a diagonally dominant sample."""
+    from tools.c6288 import deck
+    circ = deck()
+    # voltage sources first (codegen.jl:3130-3149), then the gates in netlist order, hierarchical names joined with "_"
+    assert sum(d.type == "MOS1" for d in circ.devices) == 10112 and circ.devices[33].name == "vb15"
+    assert circ.devices[34].name == "x1_xAND2_1_xmp2" and circ.devices[-1].name == "x1_xNOR2_2416_xmn2"
+    st = cj.discover(circ, {})
+    assert (st.n, st.n_nodes, st.n_currents, st.n_charges, st.n_limits) == (75908, 5090, 34, 30336, 40448)
+    rng = np.random.default_rng(0)
+    vals = rng.random(st.nnz) + 0.5
+    rows = np.repeat(np.arange(st.n), np.diff(st.rowptr))
+    vals[rows == st.colidx] += 10.0
+    prog = hip.host_lu_analyze(st.n, st.rowptr, st.colidx, vals, sample=True)
+    assert sorted(prog["rperm"].tolist()) == list(range(st.n)) and sorted(prog["cperm"].tolist()) == list(range(st.n))
+    assert len(prog["col"]) < 1.2 * st.nnz
