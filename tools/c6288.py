@@ -4,8 +4,8 @@ PSP103: n = 212 228, rebuild 0.48 s, KLU 2.72 s, doc/c6288_bottleneck_findings.m
 reference's benchmarks/vacask/c6288/cedarsim/multiplier.inc, kept as a data fixture (tests/golden/c6288_multiplier.inc).
 
 Measures deck -> structure -> symbolic LU -> restamp -> refactor + solve, and checks the GPU solve against SciPy's SuperLU.
-The DC operating point of the whole multiplier does not converge yet with the plain PCNR / gshunt / source-stepping chain
-(DESIGN.md section 9, next).      python tools/c6288.py   (needs a GPU)"""
+The DC operating point of the whole multiplier does not converge with the PCNR / gshunt / source-stepping chain -- nor does
+a 12-stage inverter chain in the oracle's restatement of that loop.      python tools/c6288.py   (needs a GPU)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
