@@ -295,6 +295,15 @@ class BatchSimulator:
         h.analyze_values(acc)
         self._analyzed = True
 
+    def analyze_at(self, u, t=0.0, gamma=0.0, instance=0):
+        """Symbolic LU phase on the Jacobian ``G + gamma*C`` of one state -- KLU's first ``klu_factor``: the pivot order of
+        the matrix the solver is about to meet (e.g. the first transient steps from a given start state, gamma = 1 / h).
+        For circuits whose composite sample (``analyze``) does not yield a usable order."""
+        uu = np.broadcast_to(np.asarray(u, dtype=float), (self.B, self.st.n)) if np.ndim(u) == 1 else np.asarray(u, dtype=float)
+        self.h.rebuild(uu, t)
+        self.h.analyze_values(self.h.jacobian(gamma)[instance])
+        self._analyzed = True
+
     def dc(self, u0=None, abstol=1e-10, maxiters=100, mode="dcop", fused=False):
         self.h.set_spec(mode=mode)
         if not self._analyzed:

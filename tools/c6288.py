@@ -3,9 +3,10 @@ instead of a batch of small ones (n = 75 908 unknowns with the level-1 cards use
 PSP103: n = 212 228, rebuild 0.48 s, KLU 2.72 s, doc/c6288_bottleneck_findings.md:75-84).  The gate-level netlist is the
 reference's benchmarks/vacask/c6288/cedarsim/multiplier.inc, kept as a data fixture (tests/golden/c6288_multiplier.inc).
 
-Measures deck -> structure -> symbolic LU -> restamp -> refactor + solve, and checks the GPU solve against SciPy's SuperLU.
-The DC operating point of the whole multiplier does not converge with the PCNR / gshunt / source-stepping chain -- nor does
-a 12-stage inverter chain in the oracle's restatement of that loop.      python tools/c6288.py   (needs a GPU)"""
+Measures deck -> structure -> symbolic LU -> restamp -> refactor + solve, checks the GPU solve against SciPy's SuperLU, and
+runs the power-up transient: supplies and inputs ramp up, the multiplier settles, the 32 output bits are the product.
+(A static DC solve of the whole multiplier does not converge with the PCNR / gshunt / source-stepping chain -- nor does a
+12-stage inverter chain in the oracle's restatement of that loop)      python tools/c6288.py   (needs a GPU)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,6 +24,40 @@ def deck(a=0xFFFF, b=0xFFFF, vdd=1.2):
     nm = dict(type=1, vto=0.4, kp=200e-6, gamma=0.3, phi=0.7, cbd=1e-15, cbs=1e-15)
     pm = dict(type=-1, vto=-0.4, kp=100e-6, gamma=0.3, phi=0.7, cbd=1e-15, cbs=1e-15)
     return cj.netlist.read_spice(d, models={"nmos": nm, "pmos": pm}, includes={"multiplier.inc": inc})[0]
+
+
+def powerup(a=0xBEEF, b=0x1234, vdd=1.2, t_end=10e-9, verbose=False):
+    """Supplies and inputs ramp from 0 in 1 ns, the transient starts from the all-zero state (consistent: every source is
+    at 0 V) -- the start-up that a static DC solve of this circuit does not find.  Returns (product read from the output
+    bits at t_end, per-instance statistics, seconds)."""
+    from cadnip_jl_amd.structure import expand_breakpoints
+    inc = open(os.path.join(ROOT, "tests", "golden", "c6288_multiplier.inc")).read()
+    ramp = "PWL(0 0 1n %g)"
+    d = '* c6288 power-up\n.include "multiplier.inc"\nvdd vdd 0 ' + ramp % vdd + '\nvss vss 0 0\nx1 '
+    d += " ".join("a%d" % k for k in range(16)) + " " + " ".join("b%d" % k for k in range(16)) + " " + " ".join("p%d" % k for k in range(32)) + " c6288\n"
+    for k in range(16):
+        d += "va%d a%d 0 %s\nvb%d b%d 0 %s\n" % (k, k, ramp % vdd if (a >> k) & 1 else "DC 0", k, k, ramp % vdd if (b >> k) & 1 else "DC 0")
+    nm = dict(type=1, vto=0.4, kp=200e-6, gamma=0.3, phi=0.7, cbd=1e-15, cbs=1e-15)
+    pm = dict(type=-1, vto=-0.4, kp=100e-6, gamma=0.3, phi=0.7, cbd=1e-15, cbs=1e-15)
+    circ = cj.netlist.read_spice(d, models={"nmos": nm, "pmos": pm}, includes={"multiplier.inc": inc})[0]
+    sim = api.BatchSimulator(api.MNACircuit(circ, {}, api.MNASpec(mode="tran")), [{}])
+    st, h = sim.st, sim.h
+    sim.analyze_at(np.zeros(st.n), t=1e-10, gamma=1e11)        # the Jacobian of the first steps (h ~ 10 ps)
+    h.set_u(np.zeros((1, st.n)))
+    h.set_spec(mode="tran")
+    t0 = time.time()
+    out, per, stats = h.tran_run(0.0, t_end, st.state_abstol(vntol=1e-4, iabstol=1e-7, chgtol=1e-4), 1e-3,
+                                 breaks=expand_breakpoints(st.breakpoints, (0.0, t_end)), save_t=np.array([t_end]),
+                                 obs=[st.index_of("p%d" % k) for k in range(32)], fused=0)
+    dt = time.time() - t0
+    sim.close()
+    p = sum((1 << k) for k in range(32) if out[0, 0, k] > 0.5 * vdd)
+    rails = bool(np.all((np.abs(out[0, 0]) < 0.05 * vdd) | (np.abs(out[0, 0] - vdd) < 0.05 * vdd)))
+    if verbose:
+        print("power-up transient to %.0f ns: %d Newton iterations, %d steps (+%d rejected), status %d, %.1f s = %.1f ms per iteration"
+              % (t_end * 1e9, per[0, 0], per[0, 1], per[0, 2], per[0, 3], dt, dt / max(1, per[0, 0]) * 1e3))
+        print("product bits 0x%08X, expected 0x%04X * 0x%04X = 0x%08X: %s (all outputs at a rail: %s)" % (p, a, b, a * b, "OK" if p == a * b else "MISMATCH", rails))
+    return p, per[0], dt
 
 
 def main():
@@ -59,6 +94,7 @@ def main():
     print("                relative residual |A x - b| / |b|: GPU %.2e, SuperLU %.2e;  max |x - x_ref| / max |x_ref| = %.2e (cond ~ 1e9 * C / gmin)"
           % (res(x), res(xr), np.max(np.abs(x - xr)) / np.max(np.abs(xr))))
     sim.close()
+    powerup(verbose=True)
 
 
 if __name__ == "__main__":
