@@ -69,6 +69,18 @@ int cadnip_create(const CadnipStructure* s, int32_t n_instances, int32_t device,
   std::vector<unsigned char> dflag(s->nnz, 0);
   for (int i = 0; i < s->n_nodes; ++i) { int p = s->diag_nz[i]; if (p >= 0 && p < s->nnz) dflag[p] = 1; }
   TRY(dev_upload(&h->d_diag_flag, dflag.data(), dflag.size()));
+  {
+    // gather lists longer than kernels.hip's LONG_LIST get a workgroup each (supply rails of large circuits)
+    const int LONG = 512;
+    std::vector<int> le, lr;
+    for (int e = 0; e < s->nnz; ++e) if (s->g_ptr[e + 1] - s->g_ptr[e] > LONG) le.push_back(e);
+    for (int e = 0; e < s->nnz; ++e) if (s->c_ptr[e + 1] - s->c_ptr[e] > LONG) le.push_back(s->nnz + e);
+    for (int i = 0; i < s->n; ++i) if (s->b_ptr[i + 1] - s->b_ptr[i] > LONG) le.push_back(2 * s->nnz + i);
+    for (int i = 0; i < s->n; ++i) if (s->rowptr[i + 1] - s->rowptr[i] > LONG) lr.push_back(i);
+    h->n_long_asm = (int)le.size(); h->n_long_rows = (int)lr.size();
+    if (!le.empty()) TRY(dev_upload(&h->d_long_asm, le.data(), le.size()));
+    if (!lr.empty()) TRY(dev_upload(&h->d_long_rows, lr.data(), lr.size()));
+  }
   TRY(dev_upload(&h->d_wave, s->wave_data, (size_t)s->n_wave_data));
   TRY(dev_upload(&h->d_limit_init, s->limit_init, (size_t)s->n_limits));
   for (int bi = 0; bi < s->n_blocks; ++bi) {
@@ -148,7 +160,7 @@ void cadnip_destroy(CadnipHandle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   cadnip_driver_free(h);
   void* ptrs[] = {h->d_rowptr, h->d_colidx, h->d_to_ref, h->d_g_ptr, h->d_g_slots, h->d_c_ptr, h->d_c_slots, h->d_b_ptr, h->d_b_slots,
-                  h->d_diag_flag, h->d_wave, h->d_limit_init, h->d_u, h->d_du, h->d_t, h->d_gamma, h->d_S, h->d_G, h->d_C, h->d_b, h->d_J,
+                  h->d_diag_flag, h->d_long_asm, h->d_long_rows, h->d_wave, h->d_limit_init, h->d_u, h->d_du, h->d_t, h->d_gamma, h->d_S, h->d_G, h->d_C, h->d_b, h->d_J,
                   h->d_resid, h->d_delta, h->d_limit_w, h->d_LU, h->d_tmp, h->d_flags, h->d_active, h->d_load_src, h->d_load_dst, h->d_ent_pos,
                   h->d_ent_diag, h->d_ent_ptr, h->d_term_a, h->d_term_b, h->d_lev_ptr, h->d_lu_rowptr, h->d_lu_col, h->d_lu_diag, h->d_rperm,
                   h->d_cperm, h->d_fwd_rows, h->d_fwd_lev_ptr, h->d_bwd_rows, h->d_bwd_lev_ptr};

@@ -87,6 +87,8 @@ struct CadnipHandle {
   int *d_rowptr = nullptr, *d_colidx = nullptr, *d_to_ref = nullptr;
   int *d_g_ptr = nullptr, *d_g_slots = nullptr, *d_c_ptr = nullptr, *d_c_slots = nullptr, *d_b_ptr = nullptr, *d_b_slots = nullptr;
   unsigned char* d_diag_flag = nullptr;   // [nnz] 1 where the entry is G[i,i] of a voltage node
+  int *d_long_asm = nullptr, *d_long_rows = nullptr;   // entries / rows whose gather lists are long (kernels.hip LONG_LIST)
+  int n_long_asm = 0, n_long_rows = 0;
   double* d_wave = nullptr;
   double* d_limit_init = nullptr;
   // device: per-instance state [B][..]

@@ -94,6 +94,39 @@ struct AsmArgs {
   int B, n, nnz, ns, ns_g, ns_c; double srcFact, gshunt;
 };
 
+// Entries that gather more than LONG_LIST slots (the supply rails of a large circuit: G[vdd,vdd] of the c6288 multiplier
+// sums 20 k stamps) are left to k_assemble_long / k_residual_long, one workgroup each: a single thread walking such a list
+// made the whole kernel take 6 ms.  The DFF has none.
+#define LONG_LIST 512
+
+__device__ __forceinline__ double block_sum_256(double v, double* red) {
+  const int t = threadIdx.x;
+  red[t] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
+  return red[0];
+}
+
+// one workgroup per (instance, long entry); `long_e` indexes the combined [G nz | C nz | b rows] space of k_assemble
+__global__ void __launch_bounds__(256) k_assemble_long(AsmArgs a, const int* long_e, int n_long) {
+  __shared__ double red[256];
+  const int inst = blockIdx.x / n_long, e = long_e[blockIdx.x % n_long];
+  if (!a.active[inst]) return;
+  const double* S = a.S + (size_t)inst * a.ns;
+  const int* ptr; const int* slots; const double* Sx; int k; double* out;
+  if (e < a.nnz) { ptr = a.g_ptr; slots = a.g_slots; Sx = S; k = e; out = a.G + (size_t)inst * a.nnz + k; }
+  else if (e < 2 * a.nnz) { ptr = a.c_ptr; slots = a.c_slots; Sx = S + a.ns_g; k = e - a.nnz; out = a.C + (size_t)inst * a.nnz + k; }
+  else { ptr = a.b_ptr; slots = a.b_slots; Sx = S + a.ns_g + a.ns_c; k = e - 2 * a.nnz; out = a.b + (size_t)inst * a.n + k; }
+  double acc = 0.0;
+  for (int p = ptr[k] + threadIdx.x; p < ptr[k + 1]; p += 256) acc += Sx[slots[p]];
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) {
+    if (e < a.nnz && a.gshunt != 0.0 && a.diag_flag[e]) acc += a.gshunt;
+    if (e >= 2 * a.nnz && a.srcFact < 1.0) acc *= a.srcFact;
+    *out = acc;
+  }
+}
+
 __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
   int per = 2 * a.nnz + a.n;
   long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -102,6 +135,7 @@ __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
   if (!a.active[inst]) return;
   const double* S = a.S + (size_t)inst * a.ns;
   if (e < a.nnz) {
+    if (a.g_ptr[e + 1] - a.g_ptr[e] > LONG_LIST) return;
     double acc = 0.0;
     for (int p = a.g_ptr[e]; p < a.g_ptr[e + 1]; ++p) acc += S[a.g_slots[p]];
     if (a.gshunt != 0.0 && a.diag_flag[e]) acc += a.gshunt;
@@ -109,12 +143,14 @@ __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
   } else if (e < 2 * a.nnz) {
     int k = e - a.nnz;
     const double* Sc = S + a.ns_g;
+    if (a.c_ptr[k + 1] - a.c_ptr[k] > LONG_LIST) return;
     double acc = 0.0;
     for (int p = a.c_ptr[k]; p < a.c_ptr[k + 1]; ++p) acc += Sc[a.c_slots[p]];
     a.C[(size_t)inst * a.nnz + k] = acc;
   } else {
     int i = e - 2 * a.nnz;
     const double* Sb = S + a.ns_g + a.ns_c;
+    if (a.b_ptr[i + 1] - a.b_ptr[i] > LONG_LIST) return;
     double acc = 0.0;
     for (int p = a.b_ptr[i]; p < a.b_ptr[i + 1]; ++p) acc += Sb[a.b_slots[p]];
     if (a.srcFact < 1.0) acc *= a.srcFact;
@@ -136,9 +172,23 @@ __global__ void __launch_bounds__(256) k_residual(ResArgs a) {
   const double* C = a.C + (size_t)inst * a.nnz;
   const double* u = a.u + (size_t)inst * a.n;
   const double* du = a.du + (size_t)inst * a.n;
+  if (a.rowptr[i + 1] - a.rowptr[i] > LONG_LIST) return;      // k_residual_long
   double accC = 0.0, accG = 0.0;
   for (int p = a.rowptr[i]; p < a.rowptr[i + 1]; ++p) { int j = a.colidx[p]; accC += C[p] * du[j]; accG += G[p] * u[j]; }
   a.r[(size_t)inst * a.n + i] = (accC + accG) - a.b[(size_t)inst * a.n + i];
+}
+__global__ void __launch_bounds__(256) k_residual_long(ResArgs a, const int* long_rows, int n_long) {
+  __shared__ double red[256];
+  const int inst = blockIdx.x / n_long, i = long_rows[blockIdx.x % n_long];
+  if (!a.active[inst]) return;
+  const double* G = a.G + (size_t)inst * a.nnz;
+  const double* C = a.C + (size_t)inst * a.nnz;
+  const double* u = a.u + (size_t)inst * a.n;
+  const double* du = a.du + (size_t)inst * a.n;
+  double acc = 0.0;
+  for (int p = a.rowptr[i] + threadIdx.x; p < a.rowptr[i + 1]; p += 256) { int j = a.colidx[p]; acc += C[p] * du[j] + G[p] * u[j]; }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) a.r[(size_t)inst * a.n + i] = acc - a.b[(size_t)inst * a.n + i];
 }
 
 // J = G + gamma*C   (precompile.jl:580-582)
@@ -288,6 +338,7 @@ int launch_rebuild(CadnipHandle* h) {
               h->d_G, h->d_C, h->d_b, h->B, h->n, h->nnz, h->ns, h->ns_g, h->ns_c, h->spec.srcFact, h->spec.gshunt};
     long total = (long)h->B * (2L * h->nnz + h->n);
     hipLaunchKernelGGL(k_assemble, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, a);
+    if (h->n_long_asm > 0) hipLaunchKernelGGL(k_assemble_long, dim3((unsigned)(h->B * h->n_long_asm)), dim3(256), 0, h->stream, a, h->d_long_asm, h->n_long_asm);
   }
   HIP_TRY(hipGetLastError());
   return CADNIP_OK;
@@ -298,6 +349,7 @@ int launch_residual(CadnipHandle* h, const double* d_du) {
   ResArgs a{h->d_G, h->d_C, h->d_b, h->d_u, d_du, h->d_rowptr, h->d_colidx, h->d_active, h->d_resid, h->B, h->n, h->nnz};
   long total = (long)h->B * h->n;
   hipLaunchKernelGGL(k_residual, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, a);
+  if (h->n_long_rows > 0) hipLaunchKernelGGL(k_residual_long, dim3((unsigned)(h->B * h->n_long_rows)), dim3(256), 0, h->stream, a, h->d_long_rows, h->n_long_rows);
   HIP_TRY(hipGetLastError());
   return CADNIP_OK;
 }
@@ -324,7 +376,11 @@ static int launch_lu(CadnipHandle* h, const char* name, int do_factor, int do_so
   if (!do_factor) { a.use_lds = 0; }   // solve-only reads the stored factors; y lives in d_tmp
   size_t shmem = a.use_lds ? lds : 0;
   if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_lu, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(k_lu, dim3(h->B), dim3(64), shmem, h->stream, a);
+  // one workgroup per instance; its size follows the work per dependency level: a wave for the small systems of a sweep
+  // (the DFF: 186 computed entries in 14 levels), 16 waves for a single large circuit whose factors live in HBM
+  // (c6288: 79 k entries, 352 k multiply-adds in 237 levels -- with one wave the refactorisation took 9.3 ms)
+  const int threads = !a.use_lds ? 1024 : (P.nnz_lu >= 8192 ? 256 : 64);
+  hipLaunchKernelGGL(k_lu, dim3(h->B), dim3(threads), shmem, h->stream, a);
   HIP_TRY(hipGetLastError());
   return CADNIP_OK;
 }
