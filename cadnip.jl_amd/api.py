@@ -310,15 +310,35 @@ class BatchSimulator:
             self.analyze()
         return self.h.dc_run(u0, abstol=abstol, maxiters=maxiters, use_pcnr=True, cold_start=u0 is None, fused=fused)
 
-    def tran(self, tspan, abstol, reltol, saveat, **kw):
+    def tran(self, tspan, abstol, reltol, saveat, initializealg="tranop", u0=None, warmup_dt=1e-12, **kw):
+        """``initializealg``: "tranop" = CedarTranOp, a DC solve in :tranop mode at t0 (dcop.jl:160-212); "uic" = CedarUICOp
+        (dcop.jl:109-151, 304-411): no DC solve -- the run starts from ``u0`` (zeros by default) and the integrator's first
+        steps, backward Euler from ``warmup_dt``, relax the algebraic constraints (for oscillators and for circuits whose
+        static operating point Newton does not find)."""
         st = self.st
+        if initializealg not in ("tranop", "uic"):
+            raise ValueError("initializealg must be 'tranop' or 'uic'")
+        breaks = expand_breakpoints(st.breakpoints, tspan)
+        if initializealg == "uic":
+            if isinstance(u0, dict):          # {unknown name: value}: the usual .IC form
+                start = np.zeros((self.B, st.n))
+                for name, value in u0.items():
+                    start[:, st.index_of(name)] = value
+            else:
+                start = np.zeros((self.B, st.n)) if u0 is None else np.broadcast_to(np.asarray(u0, dtype=float), (self.B, st.n)).copy()
+            if not self._analyzed:     # pivot order from the Jacobian the first steps will meet (h = warmup_dt)
+                self.analyze_at(start, t=tspan[0], gamma=1.0 / (10.0 * warmup_dt))
+            self.h.set_u(start)
+            self.h.set_spec(mode="tran")
+            kw.setdefault("h0", warmup_dt)
+            out, per, stats = self.h.tran_run(tspan[0], tspan[1], abstol, reltol, breaks=breaks, save_t=saveat, **kw)
+            stats["dc_newton_iters"] = 0
+            return out, per, stats
         if not self._analyzed:
             self.analyze()
-        # CedarTranOp: DC solve in :tranop mode at t0 (dcop.jl:160-212), abstol 1e-9
-        u0, conv, dcs = self.dc(abstol=1e-9, mode="tranop", fused=bool(kw.get("fused", False)))
+        u0_, conv, dcs = self.dc(abstol=1e-9, mode="tranop", fused=bool(kw.get("fused", False)))
         if not np.all(conv):
             raise RuntimeError("transient initialisation (CedarTranOp) failed for %d instance(s)" % int((~conv).sum()))
-        breaks = expand_breakpoints(st.breakpoints, tspan)
         self.h.set_spec(mode="tran")
         out, per, stats = self.h.tran_run(tspan[0], tspan[1], abstol, reltol, breaks=breaks, save_t=saveat, **kw)
         stats["dc_newton_iters"] = dcs["newton_iters"]

@@ -278,3 +278,14 @@ def test_c6288_power_up_transient_multiplies():
     from tools.c6288 import powerup
     p, per, dt = powerup(0xBEEF, 0x1234)
     assert per[3] == 1 and p == 0xBEEF * 0x1234, (hex(p), per)
+
+
+def test_uic_start_of_the_ring_oscillator():
+    """tran!(...; initializealg=CedarUICOp()) (dcop.jl:109-151): no DC solve, the run starts from the given initial
+    conditions (supply up, one stage output high -- from the all-zero state the perfectly symmetric ring would sit at
+    mid-rail for ever) and the first backward-Euler steps relax the rest; the ring passes the reference's oscillation
+    assertions (vadistiller_integration.jl:649-692)."""
+    sol = api.tran(api.MNACircuit(tc.ring_oscillator()), (0.0, 200e-9), abstol={"vntol": 1e-6, "iabstol": 1e-9, "chgtol": 1e-6}, reltol=1e-4,
+                   saveat=np.linspace(100e-9, 200e-9, 500), initializealg="uic", u0={"vdd": 3.3, "out1": 3.3}, hmax=1e-9, fused=1)
+    assert sol.retcode == "Success"
+    tc.ring_checks(np.asarray(sol["out1"]))

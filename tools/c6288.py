@@ -30,7 +30,6 @@ def powerup(a=0xBEEF, b=0x1234, vdd=1.2, t_end=10e-9, verbose=False):
     """Supplies and inputs ramp from 0 in 1 ns, the transient starts from the all-zero state (consistent: every source is
     at 0 V) -- the start-up that a static DC solve of this circuit does not find.  Returns (product read from the output
     bits at t_end, per-instance statistics, seconds)."""
-    from cadnip_jl_amd.structure import expand_breakpoints
     inc = open(os.path.join(ROOT, "tests", "golden", "c6288_multiplier.inc")).read()
     ramp = "PWL(0 0 1n %g)"
     d = '* c6288 power-up\n.include "multiplier.inc"\nvdd vdd 0 ' + ramp % vdd + '\nvss vss 0 0\nx1 '
@@ -42,13 +41,10 @@ def powerup(a=0xBEEF, b=0x1234, vdd=1.2, t_end=10e-9, verbose=False):
     circ = cj.netlist.read_spice(d, models={"nmos": nm, "pmos": pm}, includes={"multiplier.inc": inc})[0]
     sim = api.BatchSimulator(api.MNACircuit(circ, {}, api.MNASpec(mode="tran")), [{}])
     st, h = sim.st, sim.h
-    sim.analyze_at(np.zeros(st.n), t=1e-10, gamma=1e11)        # the Jacobian of the first steps (h ~ 10 ps)
-    h.set_u(np.zeros((1, st.n)))
-    h.set_spec(mode="tran")
     t0 = time.time()
-    out, per, stats = h.tran_run(0.0, t_end, st.state_abstol(vntol=1e-4, iabstol=1e-7, chgtol=1e-4), 1e-3,
-                                 breaks=expand_breakpoints(st.breakpoints, (0.0, t_end)), save_t=np.array([t_end]),
-                                 obs=[st.index_of("p%d" % k) for k in range(32)], fused=0)
+    # CedarUICOp-style start (dcop.jl:109-151): no DC solve, backward-Euler steps from the zero state
+    out, per, stats = sim.tran((0.0, t_end), st.state_abstol(vntol=1e-4, iabstol=1e-7, chgtol=1e-4), 1e-3, np.array([t_end]),
+                               initializealg="uic", obs=[st.index_of("p%d" % k) for k in range(32)], fused=0)
     dt = time.time() - t0
     sim.close()
     p = sum((1 << k) for k in range(32) if out[0, 0, k] > 0.5 * vdd)
