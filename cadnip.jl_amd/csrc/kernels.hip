@@ -239,7 +239,20 @@ __global__ void k_lu(LUArgs a) {
         const int pos = a.ent_pos[e];
         double acc = lu[pos];
         const int t1 = a.ent_ptr[e + 1];
-        for (int t = a.ent_ptr[e]; t < t1; ++t) acc -= lu[a.term_a[t]] * lu[a.term_b[t]];
+        // four terms in flight: with the factors in HBM every term is two dependent memory latencies (indices, then
+        // values); one term at a time made an entry with k terms cost 2 k latencies.  Same summation order.
+        int t = a.ent_ptr[e];
+        for (; t + 4 <= t1; t += 4) {
+          int ia[4], ib[4];
+          double va[4], vb[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { ia[q] = a.term_a[t + q]; ib[q] = a.term_b[t + q]; }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { va[q] = lu[ia[q]]; vb[q] = lu[ib[q]]; }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc -= va[q] * vb[q];
+        }
+        for (; t < t1; ++t) acc -= lu[a.term_a[t]] * lu[a.term_b[t]];
         const int dg = a.ent_diag[e];
         if (dg >= 0) acc /= lu[dg];
         lu[pos] = acc;
@@ -265,7 +278,18 @@ __global__ void k_lu(LUArgs a) {
         const int i = a.fwd_rows[r];
         double acc = y[i];
         const int p1 = a.lu_diag[i];
-        for (int p = a.lu_rowptr[i]; p < p1; ++p) acc -= lu[p] * y[a.lu_col[p]];
+        int p = a.lu_rowptr[i];
+        for (; p + 4 <= p1; p += 4) {
+          int jc[4];
+          double lv[4], yv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { jc[q] = a.lu_col[p + q]; lv[q] = lu[p + q]; }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) yv[q] = y[jc[q]];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc -= lv[q] * yv[q];
+        }
+        for (; p < p1; ++p) acc -= lu[p] * y[a.lu_col[p]];
         y[i] = acc;
       }
       __syncthreads();
@@ -276,8 +300,20 @@ __global__ void k_lu(LUArgs a) {
         const int i = a.bwd_rows[r];
         double acc = y[i];
         const int dp = a.lu_diag[i], p1 = a.lu_rowptr[i + 1];
-        for (int p = dp + 1; p < p1; ++p) acc -= lu[p] * y[a.lu_col[p]];
-        y[i] = acc / lu[dp];
+        const double piv = lu[dp];
+        int p = dp + 1;
+        for (; p + 4 <= p1; p += 4) {
+          int jc[4];
+          double lv[4], yv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { jc[q] = a.lu_col[p + q]; lv[q] = lu[p + q]; }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) yv[q] = y[jc[q]];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc -= lv[q] * yv[q];
+        }
+        for (; p < p1; ++p) acc -= lu[p] * y[a.lu_col[p]];
+        y[i] = acc / piv;
       }
       __syncthreads();
     }

@@ -273,7 +273,7 @@ def test_c6288_single_large_circuit_lu_against_superlu():
 
 def test_c6288_power_up_transient_multiplies():
     """The whole 16 x 16 multiplier as one transient on the per-op GPU path (n = 75 908): supplies and inputs ramp up from
-    the all-zero state, ~1 500 Newton iterations of restamp / refactor / solve at ~8 ms each, and the 32 output nodes
+    the all-zero state, ~1 500 Newton iterations of restamp / refactor / solve at ~7 ms each, and the 32 output nodes
     settle to the bits of 0xBEEF * 0x1234 -- stamps, LU and the BDF controller working together on a single large circuit."""
     from tools.c6288 import powerup
     p, per, dt = powerup(0xBEEF, 0x1234)
