@@ -32,7 +32,7 @@ ABSTOL = dict(vntol=1e-6, iabstol=1e-9, chgtol=1e-6)
 RELTOL = 1e-4
 
 
-PMC_SUMMARY = "r01g_fused_B4096_pmc_summary.json"   # committed rocprofv3 --pmc passes of this kernel at this batch size
+PMC_SUMMARY = "r01h_fused_B4096_pmc_summary.json"   # committed rocprofv3 --pmc passes of this kernel at this batch size
 
 
 def algorithmic_bytes(st, B, nnz_lu, rounds=8):
