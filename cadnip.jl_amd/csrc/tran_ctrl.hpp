@@ -117,8 +117,8 @@ template <class A> __device__ inline void store_state(const A& a, int inst, int 
 // every per-unknown vector in HBM (per-op path)
 struct GlobalVecs {
   static constexpr int KPF = 0;
-  double *u, *du, *up, *beta, *u0, *u1, *u2;
-  const double *delta, *lw;
+  double *__restrict__ u, *__restrict__ du, *__restrict__ up, *__restrict__ beta, *__restrict__ u0, *__restrict__ u1, *__restrict__ u2;
+  const double *__restrict__ delta, *__restrict__ lw;
   __device__ GlobalVecs(const TranArgs& a, int inst) {
     const size_t o = (size_t)inst * a.n;
     u = a.u + o; du = a.du + o; up = a.up + o; beta = a.beta + o; u0 = a.u0 + o; u1 = a.u1 + o; u2 = a.u2 + o; delta = a.delta + o; lw = a.limit_w + o;
@@ -155,6 +155,9 @@ __device__ __forceinline__ void each_elem(int n, int tid, F&& f) {
 #pragma unroll
     for (int k = 0; k < V::KPF; ++k) { const int i = tid + 64 * k; if (i < n) f(i, k); }
   }
+  // several elements in flight per lane: with every vector in HBM (per-op path, large n) an element is a chain of memory
+  // latencies, and one wave walks n / 64 of them
+#pragma unroll 4
   for (int i = tid + 64 * V::KPF; i < n; i += 64) f(i, -1);
 }
 
