@@ -415,7 +415,8 @@ static int launch_lu(CadnipHandle* h, const char* name, int do_factor, int do_so
   // one workgroup per instance; its size follows the work per dependency level: a wave for the small systems of a sweep
   // (the DFF: 186 computed entries in 14 levels), 16 waves for a single large circuit whose factors live in HBM
   // (c6288: 79 k entries, 352 k multiply-adds in 237 levels -- with one wave the refactorisation took 9.3 ms)
-  const int threads = !a.use_lds ? 1024 : (P.nnz_lu >= 8192 ? 256 : 64);
+  int threads = !a.use_lds ? 1024 : (P.nnz_lu >= 8192 ? 256 : 64);
+  if (const char* e = getenv("CADNIP_LU_THREADS")) { const int t = atoi(e); if (t >= 64 && t <= 1024 && t % 64 == 0) threads = t; }   // diagnostic
   hipLaunchKernelGGL(k_lu, dim3(h->B), dim3(threads), shmem, h->stream, a);
   HIP_TRY(hipGetLastError());
   return CADNIP_OK;
