@@ -157,8 +157,12 @@ __device__ __forceinline__ void each_elem(int n, int tid, F&& f) {
   }
   // several elements in flight per lane: with every vector in HBM (per-op path, large n) an element is a chain of memory
   // latencies, and one wave walks n / 64 of them
+  if constexpr (V::KPF == 0) {
 #pragma unroll 4
-  for (int i = tid + 64 * V::KPF; i < n; i += 64) f(i, -1);
+    for (int i = tid; i < n; i += 64) f(i, -1);
+  } else {
+    for (int i = tid + 64 * V::KPF; i < n; i += 64) f(i, -1);
+  }
 }
 
 // Set up the step that starts at (t, history) with proposed size h: clip to the next stop,
