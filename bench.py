@@ -60,7 +60,7 @@ def algorithmic_bytes(st, B, nnz_lu, rounds=8):
     return out
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--calib-copy", type=int, default=0,
                     help="also run the 8 B/lane fp64 calibration copy of this many MiB (for rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE runs)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     import torch
     import torch.distributed as dist
