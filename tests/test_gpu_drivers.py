@@ -290,22 +290,3 @@ def test_uic_start_of_the_ring_oscillator():
     assert sol.retcode == "Success"
     tc.ring_checks(np.asarray(sol["out1"]))
 
-
-def test_bench_line_contract(capsys):
-    """bench.py in-process on a small sweep: ONE JSON line with the contract fields, the roofline object of the dominant
-    kernel (live HIP-event timing) and the CPU baseline of the oracle's port."""
-    import json
-    import bench
-    bench.main(["--steps", "1", "--warmup", "0", "--instances", "64", "--cpu-sample", "32"])
-    lines = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
-    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert key in d, key
-    assert d["metric"] == "newton_iters_per_sec" and d["unit"] == "newton_iters/s" and d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 0
-    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
-    assert "workload" in d["config"] and d["config"]["instances_per_gpu"] == 64 and d["value"] > 1e6
-    r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["avg_launch_us"] > 0
-    c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and "sample" in c
