@@ -272,12 +272,14 @@ def test_c6288_single_large_circuit_lu_against_superlu():
 
 
 def test_c6288_power_up_transient_multiplies():
-    """The whole 16 x 16 multiplier as one transient on the per-op GPU path (n = 75 908): supplies and inputs ramp up from
-    the all-zero state, ~1 500 Newton iterations of restamp / refactor / solve at ~7 ms each, and the 32 output nodes
-    settle to the bits of 0xBEEF * 0x1234 -- stamps, LU and the BDF controller working together on a single large circuit."""
-    from tools.c6288 import powerup
-    p, per, dt = powerup(0xBEEF, 0x1234)
-    assert per[3] == 1 and p == 0xBEEF * 0x1234, (hex(p), per)
+    """The whole 16 x 16 multiplier as a transient on the per-op GPU path (n = 75 908), four operand pairs as four sweep
+    instances: supplies and inputs ramp up from the all-zero state (CedarUICOp-style start), ~1 500 Newton iterations of
+    restamp / refactor / solve per instance, and the 32 output nodes of every instance settle to the bits of its product --
+    stamps, LU and the BDF controller working together on large circuits."""
+    from tools.c6288 import powerup_batch
+    pairs = [(0xBEEF, 0x1234), (0xFFFF, 0xFFFF), (0x0001, 0x8000), (0xA5A5, 0x5A5A)]
+    prods, dt = powerup_batch(pairs)
+    assert prods == [a * b for a, b in pairs], [hex(p) for p in prods]
 
 
 def test_uic_start_of_the_ring_oscillator():

@@ -56,6 +56,44 @@ def powerup(a=0xBEEF, b=0x1234, vdd=1.2, t_end=10e-9, verbose=False):
     return p, per[0], dt
 
 
+def powerup_batch(pairs, vdd=1.2, t_end=10e-9, verbose=False):
+    """Several operand pairs at once: one sweep instance per pair (the input sources' amplitudes are sweep parameters), one
+    1024-thread LU workgroup per instance.  Returns the products read back, and the seconds the transient took."""
+    from cadnip_jl_amd.circuit import Param
+    inc = open(os.path.join(ROOT, "tests", "golden", "c6288_multiplier.inc")).read()
+    d = '* c6288 power-up, operands as sweep parameters\n.include "multiplier.inc"\nvdd vdd 0 PWL(0 0 1n %g)\nvss vss 0 0\nx1 ' % vdd
+    d += " ".join("a%d" % k for k in range(16)) + " " + " ".join("b%d" % k for k in range(16)) + " " + " ".join("p%d" % k for k in range(32)) + " c6288\n"
+    for k in range(16):
+        d += "va%d a%d 0 PWL(0 0 1n 1)\nvb%d b%d 0 PWL(0 0 1n 1)\n" % (k, k, k, k)
+    nm = dict(type=1, vto=0.4, kp=200e-6, gamma=0.3, phi=0.7, cbd=1e-15, cbs=1e-15)
+    pm = dict(type=-1, vto=-0.4, kp=100e-6, gamma=0.3, phi=0.7, cbd=1e-15, cbs=1e-15)
+    circ = cj.netlist.read_spice(d, models={"nmos": nm, "pmos": pm}, includes={"multiplier.inc": inc})[0]
+    for dev in circ.devices:
+        if dev.type == "V" and dev.name[:2] in ("va", "vb") and dev.name[2:].isdigit():
+            dev.params["scale"] = Param("%s%s" % (dev.name[1], dev.name[2:]))      # amplitude of bit k of operand a / b
+    pts = []
+    for a, b in pairs:
+        pt = {}
+        for k in range(16):
+            pt["a%d" % k] = vdd * ((a >> k) & 1)
+            pt["b%d" % k] = vdd * ((b >> k) & 1)
+        pts.append(pt)
+    sim = api.BatchSimulator(api.MNACircuit(circ, dict(pts[0]), api.MNASpec(mode="tran")), pts)
+    st = sim.st
+    t0 = time.time()
+    out, per, stats = sim.tran((0.0, t_end), st.state_abstol(vntol=1e-4, iabstol=1e-7, chgtol=1e-4), 1e-3, np.array([t_end]),
+                               initializealg="uic", obs=[st.index_of("p%d" % k) for k in range(32)], fused=0)
+    dt = time.time() - t0
+    sim.close()
+    prods = [sum((1 << k) for k in range(32) if out[i, 0, k] > 0.5 * vdd) for i in range(len(pairs))]
+    if verbose:
+        print("batch of %d multipliers: %.1f s, %d Newton iterations in total = %.2f ms per iteration and instance" % (
+            len(pairs), dt, stats["newton_iters"], dt / max(1, stats["newton_iters"]) * 1e3))
+        for (a, b), p in zip(pairs, prods):
+            print("   0x%04X * 0x%04X -> 0x%08X %s" % (a, b, p, "OK" if p == a * b else "MISMATCH (expected 0x%08X)" % (a * b)))
+    return prods, dt
+
+
 def main():
     import scipy.sparse as sp, scipy.sparse.linalg as spl
     t0 = time.time()
@@ -91,6 +129,7 @@ def main():
           % (res(x), res(xr), np.max(np.abs(x - xr)) / np.max(np.abs(xr))))
     sim.close()
     powerup(verbose=True)
+    powerup_batch([(0xBEEF, 0x1234), (0xFFFF, 0xFFFF), (0x0001, 0x8000), (0xA5A5, 0x5A5A), (0x0000, 0xFFFF), (0x7FFF, 0x0003), (0x1357, 0x2468), (0xC0DE, 0xF00D)], verbose=True)
 
 
 if __name__ == "__main__":
