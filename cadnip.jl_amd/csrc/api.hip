@@ -33,8 +33,33 @@ extern "C" {
 
 const char* cadnip_version(void) { return "cadnip_hip 0.1.0 (gfx950)"; }
 
+void cadnip_destroy(CadnipHandle* h);
+// inside cadnip_create, once the handle exists: a failing step releases everything created so far
+#define CREATE_TRY(x) do { int _rc = (x); if (_rc) { cadnip_destroy(h); return _rc; } } while (0)
+#define CREATE_HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cadnip::set_last_error(#expr, _e); cadnip_destroy(h); return CADNIP_HIPERROR; } } while (0)
+
 int cadnip_create(const CadnipStructure* s, int32_t n_instances, int32_t device, CadnipHandle** out) {
-  if (!s || !out || n_instances <= 0 || s->n <= 0) return CADNIP_BADARG;
+  if (!s || !out || n_instances <= 0 || s->n <= 0 || s->nnz < 0 || s->n_limits < 0 || s->n_nodes < 0 || s->n_nodes > s->n) return CADNIP_BADARG;
+  // Host-side shape checks first, before anything is allocated: every pointer the structure must carry, every prefix
+  // array (start 0, non-decreasing, end = length of its list) and every index a kernel will dereference.
+  if (!s->rowptr || !s->colidx || !s->to_ref_nz || !s->g_ptr || !s->c_ptr || !s->b_ptr || !s->diag_nz) return CADNIP_BADARG;
+  if (s->n_limits > 0 && !s->limit_init) return CADNIP_BADARG;
+  if (s->n_blocks < 0 || (s->n_blocks > 0 && !s->blocks) || s->n_wave_data < 0 || (s->n_wave_data > 0 && !s->wave_data)) return CADNIP_BADARG;
+  if (s->ns_g < 0 || s->ns_c < 0 || s->ns_b < 0) return CADNIP_BADARG;
+  {
+    auto prefix_ok = [](const int32_t* p, int len) {
+      if (p[0] != 0) return false;
+      for (int i = 0; i < len; ++i) if (p[i] > p[i + 1]) return false;
+      return true;
+    };
+    if (!prefix_ok(s->rowptr, s->n) || s->rowptr[s->n] != s->nnz) return CADNIP_BADARG;
+    if (!prefix_ok(s->g_ptr, s->nnz) || !prefix_ok(s->c_ptr, s->nnz) || !prefix_ok(s->b_ptr, s->n)) return CADNIP_BADARG;
+    if ((s->g_ptr[s->nnz] > 0 && !s->g_slots) || (s->c_ptr[s->nnz] > 0 && !s->c_slots) || (s->b_ptr[s->n] > 0 && !s->b_slots)) return CADNIP_BADARG;
+    for (int k = 0; k < s->nnz; ++k) if (s->colidx[k] < 0 || s->colidx[k] >= s->n || s->to_ref_nz[k] < 0 || s->to_ref_nz[k] >= s->nnz) return CADNIP_BADARG;
+    for (int k = 0; k < s->g_ptr[s->nnz]; ++k) if (s->g_slots[k] < 0 || s->g_slots[k] >= s->ns_g) return CADNIP_BADARG;
+    for (int k = 0; k < s->c_ptr[s->nnz]; ++k) if (s->c_slots[k] < 0 || s->c_slots[k] >= s->ns_c) return CADNIP_BADARG;
+    for (int k = 0; k < s->b_ptr[s->n]; ++k) if (s->b_slots[k] < 0 || s->b_slots[k] >= s->ns_b) return CADNIP_BADARG;
+  }
   HIP_TRY(hipSetDevice(device));
   CadnipHandle* h = new CadnipHandle();
   h->device = device;
@@ -42,33 +67,26 @@ int cadnip_create(const CadnipStructure* s, int32_t n_instances, int32_t device,
   h->n = s->n; h->n_nodes = s->n_nodes; h->n_currents = s->n_currents; h->n_charges = s->n_charges; h->n_limits = s->n_limits;
   h->nnz = s->nnz;
   h->ns_g = s->ns_g; h->ns_c = s->ns_c; h->ns_b = s->ns_b; h->ns = s->ns_g + s->ns_c + s->ns_b;
-  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreate(&h->ev0));
-  HIP_TRY(hipEventCreate(&h->ev1));
-  HIP_TRY(hipHostMalloc((void**)&h->h_pinned, 64 * sizeof(int), hipHostMallocDefault));
+  CREATE_HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  CREATE_HIP_TRY(hipEventCreate(&h->ev0));
+  CREATE_HIP_TRY(hipEventCreate(&h->ev1));
+  CREATE_HIP_TRY(hipHostMalloc((void**)&h->h_pinned, 64 * sizeof(int), hipHostMallocDefault));
   h->h_rowptr.assign(s->rowptr, s->rowptr + s->n + 1);
   h->h_colidx.assign(s->colidx, s->colidx + s->nnz);
   h->h_to_ref.assign(s->to_ref_nz, s->to_ref_nz + s->nnz);
   h->h_limit_init.assign(s->limit_init, s->limit_init + s->n_limits);
-  // host-side shape checks: every index a kernel will dereference is validated here
-  for (int i = 0; i < s->n; ++i) if (s->rowptr[i] > s->rowptr[i + 1]) { delete h; return CADNIP_BADARG; }
-  if (s->rowptr[s->n] != s->nnz) { delete h; return CADNIP_BADARG; }
-  for (int k = 0; k < s->nnz; ++k) if (s->colidx[k] < 0 || s->colidx[k] >= s->n || s->to_ref_nz[k] < 0 || s->to_ref_nz[k] >= s->nnz) { delete h; return CADNIP_BADARG; }
-  for (int k = 0; k < s->g_ptr[s->nnz]; ++k) if (s->g_slots[k] < 0 || s->g_slots[k] >= s->ns_g) { delete h; return CADNIP_BADARG; }
-  for (int k = 0; k < s->c_ptr[s->nnz]; ++k) if (s->c_slots[k] < 0 || s->c_slots[k] >= s->ns_c) { delete h; return CADNIP_BADARG; }
-  for (int k = 0; k < s->b_ptr[s->n]; ++k) if (s->b_slots[k] < 0 || s->b_slots[k] >= s->ns_b) { delete h; return CADNIP_BADARG; }
-  TRY(dev_upload(&h->d_rowptr, s->rowptr, (size_t)s->n + 1));
-  TRY(dev_upload(&h->d_colidx, s->colidx, (size_t)s->nnz));
-  TRY(dev_upload(&h->d_to_ref, s->to_ref_nz, (size_t)s->nnz));
-  TRY(dev_upload(&h->d_g_ptr, s->g_ptr, (size_t)s->nnz + 1));
-  TRY(dev_upload(&h->d_g_slots, s->g_slots, (size_t)s->g_ptr[s->nnz]));
-  TRY(dev_upload(&h->d_c_ptr, s->c_ptr, (size_t)s->nnz + 1));
-  TRY(dev_upload(&h->d_c_slots, s->c_slots, (size_t)s->c_ptr[s->nnz]));
-  TRY(dev_upload(&h->d_b_ptr, s->b_ptr, (size_t)s->n + 1));
-  TRY(dev_upload(&h->d_b_slots, s->b_slots, (size_t)s->b_ptr[s->n]));
+  CREATE_TRY(dev_upload(&h->d_rowptr, s->rowptr, (size_t)s->n + 1));
+  CREATE_TRY(dev_upload(&h->d_colidx, s->colidx, (size_t)s->nnz));
+  CREATE_TRY(dev_upload(&h->d_to_ref, s->to_ref_nz, (size_t)s->nnz));
+  CREATE_TRY(dev_upload(&h->d_g_ptr, s->g_ptr, (size_t)s->nnz + 1));
+  CREATE_TRY(dev_upload(&h->d_g_slots, s->g_slots, (size_t)s->g_ptr[s->nnz]));
+  CREATE_TRY(dev_upload(&h->d_c_ptr, s->c_ptr, (size_t)s->nnz + 1));
+  CREATE_TRY(dev_upload(&h->d_c_slots, s->c_slots, (size_t)s->c_ptr[s->nnz]));
+  CREATE_TRY(dev_upload(&h->d_b_ptr, s->b_ptr, (size_t)s->n + 1));
+  CREATE_TRY(dev_upload(&h->d_b_slots, s->b_slots, (size_t)s->b_ptr[s->n]));
   std::vector<unsigned char> dflag(s->nnz, 0);
   for (int i = 0; i < s->n_nodes; ++i) { int p = s->diag_nz[i]; if (p >= 0 && p < s->nnz) dflag[p] = 1; }
-  TRY(dev_upload(&h->d_diag_flag, dflag.data(), dflag.size()));
+  CREATE_TRY(dev_upload(&h->d_diag_flag, dflag.data(), dflag.size()));
   {
     // gather lists longer than kernels.hip's LONG_LIST get a workgroup each (supply rails of large circuits)
     const int LONG = 512;
@@ -78,17 +96,19 @@ int cadnip_create(const CadnipStructure* s, int32_t n_instances, int32_t device,
     for (int i = 0; i < s->n; ++i) if (s->b_ptr[i + 1] - s->b_ptr[i] > LONG) le.push_back(2 * s->nnz + i);
     for (int i = 0; i < s->n; ++i) if (s->rowptr[i + 1] - s->rowptr[i] > LONG) lr.push_back(i);
     h->n_long_asm = (int)le.size(); h->n_long_rows = (int)lr.size();
-    if (!le.empty()) TRY(dev_upload(&h->d_long_asm, le.data(), le.size()));
-    if (!lr.empty()) TRY(dev_upload(&h->d_long_rows, lr.data(), lr.size()));
+    if (!le.empty()) CREATE_TRY(dev_upload(&h->d_long_asm, le.data(), le.size()));
+    if (!lr.empty()) CREATE_TRY(dev_upload(&h->d_long_rows, lr.data(), lr.size()));
   }
-  TRY(dev_upload(&h->d_wave, s->wave_data, (size_t)s->n_wave_data));
-  TRY(dev_upload(&h->d_limit_init, s->limit_init, (size_t)s->n_limits));
+  CREATE_TRY(dev_upload(&h->d_wave, s->wave_data, (size_t)s->n_wave_data));
+  CREATE_TRY(dev_upload(&h->d_limit_init, s->limit_init, (size_t)s->n_limits));
   for (int bi = 0; bi < s->n_blocks; ++bi) {
     const CadnipDeviceBlock& sb = s->blocks[bi];
     DeviceBlock b;
     b.type = sb.type; b.count = sb.count; b.n_nodes = sb.n_nodes; b.n_ipar = sb.n_ipar; b.n_par = sb.n_par;
     b.g_base = sb.g_base; b.c_base = sb.c_base; b.b_base = sb.b_base; b.n_g = sb.n_g; b.n_c = sb.n_c; b.n_b = sb.n_b;
-    if (b.type < 0 || b.type >= CADNIP_DEV_NTYPES || b.count < 0) { cadnip_destroy(h); return CADNIP_BADARG; }
+    if (b.type < 0 || b.type >= CADNIP_DEV_NTYPES || b.count < 0 || b.n_nodes < 0 || b.n_ipar < 0 || b.n_par < 0 || b.n_g < 0 || b.n_c < 0 || b.n_b < 0 ||
+        b.g_base < 0 || b.c_base < 0 || b.b_base < 0) { cadnip_destroy(h); return CADNIP_BADARG; }
+    if ((b.n_nodes * b.count > 0 && !sb.nodes) || (b.n_ipar * b.count > 0 && !sb.ipar)) { cadnip_destroy(h); return CADNIP_BADARG; }
     if (b.g_base + b.n_g * b.count > s->ns_g || b.c_base + b.n_c * b.count > s->ns_c || b.b_base + b.n_b * b.count > s->ns_b) { cadnip_destroy(h); return CADNIP_BADARG; }
     for (int k = 0; k < b.n_nodes * b.count; ++k) if (sb.nodes[k] < -1 || sb.nodes[k] >= s->n) { cadnip_destroy(h); return CADNIP_BADARG; }
     if ((b.type == CADNIP_DEV_VSOURCE || b.type == CADNIP_DEV_ISOURCE)) {
@@ -135,19 +155,22 @@ int cadnip_create(const CadnipStructure* s, int32_t n_instances, int32_t device,
       if (!ok) { cadnip_destroy(h); return CADNIP_BADARG; }
     }
     b.h_nodes.assign(sb.nodes, sb.nodes + (size_t)b.n_nodes * b.count);
-    TRY(dev_upload(&b.d_nodes, sb.nodes, (size_t)b.n_nodes * b.count));
-    TRY(dev_upload(&b.d_ipar, sb.ipar, (size_t)(b.n_ipar > 0 ? b.n_ipar : 1) * b.count));
-    TRY(dev_alloc(&b.d_par, (size_t)h->B * b.n_par * b.count));
-    h->blocks.push_back(b);
+    h->blocks.push_back(b);                      // registered first: a failing upload below is cleaned up by cadnip_destroy
+    DeviceBlock& hb = h->blocks.back();
+    CREATE_TRY(dev_upload(&hb.d_nodes, sb.nodes, (size_t)b.n_nodes * b.count));
+    CREATE_TRY(dev_upload(&hb.d_ipar, sb.ipar, (size_t)(b.n_ipar > 0 ? b.n_ipar : 1) * b.count));
+    CREATE_TRY(dev_alloc(&hb.d_par, (size_t)h->B * b.n_par * b.count));
   }
   size_t B = h->B, n = h->n, nnz = h->nnz;
-  TRY(dev_alloc(&h->d_u, B * n)); TRY(dev_alloc(&h->d_du, B * n)); TRY(dev_alloc(&h->d_t, B)); TRY(dev_alloc(&h->d_gamma, B));
-  TRY(dev_alloc(&h->d_S, B * h->ns)); TRY(dev_alloc(&h->d_G, B * nnz)); TRY(dev_alloc(&h->d_C, B * nnz)); TRY(dev_alloc(&h->d_b, B * n));
-  TRY(dev_alloc(&h->d_J, B * nnz)); TRY(dev_alloc(&h->d_resid, B * n)); TRY(dev_alloc(&h->d_delta, B * n));
-  TRY(dev_alloc(&h->d_limit_w, B * n)); TRY(dev_alloc(&h->d_tmp, B * n));
-  TRY(dev_alloc(&h->d_flags, B)); TRY(dev_alloc(&h->d_active, B));
+  CREATE_TRY(dev_alloc(&h->d_u, B * n)); CREATE_TRY(dev_alloc(&h->d_du, B * n)); CREATE_TRY(dev_alloc(&h->d_t, B)); CREATE_TRY(dev_alloc(&h->d_gamma, B));
+  CREATE_TRY(dev_alloc(&h->d_S, B * h->ns)); CREATE_TRY(dev_alloc(&h->d_G, B * nnz)); CREATE_TRY(dev_alloc(&h->d_C, B * nnz)); CREATE_TRY(dev_alloc(&h->d_b, B * n));
+  CREATE_TRY(dev_alloc(&h->d_J, B * nnz)); CREATE_TRY(dev_alloc(&h->d_resid, B * n)); CREATE_TRY(dev_alloc(&h->d_delta, B * n));
+  CREATE_TRY(dev_alloc(&h->d_limit_w, B * n)); CREATE_TRY(dev_alloc(&h->d_tmp, B * n));
+  CREATE_TRY(dev_alloc(&h->d_flags, B)); CREATE_TRY(dev_alloc(&h->d_active, B)); CREATE_TRY(dev_alloc(&h->d_nonfinite, B));
+  CREATE_TRY(dev_alloc(&h->d_gshunt, B)); CREATE_TRY(dev_alloc(&h->d_srcfact, B));
+  CREATE_TRY(upload_homotopy(h, nullptr, nullptr));
   std::vector<int> ones(B, 1);
-  HIP_TRY(hipMemcpy(h->d_active, ones.data(), B * sizeof(int), hipMemcpyHostToDevice));
+  CREATE_HIP_TRY(hipMemcpy(h->d_active, ones.data(), B * sizeof(int), hipMemcpyHostToDevice));
   *out = h;
   return CADNIP_OK;
 }
@@ -161,7 +184,7 @@ void cadnip_destroy(CadnipHandle* h) {
   cadnip_driver_free(h);
   void* ptrs[] = {h->d_rowptr, h->d_colidx, h->d_to_ref, h->d_g_ptr, h->d_g_slots, h->d_c_ptr, h->d_c_slots, h->d_b_ptr, h->d_b_slots,
                   h->d_diag_flag, h->d_long_asm, h->d_long_rows, h->d_wave, h->d_limit_init, h->d_u, h->d_du, h->d_t, h->d_gamma, h->d_S, h->d_G, h->d_C, h->d_b, h->d_J,
-                  h->d_resid, h->d_delta, h->d_limit_w, h->d_LU, h->d_tmp, h->d_flags, h->d_active, h->d_load_src, h->d_load_dst, h->d_ent_pos,
+                  h->d_resid, h->d_delta, h->d_limit_w, h->d_LU, h->d_tmp, h->d_flags, h->d_active, h->d_nonfinite, h->d_gshunt, h->d_srcfact, h->d_load_src, h->d_load_dst, h->d_ent_pos,
                   h->d_ent_diag, h->d_ent_ptr, h->d_term_a, h->d_term_b, h->d_lev_ptr, h->d_lu_rowptr, h->d_lu_col, h->d_lu_diag, h->d_rperm,
                   h->d_cperm, h->d_fwd_rows, h->d_fwd_lev_ptr, h->d_bwd_rows, h->d_bwd_lev_ptr};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -200,7 +223,7 @@ int cadnip_set_params(CadnipHandle* h, int32_t block, const double* par_host) {
 int cadnip_set_spec(CadnipHandle* h, const CadnipSpec* spec) {
   if (!h || !spec || spec->mode < 0 || spec->mode > 2) return CADNIP_BADARG;
   h->spec = *spec;
-  return CADNIP_OK;
+  return upload_homotopy(h, nullptr, nullptr);
 }
 
 int cadnip_set_initjct(CadnipHandle* h, int32_t on) { if (!h) return CADNIP_BADARG; h->initjct = on ? 1 : 0; return CADNIP_OK; }
@@ -212,13 +235,21 @@ static int upload_state(CadnipHandle* h, const double* u_host, const double* t_h
   return CADNIP_OK;
 }
 
-static int check_nonfinite(CadnipHandle* h) { return CADNIP_OK; }
+// CADNIP_NONFINITE when the last restamp produced a NaN / Inf in G, C or b of any instance (the assemble kernels raise
+// d_nonfinite; the Julia shim maps the status to DomainError, which _dc_solve_with_fallbacks catches, solve.jl:887-897)
+static int check_nonfinite(CadnipHandle* h) {
+  std::vector<int> nf((size_t)h->B);
+  HIP_TRY(hipMemcpyAsync(nf.data(), h->d_nonfinite, nf.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int f : nf) if (f) return CADNIP_NONFINITE;
+  return CADNIP_OK;
+}
 
 int cadnip_rebuild(CadnipHandle* h, const double* u_host, const double* t_host) {
   if (!h) return CADNIP_BADARG;
   TRY(upload_state(h, u_host, t_host));
+  HIP_TRY(hipMemsetAsync(h->d_nonfinite, 0, (size_t)h->B * sizeof(int), h->stream));
   TRY(launch_rebuild(h));
-  HIP_TRY(hipStreamSynchronize(h->stream));
   return check_nonfinite(h);
 }
 
@@ -269,6 +300,7 @@ int cadnip_ode_rhs(CadnipHandle* h, const double* u_host, const double* t_host, 
 
 int cadnip_ode_jacobian(CadnipHandle* h, const double* u_host, const double* t_host, double* J_ref_nz_host) {
   if (!h || !J_ref_nz_host) return CADNIP_BADARG;
+  HIP_TRY(hipMemsetAsync(h->d_nonfinite, 0, (size_t)h->B * sizeof(int), h->stream));
   if (u_host) { TRY(upload_state(h, u_host, t_host)); TRY(launch_rebuild(h)); }
   HIP_TRY(hipMemsetAsync(h->d_gamma, 0, (size_t)h->B * sizeof(double), h->stream));
   TRY(launch_jacobian(h));                                // G + 0*C
@@ -459,6 +491,19 @@ int cadnip_profile_read(CadnipHandle* h, int32_t max_entries, const char** names
 }  // extern "C"
 
 namespace cadnip {
+int upload_homotopy(CadnipHandle* h, const double* gshunt, const double* srcfact) {
+  const size_t B = (size_t)h->B;
+  std::vector<double> g(B, h->spec.gshunt), sf(B, h->spec.srcFact);
+  if (gshunt) g.assign(gshunt, gshunt + B);
+  if (srcfact) sf.assign(srcfact, srcfact + B);
+  bool any = false;
+  for (size_t i = 0; i < B; ++i) if (g[i] != 0.0 || sf[i] < 1.0) any = true;
+  HIP_TRY(hipMemcpyAsync(h->d_gshunt, g.data(), B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_srcfact, sf.data(), B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));   // the host vectors go out of scope
+  h->homotopy = any;
+  return CADNIP_OK;
+}
 int upload_lu(CadnipHandle* h) {
   LUProgram& P = h->lu;
   int** olds[] = {&h->d_load_src, &h->d_load_dst, &h->d_ent_pos, &h->d_ent_diag, &h->d_ent_ptr, &h->d_term_a, &h->d_term_b, &h->d_lev_ptr,

@@ -38,7 +38,11 @@ struct Driver {
   double *atol = nullptr, *emask = nullptr, *breaks = nullptr, *save_t = nullptr, *out = nullptr;
   int* obs = nullptr;
   int* nactive = nullptr;
+  int* part = nullptr;        // [B] 1 = the instance takes part in the DC Newton run being started (k_dc_init)
   size_t out_cap = 0, brk_cap = 0, save_cap = 0, obs_cap = 0;
+  // what the DC fallback chain did, one entry per (instance, Newton run): cadnip_dc_log_*
+  struct DCLogEntry { int inst, stage; double value; int ok; long long iters; };
+  std::vector<DCLogEntry> dc_log;
 };
 
 namespace {
@@ -55,7 +59,7 @@ int ensure_driver(CadnipHandle* h) {
   TRY(dalloc(&d->bp_idx, B)); TRY(dalloc(&d->save_idx, B)); TRY(dalloc(&d->dcstate, B)); TRY(dalloc(&d->action, B));
   TRY(dalloc(&d->cnt, B * 4));
   TRY(dalloc(&d->u0, B * n)); TRY(dalloc(&d->u1, B * n)); TRY(dalloc(&d->u2, B * n)); TRY(dalloc(&d->up, B * n)); TRY(dalloc(&d->beta, B * n));
-  TRY(dalloc(&d->atol, n)); TRY(dalloc(&d->emask, n)); TRY(dalloc(&d->nactive, 2));
+  TRY(dalloc(&d->atol, n)); TRY(dalloc(&d->emask, n)); TRY(dalloc(&d->nactive, 2)); TRY(dalloc(&d->part, B));
   return CADNIP_OK;
 }
 
@@ -119,8 +123,14 @@ struct DCArgs {
   int B, n, n_limits, use_pcnr, maxiters; double abstol;
 };
 
-__global__ void __launch_bounds__(64) k_dc_init(DCArgs a, int cold_start) {
+// `part` (may be null = everyone): an instance that sits this run out is parked -- status 2, inactive -- and none of the
+// kernels of the run touches its state
+__global__ void __launch_bounds__(64) k_dc_init(DCArgs a, int cold_start, const int* part) {
   const int inst = blockIdx.x, tid = threadIdx.x, n = a.n;
+  if (part && !part[inst]) {
+    if (tid == 0) { a.status[inst] = 2; a.dcstate[inst] = 0; a.action[inst] = 0; a.active[inst] = 0; }
+    return;
+  }
   double* u = a.u + (size_t)inst * n;
   int nz = 0;
   for (int i = tid; i < n; i += 64) if (u[i] != 0.0) nz = 1;
@@ -143,7 +153,11 @@ __global__ void __launch_bounds__(64) k_dc_check(DCArgs a) {
   int st = a.dcstate[inst];
   long long it = a.cnt[(size_t)inst * 4 + 0];
   int action = 0, status = 0;
+  // The PCNR loop tests convergence at the top of iterations 1..maxiters only (solve.jl:630-663): after its last solve it
+  // returns unconverged without looking at the residual again.  The plain Newton stage gets the check after its last step.
+  const bool pcnr = a.use_pcnr && a.n_limits > 0;
   if (bad) status = -1;
+  else if (pcnr && st == 0 && it >= a.maxiters) status = -3;
   else if (nrm < a.abstol) {
     if (!a.use_pcnr || a.n_limits == 0) status = 1;
     else if (st == 0) {   // settle the limit slots, verify on the next rebuild (solve.jl:640-657)
@@ -173,7 +187,9 @@ __global__ void __launch_bounds__(64) k_dc_update(DCArgs a) {
       const double* lw = a.limit_w + (size_t)inst * n;
       for (int i = n - a.n_limits + tid; i < n; i += 64) u[i] = lw[i];
     }
-    if (tid == 0) { a.cnt[(size_t)inst * 4 + 0] += 1; if (bad) a.status[inst] = -2; }
+    // a solve that failed (zero / non-finite pivot, non-finite step) is not an iteration: the reference's count is of the
+    // updates applied (solve.jl:667-690; a SingularException leaves the loop before the counter moves)
+    if (tid == 0) { if (bad) a.status[inst] = -2; else a.cnt[(size_t)inst * 4 + 0] += 1; }
   }
   __syncthreads();
   if (tid == 0) a.active[inst] = (a.status[inst] == 0) ? 1 : 0;   // next round's rebuild mask
@@ -190,18 +206,18 @@ int count_running(CadnipHandle* h, int* out) {
 }
 
 // one DC Newton run on the whole batch with the handle's current spec; returns per-instance status in drv->status
-int dc_newton(CadnipHandle* h, double abstol, int maxiters, int use_pcnr, int cold_start, long long* iters_total, int fused = 0) {
+int dc_newton(CadnipHandle* h, double abstol, int maxiters, int use_pcnr, int cold_start, long long* iters_total, int fused = 0, const int* d_part = nullptr) {
   Driver* d = h->drv;
   DCArgs a{h->d_u, h->d_resid, h->d_delta, h->d_limit_w, h->d_limit_init, h->d_active, h->d_flags, d->status, d->dcstate, d->action, d->cnt,
            h->B, h->n, h->n_limits, (use_pcnr && h->n_limits > 0) ? 1 : 0, maxiters, abstol};
-  hipLaunchKernelGGL(k_dc_init, dim3(h->B), dim3(64), 0, h->stream, a, cold_start);
+  hipLaunchKernelGGL(k_dc_init, dim3(h->B), dim3(64), 0, h->stream, a, cold_start, d_part);
   HIP_TRY(hipMemsetAsync(h->d_gamma, 0, (size_t)h->B * sizeof(double), h->stream));
   HIP_TRY(hipMemsetAsync(h->d_du, 0, (size_t)h->B * h->n * sizeof(double), h->stream));
   HIP_TRY(hipMemsetAsync(h->d_t, 0, (size_t)h->B * sizeof(double), h->stream));
   int saved_initjct = h->initjct;
   h->initjct = (cold_start && a.use_pcnr) ? 1 : 0;   // armed for the first stamping only (solve.jl:624,632)
   int rc = CADNIP_OK;
-  if (fused && h->analyzed && h->spec.gshunt == 0.0 && h->spec.srcFact >= 1.0 && fused2_fits(h)) {
+  if (fused && h->analyzed && !h->homotopy && h->spec.gshunt == 0.0 && h->spec.srcFact >= 1.0 && fused2_fits(h)) {
     // the whole Newton loop of every instance in the fused kernel; the host only looks at the running count
     TranArgs ta{};
     ta.u = h->d_u; ta.limit_w = h->d_limit_w; ta.status = d->status; ta.cnt = d->cnt; ta.active = h->d_active; ta.flags = h->d_flags;
@@ -215,11 +231,6 @@ int dc_newton(CadnipHandle* h, double abstol, int maxiters, int use_pcnr, int co
       if (running == 0) break;
     }
     h->initjct = saved_initjct;
-    if (!rc && iters_total) {
-      std::vector<long long> cnt((size_t)h->B * 4);
-      HIP_TRY(hipMemcpy(cnt.data(), d->cnt, cnt.size() * sizeof(long long), hipMemcpyDeviceToHost));
-      for (int i = 0; i < h->B; ++i) *iters_total += cnt[(size_t)i * 4];
-    }
     return rc;
   }
   int prev_running = h->B, repivots = 0;
@@ -262,11 +273,6 @@ int dc_newton(CadnipHandle* h, double abstol, int maxiters, int use_pcnr, int co
     if (running == 0) break;
   }
   h->initjct = saved_initjct;
-  if (!rc && iters_total) {   // Newton solves actually performed (== the reference's returned iteration count)
-    std::vector<long long> cnt((size_t)h->B * 4);
-    HIP_TRY(hipMemcpy(cnt.data(), d->cnt, cnt.size() * sizeof(long long), hipMemcpyDeviceToHost));
-    for (int i = 0; i < h->B; ++i) *iters_total += cnt[(size_t)i * 4];
-  }
   return rc;
 }
 
@@ -278,7 +284,7 @@ void cadnip_driver_free(CadnipHandle* h) {
   if (!h || !h->drv) return;
   Driver* d = h->drv;
   void* ptrs[] = {d->t, d->h, d->hprev, d->hpp, d->nhist, d->order, d->k, d->status, d->bp_idx, d->save_idx, d->dcstate, d->action, d->cnt,
-                  d->u0, d->u1, d->u2, d->up, d->beta, d->atol, d->emask, d->breaks, d->save_t, d->out, d->obs, d->nactive};
+                  d->u0, d->u1, d->u2, d->up, d->beta, d->atol, d->emask, d->breaks, d->save_t, d->out, d->obs, d->nactive, d->part};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete d;
   h->drv = nullptr;
@@ -294,12 +300,23 @@ int cadnip_tran_state(CadnipHandle* h, double* t_host, double* h_host, int32_t* 
   return CADNIP_OK;
 }
 
+// DC operating point with the reference's fallback chain (_dc_solve_with_fallbacks, solve.jl:871-929), PER INSTANCE: sweep
+// points are independent circuits (sweeps.jl:696-703), so an instance leaves the chain at the first stage that converges for
+// it and its solution is never touched again; only the instances still unsolved take part in the later stages, each on its
+// own homotopy ladder (per-instance gshunt / srcFact, kernels.hip: k_assemble).
+//   stage 0  PCNR Newton from the caller's start point (solve.jl:599-698)  -- or plain Newton when use_pcnr is off
+//   stage 1  plain Newton from the caller's start point (solve.jl:899-903)
+//   stage 2  gshunt stepping from zero: 1e-3, /10 ... 1e-12, then the target; a failed rung restores the last solution
+//            and takes the square root of the factor until it is <= 1.5 (solve.jl:720-783)
+//   stage 3  source stepping from zero: srcFact 0, +0.1 ... 1; a failed rung halves the raise (solve.jl:805-850)
+// Every Newton run of every instance is logged (cadnip_dc_log_*): stage, rung value, converged, Newton solves.
 int cadnip_dc_run(CadnipHandle* h, const CadnipDCOpts* o, double* u_host, int32_t* converged_host, CadnipRunStats* st) {
   if (!h || !o || !u_host) return CADNIP_BADARG;
   TRY(ensure_driver(h));
   Driver* d = h->drv;
   const size_t B = h->B, n = h->n;
   auto w0 = std::chrono::steady_clock::now();
+  d->dc_log.clear();
   HIP_TRY(hipMemcpyAsync(h->d_u, u_host, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   // the symbolic phase needs one numeric Jacobian: stamp once at the start point
   if (!h->analyzed) {
@@ -311,101 +328,156 @@ int cadnip_dc_run(CadnipHandle* h, const CadnipDCOpts* o, double* u_host, int32_
     std::vector<double> g(B, 1e9);
     int ij = h->initjct;
     h->initjct = (o->cold_start && o->use_pcnr && h->n_limits > 0) ? 1 : 0;
-    TRY(launch_rebuild(h));
+    int rc = launch_rebuild(h);
     h->initjct = ij;
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(h->d_gamma, g.data(), B * sizeof(double), hipMemcpyHostToDevice, h->stream));
     TRY(launch_jacobian(h));
     HIP_TRY(hipStreamSynchronize(h->stream));
     TRY(cadnip_analyze(h, 0));
   }
+  // whatever happens below, the handle leaves with its own spec and no homotopy terms
+  struct HomotopyGuard {
+    CadnipHandle* h;
+    ~HomotopyGuard() { (void)upload_homotopy(h, nullptr, nullptr); }
+  } guard{h};
+  const std::vector<double> start(u_host, u_host + B * n);
+  std::vector<double> U(start), R(B * n);          // per-instance start state of the next run / states after the last run
+  std::vector<int> fin(B, 0), status(B), part(B, 1);
+  std::vector<long long> cnt(B * 4);
+  std::vector<double> gsh(B, h->spec.gshunt), sfc(B, h->spec.srcFact);
   long long iters = 0;
-  TRY(dc_newton(h, o->abstol, o->maxiters, o->use_pcnr, o->cold_start, &iters, o->fused));
-  std::vector<int> status(B);
-  HIP_TRY(hipMemcpy(status.data(), d->status, B * sizeof(int), hipMemcpyDeviceToHost));
-  int n_failed = 0;
-  for (int s : status) if (s != 1) ++n_failed;
-  CadnipSpec spec0 = h->spec;
-  if (n_failed && o->use_pcnr && h->n_limits > 0) {
-    // 1. regular solve: plain Newton from the caller's start point (solve.jl:899-903)
-    HIP_TRY(hipMemcpyAsync(h->d_u, u_host, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    TRY(dc_newton(h, o->abstol, o->maxiters, 0, 0, &iters));
+  // one Newton run of the instances in `part`, each from U[i] with its own (gsh[i], sfc[i]); results in status / R / cnt
+  auto run = [&](int use_pcnr, int cold_start, int fused, int stage, const std::vector<double>& rung) -> int {
+    HIP_TRY(hipMemcpyAsync(h->d_u, U.data(), B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d->part, part.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    TRY(upload_homotopy(h, gsh.data(), sfc.data()));
+    TRY(dc_newton(h, o->abstol, o->maxiters, use_pcnr, cold_start, nullptr, fused, d->part));
     HIP_TRY(hipMemcpy(status.data(), d->status, B * sizeof(int), hipMemcpyDeviceToHost));
-    n_failed = 0; for (int s : status) if (s != 1) ++n_failed;
+    HIP_TRY(hipMemcpy(R.data(), h->d_u, B * n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cnt.data(), d->cnt, B * 4 * sizeof(long long), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < B; ++i)
+      if (part[i]) { iters += cnt[i * 4]; d->dc_log.push_back({(int)i, stage, rung[i], status[i] == 1 ? 1 : 0, cnt[i * 4]}); }
+    return CADNIP_OK;
+  };
+  auto take = [&](size_t i) { std::copy(R.begin() + i * n, R.begin() + (i + 1) * n, U.begin() + i * n); };
+  auto n_open = [&]() { int k = 0; for (size_t i = 0; i < B; ++i) k += !fin[i]; return k; };
+  const std::vector<double> none(B, 0.0);
+  // ---- stage 0: PCNR (or plain Newton) from the caller's start point
+  TRY(run(o->use_pcnr, o->cold_start, o->fused, 0, none));
+  for (size_t i = 0; i < B; ++i) { take(i); if (status[i] == 1) fin[i] = 1; }
+  // ---- stage 1: plain Newton from the caller's start point, for those PCNR did not solve
+  if (n_open() && o->use_pcnr && h->n_limits > 0) {
+    for (size_t i = 0; i < B; ++i) { part[i] = !fin[i]; if (part[i]) std::copy(start.begin() + i * n, start.begin() + (i + 1) * n, U.begin() + i * n); }
+    TRY(run(0, 0, 0, 1, none));
+    for (size_t i = 0; i < B; ++i) if (part[i]) { take(i); if (status[i] == 1) fin[i] = 1; }
   }
-  if (n_failed && o->use_stepping) {
-    // 2. GMIN stepping (solve.jl:720-783), applied to the whole batch
-    double target = spec0.gshunt, g = 1e-3, factor = 10.0, gmin = fmax(target, 1e-12);
-    std::vector<double> saved(B * n, 0.0), cur(B * n, 0.0);
-    HIP_TRY(hipMemsetAsync(h->d_u, 0, B * n * sizeof(double), h->stream));
-    bool ok = false;
-    for (int step = 0; step < 20; ++step) {
-      CadnipSpec s = spec0; s.gshunt = g; h->spec = s;
-      TRY(dc_newton(h, o->abstol, o->maxiters, 0, 0, &iters));
-      HIP_TRY(hipMemcpy(status.data(), d->status, B * sizeof(int), hipMemcpyDeviceToHost));
-      int nf = 0; for (int x : status) if (x != 1) ++nf;
-      if (nf == 0) {
-        HIP_TRY(hipMemcpy(saved.data(), h->d_u, B * n * sizeof(double), hipMemcpyDeviceToHost));
-        if (g <= gmin) {
-          if (g != target) {
-            s.gshunt = target; h->spec = s;
-            TRY(dc_newton(h, o->abstol, o->maxiters, 0, 0, &iters));
-            HIP_TRY(hipMemcpy(status.data(), d->status, B * sizeof(int), hipMemcpyDeviceToHost));
-            nf = 0; for (int x : status) if (x != 1) ++nf;
-            ok = nf == 0;
-          } else ok = true;
-          break;
+  if (n_open() && o->use_stepping) {
+    // ---- stage 2: gshunt stepping, one ladder per open instance
+    const double target = h->spec.gshunt, gfloor = fmax(target, 1e-12);
+    struct Rung { double g = 1e-3, factor = 10.0; int steps = 0; bool finalizing = false, over = false; std::vector<double> u, saved; };
+    std::vector<Rung> L(B);
+    for (size_t i = 0; i < B; ++i) { L[i].over = fin[i]; if (!fin[i]) { L[i].u.assign(n, 0.0); L[i].saved.assign(n, 0.0); } }
+    for (;;) {
+      int k = 0;
+      for (size_t i = 0; i < B; ++i) {
+        part[i] = !L[i].over;
+        if (!part[i]) { gsh[i] = h->spec.gshunt; continue; }
+        ++k;
+        gsh[i] = L[i].finalizing ? target : L[i].g;
+        std::copy(L[i].u.begin(), L[i].u.end(), U.begin() + i * n);
+      }
+      if (!k) break;
+      TRY(run(0, 0, 0, 2, gsh));
+      for (size_t i = 0; i < B; ++i) {
+        if (!part[i]) continue;
+        Rung& r = L[i];
+        const bool ok = status[i] == 1;
+        if (r.finalizing) {                                   // the solve at the exact target ends the ladder either way
+          if (ok) { take(i); fin[i] = 1; } else std::copy(r.u.begin(), r.u.end(), U.begin() + i * n);
+          r.over = true;
+          continue;
         }
-        g /= factor; if (g < gmin) g = gmin;
-      } else {
-        if (factor <= 1.5) break;
-        factor = sqrt(factor);
-        HIP_TRY(hipMemcpy(h->d_u, saved.data(), B * n * sizeof(double), hipMemcpyHostToDevice));
+        ++r.steps;
+        if (ok) {
+          r.u.assign(R.begin() + i * n, R.begin() + (i + 1) * n);
+          r.saved = r.u;
+          if (r.g <= gfloor) {
+            if (r.g != target) r.finalizing = true;
+            else { take(i); fin[i] = 1; r.over = true; }
+          } else { r.g /= r.factor; if (r.g < gfloor) r.g = gfloor; }
+        } else {
+          if (r.factor <= 1.5) r.over = true;                 // cannot make progress
+          else { r.factor = sqrt(r.factor); r.u = r.saved; }
+        }
+        if (!r.over && !r.finalizing && r.steps >= 20) r.over = true;   // max_steps
+        if (r.over && !fin[i]) std::copy(r.u.begin(), r.u.end(), U.begin() + i * n);
       }
     }
-    h->spec = spec0;
-    n_failed = ok ? 0 : (int)B;
-    if (!ok) {
-      // 3. source stepping (solve.jl:805-850)
-      double src = 0.0, conv = 0.0, raise = 0.1;
-      std::fill(saved.begin(), saved.end(), 0.0);
-      HIP_TRY(hipMemsetAsync(h->d_u, 0, B * n * sizeof(double), h->stream));
-      for (int step = 0; step < 50; ++step) {
-        CadnipSpec s = spec0; s.srcFact = src; h->spec = s;
-        TRY(dc_newton(h, o->abstol, o->maxiters, 0, 0, &iters));
-        HIP_TRY(hipMemcpy(status.data(), d->status, B * sizeof(int), hipMemcpyDeviceToHost));
-        int nf = 0; for (int x : status) if (x != 1) ++nf;
-        if (nf == 0) {
-          conv = src;
-          HIP_TRY(hipMemcpy(saved.data(), h->d_u, B * n * sizeof(double), hipMemcpyDeviceToHost));
-          if (src >= 1.0) { ok = true; break; }
-          src = fmin(src + raise, 1.0);
-        } else {
-          if (src - conv < 1e-6) break;
-          raise /= 2.0; src = conv + raise;
-          HIP_TRY(hipMemcpy(h->d_u, saved.data(), B * n * sizeof(double), hipMemcpyHostToDevice));
+    for (size_t i = 0; i < B; ++i) gsh[i] = h->spec.gshunt;
+    // ---- stage 3: source stepping for the rest
+    if (n_open()) {
+      struct Ramp { double src = 0.0, conv = 0.0, raise = 0.1; int steps = 0; bool over = false; std::vector<double> u, saved; };
+      std::vector<Ramp> S(B);
+      for (size_t i = 0; i < B; ++i) { S[i].over = fin[i]; if (!fin[i]) { S[i].u.assign(n, 0.0); S[i].saved.assign(n, 0.0); } }
+      for (;;) {
+        int k = 0;
+        for (size_t i = 0; i < B; ++i) {
+          part[i] = !S[i].over;
+          if (!part[i]) { sfc[i] = h->spec.srcFact; continue; }
+          ++k;
+          sfc[i] = S[i].src;
+          std::copy(S[i].u.begin(), S[i].u.end(), U.begin() + i * n);
+        }
+        if (!k) break;
+        TRY(run(0, 0, 0, 3, sfc));
+        for (size_t i = 0; i < B; ++i) {
+          if (!part[i]) continue;
+          Ramp& r = S[i];
+          ++r.steps;
+          if (status[i] == 1) {
+            r.conv = r.src;
+            r.u.assign(R.begin() + i * n, R.begin() + (i + 1) * n);
+            r.saved = r.u;
+            if (r.src >= 1.0) { take(i); fin[i] = 1; r.over = true; }
+            else r.src = fmin(r.src + r.raise, 1.0);
+          } else {
+            if (r.src - r.conv < 1e-6) r.over = true;
+            else { r.raise /= 2.0; r.src = r.conv + r.raise; r.u = r.saved; }
+          }
+          if (!r.over && r.steps >= 50) r.over = true;
+          if (r.over && !fin[i]) std::copy(r.u.begin(), r.u.end(), U.begin() + i * n);
         }
       }
-      h->spec = spec0;
-      n_failed = ok ? 0 : (int)B;
-      // the homotopies move the whole batch together: all instances arrive, or none (the flags of the last partial
-      // solve, at a reduced source factor, say nothing about the real problem)
-      std::fill(status.begin(), status.end(), ok ? 1 : 0);
-    } else std::fill(status.begin(), status.end(), 1);
+      for (size_t i = 0; i < B; ++i) sfc[i] = h->spec.srcFact;
+    }
   }
-  HIP_TRY(hipMemcpy(u_host, h->d_u, B * n * sizeof(double), hipMemcpyDeviceToHost));
-  if (converged_host) for (size_t i = 0; i < B; ++i) converged_host[i] = status[i] == 1 ? 1 : 0;
+  const int n_failed = n_open();
+  memcpy(u_host, U.data(), B * n * sizeof(double));
+  HIP_TRY(hipMemcpy(h->d_u, U.data(), B * n * sizeof(double), hipMemcpyHostToDevice));
+  if (converged_host) for (size_t i = 0; i < B; ++i) converged_host[i] = fin[i];
   // leave every instance active for subsequent ABI calls
   std::vector<int> ones(B, 1);
   HIP_TRY(hipMemcpy(h->d_active, ones.data(), B * sizeof(int), hipMemcpyHostToDevice));
   if (st) {
     memset(st, 0, sizeof(*st));
-    std::vector<long long> cnt(B * 4);
-    HIP_TRY(hipMemcpy(cnt.data(), d->cnt, B * 4 * sizeof(long long), hipMemcpyDeviceToHost));
     st->newton_iters = iters;
     st->n_failed = n_failed;
     st->wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
   }
   return n_failed ? CADNIP_NOCONV : CADNIP_OK;
+}
+
+// the log of the last cadnip_dc_run: entries in execution order, per (instance, Newton run)
+int32_t cadnip_dc_log_size(CadnipHandle* h) { return (h && h->drv) ? (int32_t)h->drv->dc_log.size() : 0; }
+int cadnip_dc_log_get(CadnipHandle* h, int32_t* inst, int32_t* stage, double* value, int32_t* ok, int64_t* iters) {
+  if (!h || !h->drv) return CADNIP_NOTREADY;
+  size_t k = 0;
+  for (auto& e : h->drv->dc_log) {
+    if (inst) inst[k] = e.inst; if (stage) stage[k] = e.stage; if (value) value[k] = e.value; if (ok) ok[k] = e.ok; if (iters) iters[k] = e.iters;
+    ++k;
+  }
+  return CADNIP_OK;
 }
 
 int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, int64_t* per_inst_host, CadnipRunStats* st) {
@@ -445,8 +517,8 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
              o->max_newton > 0 ? o->max_newton : 10, o->max_order > 0 ? o->max_order : 2, o->use_pcnr};
   if (!h->analyzed) return CADNIP_NOTREADY;              // the symbolic LU phase (cadnip_analyze*) comes first
   const bool use_fused = o->fused && fused2_fits(h);     // a circuit too large for the LDS-resident kernel runs on the per-op kernels
-  int saved_mode = h->spec.mode;
-  h->spec.mode = 1;   // :tran
+  struct ModeGuard { CadnipHandle* h; int saved; ~ModeGuard() { h->spec.mode = saved; } } mode_guard{h, h->spec.mode};
+  h->spec.mode = 1;   // :tran (restored on every exit path)
   hipLaunchKernelGGL(k_tran_init, dim3(h->B), dim3(64), 0, h->stream, a);
   HIP_TRY(hipStreamSynchronize(h->stream));
   auto w0 = std::chrono::steady_clock::now();
@@ -499,7 +571,6 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
   }
   HIP_TRY(hipStreamSynchronize(h->stream));
   double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
-  h->spec.mode = saved_mode;
   if (rc) return rc;
   std::vector<long long> cnt(B * 4);
   std::vector<int> status(B);

@@ -91,12 +91,17 @@ struct CadnipHandle {
   int n_long_asm = 0, n_long_rows = 0;
   double* d_wave = nullptr;
   double* d_limit_init = nullptr;
+  // per-instance homotopy parameters of the DC fallback chain (solve.jl:720-850); equal to spec.gshunt / spec.srcFact
+  // except while cadnip_dc_run walks an instance through gshunt / source stepping
+  double *d_gshunt = nullptr, *d_srcfact = nullptr;
+  bool homotopy = false;     // some instance has gshunt != 0 or srcFact < 1: the fused kernel (no homotopy terms) must not run
   // device: per-instance state [B][..]
   double *d_u = nullptr, *d_du = nullptr, *d_t = nullptr, *d_gamma = nullptr;
   double *d_S = nullptr, *d_G = nullptr, *d_C = nullptr, *d_b = nullptr, *d_J = nullptr, *d_resid = nullptr, *d_delta = nullptr;
   double *d_limit_w = nullptr, *d_LU = nullptr, *d_tmp = nullptr;
   int* d_flags = nullptr;        // [B] per-instance status bits (1 = singular pivot, 2 = non-finite)
   int* d_active = nullptr;       // [B] 1 = instance takes part in the next launches
+  int* d_nonfinite = nullptr;    // [B] raised by the assemble kernels when a stamped value is NaN / Inf
   // LU
   bool analyzed = false;
   cadnip::LUProgram lu;
@@ -141,6 +146,7 @@ int launch_factor(CadnipHandle* h, bool fuse_jacobian);    // LU of J (or of G +
 int launch_solve(CadnipHandle* h, const double* d_rhs, double* d_x);
 int launch_factor_solve(CadnipHandle* h, bool fuse_jacobian, const double* d_rhs, double* d_x);
 int upload_lu(CadnipHandle* h);
+int upload_homotopy(CadnipHandle* h, const double* gshunt /* [B] or null = spec */, const double* srcfact /* [B] or null = spec */);
 int launch_calib_copy(CadnipHandle* h, long n, int reps);
 int launch_negate(CadnipHandle* h, double* d_x, long n);
 struct TranArgs;                                                          // tran_ctrl.hpp

@@ -90,8 +90,9 @@ static void launch_stamp_t(const StampArgs& a, hipStream_t st) {
 struct AsmArgs {
   const double* S; const int* g_ptr; const int* g_slots; const int* c_ptr; const int* c_slots; const int* b_ptr; const int* b_slots;
   const unsigned char* diag_flag; const int* active;
+  int* nonfinite;   // [B] set to 1 when an assembled G / C / b value of the instance is not finite (cadnip_rebuild -> CADNIP_NONFINITE)
   double* G; double* C; double* b;
-  int B, n, nnz, ns, ns_g, ns_c; double srcFact, gshunt;
+  int B, n, nnz, ns, ns_g, ns_c; const double* srcFact; const double* gshunt;   // [B] each
 };
 
 // Entries that gather more than LONG_LIST slots (the supply rails of a large circuit: G[vdd,vdd] of the c6288 multiplier
@@ -121,8 +122,10 @@ __global__ void __launch_bounds__(256) k_assemble_long(AsmArgs a, const int* lon
   for (int p = ptr[k] + threadIdx.x; p < ptr[k + 1]; p += 256) acc += Sx[slots[p]];
   acc = block_sum_256(acc, red);
   if (threadIdx.x == 0) {
-    if (e < a.nnz && a.gshunt != 0.0 && a.diag_flag[e]) acc += a.gshunt;
-    if (e >= 2 * a.nnz && a.srcFact < 1.0) acc *= a.srcFact;
+    const double gsh = a.gshunt[inst], sf = a.srcFact[inst];
+    if (e < a.nnz && gsh != 0.0 && a.diag_flag[e]) acc += gsh;
+    if (e >= 2 * a.nnz && sf < 1.0) acc *= sf;
+    if (!isfinite(acc)) a.nonfinite[inst] = 1;
     *out = acc;
   }
 }
@@ -138,7 +141,9 @@ __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
     if (a.g_ptr[e + 1] - a.g_ptr[e] > LONG_LIST) return;
     double acc = 0.0;
     for (int p = a.g_ptr[e]; p < a.g_ptr[e + 1]; ++p) acc += S[a.g_slots[p]];
-    if (a.gshunt != 0.0 && a.diag_flag[e]) acc += a.gshunt;
+    const double gsh = a.gshunt[inst];
+    if (gsh != 0.0 && a.diag_flag[e]) acc += gsh;
+    if (!isfinite(acc)) a.nonfinite[inst] = 1;
     a.G[(size_t)inst * a.nnz + e] = acc;
   } else if (e < 2 * a.nnz) {
     int k = e - a.nnz;
@@ -146,6 +151,7 @@ __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
     if (a.c_ptr[k + 1] - a.c_ptr[k] > LONG_LIST) return;
     double acc = 0.0;
     for (int p = a.c_ptr[k]; p < a.c_ptr[k + 1]; ++p) acc += Sc[a.c_slots[p]];
+    if (!isfinite(acc)) a.nonfinite[inst] = 1;
     a.C[(size_t)inst * a.nnz + k] = acc;
   } else {
     int i = e - 2 * a.nnz;
@@ -153,7 +159,9 @@ __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
     if (a.b_ptr[i + 1] - a.b_ptr[i] > LONG_LIST) return;
     double acc = 0.0;
     for (int p = a.b_ptr[i]; p < a.b_ptr[i + 1]; ++p) acc += Sb[a.b_slots[p]];
-    if (a.srcFact < 1.0) acc *= a.srcFact;
+    const double sf = a.srcFact[inst];
+    if (sf < 1.0) acc *= sf;
+    if (!isfinite(acc)) a.nonfinite[inst] = 1;
     a.b[(size_t)inst * a.n + i] = acc;
   }
 }
@@ -370,8 +378,8 @@ int launch_rebuild(CadnipHandle* h) {
   }
   {
     ProfScope ps(h, "assemble");
-    AsmArgs a{h->d_S, h->d_g_ptr, h->d_g_slots, h->d_c_ptr, h->d_c_slots, h->d_b_ptr, h->d_b_slots, h->d_diag_flag, h->d_active,
-              h->d_G, h->d_C, h->d_b, h->B, h->n, h->nnz, h->ns, h->ns_g, h->ns_c, h->spec.srcFact, h->spec.gshunt};
+    AsmArgs a{h->d_S, h->d_g_ptr, h->d_g_slots, h->d_c_ptr, h->d_c_slots, h->d_b_ptr, h->d_b_slots, h->d_diag_flag, h->d_active, h->d_nonfinite,
+              h->d_G, h->d_C, h->d_b, h->B, h->n, h->nnz, h->ns, h->ns_g, h->ns_c, h->d_srcfact, h->d_gshunt};
     long total = (long)h->B * (2L * h->nnz + h->n);
     hipLaunchKernelGGL(k_assemble, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, a);
     if (h->n_long_asm > 0) hipLaunchKernelGGL(k_assemble_long, dim3((unsigned)(h->B * h->n_long_asm)), dim3(256), 0, h->stream, a, h->d_long_asm, h->n_long_asm);

@@ -38,12 +38,16 @@ static int lu_analyze_mode(int n, const std::vector<int>& rowptr, const std::vec
 // `sample` = vals is such a composite; for the Jacobian of one state a singular result is reported as is.
 int lu_analyze(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, const std::vector<double>& vals,
                double pivot_tol, bool sample, LUProgram& out, std::string& err) {
-  int rc = lu_analyze_mode(n, rowptr, colidx, vals, pivot_tol, false, out, err);
+  // The program is built aside and moved into `out` only on success: a failed analysis (a singular re-pivot victim,
+  // driver.hip) must leave the caller's previous program -- and the device arrays uploaded from it -- usable.
+  LUProgram fresh;
+  int rc = lu_analyze_mode(n, rowptr, colidx, vals, pivot_tol, false, fresh, err);
   if (rc == CADNIP_SINGULAR && sample) {
     std::string err2;
-    int rc2 = lu_analyze_mode(n, rowptr, colidx, vals, pivot_tol, true, out, err2);
-    if (rc2 == CADNIP_OK) { err.clear(); return rc2; }
+    int rc2 = lu_analyze_mode(n, rowptr, colidx, vals, pivot_tol, true, fresh, err2);
+    if (rc2 == CADNIP_OK) { err.clear(); rc = rc2; }
   }
+  if (rc == CADNIP_OK) out = std::move(fresh);
   return rc;
 }
 

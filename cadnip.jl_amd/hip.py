@@ -22,7 +22,7 @@ EXPORTS = [
     "cadnip_create", "cadnip_destroy", "cadnip_set_params", "cadnip_set_spec", "cadnip_set_initjct",
     "cadnip_rebuild", "cadnip_residual", "cadnip_jacobian", "cadnip_ode_rhs", "cadnip_ode_jacobian", "cadnip_get_GCb", "cadnip_analyze",
     "cadnip_analyze_values", "cadnip_factor", "cadnip_solve", "cadnip_lu_stats", "cadnip_dc_run",
-    "cadnip_tran_run", "cadnip_tran_state", "cadnip_dev_ptr", "cadnip_stream", "cadnip_set_u", "cadnip_get_u", "cadnip_get_flags",
+    "cadnip_dc_log_size", "cadnip_dc_log_get", "cadnip_tran_run", "cadnip_tran_state", "cadnip_dev_ptr", "cadnip_stream", "cadnip_set_u", "cadnip_get_u", "cadnip_get_flags",
     "cadnip_sync", "cadnip_debug_copy", "cadnip_profile_enable", "cadnip_profile_read", "cadnip_version",
     "cadnip_host_lu_analyze", "cadnip_host_lu_size", "cadnip_host_lu_get", "cadnip_host_lu_free",
     "cadnip_host_f2_build", "cadnip_host_f2_size", "cadnip_host_f2_get", "cadnip_host_f2_free",
@@ -284,6 +284,14 @@ class Handle:
         if rc not in (OK, NOCONV) or (rc == NOCONV and raise_on_fail):
             _check(rc, "cadnip_dc_run")
         return u, conv.astype(bool), _stats(st)
+
+    def dc_log(self):
+        """The fallback chain of the last ``dc_run``: list of (instance, stage, rung value, converged, Newton solves)."""
+        k = int(self.lib.cadnip_dc_log_size(self.h))
+        inst, stage, ok = (np.zeros(max(k, 1), dtype=np.int32) for _ in range(3))
+        val, it = np.zeros(max(k, 1)), np.zeros(max(k, 1), dtype=np.int64)
+        _check(self.lib.cadnip_dc_log_get(self.h, _ip(inst), _ip(stage), _dp(val), _ip(ok), it.ctypes.data_as(C.POINTER(C.c_int64))), "cadnip_dc_log_get")
+        return [(int(inst[j]), int(stage[j]), float(val[j]), bool(ok[j]), int(it[j])) for j in range(k)]
 
     def tran_run(self, t0, t1, abstol, reltol=1e-4, breaks=(), save_t=(), obs=None, h0=0.0, hmin=0.0, hmax=0.0,
                  max_newton=10, max_order=2, use_pcnr=False, newton_tol=1e-3, max_iterations=0, fused=False,

@@ -224,6 +224,12 @@ typedef struct {
 } CadnipRunStats;
 
 /* u_host [B][n]: in = initial guess (zeros = cold start), out = solution; converged_host [B] */
+/* What the fallback chain of the last cadnip_dc_run did: one entry per (instance, Newton run) in execution order.
+ * stage 0 = PCNR (or plain Newton when use_pcnr is off), 1 = plain Newton, 2 = gshunt stepping (value = the rung's gshunt),
+ * 3 = source stepping (value = srcFact); ok = the run converged; iters = its Newton solves.  Arrays of cadnip_dc_log_size
+ * entries; any pointer may be NULL.  (The reference reports the same through @debug lines, solve.jl:887-927.) */
+int32_t cadnip_dc_log_size(CadnipHandle* h);
+int cadnip_dc_log_get(CadnipHandle* h, int32_t* inst, int32_t* stage, double* value, int32_t* ok, int64_t* iters);
 int cadnip_dc_run(CadnipHandle* h, const CadnipDCOpts* o, double* u_host, int32_t* converged_host, CadnipRunStats* st);
 /* starts from the handle's current state u (e.g. left by cadnip_dc_run in :tranop mode);
  * out_host [B][n_save][n_obs]; per_inst_host [B][4] = {newton_iters, accepted, rejected, status} */

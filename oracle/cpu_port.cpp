@@ -460,6 +460,7 @@ int port_dc(void* p, double* u, double abstol, int maxiters, int use_pcnr, int c
     residual(P, u, du.data(), F.data());
     double s = 0; bool bad = false; for (int i = 0; i < n; ++i) { if (!std::isfinite(F[i])) bad = true; s += F[i] * F[i]; }
     if (bad) { result = 0; break; }
+    if (pcnr && state == 0 && it >= maxiters) { result = 0; break; }   // PCNR tests convergence before solves 1..maxiters only (solve.jl:630-663)
     if (std::sqrt(s) < abstol) {
       if (!pcnr) { result = 1; break; }
       if (state == 0) { for (int k = 0; k < L; ++k) u[l0 + k] = P.limit_w[l0 + k]; state = 1; continue; }

@@ -278,12 +278,21 @@ def diode_vcrit(Is, Vt, n):  # devices.jl:1319-1320
     return nVt * math.log(nVt / (math.sqrt(2.0) * Is))
 
 
+def _exp(x):
+    """exp with IEEE overflow (Inf), as Julia's: math.exp raises instead.  A non-limited junction driven far forward makes
+    the stamps non-finite, which the Newton loops detect (solve.jl:560-566 retcode / :636 all(isfinite, F))."""
+    try:
+        return math.exp(x)
+    except OverflowError:
+        return math.inf
+
+
 def diode_iv(Is, nVt, v):  # _diode_iv  devices.jl:1333-1345
     xarg = v / nVt
     if xarg > 80.0:
         e80 = math.exp(80.0)
         return Is * (e80 * (1.0 + (xarg - 80.0)) - 1.0), Is / nVt * e80
-    e = math.exp(xarg)
+    e = _exp(xarg)
     return Is * (e - 1.0), Is / nVt * e
 
 
@@ -296,7 +305,7 @@ def stamp_diode(ctx, p, n, x, Is=1e-14, Vt=0.026, nf=1.0, limit_=True, name="D")
         I0, Gd = diode_iv(Is, nVt, w)
         stamp_limited_companion(ctx, p, n, w, I0, Gd)
     else:
-        e = math.exp(V0 / nVt)
+        e = _exp(V0 / nVt)
         I0 = Is * (e - 1.0)
         Gd = Is / nVt * e
         Ieq = I0 - Gd * V0
@@ -317,7 +326,7 @@ def diode_junction_cap(V, Cj0, Vj, m):  # devices.jl:1505-1516
 def stamp_diode_with_cap(ctx, p, n, x, Is=1e-14, Vt=0.026, nf=1.0, Cj0=1e-12, Vj=0.7, m=0.5):  # devices.jl:1558-1602
     V0 = x_at(x, p) - x_at(x, n)
     nVt = nf * Vt
-    e = math.exp(V0 / nVt)
+    e = _exp(V0 / nVt)
     I0 = Is * (e - 1.0)
     G = Is / nVt * e
     Ieq = I0 - G * V0

@@ -804,3 +804,15 @@ def dc(builder, params=None, spec=None, u0=None):
     spec = spec if spec is not None else MNASpec()
     spec = MNASpec(temp=spec.temp, mode="dcop")  # with_mode keeps only temp+mode (solve.jl:1976-1989)
     return solve_dc(builder, params or {}, spec, u0=u0)
+
+
+# ---- AC small-signal response at a DC point (src/ac.jl:113-170, 185-215) -----------------------------------------------------
+def ac_response(G, C, b_ac, omegas, n_nodes, gshunt=1e-12):
+    """ac!: rebuild at the DC solution, G assembled with ``gshunt = gmin`` on the voltage-node diagonals
+    (assemble_G(ctx; gshunt=gmin), ac.jl:127), descriptor system E = C, A = -G, B = b_ac, identity output;
+    freqresp: x(jw) = (jw C + G)^-1 b_ac for every state.  ``G``, ``C`` dense [n, n]; returns [len(omegas), n] complex."""
+    G = np.array(G, dtype=float)
+    C = np.asarray(C, dtype=float)
+    for i in range(n_nodes):
+        G[i, i] += gshunt
+    return np.array([np.linalg.solve(G + 1j * w * C, np.asarray(b_ac, dtype=complex)) for w in omegas])

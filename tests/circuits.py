@@ -212,3 +212,57 @@ ALL_STAMP = {
     "va_mos_inverter_rd": (lambda: va_mos_inverter(rd=40.0), {}),
     "dff": (bm.dff_circuit, {"vdd": 5.0}), "dff_meyer": (lambda: bm.dff_circuit(meyer=True), {"vdd": 5.0}),
 }
+
+
+def cs_stage(vbias=1.1472):
+    """Common-source stage of the reference's operating-point tests (test/opinfo.jl:35-42): level-1 NMOS vto = 0.7,
+    kp = 100u, lambda = 0.01, W/L = 20u/1u, Rd = 10k to a 5 V supply, gate at vbias (design bias 1.1472 V: VOV = 447.2 mV)."""
+    c = cj.Circuit("cs_stage")
+    card = dict(type=1, vto=0.7, kp=100e-6)
+    card["lambda"] = 0.01
+    c.V("vdd", "vdd", "0", dc=5.0)
+    c.V("vin", "gate", "0", dc=vbias)
+    c.MOS1("m1", "drain", "gate", "0", "0", card, w=20e-6, l=1e-6)
+    c.R("rd", "vdd", "drain", 10e3)
+    return c
+
+
+def cmos_inverter_ac():
+    """CMOS inverter of the reference's AC test against ngspice-43 (test/ac.jl:246-256): level-1 cards vto = -/+0.7,
+    kp = 50u / 100u, lambda = 0.01, cgso = cgdo = 1e-15 F/m, W/L = 2u/1u and 1u/1u, Cload = 10 fF, Vdd = 3.3 V,
+    Vin = 1.65 V DC (+ 1 V AC: the excitation is applied by the test on Vin's branch row)."""
+    c = cj.Circuit("cmos_inverter_ac")
+    pm = dict(type=-1, vto=-0.7, kp=50e-6, cgso=1e-15, cgdo=1e-15)
+    nm = dict(type=1, vto=0.7, kp=100e-6, cgso=1e-15, cgdo=1e-15)
+    pm["lambda"] = nm["lambda"] = 0.01
+    c.V("vdd", "vdd", "0", dc=3.3)
+    c.V("vin", "vin", "0", dc=1.65)
+    c.MOS1("mp", "vout", "vin", "vdd", "vdd", pm, w=2e-6, l=1e-6)
+    c.MOS1("mn", "vout", "vin", "0", "0", nm, w=1e-6, l=1e-6)
+    c.C("cload", "vout", "0", 10e-15)
+    return c
+
+
+# ---- circuits that walk the DC fallback chain (solve.jl:871-929) past its first stage -----------------------------------
+def bi_quadratic(k=0.05):
+    """2 V through 1 ohm into a node loaded by 1 ohm and a behavioural current sink k V^2 (a fixed-source iteration,
+    devices.jl:1079-1131): with abstol 1e-7 and maxiters 5 plain Newton and every gshunt rung run out of iterations from a
+    cold start, the warm-started source ramp arrives (found by scanning k / abstol / maxiters on the oracle)."""
+    c = cj.Circuit("bi_quadratic")
+    c.V("v1", "in", "0", dc=2.0)
+    c.R("r1", "in", "x", 1.0)
+    c.BI("b1", "x", "0", "%g*V(x)**2" % k)
+    c.R("r2", "x", "0", 1.0)
+    return c
+
+
+def inverter_chain(stages=8, vin=0.0):
+    """Chain of level-1 CMOS inverters (the benchmark cards): PCNR needs 16 iterations at 8 stages; plain Newton and the
+    homotopies meet non-finite stamps (the model has no sub-threshold current: DESIGN.md section 5)."""
+    c = cj.Circuit("inverter_chain")
+    c.V("vdd", "vdd", "0", dc=5.0)
+    c.V("vin", "n0", "0", dc=vin)
+    for k in range(stages):
+        c.MOS1("mn%d" % k, "n%d" % (k + 1), "n%d" % k, "0", "0", dict(bm.NFET_06V0), l=0.6e-6, w=0.36e-6)
+        c.MOS1("mp%d" % k, "n%d" % (k + 1), "n%d" % k, "vdd", "vdd", dict(bm.PFET_06V0), l=0.5e-6, w=0.495e-6)
+    return c

@@ -137,9 +137,40 @@ def test_lu_factor_solve(name):
         if name != "dff":   # random states make the DFF Jacobian numerically singular: only the backward error is meaningful
             assert np.max(np.abs(x[i] - xr)) <= 1e-6 * max(1.0, np.max(np.abs(xr))), (name, i)
         # backward error relative to |A||x| (random states make J badly conditioned)
-        assert np.max(np.abs(A @ x[i] - rhs[i]) / (abs(A) @ np.abs(x[i]) + 1.0)) <= 1e-12
+        assert np.max(np.abs(A @ x[i] - rhs[i]) / (abs(A) @ np.abs(x[i]) + np.abs(rhs[i]))) <= 1e-12
     print(name, h.lu_stats())
     h.close()
+
+
+def test_lu_forward_error_at_physical_dff_states():
+    """The DFF Jacobian is numerically singular at random states (test above: backward error only).  At the states the
+    solver actually meets -- the DC operating point and a mid-transient state, with gamma = 1/h of real steps -- the
+    solution itself must agree with SuperLU (forward error)."""
+    from cadnip_jl_amd import benchmarks as bm
+    from cadnip_jl_amd.structure import expand_breakpoints
+    circ = bm.dff_circuit()
+    sim = api_mod.BatchSimulator(api_mod.MNACircuit(circ, {"vdd": 5.0}), [{"vdd": 5.0}, {"vdd": 4.6, "temp": 110.0}, {"vdd": 5.4, "temp": -20.0}])
+    st, h = sim.st, sim.h
+    sim.analyze()
+    u_dc, conv, _ = sim.dc(abstol=1e-9, mode="tranop")
+    assert np.all(conv)
+    h.set_spec(mode="tran")
+    atol = st.state_abstol(vntol=1e-6, iabstol=1e-9, chgtol=1e-6)
+    out, _, stats = h.tran_run(0.0, 2.05e-7, atol, 1e-4, breaks=expand_breakpoints(st.breakpoints, (0.0, 2.05e-7)), save_t=[2.05e-7], fused=0)
+    assert stats["n_failed"] == 0
+    rng = np.random.default_rng(5)
+    for u, t, gam in ((u_dc, 0.0, np.array([0.0, 1e8, 1e10])), (out[:, 0, :], 2.05e-7, np.array([1e7, 1e9, 1e11]))):
+        h.rebuild(u, t)
+        J = h.jacobian(gam)
+        h.factor()
+        rhs = rng.standard_normal((3, st.n))
+        x = h.solve(rhs)
+        for i in range(3):
+            A = sp.csc_matrix((J[i], st.ref_rowval, st.ref_colptr), shape=(st.n, st.n))
+            xr = spla.splu(A).solve(rhs[i])
+            assert np.max(np.abs(x[i] - xr)) <= 1e-8 * max(1.0, np.max(np.abs(xr))), (t, i, np.max(np.abs(x[i] - xr)), np.max(np.abs(xr)))
+            assert np.max(np.abs(A @ x[i] - rhs[i]) / (abs(A) @ np.abs(x[i]) + 1e-300)) <= 1e-12
+    sim.close()
 
 
 def test_singular_matrix_reports_status():

@@ -227,3 +227,93 @@ def test_cmos_inverter_logic_levels():
     for vin, lo, hi in ((0.0, 4.99, 5.01), (5.0, -0.01, 0.01)):
         sol = M.dc(make_builder(tc.inverter_dc(vin).to_dicts()))
         assert sol.converged and lo < sol["out"] < hi
+
+
+# ---- sp_mos1 numerics: the reference's own numeric fixtures for the level-1 model ---------------------------------------
+def _dc_system(circ):
+    """dc! on the oracle, then the linearisation at the solution: dense G, C and the MNAData (names)."""
+    b = make_builder(circ.to_dicts())
+    sol = M.dc(b)
+    assert sol.converged
+    spec = M.MNASpec(mode="dcop")
+    ctx = M.build_with_detection(b, {}, spec)
+    cs = M.compile_structure(b, {}, spec, ctx=ctx)
+    ws = M.create_workspace(cs, ctx=ctx)
+    M.fast_rebuild(ws, sol.x, 0.0)
+    return sol, cs.G.toarray(), cs.C.toarray()
+
+
+# test/opinfo.jl:158-205 (hand derivation :158-163): K = kp W/L = 2 mA/V^2, VOV = 447.2 mV, ID = 200 uA, gm = K VOV = 894.4 uS
+def test_mos1_cs_stage_small_signal_numbers():
+    VOV = 1.1472 - 0.7
+    GM = 100e-6 * 20.0 * VOV
+    sol, G, _ = _dc_system(tc.cs_stage())
+    ix = lambda nm: sol.sys.index_of(nm) - 1
+    d, g = ix("drain"), ix("gate")
+    i_d = -sol["I_vdd"]                                       # opinfo.jl:92: i_m1_d == -I_vdd
+    assert i_d == pytest.approx(200e-6, rel=0.05)             # opinfo.jl:89
+    assert i_d == pytest.approx((5.0 - sol["drain"]) / 10e3, rel=1e-6)   # opinfo.jl:94 (i_rd_p)
+    gm = G[d, g]                                              # dI_d/dV_g: the drain row's gate column carries nothing else
+    assert gm == pytest.approx(GM, rel=0.05)                  # opinfo.jl:183
+    up = -M.dc(make_builder(tc.cs_stage(1.1472 + 1e-3).to_dicts()))["I_vdd"]
+    dn = -M.dc(make_builder(tc.cs_stage(1.1472 - 1e-3).to_dicts()))["I_vdd"]
+    assert gm == pytest.approx((up - dn) / 2e-3, rel=0.02)    # opinfo.jl:187-190: gm is the derivative of the drain current
+    gds = G[d, d] - 1.0 / 10e3                                # drain diagonal minus Rd (bulk junction: gmin-sized)
+    assert gds == pytest.approx(0.01 * i_d, rel=0.10)         # opinfo.jl:193
+    # vgs / vds as the model sees them are the settled $limit variables (opinfo.jl:199-200)
+    assert sol["m1_sp_mos1_lim_g_s_int"] == pytest.approx(1.1472, rel=1e-6)
+    assert sol["m1_sp_mos1_lim_d_int_s_int"] == pytest.approx(sol["drain"], rel=1e-6)
+    assert sol["drain"] > VOV                                 # saturated: vds clears vdsat (opinfo.jl:198)
+    hot = -M.dc(make_builder(tc.cs_stage(1.20).to_dicts()))["I_vdd"]
+    assert hot > i_d * 1.1                                    # opinfo.jl:142-145
+
+
+def load_ngspice_inverter():
+    import os
+    rows = np.loadtxt(os.path.join(os.path.dirname(__file__), "golden", "ngspice43_cmos_inverter_ac.csv"), delimiter=",", comments="#")
+    return rows[:, 0], rows[:, 1] + 1j * rows[:, 2]
+
+
+def check_against_ngspice(resp, ref):
+    assert np.allclose(np.abs(resp), np.abs(ref), rtol=0.05, atol=0.0)           # test/ac.jl:267
+    dph = np.abs(np.angle(resp) - np.angle(ref))
+    assert np.all(np.minimum(dph, 2 * np.pi - dph) < 0.1)                        # test/ac.jl:270-272
+
+
+# test/ac.jl:204-272: sp_mos1 CMOS inverter, H(jw) = (G + jw C)^-1 b_ac at the DC point vs the ngspice-43 table
+def test_mos1_inverter_ac_matches_ngspice_table():
+    freqs, ref = load_ngspice_inverter()
+    sol, G, C = _dc_system(tc.cmos_inverter_ac())
+    b_ac = np.zeros(G.shape[0])
+    b_ac[sol.sys.index_of("I_vin") - 1] = 1.0                 # "AC 1" on Vin: unit excitation on its branch row (get_rhs_ac)
+    resp = M.ac_response(G, C, b_ac, 2 * np.pi * freqs, sol.sys.n_nodes)[:, sol.sys.index_of("vout") - 1]
+    check_against_ngspice(resp, ref)
+    # far inside the reference's own 5 % / 0.1 rad: the table's six digits are reproduced (measured 3.4e-6 / 9e-7 rad)
+    assert np.allclose(np.abs(resp), np.abs(ref), rtol=1e-4, atol=0.0) and np.max(np.abs(np.angle(resp) - np.angle(ref))) < 1e-4    # the low-frequency gain -(gmn + gmp) / (gdsn + gdsp)
+
+
+# ---- solve.jl:720-929: shape of the fallback ladders on the oracle (the GPU side is compared rung for rung in
+# tests/test_gpu_dc_fallbacks.py) ----------------------------------------------------------------------------------------------
+def test_dc_fallback_ladders_on_oracle():
+    from tests.dc_chain_util import oracle_chain, same_ladder
+
+    def chain(circ, **kw):
+        b = make_builder(circ.to_dicts())
+        spec = M.MNASpec(mode="dcop")
+        ctx = M.build_with_detection(b, {}, spec)
+        cs = M.compile_structure(b, {}, spec, ctx=ctx)
+        return oracle_chain(cs, M.create_workspace(cs, ctx=ctx), np.zeros(cs.n), **kw)
+
+    # no limiting: plain Newton spends its 100 iterations, the gshunt ladder 1e-3, /10 ... 1e-12 and the solve at the target arrive
+    u, ok, log = chain(tc.diode_rectifier(False))
+    assert ok and log[0] == (1, 0.0, False, 100)
+    rungs = [v for s, v, _, _ in log[1:]]
+    # (repeated division leaves 1.0000000000000002e-12 > 1e-12 on the tenth rung, so an eleventh at exactly 1e-12 follows)
+    assert all(s == 2 and good for s, _, good, _ in log[1:]) and len(rungs) == 12
+    assert np.allclose(rungs[:10], [10.0 ** -k for k in range(3, 13)], rtol=1e-12) and rungs[10] == 1e-12 and rungs[11] == 0.0
+    assert u[1] == pytest.approx(M.dc(make_builder(tc.diode_rectifier().to_dicts()))["out"], abs=1e-9)
+    # a failed rung is retried from the saved solution with sqrt(factor): 10 -> 3.16 -> 1.78 -> 1.33 <= 1.5 gives up after 4
+    u, ok, log = chain(tc.bi_quadratic(), abstol=1e-7, maxiters=5)
+    assert ok and [e[:3] for e in log[:5]] == [(1, 0.0, False)] + [(2, 1e-3, False)] * 4
+    assert all(s == 3 and good for s, _, good, _ in log[5:]) and log[5][1] == 0.0 and log[-1][1] == 1.0
+    assert same_ladder([(0,) + log[0][1:]] + log[1:], log) and not same_ladder(log[:-1], log)
