@@ -88,15 +88,11 @@ int cadnip_create(const CadnipStructure* s, int32_t n_instances, int32_t device,
   for (int i = 0; i < s->n_nodes; ++i) { int p = s->diag_nz[i]; if (p >= 0 && p < s->nnz) dflag[p] = 1; }
   CREATE_TRY(dev_upload(&h->d_diag_flag, dflag.data(), dflag.size()));
   {
-    // gather lists longer than kernels.hip's LONG_LIST get a workgroup each (supply rails of large circuits)
+    // rows longer than kernels.hip's LONG_LIST get a workgroup each in the residual (supply rails of large circuits)
     const int LONG = 512;
-    std::vector<int> le, lr;
-    for (int e = 0; e < s->nnz; ++e) if (s->g_ptr[e + 1] - s->g_ptr[e] > LONG) le.push_back(e);
-    for (int e = 0; e < s->nnz; ++e) if (s->c_ptr[e + 1] - s->c_ptr[e] > LONG) le.push_back(s->nnz + e);
-    for (int i = 0; i < s->n; ++i) if (s->b_ptr[i + 1] - s->b_ptr[i] > LONG) le.push_back(2 * s->nnz + i);
+    std::vector<int> lr;
     for (int i = 0; i < s->n; ++i) if (s->rowptr[i + 1] - s->rowptr[i] > LONG) lr.push_back(i);
-    h->n_long_asm = (int)le.size(); h->n_long_rows = (int)lr.size();
-    if (!le.empty()) CREATE_TRY(dev_upload(&h->d_long_asm, le.data(), le.size()));
+    h->n_long_rows = (int)lr.size();
     if (!lr.empty()) CREATE_TRY(dev_upload(&h->d_long_rows, lr.data(), lr.size()));
   }
   CREATE_TRY(dev_upload(&h->d_wave, s->wave_data, (size_t)s->n_wave_data));
@@ -163,12 +159,13 @@ int cadnip_create(const CadnipStructure* s, int32_t n_instances, int32_t device,
   }
   size_t B = h->B, n = h->n, nnz = h->nnz;
   CREATE_TRY(dev_alloc(&h->d_u, B * n)); CREATE_TRY(dev_alloc(&h->d_du, B * n)); CREATE_TRY(dev_alloc(&h->d_t, B)); CREATE_TRY(dev_alloc(&h->d_gamma, B));
-  CREATE_TRY(dev_alloc(&h->d_S, B * h->ns)); CREATE_TRY(dev_alloc(&h->d_G, B * nnz)); CREATE_TRY(dev_alloc(&h->d_C, B * nnz)); CREATE_TRY(dev_alloc(&h->d_b, B * n));
+  CREATE_TRY(dev_alloc(&h->d_G, B * nnz)); CREATE_TRY(dev_alloc(&h->d_C, B * nnz)); CREATE_TRY(dev_alloc(&h->d_b, B * n));
   CREATE_TRY(dev_alloc(&h->d_J, B * nnz)); CREATE_TRY(dev_alloc(&h->d_resid, B * n)); CREATE_TRY(dev_alloc(&h->d_delta, B * n));
   CREATE_TRY(dev_alloc(&h->d_limit_w, B * n)); CREATE_TRY(dev_alloc(&h->d_tmp, B * n));
   CREATE_TRY(dev_alloc(&h->d_flags, B)); CREATE_TRY(dev_alloc(&h->d_active, B)); CREATE_TRY(dev_alloc(&h->d_nonfinite, B));
   CREATE_TRY(dev_alloc(&h->d_gshunt, B)); CREATE_TRY(dev_alloc(&h->d_srcfact, B));
   CREATE_TRY(upload_homotopy(h, nullptr, nullptr));
+  CREATE_TRY(build_stamp_plan(h, s));
   std::vector<int> ones(B, 1);
   CREATE_HIP_TRY(hipMemcpy(h->d_active, ones.data(), B * sizeof(int), hipMemcpyHostToDevice));
   *out = h;
@@ -183,13 +180,16 @@ void cadnip_destroy(CadnipHandle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   cadnip_driver_free(h);
   void* ptrs[] = {h->d_rowptr, h->d_colidx, h->d_to_ref, h->d_g_ptr, h->d_g_slots, h->d_c_ptr, h->d_c_slots, h->d_b_ptr, h->d_b_slots,
-                  h->d_diag_flag, h->d_long_asm, h->d_long_rows, h->d_wave, h->d_limit_init, h->d_u, h->d_du, h->d_t, h->d_gamma, h->d_S, h->d_G, h->d_C, h->d_b, h->d_J,
+                  h->d_diag_flag, h->d_prep, h->d_long_rows, h->d_wave, h->d_limit_init, h->d_u, h->d_du, h->d_t, h->d_gamma, h->d_G, h->d_C, h->d_b, h->d_J,
                   h->d_resid, h->d_delta, h->d_limit_w, h->d_LU, h->d_tmp, h->d_flags, h->d_active, h->d_nonfinite, h->d_gshunt, h->d_srcfact, h->d_load_src, h->d_load_dst, h->d_ent_pos,
                   h->d_ent_diag, h->d_ent_ptr, h->d_term_a, h->d_term_b, h->d_lev_ptr, h->d_lu_rowptr, h->d_lu_col, h->d_lu_diag, h->d_rperm,
                   h->d_cperm, h->d_fwd_rows, h->d_fwd_lev_ptr, h->d_bwd_rows, h->d_bwd_lev_ptr};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->d_f2tab) (void)hipFree(h->d_f2tab);
-  for (auto& b : h->blocks) { if (b.d_nodes) (void)hipFree(b.d_nodes); if (b.d_ipar) (void)hipFree(b.d_ipar); if (b.d_par) (void)hipFree(b.d_par); }
+  for (auto& b : h->blocks) {
+    void* bp[] = {b.d_nodes, b.d_ipar, b.d_par, b.d_sp_tptr, b.d_sp_lptr, b.d_sp_dst, b.d_sp_lst};
+    for (void* p : bp) if (p) (void)hipFree(p);
+  }
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->d_f2queue) (void)hipFree(h->d_f2queue);
   if (h->d_f2blk) (void)hipFree(h->d_f2blk);
@@ -444,7 +444,7 @@ void* cadnip_dev_ptr(CadnipHandle* h, int32_t which) {
   if (!h) return nullptr;
   switch (which) {
     case CADNIP_BUF_U: return h->d_u; case CADNIP_BUF_G: return h->d_G; case CADNIP_BUF_C: return h->d_C; case CADNIP_BUF_B: return h->d_b;
-    case CADNIP_BUF_J: return h->d_J; case CADNIP_BUF_RESID: return h->d_resid; case CADNIP_BUF_SLOTS: return h->d_S; case CADNIP_BUF_LU: return h->d_LU;
+    case CADNIP_BUF_J: return h->d_J; case CADNIP_BUF_RESID: return h->d_resid; case CADNIP_BUF_SLOTS: return nullptr;   /* the slot buffer is gone: contributions are staged in LDS (stamp_csr.hip) */ case CADNIP_BUF_LU: return h->d_LU;
     case CADNIP_BUF_FLAGS: return h->d_flags;
   }
   return nullptr;

@@ -856,7 +856,7 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
     const int k2[2] = {12 + 30 + (D ? 4 : 1), 12 + 30 + (D ? 5 : 3)};
     const double v2[2] = {D ? g[4] : g[1], D ? g[5] : g[3]};
     s.Gk(k2, v2);
-    s.B(5, D ? 0.0 : -Ieq);
+    if (Out::DIRECT || !D) s.B(5, -Ieq);   // the source-side lane owns the b entry (a store-type writer must see one writer per slot)
     if constexpr (Out::DIRECT)
       s.Rn(nsi, D ? 0.0 : mf * I5.v + (mf * type * I5.p[0]) * dW_gs + (mf * type * I5.p[1]) * dW_ds + (mf * type * I5.p[2]) * dW_bs);
   }

@@ -65,6 +65,12 @@ struct DeviceBlock {
   bool mos1_plain = false;   // sp_mos1 block: every instance has gd = gs = OxideCap = 0 (set by cadnip_set_params)
   int* d_ipar = nullptr;
   double* d_par = nullptr;   // [B][n_par][count]
+  // reduction plan of the stamping kernel (stamp_csr.hip): devices per tile, tiles per instance, and per tile the targets
+  // (CSR entries of G / C, rows of b) it contributes to with the LDS offsets of their contributions in COO order
+  int sp_cs = 0, sp_chunks = 0, sp_n_targets = 0;
+  struct Target { int chunk; unsigned word; std::vector<unsigned short> offs; };
+  std::vector<Target> sp_targets;            // build-time only
+  int *d_sp_tptr = nullptr, *d_sp_lptr = nullptr; unsigned* d_sp_dst = nullptr; unsigned short* d_sp_lst = nullptr;
 };
 
 struct ProfEntry { const char* name; double ms = 0; int64_t calls = 0; };
@@ -87,8 +93,10 @@ struct CadnipHandle {
   int *d_rowptr = nullptr, *d_colidx = nullptr, *d_to_ref = nullptr;
   int *d_g_ptr = nullptr, *d_g_slots = nullptr, *d_c_ptr = nullptr, *d_c_slots = nullptr, *d_b_ptr = nullptr, *d_b_slots = nullptr;
   unsigned char* d_diag_flag = nullptr;   // [nnz] 1 where the entry is G[i,i] of a voltage node
-  int *d_long_asm = nullptr, *d_long_rows = nullptr;   // entries / rows whose gather lists are long (kernels.hip LONG_LIST)
-  int n_long_asm = 0, n_long_rows = 0;
+  int* d_long_rows = nullptr;   // rows with more than LONG_LIST entries (kernels.hip: k_residual_long)
+  int n_long_rows = 0;
+  unsigned* d_prep = nullptr;   // words the stamping kernels do not store themselves (stamp_csr.hip: k_stamp_prep)
+  int n_prep = 0;
   double* d_wave = nullptr;
   double* d_limit_init = nullptr;
   // per-instance homotopy parameters of the DC fallback chain (solve.jl:720-850); equal to spec.gshunt / spec.srcFact
@@ -97,7 +105,7 @@ struct CadnipHandle {
   bool homotopy = false;     // some instance has gshunt != 0 or srcFact < 1: the fused kernel (no homotopy terms) must not run
   // device: per-instance state [B][..]
   double *d_u = nullptr, *d_du = nullptr, *d_t = nullptr, *d_gamma = nullptr;
-  double *d_S = nullptr, *d_G = nullptr, *d_C = nullptr, *d_b = nullptr, *d_J = nullptr, *d_resid = nullptr, *d_delta = nullptr;
+  double *d_G = nullptr, *d_C = nullptr, *d_b = nullptr, *d_J = nullptr, *d_resid = nullptr, *d_delta = nullptr;
   double *d_limit_w = nullptr, *d_LU = nullptr, *d_tmp = nullptr;
   int* d_flags = nullptr;        // [B] per-instance status bits (1 = singular pivot, 2 = non-finite)
   int* d_active = nullptr;       // [B] 1 = instance takes part in the next launches
@@ -139,7 +147,8 @@ namespace cadnip {
 int lu_analyze(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, const std::vector<double>& vals,
                double pivot_tol, bool sample, LUProgram& out, std::string& err);
 // kernels.hip launchers (all asynchronous on h->stream)
-int launch_rebuild(CadnipHandle* h);                       // stamps + assemble at (d_u, d_t)
+int launch_rebuild(CadnipHandle* h);                       // stamp_csr.hip: one stamp + reduce kernel per device type at (d_u, d_t)
+int build_stamp_plan(CadnipHandle* h, const CadnipStructure* s);   // stamp_csr.hip, once per structure
 int launch_residual(CadnipHandle* h, const double* d_du);  // d_resid = C du + G u - b
 int launch_jacobian(CadnipHandle* h);                      // d_J = G + gamma C
 int launch_factor(CadnipHandle* h, bool fuse_jacobian);    // LU of J (or of G + gamma C)

@@ -1,9 +1,8 @@
-// kernels.hip -- gfx950 kernels of the unfused hot path: one stamping kernel per device type,
-// slot->nz segmented gather (assemble), residual, Jacobian, and the batched sparse LU.
+// kernels.hip -- gfx950 kernels of the unfused hot path behind the stamping kernels (stamp_csr.hip): residual,
+// Jacobian, and the batched sparse LU.
 //
-// Parallel axes: (sweep instance, device) for stamping, (sweep instance, nz / row) for the
-// assembly-type kernels, one workgroup per sweep instance for the LU whose working set lives
-// in LDS.  All per-instance arrays are instance-major; inside an instance the device SoA
+// Parallel axes: (sweep instance, row / nz) for residual and Jacobian, one workgroup per sweep instance for the LU
+// whose working set lives in LDS.  All per-instance arrays are instance-major; inside an instance the device SoA
 // layout makes consecutive lanes touch consecutive addresses.
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -37,67 +36,8 @@ ProfScope::~ProfScope() {
   h->prof[idx].calls += 1;
 }
 
-// ------------------------------------------------------------------------------------------
-// stamping: one kernel per device type
-// ------------------------------------------------------------------------------------------
-struct StampArgs {
-  const int* nodes; const int* ipar; const double* par; const double* wave;
-  const double* u; const double* t; const int* active;
-  double* S; double* limit_w;
-  int B, count, n, n_par, ns, ns_g, ns_c, g_base, c_base, b_base, mode, initjct;
-};
-
-template <int TYPE>
-__global__ void __launch_bounds__(256) k_stamp(StampArgs a) {
-  int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= a.B * a.count) return;
-  int inst = tid / a.count, dev = tid - inst * a.count;
-  if (!a.active[inst]) return;
-  DevCtx d{a.nodes, a.ipar, a.par + (size_t)inst * a.n_par * a.count, a.wave, a.count, dev, a.t[inst], a.mode, a.initjct};
-  double* S = a.S + (size_t)inst * a.ns;
-  SlotOut s{S + a.g_base, S + a.ns_g + a.c_base, S + a.ns_g + a.ns_c + a.b_base, a.count, dev};
-  const double* u = a.u + (size_t)inst * a.n;
-  double* lw = a.limit_w + (size_t)inst * a.n;
-  if (TYPE == CADNIP_DEV_RESISTOR) stamp_resistor(d, u, s, lw);
-  else if (TYPE == CADNIP_DEV_CAPACITOR) stamp_capacitor(d, u, s, lw);
-  else if (TYPE == CADNIP_DEV_INDUCTOR) stamp_inductor(d, u, s, lw);
-  else if (TYPE == CADNIP_DEV_VSOURCE) stamp_vsource(d, u, s, lw);
-  else if (TYPE == CADNIP_DEV_ISOURCE) stamp_isource(d, u, s, lw);
-  else if (TYPE == CADNIP_DEV_VCVS) stamp_vcvs(d, u, s, lw);
-  else if (TYPE == CADNIP_DEV_VCCS) stamp_vccs(d, u, s, lw);
-  else if (TYPE == CADNIP_DEV_CCVS) stamp_ccvs(d, u, s, lw);
-  else if (TYPE == CADNIP_DEV_CCCS) stamp_cccs(d, u, s, lw);
-  else if (TYPE == CADNIP_DEV_DIODE) stamp_diode(d, u, s, lw);
-  else if (TYPE == CADNIP_DEV_DIODECAP) stamp_diodecap(d, u, s, lw);
-  else if (TYPE == CADNIP_DEV_SIMPLEMOS) stamp_simplemos(d, u, s, lw);
-  else if (TYPE == CADNIP_DEV_MOS1) stamp_mos1(d, u, s, lw);
-  else if (TYPE == CADNIP_DEV_BVSOURCE) stamp_bvsource(d, u, s, lw);
-  else if (TYPE == CADNIP_DEV_BISOURCE) stamp_bisource(d, u, s, lw);
-  else if (TYPE == CADNIP_DEV_VA) stamp_va(d, u, s, lw);
-}
-
-template <int TYPE>
-static void launch_stamp_t(const StampArgs& a, hipStream_t st) {
-  int total = a.B * a.count;
-  int bs = (TYPE == CADNIP_DEV_MOS1) ? 64 : 256;
-  hipLaunchKernelGGL(k_stamp<TYPE>, dim3((total + bs - 1) / bs), dim3(bs), 0, st, a);
-}
-
-// ------------------------------------------------------------------------------------------
-// assemble: G[nz] = sum of its G slots (COO order), likewise C and b; then the post-stamp steps
-// of fast_rebuild! (precompile.jl:508-534): deferred b is the gather itself, srcFact, gshunt.
-// ------------------------------------------------------------------------------------------
-struct AsmArgs {
-  const double* S; const int* g_ptr; const int* g_slots; const int* c_ptr; const int* c_slots; const int* b_ptr; const int* b_slots;
-  const unsigned char* diag_flag; const int* active;
-  int* nonfinite;   // [B] set to 1 when an assembled G / C / b value of the instance is not finite (cadnip_rebuild -> CADNIP_NONFINITE)
-  double* G; double* C; double* b;
-  int B, n, nnz, ns, ns_g, ns_c; const double* srcFact; const double* gshunt;   // [B] each
-};
-
-// Entries that gather more than LONG_LIST slots (the supply rails of a large circuit: G[vdd,vdd] of the c6288 multiplier
-// sums 20 k stamps) are left to k_assemble_long / k_residual_long, one workgroup each: a single thread walking such a list
-// made the whole kernel take 6 ms.  The DFF has none.
+// Rows / entries whose lists are longer than LONG_LIST get a workgroup each (k_residual_long): a single thread walking the
+// 20 k entries of a supply-rail row of the c6288 multiplier made the whole kernel take 6 ms.  The DFF has none.
 #define LONG_LIST 512
 
 __device__ __forceinline__ double block_sum_256(double v, double* red) {
@@ -106,64 +46,6 @@ __device__ __forceinline__ double block_sum_256(double v, double* red) {
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
   return red[0];
-}
-
-// one workgroup per (instance, long entry); `long_e` indexes the combined [G nz | C nz | b rows] space of k_assemble
-__global__ void __launch_bounds__(256) k_assemble_long(AsmArgs a, const int* long_e, int n_long) {
-  __shared__ double red[256];
-  const int inst = blockIdx.x / n_long, e = long_e[blockIdx.x % n_long];
-  if (!a.active[inst]) return;
-  const double* S = a.S + (size_t)inst * a.ns;
-  const int* ptr; const int* slots; const double* Sx; int k; double* out;
-  if (e < a.nnz) { ptr = a.g_ptr; slots = a.g_slots; Sx = S; k = e; out = a.G + (size_t)inst * a.nnz + k; }
-  else if (e < 2 * a.nnz) { ptr = a.c_ptr; slots = a.c_slots; Sx = S + a.ns_g; k = e - a.nnz; out = a.C + (size_t)inst * a.nnz + k; }
-  else { ptr = a.b_ptr; slots = a.b_slots; Sx = S + a.ns_g + a.ns_c; k = e - 2 * a.nnz; out = a.b + (size_t)inst * a.n + k; }
-  double acc = 0.0;
-  for (int p = ptr[k] + threadIdx.x; p < ptr[k + 1]; p += 256) acc += Sx[slots[p]];
-  acc = block_sum_256(acc, red);
-  if (threadIdx.x == 0) {
-    const double gsh = a.gshunt[inst], sf = a.srcFact[inst];
-    if (e < a.nnz && gsh != 0.0 && a.diag_flag[e]) acc += gsh;
-    if (e >= 2 * a.nnz && sf < 1.0) acc *= sf;
-    if (!isfinite(acc)) a.nonfinite[inst] = 1;
-    *out = acc;
-  }
-}
-
-__global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
-  int per = 2 * a.nnz + a.n;
-  long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= (long)a.B * per) return;
-  int inst = (int)(tid / per), e = (int)(tid - (long)inst * per);
-  if (!a.active[inst]) return;
-  const double* S = a.S + (size_t)inst * a.ns;
-  if (e < a.nnz) {
-    if (a.g_ptr[e + 1] - a.g_ptr[e] > LONG_LIST) return;
-    double acc = 0.0;
-    for (int p = a.g_ptr[e]; p < a.g_ptr[e + 1]; ++p) acc += S[a.g_slots[p]];
-    const double gsh = a.gshunt[inst];
-    if (gsh != 0.0 && a.diag_flag[e]) acc += gsh;
-    if (!isfinite(acc)) a.nonfinite[inst] = 1;
-    a.G[(size_t)inst * a.nnz + e] = acc;
-  } else if (e < 2 * a.nnz) {
-    int k = e - a.nnz;
-    const double* Sc = S + a.ns_g;
-    if (a.c_ptr[k + 1] - a.c_ptr[k] > LONG_LIST) return;
-    double acc = 0.0;
-    for (int p = a.c_ptr[k]; p < a.c_ptr[k + 1]; ++p) acc += Sc[a.c_slots[p]];
-    if (!isfinite(acc)) a.nonfinite[inst] = 1;
-    a.C[(size_t)inst * a.nnz + k] = acc;
-  } else {
-    int i = e - 2 * a.nnz;
-    const double* Sb = S + a.ns_g + a.ns_c;
-    if (a.b_ptr[i + 1] - a.b_ptr[i] > LONG_LIST) return;
-    double acc = 0.0;
-    for (int p = a.b_ptr[i]; p < a.b_ptr[i + 1]; ++p) acc += Sb[a.b_slots[p]];
-    const double sf = a.srcFact[inst];
-    if (sf < 1.0) acc *= sf;
-    if (!isfinite(acc)) a.nonfinite[inst] = 1;
-    a.b[(size_t)inst * a.n + i] = acc;
-  }
 }
 
 // resid = C*du + G*u - b   (precompile.jl:546-557), CSR row gather
@@ -358,36 +240,6 @@ int launch_calib_copy(CadnipHandle* h, long n, int reps) {
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-int launch_rebuild(CadnipHandle* h) {
-  for (auto& blk : h->blocks) {
-    if (blk.count == 0) continue;
-    StampArgs a{blk.d_nodes, blk.d_ipar, blk.d_par, h->d_wave, h->d_u, h->d_t, h->d_active, h->d_S, h->d_limit_w,
-                h->B, blk.count, h->n, blk.n_par, h->ns, h->ns_g, h->ns_c, blk.g_base, blk.c_base, blk.b_base, h->spec.mode, h->initjct};
-    switch (blk.type) {
-#define CASE(T, NAME) case T: { ProfScope ps(h, NAME); launch_stamp_t<T>(a, h->stream); } break;
-      CASE(CADNIP_DEV_RESISTOR, "stamp_resistor") CASE(CADNIP_DEV_CAPACITOR, "stamp_capacitor")
-      CASE(CADNIP_DEV_INDUCTOR, "stamp_inductor") CASE(CADNIP_DEV_VSOURCE, "stamp_vsource")
-      CASE(CADNIP_DEV_ISOURCE, "stamp_isource") CASE(CADNIP_DEV_VCVS, "stamp_vcvs") CASE(CADNIP_DEV_VCCS, "stamp_vccs")
-      CASE(CADNIP_DEV_CCVS, "stamp_ccvs") CASE(CADNIP_DEV_CCCS, "stamp_cccs") CASE(CADNIP_DEV_DIODE, "stamp_diode")
-      CASE(CADNIP_DEV_DIODECAP, "stamp_diodecap") CASE(CADNIP_DEV_SIMPLEMOS, "stamp_simplemos")
-      CASE(CADNIP_DEV_MOS1, "stamp_mos1") CASE(CADNIP_DEV_BVSOURCE, "stamp_bvsource") CASE(CADNIP_DEV_BISOURCE, "stamp_bisource")
-      CASE(CADNIP_DEV_VA, "stamp_va")
-#undef CASE
-      default: return CADNIP_BADARG;
-    }
-  }
-  {
-    ProfScope ps(h, "assemble");
-    AsmArgs a{h->d_S, h->d_g_ptr, h->d_g_slots, h->d_c_ptr, h->d_c_slots, h->d_b_ptr, h->d_b_slots, h->d_diag_flag, h->d_active, h->d_nonfinite,
-              h->d_G, h->d_C, h->d_b, h->B, h->n, h->nnz, h->ns, h->ns_g, h->ns_c, h->d_srcfact, h->d_gshunt};
-    long total = (long)h->B * (2L * h->nnz + h->n);
-    hipLaunchKernelGGL(k_assemble, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, a);
-    if (h->n_long_asm > 0) hipLaunchKernelGGL(k_assemble_long, dim3((unsigned)(h->B * h->n_long_asm)), dim3(256), 0, h->stream, a, h->d_long_asm, h->n_long_asm);
-  }
-  HIP_TRY(hipGetLastError());
-  return CADNIP_OK;
-}
-
 int launch_residual(CadnipHandle* h, const double* d_du) {
   ProfScope ps(h, "residual");
   ResArgs a{h->d_G, h->d_C, h->d_b, h->d_u, d_du, h->d_rowptr, h->d_colidx, h->d_active, h->d_resid, h->B, h->n, h->nnz};
