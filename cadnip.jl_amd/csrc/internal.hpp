@@ -67,10 +67,10 @@ struct DeviceBlock {
   double* d_par = nullptr;   // [B][n_par][count]
   // reduction plan of the stamping kernel (stamp_csr.hip): devices per tile, tiles per instance, and per tile the targets
   // (CSR entries of G / C, rows of b) it contributes to with the LDS offsets of their contributions in COO order
-  int sp_cs = 0, sp_chunks = 0, sp_n_targets = 0;
+  int sp_cs = 0, sp_chunks = 0, sp_n_targets = 0, sp_levels = 1, sp_scratch = 0;
   struct Target { int chunk; unsigned word; std::vector<unsigned short> offs; };
   std::vector<Target> sp_targets;            // build-time only
-  int *d_sp_tptr = nullptr, *d_sp_lptr = nullptr; unsigned* d_sp_dst = nullptr; unsigned short* d_sp_lst = nullptr;
+  int *d_sp_tptr = nullptr, *d_sp_info = nullptr; uint4* d_sp_rec = nullptr;
 };
 
 struct ProfEntry { const char* name; double ms = 0; int64_t calls = 0; };
@@ -96,7 +96,8 @@ struct CadnipHandle {
   int* d_long_rows = nullptr;   // rows with more than LONG_LIST entries (kernels.hip: k_residual_long)
   int n_long_rows = 0;
   unsigned* d_prep = nullptr;   // words the stamping kernels do not store themselves (stamp_csr.hip: k_stamp_prep)
-  int n_prep = 0;
+  int n_prep = 0, n_prep_atomic = 0;   // the first n_prep_atomic words are rewritten before every restamp
+  bool prep_stale = true;              // unstamped node diagonals may still hold a gshunt of an earlier restamp
   double* d_wave = nullptr;
   double* d_limit_init = nullptr;
   // per-instance homotopy parameters of the DC fallback chain (solve.jl:720-850); equal to spec.gshunt / spec.srcFact

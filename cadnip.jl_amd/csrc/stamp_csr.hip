@@ -9,13 +9,18 @@
 //   2. reduce  -- segmented reduction in LDS: the tile's *targets* (the CSR entries of G / C and the rows of b that receive
 //                 anything from this chunk, in CSR order) are dealt to the lanes; a lane sums its target's staged
 //                 contributions in the reference's COO order (nzval[map[pos]] += v, value_only.jl:414-418, addition for
-//                 addition) and writes ONE value to HBM.  Consecutive lanes write consecutive CSR positions.
+//                 addition) and writes ONE value to HBM.  Consecutive lanes write consecutive CSR positions.  A target
+//                 with more than five contributions (node diagonals, supply rails) is reduced as a 5-ary tree over
+//                 consecutive runs of its list: partial sums go to LDS scratch words and are combined on the next level,
+//                 so no lane ever walks a long list alone (one lane summing the 120 stamps of a rail made the whole wave
+//                 wait 40 k cycles).
 // No slot buffer in HBM, no separate assemble pass, no zero-fill of G / C / b: a target whose contributions all come from
 // one tile is stored; a target that an earlier kernel of the stream has already stored is read-modify-written (kernels of a
 // stream run in order, and within this kernel the tile is its only writer); only a target that receives contributions from
 // several tiles of the SAME kernel -- a boundary between tiles, e.g. a supply rail fed by every chunk of a large circuit --
 // is accumulated with a global fp64 atomic, on a word that k_stamp_prep has pre-set when no earlier kernel stores it.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <vector>
 #include "devices.hpp"
@@ -24,7 +29,9 @@
 
 namespace cadnip {
 
-enum { TGT_STORE = 0, TGT_RMW = 1, TGT_ATOMIC = 2 };   // bits 30-31 of a target word; bits 28-29: 0 G, 1 C, 2 b; bits 0-27: index
+#define N_CLS 5   // record classes of the reduction (k_stamp_csr); 5 = padding step
+enum { TGT_STORE = 0, TGT_RMW = 1, TGT_ATOMIC = 2, TGT_PARTIAL = 3 };   // bits 30-31 of a target word; bits 28-29: 0 G, 1 C, 2 b; bits 0-27: index
+                                                                       // (TGT_PARTIAL: index = LDS scratch word of the tile, relative to the tile)
 
 // LDS staging writer: slot (k, dev) of this lane's instance tile; same interface as SlotOut (devices.hpp)
 struct LdsOut {
@@ -60,16 +67,48 @@ struct CsrStampArgs {
   const double* u; const double* t; const int* active;
   double *G, *C, *b, *limit_w; int* nonfinite;
   const unsigned char* diag_flag; const double* gshunt; const double* srcFact;
-  const int* tgt_ptr; const unsigned* tgt_dst; const int* tgt_lptr; const unsigned short* lst;
-  int B, count, n, nnz, n_par, n_g, n_c, n_b, cs, n_chunks, ipw, lpd, mode, initjct, zero_first;
+  const int* step_ptr; const int* step_info; const uint4* tgt_rec;   // [n_chunks + 1] step ranges, per step class | new-level flag << 8, STEP_W records (16 B each) per step (build_stamp_plan)
+  int B, count, n, nnz, n_par, n_g, n_c, n_b, cs, n_chunks, ipw, lpd, mode, initjct, zero_first, n_levels, n_scratch;
+  int u_lds;   // the unknowns of the tile's instances are staged in LDS (small circuits): node voltages are then LDS reads
+
 };
+
+#ifdef CADNIP_TRACE
+// diagnostic build: cycles between the phases of the sp_mos1 kernel, summed over all waves and launches
+static __device__ unsigned long long g_sc_sum[8], g_sc_cnt;
+#define SC_POINT(id) do { if (TYPE == CADNIP_DEV_MOS1) { unsigned long long _t = clock64(); if (threadIdx.x == 0) atomicAdd(&g_sc_sum[id], _t - sc_last); sc_last = _t; } } while (0)
+#else
+#define SC_POINT(id) do {} while (0)
+#endif
+
+#define STEP_W 128   // records per reduction step (two per lane)
+#define PIPE 8       // steps whose records are in flight / in registers
 
 template <int TYPE>
 __global__ void __launch_bounds__(64) k_stamp_csr(CsrStampArgs a) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
+#ifdef CADNIP_TRACE
+  unsigned long long sc_last = clock64();
+  if (TYPE == CADNIP_DEV_MOS1 && threadIdx.x == 0) atomicAdd(&g_sc_cnt, 1ull);
+#endif
   const int chunk = blockIdx.x % a.n_chunks, grp = blockIdx.x / a.n_chunks;
-  const int nslots = a.n_g + a.n_c + a.n_b, tile_words = nslots * a.cs;
+  // ---- the reduction's records.  The chunk's records form *steps* of STEP_W = 128 (two per lane), every step homogeneous
+  // in class and level (build_stamp_plan pads).  The reduce loop is ROLLED -- this kernel runs once per wave, so every
+  // instruction it executes is an instruction-cache miss waiting to happen, and a 32-fold unrolled loop ran at ~800 cycles
+  // per step for that reason alone -- and keeps a shift register of PIPE steps' records: the first PIPE are requested
+  // here, before the stamp phase, a new one enters with every step.  step_lane: lane s holds the descriptor of step s
+  // (class | first-step-of-a-level flag << 8), read with v_readlane.
+  const int s0 = a.step_ptr[chunk], n_steps = a.step_ptr[chunk + 1] - s0;
+  const int step_lane = a.step_info[s0 + (lane < n_steps ? lane : 0)];   // steps beyond 64 read their descriptor from memory
+  const uint4* recs = a.tgt_rec + (size_t)s0 * STEP_W + lane;
+  uint4 pipe[PIPE][2];                                                    // stage p holds the records of step q + p
+#pragma unroll
+  for (int p = 0; p < PIPE; ++p) {
+    const int st = p < n_steps ? p : 0;
+    pipe[p][0] = recs[(size_t)st * STEP_W]; pipe[p][1] = recs[(size_t)st * STEP_W + 64];
+  }
+  const int nslots = a.n_g + a.n_c + a.n_b, tile_words = nslots * a.cs + a.n_scratch;   // staged slots | scratch of the reduction tree
   // lane -> (instance of the tile, device of the chunk, side of a lane pair)
   const int dl = lane / a.lpd, side = lane - dl * a.lpd;
   const int ii = a.n_chunks == 1 ? dl / a.count : 0;
@@ -81,13 +120,36 @@ __global__ void __launch_bounds__(64) k_stamp_csr(CsrStampArgs a) {
   const int inst_c = inst < a.B ? inst : a.B - 1;                 // clamped: every lane runs the device code (lane-pair DPP)
   double* tile = lds + (size_t)(ii < a.ipw ? ii : 0) * tile_words;
   if (a.zero_first) {
-    for (int i = lane; i < a.ipw * tile_words; i += 64) lds[i] = 0.0;
+    // (tile_words is even for every type that needs this: n_g + n_c + n_b of sp_mos1 = 114; an odd tail is covered below)
+    const int words = a.ipw * tile_words;
+    for (int i = lane; i < (words >> 1); i += 64) ((double2*)lds)[i] = make_double2(0.0, 0.0);
+    if ((words & 1) && lane == 0) lds[words - 1] = 0.0;
     CADNIP_WAVE_SYNC();
   }
+  if (lane < a.ipw) lds[(size_t)(lane + 1) * tile_words - 1] = 0.0;   // the tile's zero word: operand slots a record does not use
+  // per-instance scalars of the tile's instances, behind the tiles: the reduction reads them per instance
+  double* inst_par = lds + (size_t)a.ipw * tile_words;             // [ipw][3]: active, gshunt, srcFact
+  if (lane < a.ipw) {
+    const int i2 = grp * a.ipw + lane;
+    const bool in = i2 < a.B;
+    inst_par[3 * lane] = in && a.active[i2] ? 1.0 : 0.0;
+    inst_par[3 * lane + 1] = in ? a.gshunt[i2] : 0.0;
+    inst_par[3 * lane + 2] = in ? a.srcFact[i2] : 1.0;
+  }
+  double* u_tile = inst_par + 3 * a.ipw;                           // [ipw][n] when u_lds
+  if (a.u_lds) {
+    for (int r = 0; r < a.ipw; ++r) {
+      const int i2 = grp * a.ipw + r < a.B ? grp * a.ipw + r : a.B - 1;
+      const double* ug = a.u + (size_t)i2 * a.n;
+      for (int i = lane; i < a.n; i += 64) u_tile[(size_t)r * a.n + i] = ug[i];
+    }
+    CADNIP_WAVE_SYNC();
+  }
+  SC_POINT(0);
   {
     DevCtx d{a.nodes, a.ipar, a.par + (size_t)inst_c * a.n_par * a.count, a.wave, a.count, dev < a.count ? dev : a.count - 1, a.t[inst_c], a.mode, a.initjct};
     LdsOut s{tile, tile + (size_t)a.n_g * a.cs, tile + (size_t)(a.n_g + a.n_c) * a.cs, a.cs, ldev, valid};
-    const double* u = a.u + (size_t)inst_c * a.n;
+    const double* u = a.u_lds ? u_tile + (size_t)(ii < a.ipw ? ii : 0) * a.n : a.u + (size_t)inst_c * a.n;
     double* lw = valid ? a.limit_w + (size_t)inst_c * a.n : nullptr;
     if (TYPE == CADNIP_DEV_RESISTOR) stamp_resistor(d, u, s, lw);
     else if (TYPE == CADNIP_DEV_CAPACITOR) stamp_capacitor(d, u, s, lw);
@@ -110,26 +172,93 @@ __global__ void __launch_bounds__(64) k_stamp_csr(CsrStampArgs a) {
     else if (TYPE == CADNIP_DEV_VA) stamp_va(d, u, s, lw);
   }
   CADNIP_WAVE_SYNC();
-  // ---- segmented reduction: one target per lane and step, contributions summed in COO order out of LDS
-  const int t0 = a.tgt_ptr[chunk], nt = a.tgt_ptr[chunk + 1] - t0;
-  for (int idx = lane; idx < a.ipw * nt; idx += 64) {
-    const int ri = idx / nt, t = t0 + (idx - ri * nt);
+  SC_POINT(1);
+  // ---- segmented reduction: one target per lane and step, contributions summed in COO order out of LDS.  A target is
+  // one 16-byte record (destination, count, up to five staging offsets inline); RED_U records per lane are requested
+  // before the first is used, so the batch costs one memory latency, not one per target.
+  // Step by step: class 0 / 1 / 2 = sole writer of a word of G / C / b (plain store), 3 = partial sum into LDS scratch,
+  // 4 = the rest (read-modify-write behind an earlier kernel, atomics between tiles), 5 = padding.  Class, destination and
+  // the instance's scalars are wave-uniform, so a record costs five LDS reads issued together (operand slots it does not
+  // use point at the tile's zero word), four adds and one store.
+  // everything a record needs about its instance, gathered once (not per record: the compiler would re-read kernel
+  // arguments and LDS words in every step)
+  struct InstCtx { double *Gb, *Cb, *bb; int* nf; double sf, gsh; int tile_off; };   // (the tile is addressed by offset: an LDS pointer inside a struct decays to a generic one)
+  auto inst_ctx = [&](int ri) {
     const int rinst = grp * a.ipw + ri;
-    if (rinst >= a.B || !a.active[rinst]) continue;
-    const unsigned w = a.tgt_dst[t];
-    const unsigned e = w & 0x0FFFFFFFu, arr = (w >> 28) & 3u, md = w >> 30;
-    const double* src = lds + (size_t)ri * tile_words;
-    double acc = 0.0;
-    for (int p = a.tgt_lptr[t]; p < a.tgt_lptr[t + 1]; ++p) acc += src[a.lst[p]];
-    if (arr == 2u) { const double sf = a.srcFact[rinst]; if (sf < 1.0) acc *= sf; }          // precompile.jl:524-527
-    if (!isfinite(acc)) a.nonfinite[rinst] = 1;
-    double* dst = arr == 0u ? a.G + (size_t)rinst * a.nnz + e : arr == 1u ? a.C + (size_t)rinst * a.nnz + e : a.b + (size_t)rinst * a.n + e;
-    if (md == TGT_STORE) {
-      if (arr == 0u) { const double gsh = a.gshunt[rinst]; if (gsh != 0.0 && a.diag_flag[e]) acc += gsh; }   // precompile.jl:529-534
-      *dst = acc;
-    } else if (md == TGT_RMW) *dst += acc;
-    else unsafeAtomicAdd(dst, acc);
+    InstCtx c;
+    c.tile_off = ri * tile_words;
+    c.Gb = a.G + (size_t)rinst * a.nnz; c.Cb = a.C + (size_t)rinst * a.nnz; c.bb = a.b + (size_t)rinst * a.n;
+    c.nf = a.nonfinite + rinst;
+    c.gsh = uniform_f64(inst_par[3 * ri + 1]); c.sf = uniform_f64(inst_par[3 * ri + 2]);
+    return c;
+  };
+  const unsigned char* const diag_flag = a.diag_flag;
+  auto reduce_instance = [&](const InstCtx& c, const uint4& ra, const uint4& rb, int cls) {
+    double* src = lds + c.tile_off;
+    const double a0 = src[ra.y >> 16], a1 = src[ra.z & 0xFFFFu], a2 = src[ra.z >> 16], a3 = src[ra.w & 0xFFFFu], a4 = src[ra.w >> 16];
+    const double b0 = src[rb.y >> 16], b1 = src[rb.z & 0xFFFFu], b2 = src[rb.z >> 16], b3 = src[rb.w & 0xFFFFu], b4 = src[rb.w >> 16];
+    double acc[2] = {(((a0 + a1) + a2) + a3) + a4, (((b0 + b1) + b2) + b3) + b4};
+    const unsigned e[2] = {ra.x & 0x0FFFFFFFu, rb.x & 0x0FFFFFFFu};
+    const bool on[2] = {(ra.y & 0xFFFFu) != 0u, (rb.y & 0xFFFFu) != 0u};   // padding records inside a step have count 0
+    const unsigned wx[2] = {ra.x, rb.x};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (!on[k]) continue;
+      double v = acc[k];
+      switch (cls) {                                 // wave-uniform
+        case 0:
+          if (c.gsh != 0.0 && diag_flag[e[k]]) v += c.gsh;                                     // precompile.jl:529-534
+          if (!isfinite(v)) *c.nf = 1;
+          c.Gb[e[k]] = v;
+          break;
+        case 1:
+          if (!isfinite(v)) *c.nf = 1;
+          c.Cb[e[k]] = v;
+          break;
+        case 2:
+          if (c.sf < 1.0) v *= c.sf;                                                           // precompile.jl:524-527
+          if (!isfinite(v)) *c.nf = 1;
+          c.bb[e[k]] = v;
+          break;
+        case 3: src[e[k]] = v; break;
+        default: {
+          const unsigned arr = (wx[k] >> 28) & 3u, md = wx[k] >> 30;
+          if (arr == 2u && c.sf < 1.0) v *= c.sf;
+          if (!isfinite(v)) *c.nf = 1;
+          double* dst = (arr == 0u ? c.Gb : arr == 1u ? c.Cb : c.bb) + e[k];
+          if (md == TGT_RMW) *dst += v;
+          else unsafeAtomicAdd(dst, v);
+        }
+      }
+    }
+  };
+  const bool single = a.ipw == 1;
+  const bool single_on = single && grp < a.B && inst_par[0] != 0.0;                 // (ipw == 1: the tile's instance is grp)
+  const InstCtx c0 = inst_ctx(0);
+  // The loop body is PIPE steps (stage p of the register window serves steps p, p + PIPE, ...): a stage is refilled right
+  // after it has been consumed.  Result stores are acknowledged in order with the record reads (one vmcnt counter), so the
+  // window also decides how many steps of stores may be in flight: with 4 the loop ran at the store latency / 4 per step.
+  auto step = [&](int q, const uint4& ra, const uint4& rb) {
+    const int info = q < 64 ? __builtin_amdgcn_readlane(step_lane, q) : a.step_info[s0 + q];
+    const int cls = info & 0xFF;
+    if (info & 0x100) CADNIP_WAVE_SYNC();          // first step of a level: the partial sums below it are complete
+    if (cls >= 5) return;
+    if (single) { if (single_on) reduce_instance(c0, ra, rb, cls); return; }
+    for (int ri = 0; ri < a.ipw; ++ri)
+      if (grp * a.ipw + ri < a.B && inst_par[3 * ri] != 0.0) reduce_instance(inst_ctx(ri), ra, rb, cls);   // wave-uniform
+  };
+  for (int q0 = 0; q0 < n_steps; q0 += PIPE) {
+#pragma unroll
+    for (int p = 0; p < PIPE; ++p) {
+      const int q = q0 + p;
+      const uint4 ra = pipe[p][0], rb = pipe[p][1];
+      const int st = q + PIPE < n_steps ? q + PIPE : 0;                              // past the end: a harmless re-read of step 0
+      pipe[p][0] = recs[(size_t)st * STEP_W]; pipe[p][1] = recs[(size_t)st * STEP_W + 64];
+      if (q < n_steps) step(q, ra, rb);                                              // wave-uniform
+    }
   }
+  CADNIP_WAVE_SYNC();
+  SC_POINT(7);
 }
 
 // Pre-set words: (a) targets accumulated with atomics whose first contributions come from that same kernel, (b) diagonal
@@ -189,7 +318,7 @@ int build_stamp_plan(CadnipHandle* h, const CadnipStructure* s) {
   const int* slots[3] = {s->g_slots, s->c_slots, s->b_slots};
   const int n_tgt[3] = {nnz, nnz, n};
   const int totals[3] = {h->ns_g, h->ns_c, h->ns_b};
-  std::vector<unsigned> prep;
+  std::vector<unsigned> prep, prep_orphan;   // atomically accumulated words nobody stores first | unstamped node diagonals
   std::vector<char> is_diag((size_t)nnz, 0);
   for (int i = 0; i < s->n_nodes; ++i) if (s->diag_nz[i] >= 0 && s->diag_nz[i] < nnz) is_diag[s->diag_nz[i]] = 1;
   std::vector<Contrib> cl;
@@ -207,7 +336,7 @@ int build_stamp_plan(CadnipHandle* h, const CadnipStructure* s) {
       }
       if (cl.empty()) {
         // a G entry nobody stamps stays zero for ever -- unless it is a node diagonal, which carries gshunt
-        if (arr == 0 && is_diag[e]) prep.push_back((unsigned)e);
+        if (arr == 0 && is_diag[e]) prep_orphan.push_back((unsigned)e);
         continue;
       }
       // group by tile (block, chunk) in launch order; inside a tile the COO order is kept
@@ -235,24 +364,95 @@ int build_stamp_plan(CadnipHandle* h, const CadnipStructure* s) {
   for (auto& b : h->blocks) {
     if (b.count == 0) continue;
     std::stable_sort(b.sp_targets.begin(), b.sp_targets.end(), [](const DeviceBlock::Target& x, const DeviceBlock::Target& y) { return x.chunk < y.chunk; });
-    std::vector<int> tptr(b.sp_chunks + 1, 0), lptr(1, 0);
-    std::vector<unsigned> dst;
-    std::vector<unsigned short> lst;
+    // record = {destination word, count | off0 << 16, off1 | off2 << 16, off3 | off4 << 16}: up to five operands inline.
+    // A target with more contributions becomes a 5-ary tree: level-0 records sum consecutive runs of five staged words into
+    // scratch words of the tile, the next level combines five of those, ... until one record is left, which carries the
+    // target's real destination.  Records are grouped per chunk and level.
+    const int nslots = b.n_g + b.n_c + b.n_b, stage_words = nslots * b.sp_cs;
+    struct Rec { int chunk, level, cls; uint4 r; };
+    auto cls_of = [](unsigned word) { const unsigned md = word >> 30, arr = (word >> 28) & 3u; return md == TGT_PARTIAL ? 3 : md == TGT_STORE ? (int)arr : 4; };
+    std::vector<Rec> recs;
+    std::vector<int> scratch_used(b.sp_chunks, 0);
+    int n_levels = 1;
+    // (the zero word's offset is known only after the scratch words are counted: unused operand slots are patched below)
+    const unsigned UNUSED = 0xFFFFu;
+    auto pack = [&](unsigned word, const unsigned* o, unsigned cnt) {
+      uint4 r; unsigned v[5] = {UNUSED, UNUSED, UNUSED, UNUSED, UNUSED};
+      for (unsigned i = 0; i < cnt; ++i) v[i] = o[i];
+      r.x = word; r.y = cnt | (v[0] << 16); r.z = v[1] | (v[2] << 16); r.w = v[3] | (v[4] << 16);
+      return r;
+    };
     for (auto& t : b.sp_targets) {
-      tptr[t.chunk + 1] += 1;
-      dst.push_back(t.word);
-      lst.insert(lst.end(), t.offs.begin(), t.offs.end());
-      lptr.push_back((int)lst.size());
+      std::vector<unsigned> cur(t.offs.begin(), t.offs.end());
+      int level = 0;
+      while (cur.size() > 5) {
+        std::vector<unsigned> next;
+        for (size_t i = 0; i < cur.size(); i += 5) {
+          const unsigned cnt = (unsigned)std::min<size_t>(5, cur.size() - i);
+          if (cnt == 1) { next.push_back(cur[i]); continue; }             // a lone tail word moves up as it is
+          const unsigned so = (unsigned)(stage_words + scratch_used[t.chunk]++);
+          recs.push_back(Rec{t.chunk, level, 3, pack(((unsigned)TGT_PARTIAL << 30) | so, &cur[i], cnt)});
+          next.push_back(so);
+        }
+        cur.swap(next);
+        ++level;
+      }
+      recs.push_back(Rec{t.chunk, level, cls_of(t.word), pack(t.word, cur.data(), (unsigned)cur.size())});
+      n_levels = std::max(n_levels, level + 1);
     }
-    for (int c = 0; c < b.sp_chunks; ++c) tptr[c + 1] += tptr[c];
-    b.sp_n_targets = (int)dst.size();
+    int n_scratch = 0;
+    for (int c = 0; c < b.sp_chunks; ++c) n_scratch = std::max(n_scratch, scratch_used[c]);
+    n_scratch += 1;                                                         // + the tile's zero word (its last word)
+    if ((stage_words + n_scratch) & 1) n_scratch += 1;                      // tiles stay 16-byte aligned (zeroing uses 16-byte stores)
+    if ((size_t)stage_words + n_scratch >= 65535) return CADNIP_BADARG;
+    {
+      const unsigned zero_off = (unsigned)(stage_words + n_scratch - 1);
+      auto fix = [&](unsigned half) { return half == UNUSED ? zero_off : half; };
+      for (auto& rc_ : recs) {
+        uint4& r = rc_.r;
+        r.y = (r.y & 0xFFFFu) | (fix(r.y >> 16) << 16);
+        r.z = fix(r.z & 0xFFFFu) | (fix(r.z >> 16) << 16);
+        r.w = fix(r.w & 0xFFFFu) | (fix(r.w >> 16) << 16);
+      }
+    }
+    std::stable_sort(recs.begin(), recs.end(), [](const Rec& x, const Rec& y) { return x.chunk != y.chunk ? x.chunk < y.chunk : x.level != y.level ? x.level < y.level : x.cls < y.cls; });
+    // steps: runs of STEP_W records (two per lane), every step within one (level, class); a short last step of a group is
+    // padded with count-0 records that sum the zero word and write nothing
+    std::vector<int> sptr(b.sp_chunks + 1, 0), sinfo;
+    std::vector<uint4> rec;
+    {
+      const unsigned zo = (unsigned)(stage_words + n_scratch - 1);
+      uint4 padrec; padrec.x = 0; padrec.y = 0u | (zo << 16); padrec.z = zo | (zo << 16); padrec.w = zo | (zo << 16);
+      size_t k = 0;
+      for (int c = 0; c < b.sp_chunks; ++c) {
+        sptr[c] = (int)sinfo.size();
+        for (int l = 0; l < n_levels; ++l) {
+          bool first_of_level = l > 0;
+          for (int cls = 0; cls < N_CLS; ++cls) {
+            size_t k1 = k;
+            while (k1 < recs.size() && recs[k1].chunk == c && recs[k1].level == l && recs[k1].cls == cls) ++k1;
+            for (size_t p = k; p < k1; p += STEP_W) {
+              sinfo.push_back(cls | (first_of_level ? 0x100 : 0));
+              first_of_level = false;
+              for (size_t j = p; j < p + STEP_W; ++j) rec.push_back(j < k1 ? recs[j].r : padrec);
+            }
+            k = k1;
+          }
+          if (first_of_level) sinfo.push_back(5 | 0x100), rec.insert(rec.end(), STEP_W, padrec);   // an empty level still fences
+        }
+      }
+      sptr[b.sp_chunks] = (int)sinfo.size();
+    }
+    b.sp_n_targets = (int)rec.size();
+    b.sp_levels = n_levels; b.sp_scratch = n_scratch;
     int rc;
-    if ((rc = upload_vec(&b.d_sp_tptr, tptr))) return rc;
-    if ((rc = upload_vec(&b.d_sp_dst, dst))) return rc;
-    if ((rc = upload_vec(&b.d_sp_lptr, lptr))) return rc;
-    if ((rc = upload_vec(&b.d_sp_lst, lst))) return rc;
+    if ((rc = upload_vec(&b.d_sp_tptr, sptr))) return rc;
+    if ((rc = upload_vec(&b.d_sp_info, sinfo))) return rc;
+    if ((rc = upload_vec(&b.d_sp_rec, rec))) return rc;
     b.sp_targets.clear(); b.sp_targets.shrink_to_fit();
   }
+  h->n_prep_atomic = (int)prep.size();
+  prep.insert(prep.end(), prep_orphan.begin(), prep_orphan.end());
   h->n_prep = (int)prep.size();
   if (h->n_prep) { int rc = upload_vec(&h->d_prep, prep); if (rc) return rc; }
   return CADNIP_OK;
@@ -265,12 +465,14 @@ static int launch_stamp_csr_t(CadnipHandle* h, DeviceBlock& b) {
   const int lpd = pair ? 2 : 1;
   int ipw = 1;
   if (b.sp_chunks == 1) ipw = std::max(1, 64 / (b.count * lpd));
-  while (ipw > 1 && (size_t)ipw * nslots * b.sp_cs * 8 > 64 * 1024) --ipw;
-  const size_t shmem = (size_t)ipw * nslots * b.sp_cs * 8;
+  const size_t tile_words = (size_t)nslots * b.sp_cs + b.sp_scratch;
+  while (ipw > 1 && (size_t)ipw * tile_words * 8 > 64 * 1024) --ipw;
+  const int u_lds = (size_t)ipw * h->n * 8 <= 16 * 1024 ? 1 : 0;
+  const size_t shmem = ((size_t)ipw * tile_words + 3 * (size_t)ipw + (u_lds ? (size_t)ipw * h->n : 0)) * 8;   // tiles (staged slots + tree scratch), per-instance scalars, u
   CsrStampArgs a{b.d_nodes, b.d_ipar, b.d_par, h->d_wave, h->d_u, h->d_t, h->d_active, h->d_G, h->d_C, h->d_b, h->d_limit_w, h->d_nonfinite,
-                 h->d_diag_flag, h->d_gshunt, h->d_srcfact, b.d_sp_tptr, b.d_sp_dst, b.d_sp_lptr, b.d_sp_lst,
+                 h->d_diag_flag, h->d_gshunt, h->d_srcfact, b.d_sp_tptr, b.d_sp_info, b.d_sp_rec,
                  h->B, b.count, h->n, h->nnz, b.n_par, b.n_g, b.n_c, b.n_b, b.sp_cs, b.sp_chunks, ipw, lpd, h->spec.mode, h->initjct,
-                 (TYPE == CADNIP_DEV_MOS1 || TYPE == CADNIP_DEV_VA) ? 1 : 0};
+                 (TYPE == CADNIP_DEV_MOS1 || TYPE == CADNIP_DEV_VA) ? 1 : 0, b.sp_levels, b.sp_scratch, u_lds};
   if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_stamp_csr<TYPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   const unsigned grid = (unsigned)b.sp_chunks * (unsigned)((h->B + ipw - 1) / ipw);
   hipLaunchKernelGGL(k_stamp_csr<TYPE>, dim3(grid), dim3(64), shmem, h->stream, a);
@@ -278,7 +480,11 @@ static int launch_stamp_csr_t(CadnipHandle* h, DeviceBlock& b) {
 }
 
 int launch_rebuild(CadnipHandle* h) {
-  if (h->n_prep > 0) {
+  // the pre-set pass runs when some word is accumulated with atomics from scratch; the unstamped node diagonals carry
+  // gshunt alone, so they are rewritten only while a homotopy is on and once after it has been switched off
+  const bool prep_now = h->n_prep_atomic > 0 || (h->n_prep > 0 && (h->homotopy || h->spec.gshunt != 0.0 || h->prep_stale));
+  h->prep_stale = h->n_prep > h->n_prep_atomic && (h->homotopy || h->spec.gshunt != 0.0);
+  if (prep_now) {
     ProfScope ps(h, "stamp_prep");
     PrepArgs p{h->d_prep, h->n_prep, h->d_diag_flag, h->d_gshunt, h->d_active, h->d_G, h->d_C, h->d_b, h->B, h->n, h->nnz};
     const long total = (long)h->B * h->n_prep;
@@ -306,3 +512,13 @@ int launch_rebuild(CadnipHandle* h) {
 }
 
 }  // namespace cadnip
+
+#ifdef CADNIP_TRACE
+extern "C" int cadnip_debug_stamp_trace(unsigned long long* sum8, unsigned long long* cnt, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return CADNIP_HIPERROR;
+  if (hipMemcpyFromSymbol(sum8, HIP_SYMBOL(cadnip::g_sc_sum), 8 * sizeof(unsigned long long)) != hipSuccess) return CADNIP_HIPERROR;
+  if (hipMemcpyFromSymbol(cnt, HIP_SYMBOL(cadnip::g_sc_cnt), sizeof(unsigned long long)) != hipSuccess) return CADNIP_HIPERROR;
+  if (reset) { unsigned long long z[9] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(cadnip::g_sc_sum), z, 64); (void)hipMemcpyToSymbol(HIP_SYMBOL(cadnip::g_sc_cnt), z, 8); }
+  return CADNIP_OK;
+}
+#endif
