@@ -473,6 +473,20 @@ int cadnip_debug_copy(CadnipHandle* h, int64_t n_doubles, int32_t reps) {
   if (!h || n_doubles <= 0 || reps <= 0) return CADNIP_BADARG;
   return launch_calib_copy(h, (long)n_doubles, reps);
 }
+// `reps` back-to-back launches of the stamping kernel of one device block (block < 0: the whole restamp, every block) at the
+// handle's current state, timed with one pair of HIP events on the handle's stream: *ms_total = elapsed milliseconds
+int cadnip_debug_stamp_time(CadnipHandle* h, int32_t block, int32_t reps, double* ms_total) {
+  if (!h || reps <= 0 || !ms_total) return CADNIP_BADARG;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  for (int r = 0; r < reps; ++r) TRY(block < 0 ? launch_rebuild(h) : launch_stamp_block(h, block));
+  HIP_TRY(hipEventRecord(h->ev1, h->stream));
+  HIP_TRY(hipEventSynchronize(h->ev1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *ms_total = ms;
+  return CADNIP_OK;
+}
 int cadnip_sync(CadnipHandle* h) { if (!h) return CADNIP_BADARG; HIP_TRY(hipStreamSynchronize(h->stream)); return CADNIP_OK; }
 
 int cadnip_profile_enable(CadnipHandle* h, int32_t on) {

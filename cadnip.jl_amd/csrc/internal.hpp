@@ -150,6 +150,7 @@ int lu_analyze(int n, const std::vector<int>& rowptr, const std::vector<int>& co
 // kernels.hip launchers (all asynchronous on h->stream)
 int launch_rebuild(CadnipHandle* h);                       // stamp_csr.hip: one stamp + reduce kernel per device type at (d_u, d_t)
 int build_stamp_plan(CadnipHandle* h, const CadnipStructure* s);   // stamp_csr.hip, once per structure
+int launch_stamp_block(CadnipHandle* h, int block);                // stamp_csr.hip: the stamping kernel of one device block
 int launch_residual(CadnipHandle* h, const double* d_du);  // d_resid = C du + G u - b
 int launch_jacobian(CadnipHandle* h);                      // d_J = G + gamma C
 int launch_factor(CadnipHandle* h, bool fuse_jacobian);    // LU of J (or of G + gamma C)

@@ -479,6 +479,20 @@ static int launch_stamp_csr_t(CadnipHandle* h, DeviceBlock& b) {
   return CADNIP_OK;
 }
 
+// one stamping kernel alone (bench.py times it back to back for the stamp-kernel roofline line)
+int launch_stamp_block(CadnipHandle* h, int block) {
+  if (block < 0 || block >= (int)h->blocks.size() || h->blocks[block].count == 0) return CADNIP_BADARG;
+  DeviceBlock& blk = h->blocks[block];
+  switch (blk.type) {
+#define CASE(T) case T: return launch_stamp_csr_t<T>(h, blk);
+    CASE(CADNIP_DEV_RESISTOR) CASE(CADNIP_DEV_CAPACITOR) CASE(CADNIP_DEV_INDUCTOR) CASE(CADNIP_DEV_VSOURCE) CASE(CADNIP_DEV_ISOURCE)
+    CASE(CADNIP_DEV_VCVS) CASE(CADNIP_DEV_VCCS) CASE(CADNIP_DEV_CCVS) CASE(CADNIP_DEV_CCCS) CASE(CADNIP_DEV_DIODE) CASE(CADNIP_DEV_DIODECAP)
+    CASE(CADNIP_DEV_SIMPLEMOS) CASE(CADNIP_DEV_MOS1) CASE(CADNIP_DEV_BVSOURCE) CASE(CADNIP_DEV_BISOURCE) CASE(CADNIP_DEV_VA)
+#undef CASE
+  }
+  return CADNIP_BADARG;
+}
+
 int launch_rebuild(CadnipHandle* h) {
   // the pre-set pass runs when some word is accumulated with atomics from scratch; the unstamped node diagonals carry
   // gshunt alone, so they are rewritten only while a homotopy is on and once after it has been switched off

@@ -23,7 +23,7 @@ EXPORTS = [
     "cadnip_rebuild", "cadnip_residual", "cadnip_jacobian", "cadnip_ode_rhs", "cadnip_ode_jacobian", "cadnip_get_GCb", "cadnip_analyze",
     "cadnip_analyze_values", "cadnip_factor", "cadnip_solve", "cadnip_lu_stats", "cadnip_dc_run",
     "cadnip_dc_log_size", "cadnip_dc_log_get", "cadnip_tran_run", "cadnip_tran_state", "cadnip_dev_ptr", "cadnip_stream", "cadnip_set_u", "cadnip_get_u", "cadnip_get_flags",
-    "cadnip_sync", "cadnip_debug_copy", "cadnip_profile_enable", "cadnip_profile_read", "cadnip_version",
+    "cadnip_sync", "cadnip_debug_copy", "cadnip_debug_stamp_time", "cadnip_profile_enable", "cadnip_profile_read", "cadnip_version",
     "cadnip_host_lu_analyze", "cadnip_host_lu_size", "cadnip_host_lu_get", "cadnip_host_lu_free",
     "cadnip_host_f2_build", "cadnip_host_f2_size", "cadnip_host_f2_get", "cadnip_host_f2_free",
 ]
@@ -333,6 +333,12 @@ class Handle:
 
     def debug_copy(self, n_doubles, reps=1):
         _check(self.lib.cadnip_debug_copy(self.h, C.c_int64(n_doubles), C.c_int32(reps)), "cadnip_debug_copy")
+
+    def stamp_time(self, block=-1, reps=20):
+        """Milliseconds of ``reps`` back-to-back launches of one block's stamping kernel (block < 0: the whole restamp)."""
+        ms = C.c_double()
+        _check(self.lib.cadnip_debug_stamp_time(self.h, C.c_int32(block), C.c_int32(reps), C.byref(ms)), "cadnip_debug_stamp_time")
+        return ms.value
 
     def profile(self, on=True):
         _check(self.lib.cadnip_profile_enable(self.h, C.c_int32(1 if on else 0)), "cadnip_profile_enable")

@@ -34,16 +34,37 @@ def rank_points(n_per_gpu, rank, world):
     return pts[lo:hi], len(pts)
 
 
+def strong_points(n_total, rank, world):
+    """Strong scaling (BASELINE.json config 4 as worded): ONE global grid of ``n_total`` points -- 32 Vdd
+    values x n_total / 32 temperatures in ProductSweep order -- split into contiguous blocks, 1024 / 8 = 128 points per GPU."""
+    n_vdd = 32 if n_total >= 32 else n_total
+    pts = corner_points(n_vdd, max(1, n_total // n_vdd))
+    lo, hi = block_range(len(pts), rank, world)
+    return pts[lo:hi], len(pts)
+
+
 def gather_blocks(local_block, world, device=None):
-    """All-gather equally shaped per-rank result blocks [B_local, ...] into the global [B_total, ...] array
-    (rank order == sweep order).  Works on whatever backend torch.distributed was initialised with."""
+    """All-gather the per-rank result blocks [B_local, ...] into the global [B_total, ...] array (rank order == sweep
+    order).  Block sizes may differ by one row (block_range): blocks travel padded to the largest and are trimmed again.
+    Works on whatever backend torch.distributed was initialised with."""
     import torch
     import torch.distributed as dist
-    t = torch.from_numpy(np.ascontiguousarray(local_block))
-    if device is not None:
-        t = t.to(device)
     if world == 1:
         return local_block
+    local_block = np.ascontiguousarray(local_block)
+    rows = torch.tensor([local_block.shape[0]], dtype=torch.int64)
+    if device is not None:
+        rows = rows.to(device)
+    all_rows = [torch.empty_like(rows) for _ in range(world)]
+    dist.all_gather(all_rows, rows)
+    all_rows = [int(r.item()) for r in all_rows]
+    n_max = max(all_rows)
+    if local_block.shape[0] < n_max:
+        pad = np.zeros((n_max - local_block.shape[0],) + local_block.shape[1:], dtype=local_block.dtype)
+        local_block = np.concatenate([local_block, pad], axis=0)
+    t = torch.from_numpy(local_block)
+    if device is not None:
+        t = t.to(device)
     parts = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(parts, t)
-    return torch.cat(parts, dim=0).cpu().numpy()
+    return torch.cat([p[:r] for p, r in zip(parts, all_rows)], dim=0).cpu().numpy()

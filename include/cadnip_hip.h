@@ -255,6 +255,9 @@ const char* cadnip_version(void);
 /* PMC calibration aid (MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE must be calibrated on a known
  * byte count in the kernel's own access width): streams n_doubles fp64 values src -> dst with 8 B per lane,
  * `reps` times, through a kernel named k_calib_copy_f64.  Known traffic: 8*n_doubles read + 8*n_doubles written per rep. */
+/* measurement aid: `reps` back-to-back launches of the stamping kernel of device block `block` (< 0: all blocks = one restamp)
+ * at the handle's current u / t, timed with HIP events on the handle's stream */
+int cadnip_debug_stamp_time(CadnipHandle* h, int32_t block, int32_t reps, double* ms_total);
 int cadnip_debug_copy(CadnipHandle* h, int64_t n_doubles, int32_t reps);
 
 /* ---- host-only helpers (no GPU needed): run the symbolic phase on any CSR matrix and read the

@@ -41,3 +41,30 @@ def test_world_size_2_gloo_gather():
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GLOO_OK 128" in outs[0]
+
+
+def test_strong_partition_and_unequal_blocks():
+    """Strong scaling (config 4 as worded): 1024 points over 8 GPUs = 128 per GPU, contiguous in ProductSweep order."""
+    allp = sweep_shard.corner_points(32, 32)
+    got = []
+    for r in range(8):
+        pts, n = sweep_shard.strong_points(1024, r, 8)
+        assert n == 1024 and len(pts) == 128
+        got += pts
+    assert got == allp
+    pts, n = sweep_shard.strong_points(96, 1, 2)
+    assert n == 96 and len(pts) == 48 and pts[0] == sweep_shard.corner_points(32, 3)[48]
+
+
+def test_bench_control_flow_world_2():
+    """bench.run on two gloo ranks with a stub simulator: no rank-0-only collective (the N > 1 deadlock of round 1), weak and
+    strong workloads on every rank, SUM / MAX reductions, rank 0 assembles the line."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_bench_worker.py")], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "BENCH_FLOW_OK" in outs[0]
