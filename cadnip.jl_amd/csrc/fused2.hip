@@ -116,6 +116,7 @@ static bool f2_prepare(CadnipHandle* h, F2Tables& T, const std::vector<int>& g_p
     for (int i = 0; i < n; ++i) rowoff[i] = y0 + pinv[i];
     T.begin(S_ROWOF); T.add16(rowoff);
   }
+  T.begin(S_LOADPOS); T.add16(dst);                 // csr entry -> W word: the per-op program LU loads J = G + gamma C through it
   T.begin(S_NODES);
   h->f2_nodes_off.clear();
   {

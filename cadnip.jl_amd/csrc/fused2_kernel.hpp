@@ -18,7 +18,7 @@ typedef unsigned long long u64;
 #define F2_TRASH 64   // per-instance trash words (one per lane) that absorb stamps into ground rows / columns
 
 // table sections (offsets in 32-bit words, every section 8-byte aligned)
-enum { S_GPOS = 0, S_CDESC, S_BROW, S_NZ, S_ENT, S_TERM, S_LEV, S_QINV, S_NODES, S_ROWOF, S_NSEC };
+enum { S_GPOS = 0, S_CDESC, S_BROW, S_NZ, S_ENT, S_TERM, S_LEV, S_QINV, S_NODES, S_ROWOF, S_LOADPOS, S_NSEC };   // S_LOADPOS: csr entry -> W word (lu_f2.hip)
 
 struct F2Block {
   const int* ipar; const double* par;

@@ -1,0 +1,137 @@
+// lu_f2.hip -- per-op refactor + solve (launch_factor_solve: the KLU step of a per-op Newton round, sweeps.jl:600 /
+// solve.jl:667-670) executed with the fused kernel's entry program: J = G + gamma C scattered into a per-wave work array
+// in LDS, the unified factor / forward / backward program of f2_program.cpp run pass by pass (lane-packed entries, DPP
+// group sums, the dense core in registers), x gathered back.  One wave per sweep instance, LU_WPB instances per workgroup
+// sharing ONE copy of the program tables in LDS -- the first per-op LU (k_lu, kernels.hip) fetched every level's indices
+// from global memory behind three dependent loads and took 52 us for the DFF at B = 1024.
+// k_lu remains for what this program cannot do: factor-only / solve-only (the callback ABI's cadnip_factor /
+// cadnip_solve keep the factors in HBM) and circuits whose tables do not fit (fused2_fits).
+#include <hip/hip_runtime.h>
+#include "fused2_kernel.hpp"
+
+namespace cadnip {
+
+struct LuF2Args {
+  const unsigned* tab; int off[S_NSEC]; int tab_len;
+  const double *G, *C, *gamma, *rhs; double* x;
+  const int* active; int* flags;
+  int B, n, nnz, lu_words, n_pre, n_post, nc, dn0;
+};
+
+template <int WPB>
+__global__ void __launch_bounds__(64 * WPB) k_lu_f2(LuF2Args f) {
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), n = f.n;
+  {
+    const uint2* src = (const uint2*)f.tab;
+    uint2* dst = (uint2*)sm;
+    for (int i = tid; i < f.tab_len / 2; i += 64 * WPB) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int inst = blockIdx.x * WPB + w;
+  if (inst >= f.B || !f.active[inst]) return;
+  const unsigned* tab = (const unsigned*)sm;
+  const int nW = f.lu_words + n + F2_TRASH;
+  double* W = sm + f.tab_len / 2 + (size_t)w * nW;
+  const u16* loadpos = (const u16*)(tab + f.off[S_LOADPOS]);
+  const u64* laned = (const u64*)(tab + f.off[S_ENT]);
+  const unsigned* term = tab + f.off[S_TERM];
+  typedef const __attribute__((address_space(4))) u64* PassPtr;
+  const PassPtr passd = (PassPtr)(const u64*)(f.tab + f.off[S_LEV]);
+  const u16* qinv = (const u16*)(tab + f.off[S_QINV]);
+  const u16* rowof = (const u16*)(tab + f.off[S_ROWOF]);
+  for (int i = lane; i < (nW >> 1); i += 64) ((double2*)W)[i] = make_double2(0.0, 0.0);   // nW is even (f2_program.cpp)
+  CADNIP_WAVE_SYNC();
+  {
+    // J = G + gamma C at its L\U positions (every pattern entry has its own word: plain stores), rhs in pivot-row order
+    const double* G = f.G + (size_t)inst * f.nnz;
+    const double* C = f.C + (size_t)inst * f.nnz;
+    const double gam = f.gamma[inst];
+    for (int e = lane; e < f.nnz; e += 64) W[loadpos[e]] = G[e] + gam * C[e];   // coalesced reads of the CSR arrays
+    const double* rhs = f.rhs + (size_t)inst * n;
+    for (int i = lane; i < n; i += 64) W[rowof[i]] = rhs[i];
+  }
+  CADNIP_WAVE_SYNC();
+  int bad = 0;
+  auto run_passes = [&](const int p_first, const int p_count) {
+    if (p_count <= 0) return;
+    u64 pd = passd[p_first], pd1 = passd[p_first + 1];
+    u64 D;
+    unsigned T0;
+    {
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pd), hi = __builtin_amdgcn_readfirstlane((unsigned)(pd >> 32));
+      const int T = hi & 0x7F;
+      D = laned[lo + (lane < T ? lane : T - 1)];
+      T0 = term[(unsigned)(D >> 32) & 0xFFFFu];
+    }
+    for (int pi = p_first; pi < p_first + p_count; ++pi) {
+      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(pd >> 32));
+      const int T = hi & 0x7F, maxlg = (hi >> 8) & 7, hasdiv = (hi >> 11) & 1, fence = (hi >> 12) & 1, multi = (hi >> 13) & 1;
+      const bool act = lane < T;
+      const unsigned pos = (unsigned)D & 0xFFFFu, dg = (unsigned)(D >> 16) & 0xFFFFu, t0 = (unsigned)(D >> 32) & 0xFFFFu;
+      const unsigned dhi = (unsigned)(D >> 48);
+      const int nt = act ? (int)(dhi & 0xFFu) : 0, lg = (dhi >> 8) & 7;
+      const bool leader = act && ((dhi >> 12) & 1u);
+      const double acc0 = W[pos];
+      double piv = W[dg == NOPOS ? pos : dg];
+      const double av = W[T0 & 0xFFFFu], bv = W[T0 >> 16];
+      const unsigned lo1 = __builtin_amdgcn_readfirstlane((unsigned)pd1), hi1 = __builtin_amdgcn_readfirstlane((unsigned)(pd1 >> 32));
+      const int T1 = hi1 & 0x7F;
+      const u64 Dn = laned[lo1 + (lane < T1 ? lane : (T1 > 0 ? T1 - 1 : 0))];
+      const u64 pd2 = passd[pi + 2];
+      double part = nt > 0 ? av * bv : 0.0;
+      const unsigned T0n = term[(unsigned)(Dn >> 32) & 0xFFFFu];
+      if (multi)
+        for (int t = 1; t < nt; ++t) { const unsigned tm = term[t0 + t]; part = fma(W[tm & 0xFFFFu], W[tm >> 16], part); }
+      if (maxlg >= 1) { const double o = dpp_f64<0xB1>(part); part += lg >= 1 ? o : 0.0; }
+      if (maxlg >= 2) { const double o = dpp_f64<0x4E>(part); part += lg >= 2 ? o : 0.0; }
+      if (maxlg >= 3) { const double o = dpp_f64<0x141>(part); part += lg >= 3 ? o : 0.0; }
+      if (maxlg >= 4) { const double o = dpp_f64<0x140>(part); part += lg >= 4 ? o : 0.0; }
+      double acc = acc0 - part;
+      if (hasdiv) {
+        if (dg == NOPOS) piv = 1.0;
+        else if (act && (piv == 0.0 || !isfinite(piv))) bad = 1;
+        acc = fast_div(acc, piv);
+      }
+      if (leader) W[pos] = acc;
+      if (fence) CADNIP_WAVE_SYNC();
+      D = Dn; T0 = T0n; pd = pd1; pd1 = pd2;
+    }
+  };
+  run_passes(0, f.n_pre);
+  if (f.nc > 0) {
+    const int yc0 = f.lu_words + n - f.nc;
+    if (f.nc == 8) dense_core_solve<8>(W, f.dn0, yc0, lane, bad);
+    else if (f.nc == 12) dense_core_solve<12>(W, f.dn0, yc0, lane, bad);
+    else dense_core_solve<F2_NCMAX>(W, f.dn0, yc0, lane, bad);
+    CADNIP_WAVE_SYNC();
+  }
+  run_passes(f.n_pre, f.n_post);
+  double* x = f.x + (size_t)inst * n;
+  for (int i = lane; i < n; i += 64) { const double v = W[qinv[i]]; if (!isfinite(v)) bad = 1; x[i] = v; }
+  if (wave_any(bad) && lane == 0) atomicOr(&f.flags[inst], 1);
+}
+
+// 0 = done with the program kernel; 1 = not applicable (the caller falls back to k_lu); < 0 never
+int launch_factor_solve_f2(CadnipHandle* h, const double* d_rhs, double* d_x) {
+  if (!h->analyzed || !fused2_fits(h)) return 1;
+  ProfScope ps(h, "lu_factor_solve");
+  LuF2Args f;
+  f.tab = h->d_f2tab; for (int i = 0; i < S_NSEC; ++i) f.off[i] = h->f2off[i]; f.tab_len = h->f2len;
+  f.G = h->d_G; f.C = h->d_C; f.gamma = h->d_gamma; f.rhs = d_rhs; f.x = d_x; f.active = h->d_active; f.flags = h->d_flags;
+  f.B = h->B; f.n = h->n; f.nnz = h->nnz; f.lu_words = h->f2_lu_words; f.n_pre = h->f2_n_pre; f.n_post = h->f2_n_post; f.nc = h->f2_nc; f.dn0 = h->f2_dn0;
+  const size_t tab_dbl = (size_t)h->f2len / 2, per = (size_t)h->f2_lu_words + h->n + F2_TRASH;
+  int wpb = 8;
+  while (wpb > 1 && ((tab_dbl + wpb * per) * 8 > 160 * 1024 || h->B < 256 * wpb / 2)) wpb >>= 1;
+  const size_t shmem = (tab_dbl + wpb * per) * 8;
+  if (shmem > 160 * 1024) return 1;
+  const int grid = (h->B + wpb - 1) / wpb;
+#define LAUNCH(W) do { if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_lu_f2<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+    hipLaunchKernelGGL(k_lu_f2<W>, dim3(grid), dim3(64 * W), shmem, h->stream, f); } while (0)
+  if (wpb == 8) LAUNCH(8); else if (wpb == 4) LAUNCH(4); else if (wpb == 2) LAUNCH(2); else LAUNCH(1);
+#undef LAUNCH
+  HIP_TRY(hipGetLastError());
+  return CADNIP_OK;
+}
+
+}  // namespace cadnip
