@@ -88,6 +88,35 @@ class RunStatsC(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime():
+    """One HIP runtime per process.  The library links /opt/rocm's libamdhip64.so.7; a PyTorch wheel carries its own copy and
+    asks for it by file name (libamdhip64.so), which the dynamic loader does not match against a copy that was loaded under
+    its soname -- so a torch imported AFTER this library brought a second HIP / HSA runtime into the process and found no
+    device (round 1 had to order its tests around that).  If torch is installed but not loaded yet, its copy is loaded
+    first, globally, under the name torch will ask for: the library (which asks for the soname) and a later torch then
+    resolve to the same runtime, exactly as when torch comes first.  CADNIP_HIP_RUNTIME=<path> names another runtime to
+    share, CADNIP_HIP_RUNTIME=system skips this."""
+    import importlib.util
+    import sys
+    want = os.environ.get("CADNIP_HIP_RUNTIME", "")
+    if want == "system" or "torch" in sys.modules:
+        return
+    cand = want
+    if not cand:
+        try:
+            spec = importlib.util.find_spec("torch")
+        except (ImportError, ValueError):
+            spec = None
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """dlopen the in-tree extension; raises if it has not been built (no fallback)."""
     global _lib
@@ -95,6 +124,7 @@ def load_library():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    _share_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     lib.cadnip_version.restype = C.c_char_p
     lib.cadnip_dev_ptr.restype = C.c_void_p

@@ -1,6 +1,5 @@
-"""bench.py's output contract, run in-process.  This module sorts first on purpose: bench.py initialises torch's HIP context
-before the library (as it does when the driver runs it); after other GPU tests have initialised HIP through the library,
-a torch imported later in the same process reports no device, and the test skips."""
+"""bench.py's output contract, run in-process (the library and torch share one HIP runtime in either load order:
+hip.py _share_hip_runtime, tests/test_gpu_coexist.py -- this module no longer has to run first)."""
 import numpy as np
 import pytest
 
@@ -10,8 +9,7 @@ def test_bench_line_contract(capsys):
     kernel (live HIP-event timing) and the CPU baseline of the oracle's port."""
     import json
     import torch
-    if not torch.cuda.is_available():
-        pytest.skip("torch was initialised after the library in this process: run this module first / alone")
+    assert torch.cuda.is_available()
     import bench
     bench.main(["--steps", "1", "--warmup", "0", "--instances", "64", "--cpu-sample", "32", "--total-instances", "64"])
     lines = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
