@@ -24,32 +24,209 @@ Supported::
 
     branch (a,b) name;   V(name)  I(name) <+ ...                 // named branches
 
+The constructs the reference's own model files need on top of that (models/VADistillerModels.jl/va/*.va, read by
+tests/test_va_reference_models.py straight from the reference checkout)::
+
+    `include (dropped: the standard constants are predefined), `define NAME[(args)] body, `undef, `ifdef / `ifndef / `else / `endif
+    (* attributes *) in front of declarations;  aliasparam a = p;  localparam;  parameter string;  from / exclude ranges
+    real x = expr, y;          // module-scope initialisers: applied at the start of every evaluation of the analog block
+    analog function with output / inout arguments (by reference);  a function call as a statement
+    case (e) v1, v2: stmt ... default: stmt endcase;   for (i = a; c; i = i + 1) stmt;   while (c) stmt
+    $param_given(p)   $simparam(name[, default]) for every name (MNASpec fields resolve, the rest take their default;
+    "iniLim" is the PCNR initjct flag, vasim.jl:1198-1206)   analysis("dc" | "static" | "tran" | ...)   $abstime
+    system tasks $warning $strobe $display $write $debug $info $discontinuity $bound_step $finish (no-ops, vasim.jl:2196-2225),
+    $error / $fatal (raise when a host evaluation executes them)
+    white_noise / flicker_noise / noise_table contributions: zero on the DC / transient path
+    (noise_enabled(::DirectStampContext) = false, value_only.jl:177)
+    % ** << >> & | ^ ~   floor ceil int asin acos tan atan2 hypot asinh acosh atanh
+
 Not supported (an error, never a silent approximation): other potential contributions ``V() <+ expr``,
-``@(...)`` events, loops, ``idt``, noise sources, the string form of ``$limit``.
+``@(...)`` events other than initial_step, ``idt``, array variables, the string form of ``$limit``.
 """
+import os
 import re
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
 _SCALE = {"T": 1e12, "G": 1e9, "M": 1e6, "K": 1e3, "k": 1e3, "m": 1e-3, "u": 1e-6, "n": 1e-9, "p": 1e-12, "f": 1e-15, "a": 1e-18}
 _TOKEN = re.compile(r"""
-    (?P<ws>\s+|//[^\n]*|/\*.*?\*/)
+    (?P<ws>\s+|//[^\n]*|/\*.*?\*/|\(\*(?!\s*\)).*?\*\))
   | (?P<num>(?:\d+\.?\d*|\.\d+)(?:[eE][+-]?\d+)?[TGMKkmunpfa]?(?![A-Za-z_0-9]))
   | (?P<id>\$?[A-Za-z_][A-Za-z_0-9$]*)
   | (?P<str>"[^"]*")
-  | (?P<op><\+|==|!=|<=|>=|&&|\|\||[-+*/()<>!?:;,=@\[\]{}])
+  | (?P<op><\+|==|!=|<=|>=|&&|\|\||\*\*|<<|>>|[-+*/%()<>!?:;,=@\[\]{}&|^~#.])
 """, re.X | re.S)
 
 FUNCS = {"exp": 1, "ln": 1, "log": 1, "sqrt": 1, "pow": 2, "abs": 1, "min": 2, "max": 2, "limexp": 1, "tanh": 1, "sinh": 1,
-         "cosh": 1, "sin": 1, "cos": 1, "atan": 1}
+         "cosh": 1, "sin": 1, "cos": 1, "atan": 1, "tan": 1, "asin": 1, "acos": 1, "atan2": 2, "hypot": 2, "asinh": 1, "acosh": 1,
+         "atanh": 1, "floor": 1, "ceil": 1, "int": 1}
+NOISE_FUNCS = ("white_noise", "flicker_noise", "noise_table")
+SILENT_TASKS = ("$warning", "$strobe", "$display", "$write", "$debug", "$info", "$discontinuity", "$bound_step", "$finish", "$monitor")
+FATAL_TASKS = ("$error", "$fatal")
+# constants.vams (Verilog-AMS LRM 2.4 annex D): the macros compact models take from the standard include
+STD_DEFINES = {
+    "M_E": "2.7182818284590452354", "M_LOG2E": "1.4426950408889634074", "M_LOG10E": "0.43429448190325182765", "M_LN2": "0.69314718055994530942",
+    "M_LN10": "2.30258509299404568402", "M_PI": "3.14159265358979323846", "M_TWO_PI": "6.28318530717958647693", "M_PI_2": "1.57079632679489661923",
+    "M_PI_4": "0.78539816339744830962", "M_1_PI": "0.31830988618379067154", "M_2_PI": "0.63661977236758134308", "M_2_SQRTPI": "1.12837916709551257390",
+    "M_SQRT2": "1.41421356237309504880", "M_SQRT1_2": "0.70710678118654752440",
+    "P_Q": "1.602176462e-19", "P_C": "2.99792458e8", "P_K": "1.3806503e-23", "P_H": "6.62606876e-34", "P_EPS0": "8.854187817e-12",
+    "P_U0": "(4.0e-7 * 3.14159265358979323846)", "P_CELSIUS0": "273.15",
+}
 
 
 class VAError(ValueError):
     pass
 
 
-def tokenize(text):
-    text = "\n".join(l for l in text.splitlines() if not l.lstrip().startswith("`"))   # `include / `define lines
+STD_INCLUDES = ("constants.vams", "disciplines.vams", "discipline.h", "constants.h", "disciplines.h", "constants.va", "disciplines.va")
+
+
+def preprocess(text, defines=None, include_dir=None, _macros=None, _depth=0):
+    """The compiler directives compact models use: `include (dropped -- constants.vams / disciplines.vams content is
+    predefined), `define with or without arguments, `undef, `ifdef / `ifndef / `else / `elsif / `endif, and macro
+    references `NAME / `NAME(args), expanded recursively.  Line continuations (backslash newline) join lines first."""
+    if _macros is None:
+        macros = {k: (None, v) for k, v in STD_DEFINES.items()}
+        if defines:
+            macros.update({k: (None, str(v)) for k, v in defines.items()})
+    else:
+        macros = _macros                      # an included file shares (and extends) the includer's macros
+    if _depth > 20:
+        raise VAError("`include nesting too deep")
+    text = re.sub(r"\\\r?\n", " ", text)
+    text = re.sub(r"/\*.*?\*/", lambda m: "\n" * m.group(0).count("\n"), text, flags=re.S)   # block comments (keep line numbers)
+    out, stack = [], []          # stack of [taking, any branch taken so far]
+
+    def expand(line, depth=0):
+        if "`" not in line:
+            return line
+        if depth > 50:
+            raise VAError("macro expansion does not terminate")
+        res, i = [], 0
+        while i < len(line):
+            ch = line[i]
+            if ch == '"':                                    # strings are opaque
+                j = line.index('"', i + 1) if '"' in line[i + 1:] else len(line) - 1
+                res.append(line[i:j + 1]); i = j + 1
+                continue
+            if ch == "/" and line[i:i + 2] == "//":
+                break
+            if ch != "`":
+                res.append(ch); i += 1
+                continue
+            m = re.match(r"`([A-Za-z_][A-Za-z_0-9]*)", line[i:])
+            if not m:
+                raise VAError("stray ` in %r" % line.strip())
+            name = m.group(1)
+            i += m.end()
+            if name not in macros:
+                raise VAError("macro `%s is not defined" % name)
+            params, body = macros[name]
+            if params is not None:
+                while i < len(line) and line[i] in " \t":
+                    i += 1
+                if i >= len(line) or line[i] != "(":
+                    raise VAError("macro `%s needs arguments" % name)
+                depth_p, j, args, cur = 0, i, [], []
+                while True:
+                    if j >= len(line):
+                        raise VAError("unterminated argument list of `%s" % name)
+                    c = line[j]
+                    if c == '"':                                   # a string argument may hold commas and parentheses
+                        k = line.index('"', j + 1) if '"' in line[j + 1:] else len(line) - 1
+                        cur.append(line[j:k + 1]); j = k + 1
+                        continue
+                    if c in "([{":
+                        depth_p += 1
+                        if depth_p > 1:
+                            cur.append(c)
+                    elif c in ")]}":
+                        depth_p -= 1
+                        if depth_p == 0:
+                            args.append("".join(cur).strip())
+                            break
+                        cur.append(c)
+                    elif c == "," and depth_p == 1:
+                        args.append("".join(cur).strip()); cur = []
+                    else:
+                        cur.append(c)
+                    j += 1
+                i = j + 1
+                if len(args) != len(params) and not (len(params) == 0 and args == [""]):
+                    raise VAError("macro `%s takes %d argument(s), %d given" % (name, len(params), len(args)))
+                sub = body
+                if params:
+                    sub = re.sub(r"\b(%s)\b" % "|".join(map(re.escape, params)), lambda mm: args[params.index(mm.group(1))], body)
+                res.append(expand(sub, depth + 1))
+            else:
+                res.append(expand(body, depth + 1))
+        return "".join(res)
+
+    for raw in text.split("\n"):
+        line = raw.strip()
+        taking = all(t[0] for t in stack)
+        if line.startswith("`"):
+            m = re.match(r"`(\w+)\s*(.*)", line)
+            d, rest = m.group(1), m.group(2)
+            if d in ("ifdef", "ifndef"):
+                name = rest.split()[0] if rest.split() else ""
+                cond = (name in macros) == (d == "ifdef")
+                stack.append([taking and cond, cond])
+                out.append(""); continue
+            if d == "elsif":
+                name = rest.split()[0] if rest.split() else ""
+                outer = all(t[0] for t in stack[:-1])
+                cond = (name in macros) and not stack[-1][1]
+                stack[-1] = [outer and cond, stack[-1][1] or cond]
+                out.append(""); continue
+            if d == "else":
+                outer = all(t[0] for t in stack[:-1])
+                stack[-1] = [outer and not stack[-1][1], True]
+                out.append(""); continue
+            if d == "endif":
+                stack.pop()
+                out.append(""); continue
+            if not taking:
+                out.append(""); continue
+            if d == "include":
+                mi = re.match(r'"([^"]+)"', rest)
+                fn = mi.group(1) if mi else ""
+                if os.path.basename(fn) in STD_INCLUDES:
+                    out.append(""); continue       # the standard headers: their constants are predefined (STD_DEFINES)
+                if include_dir is None:
+                    raise VAError("`include \"%s\": no include directory (parse the module with parse_file)" % fn)
+                path = os.path.join(include_dir, fn)
+                if not os.path.exists(path):
+                    raise VAError("`include \"%s\": no such file in %s" % (fn, include_dir))
+                out.append(preprocess(open(path).read(), None, include_dir, macros, _depth + 1))
+                continue
+            if d in ("timescale", "default_nettype", "resetall", "begin_keywords", "end_keywords", "pragma", "line"):
+                out.append(""); continue
+            if d == "define":
+                m2 = re.match(r"([A-Za-z_][A-Za-z_0-9]*)(\(([^)]*)\))?\s*(.*)", rest)
+                name, has_args, plist, body = m2.group(1), m2.group(2), m2.group(3), m2.group(4)
+                body = re.sub(r"//.*$", "", body).strip()
+                # `define NAME (x) ... : with a space before the parenthesis the parenthesis belongs to the body
+                if has_args and rest[len(name):len(name) + 1] == "(":
+                    params = [p.strip() for p in plist.split(",")] if plist.strip() else []
+                    macros[name] = (params, body)
+                else:
+                    macros[name] = (None, (has_args or "") + (" " if has_args else "") + body if has_args else body)
+                out.append(""); continue
+            if d == "undef":
+                macros.pop(rest.split()[0], None)
+                out.append(""); continue
+            # a macro call at the start of a line
+        if not taking:
+            out.append(""); continue
+        out.append(expand(raw))
+    if stack:
+        raise VAError("unterminated `ifdef")
+    return "\n".join(out)
+
+
+def tokenize(text, include_dir=None, defines=None):
+    text = preprocess(text, defines, include_dir)
     out, pos = [], 0
     while pos < len(text):
         m = _TOKEN.match(text, pos)
@@ -79,6 +256,10 @@ class VAModule:
     limit_branches: List[Tuple[int, int]] = field(default_factory=list)   # probe branches of the $limit sites, first-use order
     limit_sites: List[int] = field(default_factory=list)              # per $limit call site (evaluation order): its limit branch
     shorts: List[tuple] = field(default_factory=list)                 # V(a,b) <+ 0: (a, b, [(static condition, wanted truth)])
+    local_init: List[tuple] = field(default_factory=list)             # module-scope `real x = expr`: (name, expr) in declaration order
+    aliasparams: Dict[str, str] = field(default_factory=dict)         # aliasparam alias = parameter
+    param_kind: Dict[str, str] = field(default_factory=dict)          # parameter -> "real" | "integer" | "string"
+    func_dirs: Dict[str, list] = field(default_factory=dict)          # analog function -> direction of every argument ("in" | "out" | "inout")
     source: str = ""
 
     @property
@@ -93,30 +274,13 @@ class VAModule:
     def n_sites(self):
         return len(self.limit_sites)
 
-    def aliases(self, par):
-        """Node collapse of one instance: internal node index -> the node it is merged into, for the ``V(a,b) <+ 0``
-        statements whose (parameter-only) conditions hold with the parameter values ``par``."""
-        from .host_eval import static_eval
-        out = {}
-        np_ = len(self.ports)
-
-        def root(i):
-            while i in out:
-                i = out[i]
-            return i
-        for a, b, guards in self.shorts:
-            if all(bool(static_eval(c, par)) == want for c, want in guards):
-                a, b = root(a), root(b)
-                if a == b:
-                    continue
-                if a >= np_:
-                    out[a] = b
-                elif b >= np_:
-                    out[b] = a
-                else:
-                    raise VAError("%s: V(%s,%s) <+ 0 between two terminals needs a branch current (not supported)"
-                                  % (self.name, self.nodes[a], self.nodes[b]))
-        return {k: root(k) for k in out}
+    def aliases(self, par, given=None):
+        """Node collapse of one instance: internal node index -> the node it is merged into (-1 = ground), for the
+        ``V(a,b) <+ 0`` / ``V(a) <+ 0`` statements whose conditions -- decided by the parameters, possibly through
+        variables the analog block computes from them -- hold with the parameter values ``par`` (``given``: the names
+        of the parameters the instance sets explicitly, for $param_given)."""
+        from .host_eval import collapsed_nodes
+        return collapsed_nodes(self, par, given)
 
     # ---- stamp layout (structure.py / hipgen.py / oracle agree on it) ------------------------------------------
     # local unknowns: nodes 0..N-1, then one charge unknown per branch (ground when the branch has none), then one limit
@@ -173,8 +337,8 @@ class VAModule:
 
 
 class _Parser:
-    def __init__(self, text):
-        self.toks = tokenize(text)
+    def __init__(self, text, include_dir=None, defines=None):
+        self.toks = tokenize(text, include_dir, defines)
         self.i = 0
         self.functions = {}
         self.named = {}         # branch (a,b) name;
@@ -225,16 +389,28 @@ class _Parser:
         return self._left(self.and_, ("||",))
 
     def and_(self):
-        return self._left(self.cmp, ("&&",))
+        return self._left(self.bor, ("&&",))
+
+    def bor(self):
+        return self._left(self.bxor, ("|",))
+
+    def bxor(self):
+        return self._left(self.band, ("^",))
+
+    def band(self):
+        return self._left(self.cmp, ("&",))
 
     def cmp(self):
-        return self._left(self.add, ("==", "!=", "<", ">", "<=", ">="))
+        return self._left(self.shift, ("==", "!=", "<", ">", "<=", ">="))
+
+    def shift(self):
+        return self._left(self.add, ("<<", ">>"))
 
     def add(self):
         return self._left(self.mul, ("+", "-"))
 
     def mul(self):
-        return self._left(self.unary, ("*", "/"))
+        return self._left(self.unary, ("*", "/", "%"))
 
     def unary(self):
         if self.accept("-"):
@@ -243,7 +419,16 @@ class _Parser:
             return self.unary()
         if self.accept("!"):
             return ("un", "!", self.unary())
-        return self.primary()
+        if self.accept("~"):
+            return ("un", "~", self.unary())
+        return self.power()
+
+    def power(self):
+        e = self.primary()
+        if self.peek() == ("op", "**"):
+            self.next()
+            return ("call", "pow", [e, self.unary()])       # right associative, binds tighter than unary minus on its left
+        return e
 
     def primary(self):
         kind, v = self.next()
@@ -255,19 +440,72 @@ class _Parser:
             e = self.expr()
             self.expect(")")
             return e
+        if kind == "str":
+            return ("str", v.strip('"'))
         if kind != "id":
             raise VAError("unexpected %r in an expression" % v)
+        if v == "$param_given":
+            self.expect("(")
+            pn = self.ident()
+            self.expect(")")
+            return ("given", pn)
+        if v == "$port_connected":
+            self.expect("(")
+            self.ident()
+            self.expect(")")
+            return ("num", 1.0)
+        if v == "analysis" and self.peek()[1] == "(":
+            self.next()
+            kinds = []
+            while not self.accept(")"):
+                t = self.next()
+                if t[0] != "str":
+                    raise VAError("analysis() takes string literals")
+                kinds.append(t[1].strip('"'))
+                self.accept(",")
+            return ("analysis", kinds)
+        if v in NOISE_FUNCS and self.peek()[1] == "(":
+            self.next()
+            depth = 1
+            while depth:                                     # the arguments play no role on the DC / transient path
+                t = self.next()
+                if t[0] == "eof":
+                    raise VAError("unterminated %s(" % v)
+                depth += (t[1] == "(") - (t[1] == ")")
+            return ("noise", v)
         if v == "V" and self.peek()[1] == "(":
             self.next()
             a, b = self.probe_nets()
             return ("V", a, b)
         if v == "I" and self.peek()[1] == "(":
-            raise VAError("branch current probes I(...) inside expressions are not supported")
+            self.next()
+            if self.peek()[1] in self.named and self.peek(1)[1] == ")":
+                # the current of a NAMED branch: such branches (parallel helper branches of correlated-noise models) carry no
+                # potential contribution here, and the reference reads their current as 0.0 on the DC / transient path
+                # (vasim.jl:3641-3650)
+                self.next(); self.next()
+                return ("num", 0.0)
+            a, b = self.probe_nets()
+            return ("Iprobe", a, b)      # allowed for branches that carry noise only (their current is zero on this path): _analyse
         if v == "ddt":
             self.expect("(")
             e = self.expr()
             self.expect(")")
             return ("ddt", e)
+        if v == "ddx" and self.peek()[1] == "(":
+            # ddx(expr, V(a)): the partial of expr with respect to the potential of net a -- the model's own small-signal
+            # read-outs (gm = ddx(Ids, V(G)), ...): a plain number (its own derivatives are not tracked)
+            self.next()
+            e = self.expr()
+            self.expect(",")
+            if self.next()[1] != "V":
+                raise VAError("ddx: the second argument must be a potential probe V(net)")
+            self.expect("(")
+            a, b = self.probe_nets()
+            if b is not None:
+                raise VAError("ddx: derivative with respect to a branch potential V(a,b) is not supported")
+            self.expect(")")
+            return ("ddx", e, a)
         if v == "$limit":
             self.expect("(")
             if self.next()[1] != "V":
@@ -290,20 +528,16 @@ class _Parser:
                     t = self.peek()
                     args.append(("str", self.next()[1].strip('"')) if t[0] == "str" else self.expr())
                     self.accept(",")
-            if v not in ("$vt", "$temperature", "$mfactor", "$simparam"):
+            if v not in ("$vt", "$temperature", "$mfactor", "$simparam", "$abstime", "$realtime"):
                 raise VAError("system function %s is not supported" % v)
             return ("sys", v, args)
         if self.peek()[1] == "(":
-            if v not in FUNCS and v not in self.functions:
-                raise VAError("function %s is not supported" % v)
             self.next()
             args = []
             while not self.accept(")"):
                 args.append(self.expr())
                 self.accept(",")
-            if v in self.functions:
-                if len(args) != len(self.functions[v][0]):
-                    raise VAError("%s takes %d argument(s)" % (v, len(self.functions[v][0])))
+            if v not in FUNCS:                                 # an analog function, possibly defined further down: checked in _analyse
                 return ("ucall", v, args)
             if len(args) != FUNCS[v]:
                 raise VAError("%s takes %d argument(s)" % (v, FUNCS[v]))
@@ -321,9 +555,17 @@ class _Parser:
 
     # ---- statements --------------------------------------------------------------------------------------------------
     def stmt(self):
+        if self.accept(";"):
+            return ("block", [])
         if self.accept("begin"):
+            if self.accept(":"):
+                self.ident()                                  # named block
             body = []
             while not self.accept("end"):
+                if self.peek()[1] in ("real", "integer") and self.peek()[0] == "id":   # block-local declarations join the module's variables
+                    self.next()
+                    self.decl_list(self.block_locals, self.block_init)
+                    continue
                 body.append(self.stmt())
             return ("block", body)
         if self.accept("if"):
@@ -333,8 +575,47 @@ class _Parser:
             a = self.stmt()
             b = self.stmt() if self.accept("else") else ("block", [])
             return ("if", c, a, b)
+        if self.accept("case"):
+            self.expect("(")
+            sel = self.expr()
+            self.expect(")")
+            items = []                                         # ([values] or None for default, statement)
+            while not self.accept("endcase"):
+                if self.accept("default"):
+                    self.accept(":")
+                    items.append((None, self.stmt()))
+                    continue
+                vals = [self.expr()]
+                while self.accept(","):
+                    vals.append(self.expr())
+                self.expect(":")
+                items.append((vals, self.stmt()))
+            return ("case", sel, items)
+        if self.accept("for"):
+            self.expect("(")
+            iv = self.ident(); self.expect("="); ie = self.expr(); self.expect(";")
+            c = self.expr(); self.expect(";")
+            sv = self.ident(); self.expect("="); se = self.expr(); self.expect(")")
+            return ("for", ("assign", iv, ie), c, ("assign", sv, se), self.stmt())
+        if self.accept("while"):
+            self.expect("(")
+            c = self.expr()
+            self.expect(")")
+            return ("while", c, self.stmt())
         if self.peek()[1] == "@":
-            raise VAError("event controls @(...) are not supported")
+            self.next()
+            self.expect("(")
+            ev = self.ident()
+            if self.accept("("):
+                while not self.accept(")"):
+                    self.next()
+            self.expect(")")
+            body = self.stmt()
+            if ev == "initial_step":
+                return body                                   # runs with the first evaluation; the models use it for initialisation only
+            if ev == "final_step":
+                return ("block", [])
+            raise VAError("event controls other than @(initial_step) / @(final_step) are not supported")
         if self.peek()[1] in ("I", "V") and self.peek(1)[1] == "(":
             acc = self.next()[1]
             self.next()
@@ -351,13 +632,55 @@ class _Parser:
                     return ("short", a, b)
                 return ("contrib", a, b, e)
             raise VAError("expected <+ after %s(%s...)" % (acc, a))
+        kind, name = self.peek()
+        if kind == "id" and name.startswith("$"):
+            self.next()
+            args = []
+            if self.accept("("):
+                depth = 1
+                while depth:
+                    t = self.next()
+                    if t[0] == "eof":
+                        raise VAError("unterminated %s(" % name)
+                    depth += (t[1] == "(") - (t[1] == ")")
+                    if depth:
+                        args.append(t[1])
+            self.expect(";")
+            if name in SILENT_TASKS:
+                return ("block", [])
+            if name in FATAL_TASKS:
+                return ("fatal", name, " ".join(args))
+            raise VAError("system task %s is not supported" % name)
         name = self.ident()
-        if name in ("for", "while", "case", "repeat"):
-            raise VAError("%s statements are not supported" % name)
+        if name == "repeat":
+            raise VAError("repeat statements are not supported")
+        if self.peek()[1] == "(":                             # a function called for its output arguments (possibly defined further down)
+            self.next()
+            args = []
+            while not self.accept(")"):
+                args.append(self.expr())
+                self.accept(",")
+            self.expect(";")
+            return ("callstmt", name, args)
+        if self.peek()[1] == "[":
+            raise VAError("array variables are not supported (%s[...])" % name)
         self.expect("=")
         e = self.expr()
         self.expect(";")
         return ("assign", name, e)
+
+    def decl_list(self, names, inits):
+        """``a, b = expr, c;`` after a type keyword"""
+        while True:
+            nm = self.ident()
+            if self.peek()[1] == "[":
+                raise VAError("array variables are not supported (%s[...])" % nm)
+            names.append(nm)
+            if self.accept("="):
+                inits.append((nm, self.expr()))
+            if self.accept(";"):
+                return
+            self.expect(",")
 
     # ---- module --------------------------------------------------------------------------------------------------------
     def module(self):
@@ -370,53 +693,68 @@ class _Parser:
                 self.accept(",")
         self.expect(";")
         nets, params, locals_, body = [], {}, [], None
+        inits, aliasp, pkind, fdirs = [], {}, {}, {}
+        self.block_locals, self.block_init = locals_, inits
         while not self.accept("endmodule"):
             t = self.peek()[1]
             if t in ("inout", "input", "output"):
                 self.next()
                 while not self.accept(";"):
                     self.next()
-            elif t in ("electrical", "ground"):
+            elif t in ("electrical", "ground", "thermal"):
                 self.next()
                 while True:
                     nets.append(self.ident())
                     if self.accept(";"):
                         break
                     self.expect(",")
-            elif t == "parameter":
+            elif t in ("parameter", "localparam"):
                 self.next()
-                if self.peek()[1] in ("real", "integer"):
-                    self.next()
-                pn = self.ident()
-                self.expect("=")
-                params[pn] = self.expr()
-                while not self.accept(";"):       # from [..) / exclude ...: ranges are not enforced
-                    self.next()
-            elif t in ("real", "integer"):
-                self.next()
+                ptype = "real"
+                if self.peek()[1] in ("real", "integer", "string"):
+                    ptype = self.next()[1]
                 while True:
-                    locals_.append(self.ident())
+                    pn = self.ident()
+                    self.expect("=")
+                    params[pn] = self.expr()
+                    pkind[pn] = ptype
+                    while self.peek()[1] not in (";", ",") or self._in_range():   # from [..) / exclude ...: ranges are not enforced
+                        self.next()
                     if self.accept(";"):
                         break
                     self.expect(",")
+            elif t == "aliasparam":
+                self.next()
+                al = self.ident()
+                self.expect("=")
+                aliasp[al] = self.ident()
+                self.expect(";")
+            elif t in ("real", "integer", "string", "genvar"):
+                self.next()
+                self.decl_list(locals_, inits)
             elif t == "analog" and self.peek(1)[1] == "function":
                 self.next(); self.next()
                 if self.peek()[1] in ("real", "integer"):
                     self.next()
                 fname = self.ident()
                 self.expect(";")
-                f_in, f_loc = [], []
-                while self.peek()[1] in ("input", "real", "integer"):
-                    tgt = f_in if self.next()[1] == "input" else f_loc
+                f_args, f_dir, f_loc = [], [], []
+                while self.peek()[1] in ("input", "output", "inout", "real", "integer"):
+                    kw = self.next()[1]
                     while True:
-                        tgt.append(self.ident())
+                        nm = self.ident()
+                        if kw in ("input", "output", "inout"):
+                            f_args.append(nm); f_dir.append({"input": "in", "output": "out", "inout": "inout"}[kw])
+                        else:
+                            f_loc.append(nm)
                         if self.accept(";"):
                             break
                         self.expect(",")
-                self.functions[fname] = (f_in, [x for x in f_loc if x not in f_in], None)   # visible to its own body (recursion is refused below)
+                self.functions[fname] = (f_args, [x for x in f_loc if x not in f_args], None)   # visible to its own body (recursion is refused below)
+                fdirs[fname] = f_dir
                 fbody = self.stmt()
                 self.expect("endfunction")
-                self.functions[fname] = (f_in, [x for x in f_loc if x not in f_in], fbody[1] if fbody[0] == "block" else [fbody])
+                self.functions[fname] = (f_args, [x for x in f_loc if x not in f_args], fbody[1] if fbody[0] == "block" else [fbody])
             elif t == "analog":
                 self.next()
                 if body is not None:
@@ -441,7 +779,17 @@ class _Parser:
             if p not in nets:
                 raise VAError("port %s of %s is not declared electrical" % (p, name))
         nodes = list(ports) + [x for x in nets if x not in ports]
-        return VAModule(name, ports, nodes, params, locals_, body[1] if body[0] == "block" else [body], functions=dict(self.functions))
+        seen_l = []
+        for x in locals_:                                      # (a name declared twice keeps its first position)
+            if x not in seen_l:
+                seen_l.append(x)
+        return VAModule(name, ports, nodes, params, seen_l, body[1] if body[0] == "block" else [body], functions=dict(self.functions),
+                        local_init=inits, aliasparams=aliasp, param_kind=pkind, func_dirs=fdirs)
+
+    def _in_range(self):
+        """inside a ``from [a:b)`` / ``exclude ...`` clause a comma may separate range bounds? (it does not: bounds use ':'),
+        so a ',' always ends the declarator; kept as a hook"""
+        return False
 
 
 def _walk(stmts):
@@ -451,6 +799,32 @@ def _walk(stmts):
             yield from _walk(s[1])
         elif s[0] == "if":
             yield from _walk([s[2], s[3]])
+        elif s[0] == "case":
+            yield from _walk([it[1] for it in s[2]])
+        elif s[0] == "for":
+            yield from _walk([s[1], s[3], s[4]])
+        elif s[0] == "while":
+            yield from _walk([s[2]])
+
+
+def _subexprs(s):
+    """the expressions a statement evaluates itself (not those of nested statements)"""
+    k = s[0]
+    if k == "assign":
+        return [s[2]]
+    if k == "contrib":
+        return [s[3]]
+    if k == "if":
+        return [s[1]]
+    if k == "case":
+        return [s[1]] + [v for it in s[2] if it[0] is not None for v in it[0]]
+    if k == "for":
+        return [s[2]]
+    if k == "while":
+        return [s[1]]
+    if k == "callstmt":
+        return list(s[2])
+    return []
 
 
 def _analyse(m: VAModule):
@@ -464,9 +838,23 @@ def _analyse(m: VAModule):
         return idx[nm]
 
     names = set(m.params) | set(m.locals_)
+    probes = []          # branches whose current is read: must carry noise only
 
     def check(e, names=names, in_func=False):
         k = e[0]
+        if k in ("str", "noise", "analysis", "num"):
+            return
+        if k == "ddx":
+            node(e[2])
+            check(e[1], names, in_func)
+            return
+        if k == "Iprobe":
+            probes.append((node(e[1]), node(e[2])))
+            return
+        if k == "given":
+            if e[1] not in m.params and e[1] not in m.aliasparams:
+                raise VAError("%s: $param_given(%s): no such parameter" % (m.name, e[1]))
+            return
         if k == "var" and e[1] not in names:
             raise VAError("%s: %s is neither a parameter nor a declared variable" % (m.name, e[1]))
         if k in ("V", "ddt", "limit") and in_func:
@@ -490,34 +878,117 @@ def _analyse(m: VAModule):
                     if isinstance(a, tuple):
                         check(a, names, in_func)
 
-    # ---- analog functions: pure, non-recursive (a function sees the ones defined before it)
-    seen = set()
+    # ---- analog functions: non-recursive; arguments are passed by reference when declared output / inout
+    calls = {f: set() for f in m.functions}
+
+    def callees(e, acc):
+        if e[0] in ("ucall", "callstmt"):
+            if e[1] not in m.functions:
+                raise VAError("%s: call of the unknown function %s" % (m.name, e[1]))
+            if len(e[2]) != len(m.functions[e[1]][0]):
+                raise VAError("%s: %s takes %d argument(s), %d given" % (m.name, e[1], len(m.functions[e[1]][0]), len(e[2])))
+            acc.add(e[1])
+        for sub in e[1:]:
+            for a in (sub if isinstance(sub, list) else [sub]):
+                if isinstance(a, tuple) and a and isinstance(a[0], str) and a[0] != "str":
+                    callees(a, acc)
     for fname, (f_in, f_loc, f_body) in m.functions.items():
         fnames = set(f_in) | set(f_loc) | {fname}
-
-        def fcheck(e):
-            if e[0] == "ucall" and e[1] not in seen:
-                raise VAError("%s: %s calls %s, which is not defined before it" % (m.name, fname, e[1]))
-            for sub in e[1:]:
-                for a in (sub if isinstance(sub, list) else [sub]):
-                    if isinstance(a, tuple) and a and isinstance(a[0], str):
-                        fcheck(a)
         for s in _walk(f_body):
-            if s[0] == "assign":
-                if s[1] not in fnames:
-                    raise VAError("%s: %s assigns %s, which it does not declare" % (m.name, fname, s[1]))
-                check(s[2], fnames, True); fcheck(s[2])
-            elif s[0] == "if":
-                check(s[1], fnames, True); fcheck(s[1])
-            elif s[0] == "contrib":
+            if s[0] == "assign" and s[1] not in fnames:
+                raise VAError("%s: %s assigns %s, which it does not declare" % (m.name, fname, s[1]))
+            if s[0] == "contrib":
                 raise VAError("%s: contribution inside the analog function %s" % (m.name, fname))
-        seen.add(fname)
+            if s[0] == "callstmt":
+                callees(s, calls[fname])
+            for e in _subexprs(s):
+                check(e, fnames, True); callees(e, calls[fname])
+    state = {}
+
+    def visit(f):
+        if state.get(f) == 1:
+            raise VAError("%s: the analog function %s is recursive" % (m.name, f))
+        if state.get(f) == 2:
+            return
+        state[f] = 1
+        for g in calls[f]:
+            visit(g)
+        state[f] = 2
+    for f in m.functions:
+        visit(f)
+    m.func_order = [f for f in sorted(m.functions, key=lambda f: 0)]   # (definition order; the generators emit callees first)
+
+    # ---- which variables are decided by the parameters alone (never assigned from a voltage, the analysis mode, the
+    # initjct flag, or under a condition that depends on one)?  Flow-insensitive fixpoint.
+    dyn = {v: False for v in m.locals_}
+
+    def expr_dyn(e):
+        k = e[0]
+        if k in ("V", "ddt", "limit", "analysis", "ddx"):
+            return True
+        if k in ("given", "num", "str", "noise", "Iprobe"):
+            return False
+        if k == "var":
+            return dyn.get(e[1], False)
+        if k == "sys":
+            if e[1] in ("$abstime", "$realtime"):
+                return True
+            if e[1] == "$simparam" and e[2] and e[2][0][0] == "str" and e[2][0][1] in ("initjct", "iniLim", "iteration"):
+                return True
+        return any(expr_dyn(a) for sub in e[1:] for a in (sub if isinstance(sub, list) else [sub])
+                   if isinstance(a, tuple) and a and isinstance(a[0], str) and a[0] != "str")
+
+    def mark(stmts, under_dyn):
+        ch = False
+        for st in stmts:
+            k = st[0]
+            if k == "assign":
+                if (under_dyn or expr_dyn(st[2])) and st[1] in dyn and not dyn[st[1]]:
+                    dyn[st[1]] = True; ch = True
+            elif k == "callstmt" or k == "assign":
+                pass
+            if k in ("assign", "callstmt", "contrib", "if", "case", "while", "for"):
+                for e in ([st] if k == "callstmt" else _subexprs(st)):
+                    for cal in _calls_in(e):
+                        d = under_dyn or any(expr_dyn(a) for a in cal[2])
+                        for a, dr in zip(cal[2], m.func_dirs.get(cal[1], [])):
+                            if dr != "in" and a[0] == "var" and d and a[1] in dyn and not dyn[a[1]]:
+                                dyn[a[1]] = True; ch = True
+            if k == "block":
+                ch |= mark(st[1], under_dyn)
+            elif k == "if":
+                ch |= mark([st[2], st[3]], under_dyn or expr_dyn(st[1]))
+            elif k == "case":
+                ch |= mark([it[1] for it in st[2]], under_dyn or any(expr_dyn(e) for e in _subexprs(st)))
+            elif k == "while":
+                ch |= mark([st[2]], under_dyn or expr_dyn(st[1]))
+            elif k == "for":
+                ch |= mark([st[1], st[3], st[4]], under_dyn or expr_dyn(st[2]))
+        return ch
+
+    def _calls_in(e):
+        res = []
+        if e[0] in ("ucall", "callstmt"):
+            res.append(e)
+        for sub in e[1:]:
+            for a in (sub if isinstance(sub, list) else [sub]):
+                if isinstance(a, tuple) and a and isinstance(a[0], str) and a[0] != "str":
+                    res += _calls_in(a)
+        return res
+    while mark(m.body, False):
+        pass
+    m.var_is_static = {v: not d for v, d in dyn.items()}
 
     # ---- V(a,b) <+ 0: collected with the conditions that guard them, which must be decidable from the parameters
     def is_static(e):
+        return not expr_dyn(e)
+
+    def _unused_is_static(e):
         k = e[0]
-        if k in ("V", "ddt", "limit", "ucall"):
+        if k in ("V", "ddt", "limit", "ucall", "analysis"):
             return False
+        if k in ("given", "num", "str", "noise"):
+            return True
         if k == "var":
             return e[1] in m.params
         if k == "sys":
@@ -528,8 +999,10 @@ def _analyse(m: VAModule):
         for s in stmts:
             if s[0] == "short":
                 a, b = node(s[1]), node(s[2])
-                if a < 0 or b < 0 or a == b:
+                if a < 0 or a == b:
                     raise VAError("%s: V(%s,%s) <+ 0 must join two distinct nets of the module" % (m.name, s[1], s[2]))
+                if b < 0 and a < len(m.ports):
+                    raise VAError("%s: V(%s) <+ 0 would ground a terminal" % (m.name, s[1]))
                 for c, _ in guards:
                     if not is_static(c):
                         raise VAError("%s: V(%s,%s) <+ 0 under a condition that is not decided by the parameters" % (m.name, s[1], s[2]))
@@ -539,6 +1012,10 @@ def _analyse(m: VAModule):
             elif s[0] == "if":
                 short_walk([s[2]], guards + [(s[1], True)])
                 short_walk([s[3]], guards + [(s[1], False)])
+            elif s[0] in ("case", "for", "while"):
+                for inner in _walk([s]):
+                    if inner[0] == "short":
+                        raise VAError("%s: V(%s,%s) <+ 0 inside a case / loop statement" % (m.name, inner[1], inner[2]))
     short_walk(m.body, [])
 
     # ---- $limit call sites: numbered in source order; top level of the analog block only (vasim.jl:1278-1279)
@@ -567,24 +1044,36 @@ def _analyse(m: VAModule):
             elif s[0] == "if":
                 sites(s[1], False)
                 site_walk([s[2], s[3]], False)
+            elif s[0] in ("case", "for", "while", "callstmt"):
+                for inner in _walk([s]):
+                    for e in _subexprs(inner):
+                        sites(e, False)
     site_walk(m.body, True)
 
+    def only_noise(e):
+        """a contribution whose value is noise alone adds nothing on the DC / transient path: it declares no branch"""
+        return e[0] == "noise"
+
     for s in _walk(m.body):
-        if s[0] == "assign":
-            if s[1] not in m.locals_:
-                raise VAError("%s: assignment to %s, which is not a declared variable" % (m.name, s[1]))
-            check(s[2])
-        elif s[0] == "contrib":
+        if s[0] == "assign" and s[1] not in m.locals_:
+            raise VAError("%s: assignment to %s, which is not a declared variable" % (m.name, s[1]))
+        if s[0] == "contrib" and not only_noise(s[3]):
             br = (node(s[1]), node(s[2]))
             if br[0] == br[1]:
                 raise VAError("%s: contribution to the degenerate branch (%s,%s)" % (m.name, s[1], s[2]))
             if br not in m.branches:
                 m.branches.append(br)
-            check(s[3])
-        elif s[0] == "if":
-            check(s[1])
+        if s[0] == "callstmt":
+            callees(s, set())
+            for a, d in zip(s[2], m.func_dirs.get(s[1], [])):
+                if d != "in" and (a[0] != "var" or a[1] not in m.locals_):
+                    raise VAError("%s: %s: an output argument must be a variable" % (m.name, s[1]))
+        for e in _subexprs(s):
+            check(e); callees(e, set())
     for pe in m.params.values():
         check(pe)
+    for _, ie in m.local_init:
+        check(ie)
 
     # ---- which locals depend on voltages (duals), which carry a ddt() part: fixpoints over the assignments
     dual = {v: False for v in m.locals_}
@@ -594,45 +1083,120 @@ def _analyse(m: VAModule):
         k = e[0]
         if k in ("V", "limit"):
             return True
+        if k in ("str", "noise", "analysis", "given", "num", "Iprobe", "ddx"):
+            return False
         if k == "var":
             return dual.get(e[1], False)
         return any(is_dual(a) for sub in e[1:] for a in (sub if isinstance(sub, list) else [sub]) if isinstance(a, tuple))
 
-    def is_react(e):
+    def _react(e, R):
+        """does the expression carry a ddt() part, with the variables' states in R?"""
         k = e[0]
+        if k in ("str", "noise", "analysis", "given", "num", "Iprobe", "V", "ddx"):
+            return False
         if k == "ddt":
-            if is_react(e[1]):
-                raise VAError("%s: nested ddt()" % m.name)
-            return True
+            return True            # ddt of a value that already has a reactive part takes its resistive part (contrib.jl:363-369)
         if k == "var":
-            return react.get(e[1], False)
+            return R.get(e[1], False)
         if k == "un":
-            return e[1] == "-" and is_react(e[2])
+            return e[1] == "-" and _react(e[2], R)
         if k == "bin":
-            l, r = is_react(e[2]), is_react(e[3])
+            l, r = _react(e[2], R), _react(e[3], R)
             if e[1] in ("+", "-"):
                 return l or r
             if e[1] == "*":
-                if l and r:
-                    raise VAError("%s: product of two ddt() terms" % m.name)
-                return l or r
+                return (l or r) and not (l and r)
             if e[1] == "/":
-                if r:
-                    raise VAError("%s: division by a ddt() term" % m.name)
-                return l
-            if l or r:
-                raise VAError("%s: ddt() inside a comparison / logical expression" % m.name)
+                return l and not r
             return False
         if k == "cond":
-            if is_react(e[1]):
-                raise VAError("%s: ddt() inside a condition" % m.name)
-            return is_react(e[2]) or is_react(e[3])
-        if k in ("call", "sys", "ucall"):
-            if any(isinstance(a, tuple) and a[0] != "str" and is_react(a) for a in e[2]):
-                raise VAError("%s: ddt() inside a function argument" % m.name)
-        if k == "limit" and any(is_react(a) for a in e[4]):
-            raise VAError("%s: ddt() inside a $limit argument" % m.name)
+            return _react(e[2], R) or _react(e[3], R)
+        # a function / comparison / $limit argument with a ddt() part is evaluated on its resistive part (the value the
+        # reference's contribution dual carries in its primal slot); what is computed from it is marked (_taint) and
+        # must not reach a contribution
         return False
+
+    def is_react(e):
+        return _react(e, react)
+
+    def _taint(e, R, T):
+        """does the value depend on a nonlinear function of a ddt() term (whose reactive part was dropped)?"""
+        k = e[0]
+        if k in ("str", "noise", "analysis", "given", "num", "V", "Iprobe", "ddx"):
+            return False
+        if k == "var":
+            return T.get(e[1], False)
+        if k == "ddt":
+            return _taint(e[1], R, T)
+        if k == "bin":
+            l, r = _react(e[2], R), _react(e[3], R)
+            if (e[1] == "*" and l and r) or (e[1] == "/" and r) or (e[1] not in ("+", "-", "*", "/") and (l or r)):
+                return True
+            return _taint(e[2], R, T) or _taint(e[3], R, T)
+        if k == "cond":
+            return _react(e[1], R) or _taint(e[1], R, T) or _taint(e[2], R, T) or _taint(e[3], R, T)
+        if k in ("call", "ucall", "sys"):
+            args = [a for a in e[2] if isinstance(a, tuple) and a[0] != "str"]
+            return any(_react(a, R) or _taint(a, R, T) for a in args)
+        if k == "limit":
+            return any(_react(a, R) or _taint(a, R, T) for a in e[4])
+        if k == "un":
+            return (e[1] != "-" and _react(e[2], R)) or _taint(e[2], R, T)
+        return False
+
+    def taint_flow(stmts, R, T):
+        """forward pass in program order: the reference's contribution duals are run-time values, so whether a variable
+        carries a ddt() part is a property of the program point, not of the variable"""
+        for st in stmts:
+            k = st[0]
+            if k == "assign":
+                r, t = _react(st[2], R), _taint(st[2], R, T)
+                R[st[1]], T[st[1]] = r, t
+            elif k == "contrib":
+                if not only_noise(st[3]) and _taint(st[3], R, T):
+                    raise VAError("%s: a contribution to (%s,%s) depends on a nonlinear function of a ddt() term" % (m.name, st[1], st[2]))
+            elif k == "block":
+                taint_flow(st[1], R, T)
+            elif k in ("if", "case"):
+                arms = [st[2], st[3]] if k == "if" else [it[1] for it in st[2]] + ([] if any(it[0] is None for it in st[2]) else [("block", [])])
+                outs = []
+                for arm in arms:
+                    R1, T1 = dict(R), dict(T)
+                    taint_flow([arm], R1, T1)
+                    outs.append((R1, T1))
+                for v in set().union(*[o[0].keys() for o in outs]):
+                    R[v] = any(o[0].get(v, False) for o in outs)
+                    T[v] = any(o[1].get(v, False) for o in outs)
+            elif k in ("while", "for"):
+                body = [st[2]] if k == "while" else [st[1], st[4], st[3]]
+                for _ in range(2):
+                    R1, T1 = dict(R), dict(T)
+                    taint_flow(body, R1, T1)
+                    for v in R1:
+                        R[v] = R.get(v, False) or R1[v]
+                        T[v] = T.get(v, False) or T1[v]
+            for e in ([st] if k == "callstmt" else _subexprs(st)):
+                for cal in _calls_in(e):
+                    bad = any(_react(a, R) or _taint(a, R, T) for a in cal[2])
+                    for a, dr in zip(cal[2], m.func_dirs.get(cal[1], [])):
+                        if dr != "in" and a[0] == "var":
+                            R[a[1]] = False
+                            T[a[1]] = bad
+
+    def out_args(e):
+        """variables written through output / inout arguments of the function calls inside ``e`` -> is any argument a dual?"""
+        res = []
+        if e[0] in ("ucall",) or e[0] == "callstmt":
+            dirs = m.func_dirs.get(e[1], [])
+            any_dual = any(is_dual(a) for a in e[2])
+            for a, d in zip(e[2], dirs):
+                if d != "in" and a[0] == "var":
+                    res.append((a[1], any_dual))
+        for sub in e[1:]:
+            for a in (sub if isinstance(sub, list) else [sub]):
+                if isinstance(a, tuple) and a and isinstance(a[0], str) and a[0] not in ("str",):
+                    res += out_args(a)
+        return res
 
     changed = True
     while changed:
@@ -644,20 +1208,32 @@ def _analyse(m: VAModule):
                     dual[s[1]] = True; changed = True
                 if r and not react[s[1]]:
                     react[s[1]] = True; changed = True
-    for s in _walk(m.body):
-        if s[0] == "if" and is_react(s[1]):
-            raise VAError("%s: ddt() inside an if condition" % m.name)
+            targets = out_args(s) if s[0] == "callstmt" else [t for e in _subexprs(s) for t in out_args(e)]
+            for v, d in targets:
+                if d and v in dual and not dual[v]:
+                    dual[v] = True; changed = True
+    taint_flow(m.body, {}, {})
+    # current probes: only of branches that carry nothing but noise (correlated-noise helper branches): zero on this path
+    for br in probes:
+        if br in m.branches:
+            raise VAError("%s: I(%s,%s) is read in an expression and the branch carries a contribution: branch-current "
+                          "unknowns are not supported" % (m.name, m.nodes[br[0]] if br[0] >= 0 else "gnd", m.nodes[br[1]] if br[1] >= 0 else "gnd"))
     m.var_is_dual, m.var_is_reactive = dual, react
     m.reactive = [False] * len(m.branches)
     for s in _walk(m.body):
-        if s[0] == "contrib" and is_react(s[3]):
+        if s[0] == "contrib" and not only_noise(s[3]) and is_react(s[3]):
             m.reactive[m.branches.index((node(s[1]), node(s[2])))] = True
     m.is_dual, m.is_react, m.node_index = is_dual, is_react, node
     return m
 
 
-def parse_module(text) -> VAModule:
-    p = _Parser(text)
+def parse_file(path, defines=None) -> VAModule:
+    """parse_module on a file: `include directives resolve relative to the file's directory"""
+    return parse_module(open(path).read(), os.path.dirname(os.path.abspath(path)), defines)
+
+
+def parse_module(text, include_dir=None, defines=None) -> VAModule:
+    p = _Parser(text, include_dir, defines)
     m = p.module()
     if p.peek()[0] != "eof":
         raise VAError("text after endmodule (one module per source)")

@@ -24,8 +24,17 @@ def _limexp(x):
     return math.exp(x) if x < 80.0 else math.exp(80.0) * (1.0 + x - 80.0)
 
 
+def _trunc(x):
+    return float(math.trunc(x))
+
+
 _F = {"exp": math.exp, "ln": math.log, "log": math.log10, "sqrt": math.sqrt, "pow": math.pow, "abs": abs, "min": min, "max": max,
-      "limexp": _limexp, "tanh": math.tanh, "sinh": math.sinh, "cosh": math.cosh, "sin": math.sin, "cos": math.cos, "atan": math.atan}
+      "limexp": _limexp, "tanh": math.tanh, "sinh": math.sinh, "cosh": math.cosh, "sin": math.sin, "cos": math.cos, "atan": math.atan,
+      "tan": math.tan, "asin": math.asin, "acos": math.acos, "atan2": math.atan2, "hypot": math.hypot, "asinh": math.asinh,
+      "acosh": math.acosh, "atanh": math.atanh, "floor": lambda x: float(math.floor(x)), "ceil": lambda x: float(math.ceil(x)), "int": _trunc}
+
+# $simparam(name[, default]): MNASpec fields resolve (vasim.jl:1190-1218), the rest take their default
+SPEC_SIMPARAMS = {"tnom": 27.0, "gshunt": 0.0, "srcFact": 1.0, "abstol": 1e-12, "reltol": 1e-3, "vntol": 1e-6, "iabstol": 1e-12, "time": 0.0}
 
 
 def _r(x):
@@ -36,38 +45,69 @@ def _q(x):
     return x.q if isinstance(x, _Pair) else 0.0
 
 
-def evaluate(m, V, par, temp_k=300.15, mfactor=1.0, gmin=1e-12, vold=None, initjct=0):
+def evaluate(m, V, par, temp_k=300.15, mfactor=1.0, gmin=1e-12, vold=None, initjct=0, given=None, mode="tran", simparams=None,
+             on_short=None):
     """Branch values of module ``m`` at node voltages ``V`` (list over m.nodes): ``[(I_b, q_b)]`` per branch, before the
     multiplicity factor.  ``par``: parameter name -> number (all of them; see ``defaults``); ``vold``: the value of the
-    limit unknown of every $limit probe branch (zeros when omitted)."""
+    limit unknown of every $limit probe branch (zeros when omitted); ``given``: the parameters the instance sets explicitly
+    ($param_given; default: all of ``par``); ``on_short(a, b)``: called for every V(a,b) <+ 0 that executes."""
+    given = set(par) if given is None else {g for g in given}
+    for al, target in m.aliasparams.items():
+        if al in given:
+            given.add(target)
+    sp = dict(SPEC_SIMPARAMS, temp=temp_k - 273.15)
+    if simparams:
+        sp.update(simparams)
     env = {v: 0.0 for v in m.locals_}
     acc = [_Pair(0.0, 0.0) for _ in m.branches]
     vold = list(vold) if vold is not None else [0.0] * len(m.limit_branches)
-    scope = [None]          # the analog function being evaluated: its variables shadow everything
+    scopes = []             # analog-function frames: the innermost shadows everything
 
-    def call(fname, args):
-        f_in, f_loc, f_body = m.functions[fname]
-        saved = scope[0]
-        scope[0] = dict({v: 0.0 for v in f_loc}, **dict(zip(f_in, args)), **{fname: 0.0})
-        fenv = scope[0]
-        run(f_body)
-        scope[0] = saved
-        return fenv[fname]
+    def lookup(name):
+        if scopes:
+            return scopes[-1][name]
+        return par[name] if name in par else env[name]
+
+    def store(name, value):
+        if scopes:
+            scopes[-1][name] = value
+        else:
+            env[name] = value
+
+    def call(fname, arg_exprs):
+        f_args, f_loc, f_body = m.functions[fname]
+        dirs = m.func_dirs.get(fname) or ["in"] * len(f_args)
+        vals = [ev(a) for a in arg_exprs]
+        frame = dict({v: 0.0 for v in f_loc}, **dict(zip(f_args, vals)), **{fname: 0.0})
+        scopes.append(frame)
+        try:
+            run(f_body)
+        finally:
+            scopes.pop()
+        for a, d, nm in zip(arg_exprs, dirs, f_args):         # output / inout arguments are passed by reference
+            if d != "in":
+                store(a[1], frame[nm])
+        return frame[fname]
 
     def ev(e):
         k = e[0]
-        if k == "num":
+        if k in ("num", "str"):
             return e[1]
         if k == "var":
-            if scope[0] is not None:
-                return scope[0][e[1]]
-            return par[e[1]] if e[1] in par else env[e[1]]
+            return lookup(e[1])
+        if k == "given":
+            return 1.0 if e[1] in given else 0.0
+        if k == "analysis":
+            return float(any((a in ("dc", "static") and mode == "dcop") or (a in ("tran", "transient") and mode == "tran")
+                             or (a == "ac" and mode == "ac") for a in e[1]))
+        if k in ("noise", "Iprobe", "ddx"):
+            return 0.0           # noise: no current on this path; ddx: a derivative read-out, not a value the stamps use
         if k == "ucall":
-            return call(e[1], [ev(a) for a in e[2]])
+            return call(e[1], e[2])
         if k == "limit":
             a, b = m.node_index(e[1]), m.node_index(e[2])
             vnew = (V[a] if a >= 0 else 0.0) - (V[b] if b >= 0 else 0.0)
-            return call(e[3], [vnew, vold[m.limit_sites[e[5][0]]]] + [ev(x) for x in e[4]])
+            return call(e[3], [("num", vnew), ("num", vold[m.limit_sites[e[5][0]]])] + [("num", _r(ev(x))) for x in e[4]])
         if k == "V":
             a, b = m.node_index(e[1]), m.node_index(e[2])
             return (V[a] if a >= 0 else 0.0) - (V[b] if b >= 0 else 0.0)
@@ -76,26 +116,33 @@ def evaluate(m, V, par, temp_k=300.15, mfactor=1.0, gmin=1e-12, vold=None, initj
         if k == "un":
             x = ev(e[2])
             if e[1] == "!":
-                return 0.0 if x else 1.0
+                return 0.0 if _r(x) else 1.0
+            if e[1] == "~":
+                return float(~int(_r(x)))
             return _Pair(-x.r, -x.q) if isinstance(x, _Pair) else -x
         if k == "cond":
-            return ev(e[2]) if ev(e[1]) else ev(e[3])
+            return ev(e[2]) if _r(ev(e[1])) else ev(e[3])
         if k == "call":
-            return _F[e[1]](*[ev(a) for a in e[2]])
+            return _F[e[1]](*[_r(ev(a)) for a in e[2]])
         if k == "sys":
             if e[1] == "$temperature":
                 return temp_k
             if e[1] == "$vt":
-                return K_BOLTZ * (ev(e[2][0]) if e[2] else temp_k) / Q_ELEM
+                return K_BOLTZ * (_r(ev(e[2][0])) if e[2] else temp_k) / Q_ELEM
             if e[1] == "$mfactor":
                 return mfactor
-            if e[2] and e[2][0] == ("str", "gmin"):
+            if e[1] in ("$abstime", "$realtime"):
+                return float(sp.get("time", 0.0))
+            name = e[2][0][1] if e[2] and e[2][0][0] == "str" else None
+            if name == "gmin":
                 return gmin
-            if e[2] and e[2][0] == ("str", "initjct"):
+            if name in ("initjct", "iniLim"):
                 return float(initjct)
+            if name in sp:
+                return float(sp[name])
             if len(e[2]) > 1:
                 return ev(e[2][1])
-            raise VAError("$simparam(%r) has no value here" % (e[2][0][1] if e[2] else ""))
+            raise VAError("$simparam(%r) has no value here" % name)
         op, l, r = e[1], ev(e[2]), ev(e[3])
         if op in ("+", "-"):
             s = 1.0 if op == "+" else -1.0
@@ -103,31 +150,105 @@ def evaluate(m, V, par, temp_k=300.15, mfactor=1.0, gmin=1e-12, vold=None, initj
                 return _Pair(_r(l) + s * _r(r), _q(l) + s * _q(r))
             return l + s * r
         if op == "*":
+            if isinstance(l, _Pair) and isinstance(r, _Pair):
+                return l.r * r.r
             if isinstance(l, _Pair):
                 return _Pair(l.r * r, l.q * r)
             if isinstance(r, _Pair):
                 return _Pair(l * r.r, l * r.q)
             return l * r
         if op == "/":
-            return _Pair(l.r / r, l.q / r) if isinstance(l, _Pair) else l / r
+            return _Pair(l.r / _r(r), l.q / _r(r)) if isinstance(l, _Pair) else l / _r(r)
+        l, r = _r(l), _r(r)
+        if op == "%":
+            return math.fmod(l, r)
+        if op in ("&", "|", "^", "<<", ">>"):
+            a, b = int(l), int(r)
+            return float({"&": a & b, "|": a | b, "^": a ^ b, "<<": a << b, ">>": a >> b}[op])
         return float({"==": l == r, "!=": l != r, "<": l < r, ">": l > r, "<=": l <= r, ">=": l >= r,
                       "&&": bool(l) and bool(r), "||": bool(l) or bool(r)}[op])
 
     def run(stmts):
         for s in stmts:
-            if s[0] == "assign":
-                (scope[0] if scope[0] is not None else env)[s[1]] = ev(s[2])
-            elif s[0] == "contrib":
+            k = s[0]
+            if k == "assign":
+                store(s[1], ev(s[2]))
+            elif k == "contrib":
+                if s[3][0] == "noise":
+                    continue
                 b = m.branches.index((m.node_index(s[1]), m.node_index(s[2])))
                 x = ev(s[3])
                 acc[b] = _Pair(acc[b].r + _r(x), acc[b].q + _q(x))
-            elif s[0] == "block":
+            elif k == "block":
                 run(s[1])
-            elif s[0] == "if":
-                run([s[2]] if ev(s[1]) else [s[3]])
+            elif k == "if":
+                run([s[2]] if _r(ev(s[1])) else [s[3]])
+            elif k == "case":
+                sel = _r(ev(s[1]))
+                chosen = None
+                for vals, body in s[2]:
+                    if vals is not None and any(_r(ev(v)) == sel for v in vals):
+                        chosen = body
+                        break
+                if chosen is None:
+                    chosen = next((body for vals, body in s[2] if vals is None), None)
+                if chosen is not None:
+                    run([chosen])
+            elif k == "while":
+                n = 0
+                while _r(ev(s[1])):
+                    run([s[2]])
+                    n += 1
+                    if n > 100000:
+                        raise VAError("%s: while loop does not terminate" % m.name)
+            elif k == "for":
+                run([s[1]])
+                n = 0
+                while _r(ev(s[2])):
+                    run([s[4]]); run([s[3]])
+                    n += 1
+                    if n > 100000:
+                        raise VAError("%s: for loop does not terminate" % m.name)
+            elif k == "callstmt":
+                call(s[1], s[2])
+            elif k == "fatal":
+                raise VAError("%s: %s %s" % (m.name, s[1], s[2]))
+            elif k == "short":
+                if on_short is not None:
+                    on_short(m.node_index(s[1]), m.node_index(s[2]))
 
+    for name, ie in m.local_init:                               # module-scope initialisers, in declaration order
+        env[name] = ev(ie)
     run(m.body)
     return [(a.r, a.q) for a in acc]
+
+
+def collapsed_nodes(m, par, given=None, temp_k=300.15, mfactor=1.0, gmin=1e-12):
+    """internal node -> the node it is merged into (-1 = ground) for this instance: the V(a,b) <+ 0 statements that execute in
+    one evaluation at zero bias (their conditions are decided by the parameters: frontend._analyse)."""
+    np_ = len(m.ports)
+    out = {}
+
+    def root(i):
+        while i in out and i >= 0:
+            i = out[i]
+        return i
+
+    def on_short(a, b):
+        a, b = root(a), root(b)
+        if a == b:
+            return
+        if a >= np_:
+            out[a] = b
+        elif b >= np_:
+            out[b] = a
+        else:
+            raise VAError("%s: V(%s,%s) <+ 0 between two terminals needs a branch current (not supported)" % (m.name, m.nodes[a], m.nodes[b]))
+    try:
+        evaluate(m, [0.0] * m.n_nodes, par, temp_k, mfactor, gmin, given=given, on_short=on_short)
+    except (ValueError, ZeroDivisionError, OverflowError):
+        pass                    # a zero-bias probe may leave the model's domain after the collapse statements (setup section) ran
+    return {k: root(k) for k in out}
 
 
 def static_eval(e, par, temp_k=300.15, mfactor=1.0, gmin=1e-12):
@@ -186,6 +307,16 @@ def defaults(m, given=None):
             if k == "bin" and e[1] in "+-*/":
                 l, r = ev(e[2]), ev(e[3])
                 return l + r if e[1] == "+" else l - r if e[1] == "-" else l * r if e[1] == "*" else l / r
+            if k == "str":
+                return e[1]
+            if k == "cond":
+                return ev(e[2]) if ev(e[1]) else ev(e[3])
+            if k == "bin":
+                l, r = ev(e[2]), ev(e[3])
+                return float({"==": l == r, "!=": l != r, "<": l < r, ">": l > r, "<=": l <= r, ">=": l >= r,
+                              "&&": bool(l) and bool(r), "||": bool(l) or bool(r)}[e[1]])
+            if k == "sys" and e[1] == "$simparam" and len(e[2]) > 1:
+                return ev(e[2][1])
             raise VAError("%s: unsupported construct in the default of %s" % (m.name, name))
         par[name] = ev(expr)
     return par

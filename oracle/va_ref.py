@@ -53,49 +53,143 @@ def _limexp(v):
     return math.exp(v) if v < 80.0 else math.exp(80.0) * (1.0 + v - 80.0)
 
 
+def _res(x):
+    """a value with a ddt() part enters nonlinear functions, comparisons and conditions with its resistive part: the primal
+    slot of the reference's Dual{ContributionTag} (contrib.jl:356-375)"""
+    return x.r if isinstance(x, CDual) else x
+
+
+def _u(fn, dfn):
+    g = _unary(fn, dfn)
+    return lambda x: g(_res(x))
+
+
+def _atan2(y, x):
+    y, x = _res(y), _res(x)
+    yv, xv = val(y), val(x)
+    f = math.atan2(yv, xv)
+    d = xv * xv + yv * yv
+    p = 0.0
+    if isinstance(y, Dual):
+        p = p + y.p * (xv / d)
+    if isinstance(x, Dual):
+        p = p + x.p * (-yv / d)
+    return Dual(f, p) if isinstance(y, Dual) or isinstance(x, Dual) else f
+
+
+def _hypot(a, b):
+    a, b = _res(a), _res(b)
+    return dsqrt(a * a + b * b)
+
+
+def _int_like(fn):
+    return lambda x: float(fn(val(_res(x))))          # piecewise constant: no partials
+
+
 FUNCS = {
-    "exp": dexp, "ln": dln, "sqrt": dsqrt, "abs": dabs, "pow": _pow,
-    "log": _unary(math.log10, lambda v, f: 1.0 / (v * math.log(10.0))),
-    "limexp": _unary(_limexp, lambda v, f: f if v < 80.0 else math.exp(80.0)),
-    "tanh": _unary(math.tanh, lambda v, f: 1.0 - f * f), "sinh": _unary(math.sinh, lambda v, f: math.cosh(v)),
-    "cosh": _unary(math.cosh, lambda v, f: math.sinh(v)), "sin": _unary(math.sin, lambda v, f: math.cos(v)),
-    "cos": _unary(math.cos, lambda v, f: -math.sin(v)), "atan": _unary(math.atan, lambda v, f: 1.0 / (1.0 + v * v)),
+    "exp": lambda x: dexp(_res(x)), "ln": lambda x: dln(_res(x)), "sqrt": lambda x: dsqrt(_res(x)), "abs": lambda x: dabs(_res(x)),
+    "pow": lambda a, b: _pow(_res(a), _res(b)),
+    "log": _u(math.log10, lambda v, f: 1.0 / (v * math.log(10.0))),
+    "limexp": _u(_limexp, lambda v, f: f if v < 80.0 else math.exp(80.0)),
+    "tanh": _u(math.tanh, lambda v, f: 1.0 - f * f), "sinh": _u(math.sinh, lambda v, f: math.cosh(v)),
+    "cosh": _u(math.cosh, lambda v, f: math.sinh(v)), "sin": _u(math.sin, lambda v, f: math.cos(v)),
+    "cos": _u(math.cos, lambda v, f: -math.sin(v)), "atan": _u(math.atan, lambda v, f: 1.0 / (1.0 + v * v)),
+    "tan": _u(math.tan, lambda v, f: 1.0 + f * f), "asin": _u(math.asin, lambda v, f: 1.0 / math.sqrt(1.0 - v * v)),
+    "acos": _u(math.acos, lambda v, f: -1.0 / math.sqrt(1.0 - v * v)), "asinh": _u(math.asinh, lambda v, f: 1.0 / math.sqrt(v * v + 1.0)),
+    "acosh": _u(math.acosh, lambda v, f: 1.0 / math.sqrt(v * v - 1.0)), "atanh": _u(math.atanh, lambda v, f: 1.0 / (1.0 - v * v)),
+    "atan2": _atan2, "hypot": _hypot,
+    "floor": _int_like(math.floor), "ceil": _int_like(math.ceil), "int": _int_like(lambda v: math.trunc(v)),
     # ties take the first operand (the product's va_max / va_min)
-    "max": lambda a, b: b if val(b) > val(a) else a, "min": lambda a, b: b if val(b) < val(a) else a,
+    "max": lambda a, b: _res(b) if val(_res(b)) > val(_res(a)) else _res(a), "min": lambda a, b: _res(b) if val(_res(b)) < val(_res(a)) else _res(a),
 }
 
+# $simparam(name[, default]): names that are MNASpec fields resolve, everything else takes its default (vasim.jl:1190-1218)
+SPEC_SIMPARAMS = ("temp", "gmin", "gshunt", "srcFact", "tnom", "abstol", "reltol", "vntol", "iabstol", "time")
 
-def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False):
+
+class VAFatal(RuntimeError):
+    pass
+
+
+def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False, given=None, spec=None, on_short=None):
     """Branch contributions of ``mod`` on dual node voltages ``Vd``: one Dual / CDual / float per branch.
-    ``limit_site(j, vnew_dual, fn)`` implements a $limit call site (stamp_va)."""
+    ``limit_site(j, vnew_dual, fn)`` implements a $limit call site (stamp_va); ``given``: the parameters the instance sets
+    explicitly ($param_given); ``on_short(a, b)``: called for every executed V(a,b) <+ 0."""
+    given = set(par) if given is None else set(given)
+    for al, target in mod.aliasparams.items():
+        if al in given:
+            given.add(target)
     env = {v: 0.0 for v in mod.locals_}
     acc = [0.0 for _ in mod.branches]
-    scope = [None]
+    scopes = []          # analog-function frames: the innermost shadows everything
+    mode = getattr(spec, "mode", "tran") if spec is not None else "tran"
 
-    def call(fname, args):
-        f_in, f_loc, f_body = mod.functions[fname]
-        saved = scope[0]
-        fenv = dict({v: 0.0 for v in f_loc}, **dict(zip(f_in, args)), **{fname: 0.0})
-        scope[0] = fenv
-        run(f_body)
-        scope[0] = saved
-        return fenv[fname]
+    def lookup(name):
+        if scopes:
+            return scopes[-1][name]
+        return par[name] if name in par else env[name]
+
+    def store(name, value):
+        if scopes:
+            scopes[-1][name] = value
+        else:
+            env[name] = value
+
+    def call(fname, arg_exprs):
+        f_args, f_loc, f_body = mod.functions[fname]
+        dirs = mod.func_dirs.get(fname) or ["in"] * len(f_args)
+        vals = [ev(a) for a in arg_exprs]
+        frame = dict({v: 0.0 for v in f_loc}, **dict(zip(f_args, vals)), **{fname: 0.0})
+        scopes.append(frame)
+        try:
+            run(f_body)
+        finally:
+            scopes.pop()
+        for a, d, nm in zip(arg_exprs, dirs, f_args):         # output / inout arguments are passed by reference
+            if d != "in":
+                store(a[1], frame[nm])
+        return frame[fname]
+
+    def simparam(e):
+        name = e[2][0][1] if e[2] and e[2][0][0] == "str" else None
+        if name in ("initjct", "iniLim"):                      # ngspice MODEINITJCT -> the PCNR initjct flag (vasim.jl:1198-1206)
+            return 1.0 if initjct else 0.0
+        if name == "gmin":
+            return gmin
+        if name in SPEC_SIMPARAMS and spec is not None and hasattr(spec, name):
+            return float(getattr(spec, name))
+        if len(e[2]) > 1:
+            return ev(e[2][1])
+        raise KeyError("Unknown simparam: %s" % name)
 
     def ev(e):
         k = e[0]
         if k == "num":
             return e[1]
+        if k == "str":
+            return e[1]
         if k == "var":
-            if scope[0] is not None:
-                return scope[0][e[1]]
-            return par[e[1]] if e[1] in par else env[e[1]]
+            return lookup(e[1])
+        if k == "given":
+            return 1.0 if (e[1] in given) else 0.0
+        if k == "analysis":
+            # vasim.jl:1220-1250: dc / static -> :dcop, tran / transient -> :tran, ac -> :ac, nodeset -> false
+            return float(any((a in ("dc", "static") and mode == "dcop") or (a in ("tran", "transient") and mode == "tran")
+                             or (a == "ac" and mode == "ac") for a in e[1]))
+        if k in ("noise", "Iprobe"):
+            return 0.0                                          # noise sources contribute no current on this path
+        if k == "ddx":
+            x = _res(ev(e[1]))
+            a = mod.node_index(e[2])
+            return float(x.p[a]) if isinstance(x, Dual) and a >= 0 else 0.0
         if k == "ucall":
-            return call(e[1], [ev(a) for a in e[2]])
+            return call(e[1], e[2])
         if k == "limit":
             a, b = mod.node_index(e[1]), mod.node_index(e[2])
             vnew = (Vd[a] if a >= 0 else 0.0) - (Vd[b] if b >= 0 else 0.0)
-            user = [ev(x) for x in e[4]]
-            return limit_site(e[5][0], vnew, lambda vn, vo: call(e[3], [vn, vo] + user))
+            user = [_res(ev(x)) for x in e[4]]
+            fn = e[3]
+            return limit_site(e[5][0], vnew, lambda vn, vo: call(fn, [("num", vn), ("num", vo)] + [("num", val(u)) for u in user]))
         if k == "V":
             a, b = mod.node_index(e[1]), mod.node_index(e[2])
             return (Vd[a] if a >= 0 else 0.0) - (Vd[b] if b >= 0 else 0.0)
@@ -103,66 +197,142 @@ def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False
             return va_ddt(ev(e[1]))
         if k == "un":
             x = ev(e[2])
-            return (0.0 if val(x) else 1.0) if e[1] == "!" else -x
+            if e[1] == "!":
+                return 0.0 if val(_res(x)) else 1.0
+            if e[1] == "~":
+                return float(~int(val(_res(x))))
+            return -x
         if k == "cond":
-            return ev(e[2]) if val(ev(e[1])) else ev(e[3])
+            return ev(e[2]) if val(_res(ev(e[1]))) else ev(e[3])
         if k == "call":
             return FUNCS[e[1]](*[ev(a) for a in e[2]])
         if k == "sys":
             if e[1] == "$temperature":
                 return temp_k
             if e[1] == "$vt":
-                return K_BOLTZ * (ev(e[2][0]) if e[2] else temp_k) / Q_ELEM
+                return K_BOLTZ * (val(_res(ev(e[2][0]))) if e[2] else temp_k) / Q_ELEM
             if e[1] == "$mfactor":
                 return mfactor
-            if e[2] and e[2][0] == ("str", "gmin"):
-                return gmin
-            if e[2] and e[2][0] == ("str", "initjct"):
-                return 1.0 if initjct else 0.0
-            return ev(e[2][1])
+            if e[1] in ("$abstime", "$realtime"):
+                return float(getattr(spec, "time", 0.0)) if spec is not None else 0.0
+            return simparam(e)
         op, l, r = e[1], ev(e[2]), ev(e[3])
         if op == "+":
             return l + r
         if op == "-":
             return l - r
         if op == "*":
+            if isinstance(l, CDual) and isinstance(r, CDual):
+                return l.r * r.r                                # (no model multiplies two ddt() terms: resistive parts)
             return l * r
         if op == "/":
-            return l / r
-        lv, rv = val(l), val(r)
+            return l / _res(r)
+        lv, rv = val(_res(l)), val(_res(r))
+        if op == "%":
+            return math.fmod(lv, rv)
+        if op in ("&", "|", "^", "<<", ">>"):
+            a, b = int(lv), int(rv)
+            return float({"&": a & b, "|": a | b, "^": a ^ b, "<<": a << b, ">>": a >> b}[op])
         return float({"==": lv == rv, "!=": lv != rv, "<": lv < rv, ">": lv > rv, "<=": lv <= rv, ">=": lv >= rv,
                       "&&": bool(lv) and bool(rv), "||": bool(lv) or bool(rv)}[op])
 
     def run(stmts):
         for s in stmts:
-            if s[0] == "assign":
-                (scope[0] if scope[0] is not None else env)[s[1]] = ev(s[2])
-            elif s[0] == "contrib":
+            k = s[0]
+            if k == "assign":
+                store(s[1], ev(s[2]))
+            elif k == "contrib":
+                if s[3][0] == "noise":
+                    continue
                 b = mod.branches.index((mod.node_index(s[1]), mod.node_index(s[2])))
                 acc[b] = acc[b] + ev(s[3])
-            elif s[0] == "block":
+            elif k == "block":
                 run(s[1])
-            elif s[0] == "if":
-                run([s[2]] if val(ev(s[1])) else [s[3]])
-            # "short" (V(a,b) <+ 0): structural, nothing to evaluate
+            elif k == "if":
+                run([s[2]] if val(_res(ev(s[1]))) else [s[3]])
+            elif k == "case":
+                sel = val(_res(ev(s[1])))
+                chosen = None
+                for vals, body in s[2]:
+                    if vals is not None and any(val(_res(ev(v))) == sel for v in vals):
+                        chosen = body
+                        break
+                if chosen is None:
+                    chosen = next((body for vals, body in s[2] if vals is None), None)
+                if chosen is not None:
+                    run([chosen])
+            elif k == "while":
+                n = 0
+                while val(_res(ev(s[1]))):
+                    run([s[2]])
+                    n += 1
+                    if n > 100000:
+                        raise RuntimeError("while loop does not terminate")
+            elif k == "for":
+                run([s[1]])
+                n = 0
+                while val(_res(ev(s[2]))):
+                    run([s[4]]); run([s[3]])
+                    n += 1
+                    if n > 100000:
+                        raise RuntimeError("for loop does not terminate")
+            elif k == "callstmt":
+                call(s[1], s[2])
+            elif k == "fatal":
+                raise VAFatal("%s: %s %s" % (mod.name, s[1], s[2]))
+            elif k == "short":
+                if on_short is not None:
+                    on_short(mod.node_index(s[1]), mod.node_index(s[2]))
 
+    for name, ie in mod.local_init:                             # module-scope initialisers, in declaration order
+        env[name] = ev(ie)
     run(mod.body)
     return acc
 
 
-def stamp_va(ctx, mod, ext_nodes, x, par, spec, instance, mfactor=1.0, gmin=None):
+def collapsed_nodes(mod, par, given, spec, mfactor=1.0, gmin=1e-12):
+    """Which internal nodes does this instance collapse?  The V(a,b) <+ 0 statements sit under conditions decided by the
+    parameters (vasim.jl:2313-2395, 3533-3564); one evaluation of the analog block on plain numbers at zero bias executes
+    exactly the ones that apply.  Returns internal node -> node it is merged into (-1 = ground)."""
+    np_ = len(mod.ports)
+    out = {}
+
+    def root(i):
+        while i in out and i >= 0:
+            i = out[i]
+        return i
+
+    def on_short(a, b):
+        a, b = root(a), root(b)
+        if a == b:
+            return
+        if a >= np_:
+            out[a] = b
+        elif b >= np_:
+            out[b] = a
+        else:
+            raise ValueError("%s: V(%s,%s) <+ 0 between two terminals" % (mod.name, mod.nodes[a], mod.nodes[b]))
+    temp_k = float(getattr(spec, "temp", 27.0)) + 273.15
+    try:
+        evaluate(mod, [0.0] * len(mod.nodes), par, temp_k, mfactor, gmin, lambda j, vnew, fn: vnew, False, given, spec, on_short)
+    except (ValueError, ZeroDivisionError, OverflowError, VAFatal):
+        pass                      # a zero-bias probe may leave a model's domain after the collapse statements (the setup section) ran
+    return {k: root(k) for k in out}
+
+
+def stamp_va(ctx, mod, ext_nodes, x, par, spec, instance, mfactor=1.0, gmin=None, given=None):
     """The generated stamp! body for one instance of ``mod`` (vasim.jl:3886-3963)."""
     N, S = len(mod.nodes), mod.n_sites
     W = N + S
     # internal node allocation with short-circuit aliasing (vasim.jl:3533-3564): V(a,b) <+ 0 under a parameter condition
-    alias = mod.aliases(par)
+    alias = collapsed_nodes(mod, par, given, spec, mfactor, spec.gmin if gmin is None else gmin)
     node = list(ext_nodes) + [None] * (N - len(mod.ports))
     for k in range(len(mod.ports), N):
         if k not in alias:
             node[k] = ctx.alloc_internal_node("%s_%s_%s" % (instance, mod.name, mod.nodes[k]))
     for k in range(len(mod.ports), N):
         if k in alias:
-            node[k] = node[alias[k]]
+            node[k] = node[alias[k]] if alias[k] >= 0 else 0
     # $limit preamble (vasim.jl:3110-3138): one limit unknown per probe branch, its tracking row u_l - (V_p - V_n) = 0
     lidx, vold = [], []
     for (pl, nl) in mod.limit_branches:
@@ -193,7 +363,7 @@ def stamp_va(ctx, mod, ext_nodes, x, par, spec, instance, mfactor=1.0, gmin=None
         return (Vf[pl] if pl >= 0 else 0.0) - (Vf[nl] if nl >= 0 else 0.0) - limw[j]
 
     temp_k = float(getattr(spec, "temp", 27.0)) + 273.15
-    Ibr = evaluate(mod, Vd, par, temp_k, mfactor, spec.gmin if gmin is None else gmin, limit_site, ctx.initjct)
+    Ibr = evaluate(mod, Vd, par, temp_k, mfactor, spec.gmin if gmin is None else gmin, limit_site, ctx.initjct, given, spec)
     for b, (pl, nl) in enumerate(mod.branches):
         p_node = node[pl] if pl >= 0 else 0
         n_node = node[nl] if nl >= 0 else 0

@@ -669,7 +669,7 @@ def test_verilog_a_front_end_and_generator():
                 "module x(a); electrical a; analog I(a) <+ exp(ddt(V(a))); endmodule",            # ddt inside a function
                 "module x(a); electrical a; analog I(a) <+ undeclared * V(a); endmodule",
                 "module x(a); electrical a; analog I(a, b) <+ V(a); endmodule",                    # unknown net
-                "module x(a); electrical a; analog @(initial_step) I(a) <+ 1; endmodule",
+                "module x(a); electrical a; analog @(cross(V(a), 1)) I(a) <+ 1; endmodule",
                 "module x(a); analog I(a) <+ 1; endmodule"):                                       # port not electrical
         with pytest.raises(va.VAError):
             va.parse_module(bad)
