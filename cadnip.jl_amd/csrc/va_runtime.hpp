@@ -6,8 +6,8 @@
 
 namespace cadnip {
 
-// what $temperature, $mfactor and $simparam("gmin" | "initjct") read
-struct VaSys { double temp, mf, gmin, initjct; };
+// what $temperature, $mfactor, $simparam("gmin" | "initjct" / "iniLim"), analysis() and $abstime read
+struct VaSys { double temp, mf, gmin, initjct; int mode; double time; };
 
 template <class X> __device__ __forceinline__ double va_val(X x) { return (double)x; }
 template <int N> __device__ __forceinline__ double va_val(const Dual<N>& x) { return x.v; }
@@ -34,9 +34,22 @@ VA_UNARY(cosh, cosh(x), sinh(x))
 VA_UNARY(sin, sin(x), cos(x))
 VA_UNARY(cos, cos(x), -sin(x))
 VA_UNARY(atan, atan(x), 1.0 / (1.0 + x * x))
+VA_UNARY(tan, tan(x), 1.0 + f * f)
+VA_UNARY(asin, asin(x), 1.0 / sqrt(1.0 - x * x))
+VA_UNARY(acos, acos(x), -1.0 / sqrt(1.0 - x * x))
+VA_UNARY(asinh, asinh(x), 1.0 / sqrt(x * x + 1.0))
+VA_UNARY(acosh, acosh(x), 1.0 / sqrt(x * x - 1.0))
+VA_UNARY(atanh, atanh(x), 1.0 / (1.0 - x * x))
 // limexp: exp below 80, its tangent above (the usual SPICE continuation)
 VA_UNARY(limexp, (x < 80.0 ? exp(x) : exp(80.0) * (1.0 + x - 80.0)), (x < 80.0 ? f : exp(80.0)))
 #undef VA_UNARY
+// piecewise constant functions: plain numbers
+template <class X> __device__ __forceinline__ double va_floor(const X& x) { return floor(va_val(x)); }
+template <class X> __device__ __forceinline__ double va_ceil(const X& x) { return ceil(va_val(x)); }
+template <class X> __device__ __forceinline__ double va_int(const X& x) { return trunc(va_val(x)); }
+// ddx(expr, V(node k)): the partial itself, a plain number
+__device__ __forceinline__ double va_ddx(double, int) { return 0.0; }
+template <int N> __device__ __forceinline__ double va_ddx(const Dual<N>& a, int k) { return a.p[k]; }
 __device__ __forceinline__ double va_abs(double x) { return fabs(x); }
 template <int N> __device__ __forceinline__ Dual<N> va_abs(const Dual<N>& a) { return a.v >= 0.0 ? a : -a; }
 
@@ -57,6 +70,18 @@ template <int N> __device__ __forceinline__ Dual<N> va_pow(const Dual<N>& a, con
   for (int i = 0; i < N; ++i) r.p[i] = a.p[i] * da + (b.p[i] != 0.0 ? b.p[i] * db : 0.0);
   return r;
 }
+__device__ __forceinline__ double va_atan2(double y, double x) { return atan2(y, x); }
+template <int N> __device__ __forceinline__ Dual<N> va_atan2(const Dual<N>& y, const Dual<N>& x) {
+  const double d = x.v * x.v + y.v * y.v;
+  Dual<N> r; r.v = atan2(y.v, x.v);
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.p[i] = (y.p[i] * x.v - x.p[i] * y.v) / d;
+  return r;
+}
+template <int N> __device__ __forceinline__ Dual<N> va_atan2(const Dual<N>& y, double x) { return va_atan2(y, Dual<N>(x)); }
+template <int N> __device__ __forceinline__ Dual<N> va_atan2(double y, const Dual<N>& x) { return va_atan2(Dual<N>(y), x); }
+__device__ __forceinline__ double va_hypot(double a, double b) { return hypot(a, b); }
+template <class A, class B> __device__ __forceinline__ auto va_hypot(const A& a, const B& b) -> decltype(va_sqrt(a * a + b * b)) { return va_sqrt(a * a + b * b); }
 // min / max select by value and carry the selected operand's partials (ForwardDiff semantics); ties take the first
 __device__ __forceinline__ double va_max(double a, double b) { return b > a ? b : a; }
 __device__ __forceinline__ double va_min(double a, double b) { return b < a ? b : a; }

@@ -407,7 +407,7 @@ def detect_va_vdep(circuit: Circuit, params: Dict[str, float], seed: int = 0xDEA
             n_m1q += sum(m1v)
         elif ty.startswith("VA:"):
             mod = va.get(ty[3:])[1]
-            alias = mod.aliases(va.host_eval.defaults(mod, {k: float(np.asarray(resolve(v, params)).flat[0]) for k, v in d.model.items()}))
+            alias = mod.aliases(va.host_eval.defaults(mod, {k: float(np.asarray(resolve(v, params)).flat[0]) for k, v in d.model.items()}), set(d.model))
             ext = [A.node(nm) for nm in d.nodes]
             loc = list(ext) + [None] * mod.n_internal
             for k in range(len(mod.ports), mod.n_nodes):
@@ -415,7 +415,7 @@ def detect_va_vdep(circuit: Circuit, params: Dict[str, float], seed: int = 0xDEA
                     loc[k] = A.node("%s_%s_%s" % (d.name, mod.name, mod.nodes[k]))
             for k in range(len(mod.ports), mod.n_nodes):
                 if k in alias:
-                    loc[k] = loc[alias[k]]
+                    loc[k] = loc[alias[k]] if alias[k] >= 0 else A.node("0")       # V(a) <+ 0: the internal node is ground
             internal[d.name] = loc[len(mod.ports):]
             n_lim += len(mod.limit_branches)
     n_nodes = len(A.node_names)
@@ -464,7 +464,7 @@ def detect_va_vdep(circuit: Circuit, params: Dict[str, float], seed: int = 0xDEA
                 lim_sf += 1
                 vold.append(xat(len(seen_nodes) + cur_sf + q_sf + lim_sf - 1))
             mf = float(np.asarray(resolve(d.params["m"], params)).flat[0])
-            vals = va.host_eval.evaluate(mod, V, par, 27.0 + 273.15, mf, 1e-12, vold=vold)
+            vals = va.host_eval.evaluate(mod, V, par, 27.0 + 273.15, mf, 1e-12, vold=vold, given=set(d.model))
             flags, pos = [], 0
             for b, (pn, nn) in enumerate(mod.branches):
                 if not mod.reactive[b]:
@@ -563,9 +563,12 @@ def discover(circuit: Circuit, params: Dict[str, float]) -> Structure:
                 raise ValueError("%s: %d nets for the %d ports of %s" % (dev.name, len(dev.nodes), len(mod.ports), mod.name))
             # internal nodes, then one charge unknown per voltage-dependent reactive branch, allocated in branch order as
             # the branches are stamped (vasim.jl:3533-3564, 3433-3472)
-            alias = mod.aliases(va.host_eval.defaults(mod, {k: float(np.asarray(resolve(v, params)).flat[0]) for k, v in dev.model.items()}))
+            alias = mod.aliases(va.host_eval.defaults(mod, {k: float(np.asarray(resolve(v, params)).flat[0]) for k, v in dev.model.items()}), set(dev.model))
             for k in range(len(mod.ports), mod.n_nodes):     # a collapsed internal node is its neighbour's unknown (vasim.jl:3533-3564)
-                nodes.append(nodes[alias[k]] if k in alias and alias[k] < k else None if k in alias else A.node("%s_%s_%s" % (dev.name, mod.name, mod.nodes[k])))
+                if k in alias and alias[k] < 0:
+                    nodes.append(GND)                         # V(a) <+ 0: the internal node is ground
+                else:
+                    nodes.append(nodes[alias[k]] if k in alias and alias[k] < k else None if k in alias else A.node("%s_%s_%s" % (dev.name, mod.name, mod.nodes[k])))
             for k in range(len(mod.ports), mod.n_nodes):     # ... also when the neighbour is a later internal node
                 if nodes[k] is None:
                     nodes[k] = nodes[alias[k]]
@@ -716,10 +719,17 @@ def pack_params(st: Structure, circuit: Circuit, params: Dict[str, np.ndarray], 
                 mod = va.get(ty[3:])[1]
                 par = va.host_eval.defaults(mod, {k: resolve(v, params) for k, v in dev.model.items()})
                 for k, nm in enumerate(mod.params):
-                    arr[:, k, j] = par[nm]
+                    if mod.param_kind.get(nm) != "string":
+                        arr[:, k, j] = par[nm]
                 np_ = len(mod.params)
+                for k, (sp, lit) in enumerate(mod.string_tests):               # string parameter == literal: decided here
+                    arr[:, np_ + 3 + (np_ if mod.uses_given else 0) + k, j] = 1.0 if str(par[sp]) == lit else 0.0
                 arr[:, np_, j] = np.asarray(temp_c, dtype=float) + 273.15     # $temperature
                 arr[:, np_ + 1, j] = g("m")                                     # $mfactor
                 arr[:, np_ + 2, j] = gmin                                       # $simparam("gmin")
+                if mod.uses_given:                                              # $param_given: one flag per parameter
+                    given = {k.lower() for k in dev.model} | {mod.aliasparams[k].lower() for k in dev.model if k in mod.aliasparams}
+                    for k, nm in enumerate(mod.params):
+                        arr[:, np_ + 3 + k, j] = 1.0 if nm.lower() in given else 0.0
         out.append(np.ascontiguousarray(arr))
     return out

@@ -8,7 +8,7 @@ from . import host_eval
 
 MODEL_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models")
 # the modules compiled into libcadnip_hip.so, in model-id order (csrc/build.sh passes the same list to hipgen.py)
-MODEL_FILES = ("va_resistor.va", "va_capacitor.va", "va_diode.va", "va_sqmos.va", "va_dlim.va", "va_mos1l.va")
+MODEL_FILES = ("va_resistor.va", "va_capacitor.va", "va_diode.va", "va_sqmos.va", "va_dlim.va", "va_mos1l.va", "va_feat.va")
 
 _cache = {}
 
@@ -17,7 +17,7 @@ def registry():
     """name -> (model id, VAModule) of the built-in modules."""
     if not _cache:
         for i, fn in enumerate(MODEL_FILES):
-            m = parse_module(open(os.path.join(MODEL_DIR, fn)).read())
+            m = parse_module(open(os.path.join(MODEL_DIR, fn)).read(), MODEL_DIR)
             _cache[m.name] = (i, m)
     return _cache
 

@@ -260,6 +260,8 @@ class VAModule:
     aliasparams: Dict[str, str] = field(default_factory=dict)         # aliasparam alias = parameter
     param_kind: Dict[str, str] = field(default_factory=dict)          # parameter -> "real" | "integer" | "string"
     func_dirs: Dict[str, list] = field(default_factory=dict)          # analog function -> direction of every argument ("in" | "out" | "inout")
+    uses_given: bool = False                                          # the module asks $param_given(...): instances carry one flag per parameter
+    string_tests: List[tuple] = field(default_factory=list)           # (string parameter, literal) pairs the module compares: one host-evaluated flag each
     source: str = ""
 
     @property
@@ -292,6 +294,9 @@ class VAModule:
     def shape(self):
         N, B, L = self.n_nodes, len(self.branches), len(self.limit_branches)
         n_par = len(self.params) + 3        # + temperature [K], mfactor, gmin
+        if self.uses_given:
+            n_par += len(self.params)       # + one $param_given flag per parameter
+        n_par += len(self.string_tests)     # + one flag per (string parameter == literal) test
         return (N + B + L, 2 * N * B + (N + 1) * B + 3 * L, 2 * B + 2 * N * B, 3 * B, n_par, 2)
 
     def program(self, vdep):
@@ -1223,6 +1228,27 @@ def _analyse(m: VAModule):
     for s in _walk(m.body):
         if s[0] == "contrib" and not only_noise(s[3]) and is_react(s[3]):
             m.reactive[m.branches.index((node(s[1]), node(s[2])))] = True
+    def has_given(e):
+        if e[0] == "given":
+            return True
+        return any(has_given(a) for sub in e[1:] for a in (sub if isinstance(sub, list) else [sub])
+                   if isinstance(a, tuple) and a and isinstance(a[0], str) and a[0] != "str")
+    def string_tests(e):
+        if e[0] == "bin" and e[1] in ("==", "!="):
+            for x, y in ((e[2], e[3]), (e[3], e[2])):
+                if x[0] == "var" and m.param_kind.get(x[1]) == "string" and y[0] == "str" and (x[1], y[1]) not in m.string_tests:
+                    m.string_tests.append((x[1], y[1]))
+        for sub in e[1:]:
+            for a in (sub if isinstance(sub, list) else [sub]):
+                if isinstance(a, tuple) and a and isinstance(a[0], str) and a[0] != "str":
+                    string_tests(a)
+    bodies = [m.body] + [f[2] for f in m.functions.values()]
+    for body in bodies:
+        for st in _walk(body):
+            for e in ([st] if st[0] == "callstmt" else _subexprs(st)):
+                string_tests(e)
+    m.uses_given = any(has_given(e) for body in bodies for st in _walk(body) for e in ([st] if st[0] == "callstmt" else _subexprs(st))) \
+        or any(has_given(ie) for _, ie in m.local_init)
     m.is_dual, m.is_react, m.node_index = is_dual, is_react, node
     return m
 

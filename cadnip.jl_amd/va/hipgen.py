@@ -11,9 +11,11 @@ are the hand-written ``va_emit_branch`` in devices.hpp.
 """
 import sys
 
-from .frontend import VAError, parse_module
+from .frontend import VAError, parse_file, parse_module
 
 K_OVER_Q = 1.380649e-23 / 1.602176634e-19
+# $simparam names that are MNASpec fields (vasim.jl:1190-1218) and are the same for every instance of a handle
+SPEC_CONST = {"tnom": 27.0, "gshunt": 0.0, "srcFact": 1.0, "abstol": 1e-12, "reltol": 1e-3, "vntol": 1e-6, "iabstol": 1e-12}
 
 
 def _lit(x):
@@ -40,6 +42,25 @@ class _Gen:
         m, k = self.m, e[0]
         if k == "num":
             return _lit(e[1]), False, None
+        if k == "str":
+            raise VAError("%s: a string value has no meaning on the device" % m.name)
+        if k == "given":
+            pn = m.aliasparams.get(e[1], e[1])
+            return "(g_%s != 0.0 ? 1.0 : 0.0)" % pn, False, None
+        if k == "analysis":
+            # vasim.jl:1220-1250: "dc" / "static" <-> :dcop (mode 0), "tran" / "transient" <-> :tran (mode 1); :tranop is neither
+            tests = []
+            if any(a in ("dc", "static") for a in e[1]):
+                tests.append("sys.mode == 0")
+            if any(a in ("tran", "transient") for a in e[1]):
+                tests.append("sys.mode == 1")
+            return "((%s) ? 1.0 : 0.0)" % (" || ".join(tests) if tests else "false"), False, None
+        if k in ("noise", "Iprobe"):
+            return "0.0", False, None
+        if k == "ddx":
+            c, t, _ = self.g(e[1])
+            a = m.node_index(e[2])
+            return ("va_ddx(%s, %d)" % (c, a)) if (t and a >= 0) else "0.0", False, None
         if k == "var":
             if self.func:
                 return "f_" + e[1], True, None
@@ -47,13 +68,7 @@ class _Gen:
                 return "p_" + e[1], False, None
             return "v_" + e[1], m.var_is_dual[e[1]], ("v_%s_q" % e[1]) if m.var_is_reactive[e[1]] else None
         if k == "ucall":
-            args = [self.g(a) for a in e[2]]
-            t = any(a[1] for a in args)
-            if self.func:
-                return "%s<X>(%s, sys)" % (self.fname(e[1]), ", ".join(self.T(a[0], a[1]) for a in args)), True, None
-            if t:
-                return "%s<T>(%s, sys)" % (self.fname(e[1]), ", ".join(self.T(a[0], a[1]) for a in args)), True, None
-            return "%s<double>(%s, sys)" % (self.fname(e[1]), ", ".join(a[0] for a in args)), False, None
+            return self.call(e[1], e[2])
         if k == "limit":
             # vasim.jl:1258-1330: w = limiter(vnew, vold, args...) on values; the site's dual is anchored at w, keeps the
             # probe's node partials and owns partial N + j
@@ -78,7 +93,9 @@ class _Gen:
         if k == "un":
             c, t, q = self.g(e[2])
             if e[1] == "!":
-                return "(!va_true(%s))" % c, False, None
+                return "(va_true(%s) ? 0.0 : 1.0)" % c, False, None
+            if e[1] == "~":
+                return "(double)(~(long long)va_val(%s))" % c, False, None
             return "(-%s)" % c, t, ("(-%s)" % q) if q else None
         if k == "cond":
             cc = self.g(e[1])[0]
@@ -92,7 +109,7 @@ class _Gen:
             return r, t, q
         if k == "call":
             args = [self.g(a) for a in e[2]]
-            return "va_%s(%s)" % (e[1], ", ".join(a[0] for a in args)), any(a[1] for a in args), None
+            return "va_%s(%s)" % (e[1], ", ".join(a[0] for a in args)), any(a[1] for a in args) and e[1] not in ("floor", "ceil", "int"), None
         if k == "sys":
             if e[1] == "$temperature":
                 return "sys.temp", False, None
@@ -103,14 +120,24 @@ class _Gen:
                     c, t, _ = self.g(e[2][0])
                     return "(%s * %s)" % (_lit(K_OVER_Q), c), t, None
                 return "(%s * sys.temp)" % _lit(K_OVER_Q), False, None
-            if e[2] and e[2][0] == ("str", "gmin"):
+            if e[1] in ("$abstime", "$realtime"):
+                return "sys.time", False, None
+            name = e[2][0][1] if e[2] and e[2][0][0] == "str" else None
+            if name == "gmin":
                 return "sys.gmin", False, None
-            if e[2] and e[2][0] == ("str", "initjct"):
+            if name in ("initjct", "iniLim"):
                 return "sys.initjct", False, None
+            if name in SPEC_CONST:
+                return _lit(SPEC_CONST[name]), False, None
             if len(e[2]) > 1:
                 return self.g(e[2][1])
-            raise VAError("$simparam(%r) has no value on the device" % (e[2][0][1] if e[2] else ""))
+            raise VAError("$simparam(%r) has no value on the device" % name)
         op = e[1]
+        if op in ("==", "!="):                       # a string parameter against a literal: decided on the host, one flag per test
+            for x, y in ((e[2], e[3]), (e[3], e[2])):
+                if x[0] == "var" and m.param_kind.get(x[1]) == "string" and y[0] == "str":
+                    i = m.string_tests.index((x[1], y[1]))
+                    return "(st_%d %s 0.0 ? 1.0 : 0.0)" % (i, "!=" if op == "==" else "=="), False, None
         l, tl, ql = self.g(e[2])
         r, tr, qr = self.g(e[3])
         if op in ("+", "-"):
@@ -128,13 +155,74 @@ class _Gen:
         if op == "/":
             return "(%s / %s)" % (l, r), tl or tr, ("(%s / %s)" % (ql, r)) if ql else None
         if op in ("&&", "||"):
-            return "(va_true(%s) %s va_true(%s))" % (l, op, r), False, None
-        return "(va_val(%s) %s va_val(%s))" % (l, op, r), False, None
+            return "((va_true(%s) %s va_true(%s)) ? 1.0 : 0.0)" % (l, op, r), False, None
+        if op == "%":
+            return "fmod(va_val(%s), va_val(%s))" % (l, r), False, None
+        if op in ("&", "|", "^", "<<", ">>"):
+            return "(double)((long long)va_val(%s) %s (long long)va_val(%s))" % (l, op, r), False, None
+        return "((va_val(%s) %s va_val(%s)) ? 1.0 : 0.0)" % (l, op, r), False, None
+
+    def call(self, fname, arg_exprs):
+        """an analog-function call; output / inout arguments are passed by reference (they are variables of the call's
+        numeric type: _analyse types a variable as a dual as soon as one call writes a dual into it)"""
+        m = self.m
+        dirs = m.func_dirs.get(fname) or ["in"] * len(arg_exprs)
+        args = [self.g(a) for a in arg_exprs]
+        dual = self.func is not None or any(a[1] for a in args)
+        ty = ("X" if self.func else "T") if dual else "double"
+        parts = []
+        for a, d, ex in zip(args, dirs, arg_exprs):
+            if d == "in":
+                parts.append(self.T(a[0], a[1]) if dual else a[0])
+            else:
+                if ex[0] != "var":
+                    raise VAError("%s: %s: an output argument must be a variable" % (m.name, fname))
+                if not self.func and bool(m.var_is_dual.get(ex[1], False)) != dual:
+                    raise VAError("%s: %s: output argument %s is %s, the call is %s" % (m.name, fname, ex[1],
+                                  "a dual" if m.var_is_dual.get(ex[1]) else "a plain number", "on duals" if dual else "on plain numbers"))
+                parts.append(a[0])
+        return "%s<%s>(%s)" % (self.fname(fname), ty, ", ".join(parts + ["sys"])), dual, None
 
     def stmts(self, body, ind):
         m, pad = self.m, "  " * ind
         for s in body:
-            if s[0] == "assign":
+            if s[0] == "callstmt":
+                c = self.call(s[1], s[2])[0]
+                self.flush(pad)
+                self.lines.append("%s(void)%s;" % (pad, c))
+            elif s[0] == "fatal":
+                self.lines.append("%s// %s: not raised on the device (the host evaluation of the instance's parameters raises it)" % (pad, s[1]))
+            elif s[0] == "case":
+                sel = self.g(s[1])[0]
+                self.flush(pad)
+                self.lines.append("%s{ const double case_sel = va_val(%s);" % (pad, sel))
+                first = True
+                default = None
+                for vals, body_ in s[2]:
+                    if vals is None:
+                        default = body_
+                        continue
+                    cond = " || ".join("case_sel == va_val(%s)" % self.g(v)[0] for v in vals)
+                    self.lines.append("%s%sif (%s) {" % (pad, "" if first else "} else ", cond))
+                    first = False
+                    self.stmts([body_], ind + 1)
+                if default is not None:
+                    self.lines.append("%s%s{" % (pad, "" if first else "} else "))
+                    self.stmts([default], ind + 1)
+                    first = False
+                if not first:
+                    self.lines.append("%s}" % pad)
+                self.lines.append("%s}" % pad)
+            elif s[0] == "while":
+                self.lines.append("%swhile (va_true(%s)) {" % (pad, self.g(s[1])[0]))
+                self.stmts([s[2]], ind + 1)
+                self.lines.append("%s}" % pad)
+            elif s[0] == "for":
+                self.stmts([s[1]], ind)
+                self.lines.append("%swhile (va_true(%s)) {" % (pad, self.g(s[2])[0]))
+                self.stmts([s[4], s[3]], ind + 1)
+                self.lines.append("%s}" % pad)
+            elif s[0] == "assign":
                 c, t, q = self.g(s[2])
                 self.flush(pad)
                 if self.func:
@@ -144,6 +232,8 @@ class _Gen:
                 if m.var_is_reactive[s[1]]:
                     self.lines.append("%sv_%s_q = %s;" % (pad, s[1], q or "T(0.0)"))
             elif s[0] == "contrib":
+                if s[3][0] == "noise":
+                    continue                                  # noise sources: no current on the DC / transient path
                 b = m.branches.index((m.node_index(s[1]), m.node_index(s[2])))
                 c, t, q = self.g(s[3])
                 self.flush(pad)
@@ -173,20 +263,24 @@ _Gen.flush = _flush
 
 
 def generate_analog_functions(m):
-    """``template <class X> X vaf_<module>_<name>(X inputs..., const VaSys& sys)`` per analog function: instantiated
-    with double ($limit limiters, voltage-independent calls) and with the module's dual type."""
-    out = []
-    for fname, (f_in, f_loc, f_body) in m.functions.items():
+    """``template <class X> X vaf_<module>_<name>(X inputs..., X& outputs..., const VaSys& sys)`` per analog function:
+    instantiated with double ($limit limiters, voltage-independent calls) and with the module's dual type.  Functions may
+    call each other in any order: all are declared before the first is defined."""
+    out, defs = [], []
+    for fname, (f_args, f_loc, f_body) in m.functions.items():
+        dirs = m.func_dirs.get(fname) or ["in"] * len(f_args)
+        sig = "__device__ inline X vaf_%s_%s(%s)" % (m.name, fname, ", ".join(["X%s f_%s" % ("" if d == "in" else "&", a) for a, d in zip(f_args, dirs)] + ["const VaSys& sys"]))
+        out.append("template <class X> %s;" % sig)
         g = _Gen(m, func=fname)
-        out.append("template <class X>")
-        out.append("__device__ inline X vaf_%s_%s(%s) {" % (m.name, fname, ", ".join(["X f_%s" % a for a in f_in] + ["const VaSys& sys"])))
+        defs.append("template <class X>")
+        defs.append(sig + " {")
         for v in f_loc + [fname]:
-            out.append("  X f_%s = 0.0;" % v)
+            defs.append("  X f_%s = 0.0;" % v)
         g.stmts(f_body, 1)
-        out.extend(g.lines)
-        out.append("  return f_%s;" % fname)
-        out.append("}")
-    return "\n".join(out)
+        defs.extend(g.lines)
+        defs.append("  return f_%s;" % fname)
+        defs.append("}")
+    return "\n".join(out + defs)
 
 
 def generate_function(m):
@@ -211,8 +305,15 @@ def generate_function(m):
     for k in range(N):
         L.append("  const T V%d = T::seed(Vf[%d], %d);   // V(%s)" % (k, k, k, m.nodes[k]))
     for i, p in enumerate(m.params):
+        if m.param_kind.get(p) == "string":
+            continue
         L.append("  const double p_%s = par_of(d, %d);" % (p, i))
-    L.append("  const VaSys sys{par_of(d, %d), par_of(d, %d), par_of(d, %d), d.initjct ? 1.0 : 0.0};   // $temperature, $mfactor, gmin, initjct" % (NP, NP + 1, NP + 2))
+    L.append("  const VaSys sys{par_of(d, %d), par_of(d, %d), par_of(d, %d), d.initjct ? 1.0 : 0.0, d.mode, d.t};   // $temperature, $mfactor, gmin, initjct, analysis(), $abstime" % (NP, NP + 1, NP + 2))
+    if m.uses_given:
+        for i, p in enumerate(m.params):
+            L.append("  const double g_%s = par_of(d, %d);   // $param_given(%s)" % (p, NP + 3 + i, p))
+    for i, (p, lit) in enumerate(m.string_tests):
+        L.append("  const double st_%d = par_of(d, %d);   // %s == \"%s\"" % (i, NP + 3 + (NP if m.uses_given else 0) + i, p, lit))
     L.append("  double ld[S > 0 ? S : 1] = {0.0};    // per $limit site: V(probe) - w, the lim_rhs delta (vasim.jl:2957-2966)")
     for lb, (p, n) in enumerate(m.limit_branches):
         L.append("  const double vold%d = u[nd[N + B + %d]];   // limit unknown of probe branch (%s,%s)" % (
@@ -224,6 +325,7 @@ def generate_function(m):
             L.append("  T v_%s_q = 0.0;" % v)
     for b in range(B):
         L.append("  T br%d_r = 0.0, br%d_q = 0.0;" % (b, b))
+    g.stmts([("assign", nm, ie) for nm, ie in m.local_init], 1)       # module-scope initialisers, in declaration order
     g.stmts(m.body, 1)
     L.append("  const int vdep = d.ipar[1 * d.count + d.dev];   // bit b: branch b uses a charge unknown")
     for b, ((p, n), r) in enumerate(zip(m.branches, m.reactive)):
@@ -269,7 +371,7 @@ def generate_header(modules):
 
 
 def main(argv):
-    mods = [parse_module(open(fn).read()) for fn in argv]
+    mods = [parse_file(fn) for fn in argv]
     sys.stdout.write(generate_header(mods))
 
 

@@ -284,7 +284,8 @@ def static_eval(e, par, temp_k=300.15, mfactor=1.0, gmin=1e-12):
 def defaults(m, given=None):
     """All parameter values of an instance: ``given`` overrides, the rest from the declarations (which may refer to
     earlier parameters)."""
-    given = {k.lower(): v for k, v in (given or {}).items()}
+    alias = {a.lower(): t.lower() for a, t in m.aliasparams.items()}
+    given = {alias.get(k.lower(), k.lower()): v for k, v in (given or {}).items()}      # aliasparam a = p: a sets p
     unknown = set(given) - {p.lower() for p in m.params}
     if unknown:
         raise VAError("%s has no parameter %s" % (m.name, ", ".join(sorted(unknown))))

@@ -123,7 +123,7 @@ def make_builder(devices):
                 from cadnip_jl_amd import va
                 mod = va.get(ty[3:])[1]
                 par = va.host_eval.defaults(mod, {k: _num(v, params) for k, v in dev["model"].items()})
-                stamp_va(ctx, mod, nodes, x, par, spec, name, mfactor=g("m", 1.0))
+                stamp_va(ctx, mod, nodes, x, par, spec, name, mfactor=g("m", 1.0), given=set(dev["model"]))
             else:
                 raise ValueError("unknown device type %r" % ty)
         return ctx

@@ -204,11 +204,24 @@ def ring_checks(v):
     return lo, hi, crossings
 
 
+def va_feat():
+    """Two instances of va_feat (cadnip.jl_amd/va/models): one with tc given (so $param_given differs between them), level 1 and
+    the internal node collapsed; one at level 3 with a series resistance (genuine internal node), through the alias gg."""
+    c = cj.Circuit("va_feat")
+    c.V("v1", "in", "0", dc=1.0)
+    c.R("r1", "in", "p", 50.0)
+    c.VA("x1", "va_feat", ("p", "q", "r"), g0=2e-3, tc=1e-3, cj=2e-12)
+    c.VA("x2", "va_feat", ("q", "0", "r"), gg=5e-4, rs=5.0, lev=3)
+    c.R("r2", "r", "0", 1e3)
+    c.R("r3", "q", "0", 2e3)
+    return c
+
+
 ALL_STAMP = {
     "divider": (divider, {}), "linear_zoo": (linear_zoo, {}), "diode": (diode_rectifier, {}),
     "diode_nolimit": (lambda: diode_rectifier(False), {}), "diode_chain": (diode_chain, {}),
     "nonlinear_zoo": (nonlinear_zoo, {}), "behavioral": (behavioral, {}), "inverter": (inverter_dc, {}), "mos1_rd": (mos1_rd, {}),
-    "va_zoo": (va_zoo, {}), "va_limited": (va_limited, {}), "va_mos_inverter": (va_mos_inverter, {}),
+    "va_zoo": (va_zoo, {}), "va_feat": (va_feat, {}), "va_limited": (va_limited, {}), "va_mos_inverter": (va_mos_inverter, {}),
     "va_mos_inverter_rd": (lambda: va_mos_inverter(rd=40.0), {}),
     "dff": (bm.dff_circuit, {"vdd": 5.0}), "dff_meyer": (lambda: bm.dff_circuit(meyer=True), {"vdd": 5.0}),
 }
