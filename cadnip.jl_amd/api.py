@@ -232,7 +232,7 @@ def clip_sample(J, headroom=1e6):
 class BatchSimulator:
     """One structure, B resident sweep instances on one GPU."""
 
-    def __init__(self, mc: MNACircuit, points: Optional[List[Dict[str, Any]]] = None, device: int = 0):
+    def __init__(self, mc: MNACircuit, points: Optional[List[Dict[str, Any]]] = None, device: int = 0, st: Optional[Structure] = None):
         from . import hip
         self.mc = mc
         points = points if points else [{}]
@@ -249,7 +249,7 @@ class BatchSimulator:
                     params[k][i] = float(v)
         self.params, self.temps = params, temps
         p0 = {k: float(v[0]) for k, v in params.items()}
-        self.st = discover(mc.circuit, p0)
+        self.st = st if st is not None else discover(mc.circuit, p0)
         self.h = hip.Handle(self.st, B, device)
         self.h.set_params(pack_params(self.st, mc.circuit, params, temps, B, gmin=mc.spec.gmin, tnom_c=mc.spec.tnom))
         self.h.set_spec(mode=mc.spec.mode if mc.spec.mode in ("dcop", "tran", "tranop") else "tran",
@@ -304,11 +304,43 @@ class BatchSimulator:
         self.h.analyze_values(self.h.jacobian(gamma)[instance])
         self._analyzed = True
 
-    def dc(self, u0=None, abstol=1e-10, maxiters=100, mode="dcop", fused=False):
+    def dc(self, u0=None, abstol=1e-10, maxiters=100, mode="dcop", fused=False, participate=None, cold_start=None):
         self.h.set_spec(mode=mode)
         if not self._analyzed:
             self.analyze()
-        return self.h.dc_run(u0, abstol=abstol, maxiters=maxiters, use_pcnr=True, cold_start=u0 is None, fused=fused)
+        return self.h.dc_run(u0, abstol=abstol, maxiters=maxiters, use_pcnr=True, cold_start=(u0 is None) if cold_start is None else cold_start,
+                             fused=fused, participate=participate)
+
+    def dc_continuation(self, abstol=1e-10, maxiters=100, mode="dcop", fused=False):
+        """dc!(cs; continuation=true) (sweeps.jl:489-532) for a resident batch.  The reference walks the sweep serially and
+        starts every point from the last CONVERGED solution.  Here the sweep is solved in 1 + ceil(log2 B) batch stages
+        (``continuation_stages``): point 0 cold, then the midpoints, quarter points, ... each started from the nearest
+        converged point of the earlier stages at a lower index (the reference's direction), else the nearest converged
+        one at all, else cold.  Continuation changes the path Newton takes, not where it lands (test/sweep.jl:332-345);
+        a point that failed is never a starting guess (sweeps.jl:522-524).  Returns (u, converged, stats)."""
+        st = self.st
+        u = np.zeros((self.B, st.n))
+        conv = np.zeros(self.B, dtype=bool)
+        solved = np.zeros(self.B, dtype=bool)
+        total = {"newton_iters": 0, "stages": 0, "cold_points": 0}
+        for stage in continuation_stages(self.B):
+            start = np.zeros((self.B, st.n))
+            mask = np.zeros(self.B, dtype=bool)
+            mask[stage] = True
+            good = np.flatnonzero(solved & conv)
+            for i in stage:
+                j = seed_for(i, good)
+                if j is None:
+                    total["cold_points"] += 1                    # zeros: dc_run seeds the limit variables and arms initjct for it
+                else:
+                    start[i] = u[j]
+            start[~mask] = u[~mask]
+            ui, ci, stats = self.dc(start, abstol=abstol, maxiters=maxiters, mode=mode, fused=fused, participate=mask, cold_start=True)
+            u[mask], conv[mask] = ui[mask], ci[mask]
+            solved |= mask
+            total["newton_iters"] += stats["newton_iters"]
+            total["stages"] += 1
+        return u, conv, total
 
     def tran(self, tspan, abstol, reltol, saveat, initializealg="tranop", u0=None, warmup_dt=1e-12, **kw):
         """``initializealg``: "tranop" = CedarTranOp, a DC solve in :tranop mode at t0 (dcop.jl:160-212); "uic" = CedarUICOp
@@ -345,6 +377,60 @@ class BatchSimulator:
         return out, per, stats
 
 
+def continuation_stages(n):
+    """Index sets of the staged continuation: [0], then for stride s = 2^k (largest first) the indices i = s (mod 2s): each
+    lies midway between two indices of the earlier stages, and i - s is always among them."""
+    if n <= 0:
+        return []
+    stages = [[0]]
+    s = 1
+    while s < n:
+        s *= 2
+    s //= 2
+    while s >= 1:
+        idx = list(range(s, n, 2 * s))
+        if idx:
+            stages.append(idx)
+        s //= 2
+    return stages
+
+
+def seed_for(i, good):
+    """the converged point a staged-continuation point starts from: the nearest one below it, else the nearest at all"""
+    good = np.asarray(good)
+    if good.size == 0:
+        return None
+    below = good[good < i]
+    if below.size:
+        return int(below[-1])
+    return int(good[np.argmin(np.abs(good - i))])
+
+
+def structure_classes(mc: MNACircuit, points):
+    """Partition sweep points by circuit STRUCTURE (unknowns, pattern, slot maps): a sweep may move a parameter across a
+    value that changes it -- a series resistance reaching zero collapses an internal node (mos1.va:716-721,
+    vasim.jl:3537-3553), a junction capacitance reaching zero removes a charge unknown (contrib.jl:214-257).  The reference
+    rebuilds every point from scratch; here every class gets its own resident batch.  Discovery runs once per distinct
+    value tuple of the parameters that device MODEL cards refer to (sweeping a source value or the temperature never
+    changes the structure).  Returns [(point indices, Structure)]."""
+    from .circuit import Param
+    model_pars = sorted({v.name for d in mc.circuit.devices if d.model for v in d.model.values() if isinstance(v, Param)})
+    classes, by_key, sig_class = [], {}, {}
+    for i, pt in enumerate(points):
+        p = dict(mc.params)
+        p.update({k: v for k, v in pt.items() if k != "temp"})
+        key = tuple(float(p[k]) for k in model_pars)
+        if key not in by_key:
+            st = discover(mc.circuit, {k: float(v) for k, v in p.items()})
+            sig = st.signature()
+            if sig not in sig_class:
+                sig_class[sig] = len(classes)
+                classes.append(([], st))
+            by_key[key] = sig_class[sig]
+        classes[by_key[key]][0].append(i)
+    return classes
+
+
 def _resolve_abstol(abstol, st):
     """_resolve_abstol (sweeps.jl:626): per-class NamedTuple -> vector via state_abstol."""
     if isinstance(abstol, dict):
@@ -352,18 +438,25 @@ def _resolve_abstol(abstol, st):
     return np.broadcast_to(np.asarray(abstol, dtype=float), (st.n,)).copy()
 
 
-def dc(target, u0=None, device=0):
-    """dc!(circuit) / dc!(cs::CircuitSweep) -- sweeps.jl:450-455, 511-532.  Goes through with_mode(:dcop),
-    which keeps only temp+mode of the spec (solve.jl:1976-1989)."""
+def dc(target, u0=None, device=0, continuation=True):
+    """dc!(circuit) / dc!(cs::CircuitSweep; continuation=true) -- sweeps.jl:450-455, 489-532.  Goes through
+    with_mode(:dcop), which keeps only temp+mode of the spec (solve.jl:1976-1989).  A sweep is partitioned by structure
+    (``structure_classes``); each class is one resident batch, solved with the staged continuation or as independent cold
+    solves (``continuation=False``: e.g. circuits with several DC solutions)."""
     if isinstance(target, CircuitSweep):
         mc = target.circuit
         mc = MNACircuit(mc.circuit, mc.params, MNASpec(temp=mc.spec.temp, mode="dcop"))
-        sim = BatchSimulator(mc, target.points(), device)
-        try:
-            u, conv, _ = sim.dc()
-            return SweepResult(target.points(), [DCSolution(sim.st, u[i], conv[i]) for i in range(sim.B)])
-        finally:
-            sim.close()
+        pts = target.points()
+        sols = [None] * len(pts)
+        for idx, st in structure_classes(mc, pts):
+            sim = BatchSimulator(mc, [pts[i] for i in idx], device, st=st)
+            try:
+                u, conv, _ = sim.dc_continuation() if continuation else sim.dc()
+                for k, i in enumerate(idx):
+                    sols[i] = DCSolution(sim.st, u[k], conv[k])
+            finally:
+                sim.close()
+        return SweepResult(pts, sols)
     mc = MNACircuit(target.circuit, target.params, MNASpec(temp=target.spec.temp, mode="dcop"))
     sim = BatchSimulator(mc, None, device)
     try:

@@ -163,11 +163,12 @@ int cadnip_create(const CadnipStructure* s, int32_t n_instances, int32_t device,
   CREATE_TRY(dev_alloc(&h->d_J, B * nnz)); CREATE_TRY(dev_alloc(&h->d_resid, B * n)); CREATE_TRY(dev_alloc(&h->d_delta, B * n));
   CREATE_TRY(dev_alloc(&h->d_limit_w, B * n)); CREATE_TRY(dev_alloc(&h->d_tmp, B * n));
   CREATE_TRY(dev_alloc(&h->d_flags, B)); CREATE_TRY(dev_alloc(&h->d_active, B)); CREATE_TRY(dev_alloc(&h->d_nonfinite, B));
-  CREATE_TRY(dev_alloc(&h->d_gshunt, B)); CREATE_TRY(dev_alloc(&h->d_srcfact, B));
+  CREATE_TRY(dev_alloc(&h->d_gshunt, B)); CREATE_TRY(dev_alloc(&h->d_srcfact, B)); CREATE_TRY(dev_alloc(&h->d_cold, B));
   CREATE_TRY(upload_homotopy(h, nullptr, nullptr));
   CREATE_TRY(build_stamp_plan(h, s));
   std::vector<int> ones(B, 1);
   CREATE_HIP_TRY(hipMemcpy(h->d_active, ones.data(), B * sizeof(int), hipMemcpyHostToDevice));
+  CREATE_HIP_TRY(hipMemcpy(h->d_cold, ones.data(), B * sizeof(int), hipMemcpyHostToDevice));
   *out = h;
   return CADNIP_OK;
 }
@@ -181,7 +182,7 @@ void cadnip_destroy(CadnipHandle* h) {
   cadnip_driver_free(h);
   void* ptrs[] = {h->d_rowptr, h->d_colidx, h->d_to_ref, h->d_g_ptr, h->d_g_slots, h->d_c_ptr, h->d_c_slots, h->d_b_ptr, h->d_b_slots,
                   h->d_diag_flag, h->d_prep, h->d_long_rows, h->d_wave, h->d_limit_init, h->d_u, h->d_du, h->d_t, h->d_gamma, h->d_G, h->d_C, h->d_b, h->d_J,
-                  h->d_resid, h->d_delta, h->d_limit_w, h->d_LU, h->d_tmp, h->d_flags, h->d_active, h->d_nonfinite, h->d_gshunt, h->d_srcfact, h->d_load_src, h->d_load_dst, h->d_ent_pos,
+                  h->d_resid, h->d_delta, h->d_limit_w, h->d_LU, h->d_tmp, h->d_flags, h->d_active, h->d_nonfinite, h->d_gshunt, h->d_srcfact, h->d_cold, h->d_load_src, h->d_load_dst, h->d_ent_pos,
                   h->d_ent_diag, h->d_ent_ptr, h->d_term_a, h->d_term_b, h->d_lev_ptr, h->d_lu_rowptr, h->d_lu_col, h->d_lu_diag, h->d_rperm,
                   h->d_cperm, h->d_fwd_rows, h->d_fwd_lev_ptr, h->d_bwd_rows, h->d_bwd_lev_ptr};
   for (void* p : ptrs) if (p) (void)hipFree(p);

@@ -119,7 +119,7 @@ __global__ void k_count_running(const int* status, int B, int* nactive) {
 // ------------------------------------------------------------------------------------------
 struct DCArgs {
   double *u, *resid, *delta, *limit_w; const double* limit_init;
-  int *active, *flags, *status, *dcstate, *action; long long* cnt;
+  int *active, *flags, *status, *dcstate, *action, *cold; long long* cnt;
   int B, n, n_limits, use_pcnr, maxiters; double abstol;
 };
 
@@ -138,6 +138,9 @@ __global__ void __launch_bounds__(64) k_dc_init(DCArgs a, int cold_start, const 
   // cold start (iszero(u0)): seed the limit variables (solve.jl:620-625)
   if (cold_start && !nz && a.use_pcnr)
     for (int k = tid; k < a.n_limits; k += 64) u[n - a.n_limits + k] = a.limit_init[k];
+  // initjct (armed by the host for the first stamping of the run) applies to the instances that start cold; a warm start --
+  // a sweep point continued from its neighbour's solution -- is stamped at its start state (solve.jl:615-625)
+  if (tid == 0) a.cold[inst] = (cold_start && !nz) ? 1 : 0;
   if (tid == 0) { a.status[inst] = 0; a.dcstate[inst] = 0; a.action[inst] = 0; a.active[inst] = 1; a.flags[inst] = 0; for (int c = 0; c < 4; ++c) a.cnt[(size_t)inst * 4 + c] = 0; }
 }
 
@@ -208,7 +211,7 @@ int count_running(CadnipHandle* h, int* out) {
 // one DC Newton run on the whole batch with the handle's current spec; returns per-instance status in drv->status
 int dc_newton(CadnipHandle* h, double abstol, int maxiters, int use_pcnr, int cold_start, long long* iters_total, int fused = 0, const int* d_part = nullptr) {
   Driver* d = h->drv;
-  DCArgs a{h->d_u, h->d_resid, h->d_delta, h->d_limit_w, h->d_limit_init, h->d_active, h->d_flags, d->status, d->dcstate, d->action, d->cnt,
+  DCArgs a{h->d_u, h->d_resid, h->d_delta, h->d_limit_w, h->d_limit_init, h->d_active, h->d_flags, d->status, d->dcstate, d->action, h->d_cold, d->cnt,
            h->B, h->n, h->n_limits, (use_pcnr && h->n_limits > 0) ? 1 : 0, maxiters, abstol};
   hipLaunchKernelGGL(k_dc_init, dim3(h->B), dim3(64), 0, h->stream, a, cold_start, d_part);
   HIP_TRY(hipMemsetAsync(h->d_gamma, 0, (size_t)h->B * sizeof(double), h->stream));
@@ -343,7 +346,9 @@ int cadnip_dc_run(CadnipHandle* h, const CadnipDCOpts* o, double* u_host, int32_
   } guard{h};
   const std::vector<double> start(u_host, u_host + B * n);
   std::vector<double> U(start), R(B * n);          // per-instance start state of the next run / states after the last run
-  std::vector<int> fin(B, 0), status(B), part(B, 1);
+  std::vector<int> fin(B, 0), status(B), part(B, 1), out_of_run(B, 0);
+  if (o->participate)
+    for (size_t i = 0; i < B; ++i) if (!o->participate[i]) { part[i] = 0; out_of_run[i] = 1; fin[i] = 1; }   // (fin: no stage picks them up)
   std::vector<long long> cnt(B * 4);
   std::vector<double> gsh(B, h->spec.gshunt), sfc(B, h->spec.srcFact);
   long long iters = 0;
@@ -365,7 +370,7 @@ int cadnip_dc_run(CadnipHandle* h, const CadnipDCOpts* o, double* u_host, int32_
   const std::vector<double> none(B, 0.0);
   // ---- stage 0: PCNR (or plain Newton) from the caller's start point
   TRY(run(o->use_pcnr, o->cold_start, o->fused, 0, none));
-  for (size_t i = 0; i < B; ++i) { take(i); if (status[i] == 1) fin[i] = 1; }
+  for (size_t i = 0; i < B; ++i) if (part[i]) { take(i); if (status[i] == 1) fin[i] = 1; }
   // ---- stage 1: plain Newton from the caller's start point, for those PCNR did not solve
   if (n_open() && o->use_pcnr && h->n_limits > 0) {
     for (size_t i = 0; i < B; ++i) { part[i] = !fin[i]; if (part[i]) std::copy(start.begin() + i * n, start.begin() + (i + 1) * n, U.begin() + i * n); }
@@ -455,10 +460,11 @@ int cadnip_dc_run(CadnipHandle* h, const CadnipDCOpts* o, double* u_host, int32_
   const int n_failed = n_open();
   memcpy(u_host, U.data(), B * n * sizeof(double));
   HIP_TRY(hipMemcpy(h->d_u, U.data(), B * n * sizeof(double), hipMemcpyHostToDevice));
-  if (converged_host) for (size_t i = 0; i < B; ++i) converged_host[i] = fin[i];
-  // leave every instance active for subsequent ABI calls
+  if (converged_host) for (size_t i = 0; i < B; ++i) converged_host[i] = out_of_run[i] ? 0 : fin[i];
+  // leave every instance active for subsequent ABI calls (and subject to a cadnip_set_initjct of the caller's)
   std::vector<int> ones(B, 1);
   HIP_TRY(hipMemcpy(h->d_active, ones.data(), B * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_cold, ones.data(), B * sizeof(int), hipMemcpyHostToDevice));
   if (st) {
     memset(st, 0, sizeof(*st));
     st->newton_iters = iters;

@@ -218,7 +218,7 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
   f.tab_len = h->f2len;
   f.n = h->n; f.nnz = h->nnz; f.nnz_lu = h->f2_lu_words;
   f.n_pre = h->f2_n_pre; f.n_post = h->f2_n_post; f.nc = h->f2_nc; f.dn0 = h->f2_dn0;
-  f.rounds = rounds; f.B = h->B; f.t = t;
+  f.rounds = rounds; f.B = h->B; f.t = t; f.cold = h->d_cold;
   f.dc_abstol = 0; f.dc_maxiters = 0; f.dc_pcnr = 0; f.dc_mode = 1; f.dc_initjct = 0; f.dcstate = nullptr;
   if (dc) { f.dc_abstol = dc->abstol; f.dc_maxiters = dc->maxiters; f.dc_pcnr = dc->use_pcnr; f.dc_mode = dc->mode; f.dc_initjct = dc->initjct; f.dcstate = dc->dcstate; }
   const size_t tab_dbl = (size_t)h->f2len / 2;

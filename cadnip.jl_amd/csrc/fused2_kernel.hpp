@@ -49,6 +49,7 @@ struct F2Args {
   int n_pre, n_post, nc, dn0;       // passes before / after the dense core solve, core size, first word of the core block
   // DC mode (k_fused2<WPB, true>): PCNR / plain Newton on G u = b (driver.hip: k_dc_check, k_dc_update)
   double dc_abstol; int dc_maxiters, dc_pcnr, dc_mode, dc_initjct; int* dcstate;
+  const int* cold;           // [B] DC mode: 1 = the instance starts cold (initjct applies to it), driver.hip: k_dc_init
   int* queue;                // next not-yet-resident instance (relative to gridDim.x * WPB); zeroed before every launch
   TranArgs t;
 };
@@ -406,7 +407,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
   }
   // DC state of this instance: settle flag of the PCNR loop (solve.jl:640-657), Newton solves done in this launch
   int dc_state = 0, dc_iters = 0, dc_first = 0;
-  if (DC) { dc_state = __builtin_amdgcn_readfirstlane(kargs()->dcstate[inst]); dc_first = f.dc_initjct; }
+  if (DC) { dc_state = __builtin_amdgcn_readfirstlane(kargs()->dcstate[inst]); dc_first = f.dc_initjct && __builtin_amdgcn_readfirstlane(kargs()->cold[inst]); }
   double rc_val[2] = {0.0, 0.0};   // values of the first capacitor / resistor block: constant for the instance, kept in registers
   if (f.rc_blk >= 0) {
     const F2Block B = load_block(f.blk, f.rc_blk);

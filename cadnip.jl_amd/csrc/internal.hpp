@@ -111,6 +111,7 @@ struct CadnipHandle {
   int* d_flags = nullptr;        // [B] per-instance status bits (1 = singular pivot, 2 = non-finite)
   int* d_active = nullptr;       // [B] 1 = instance takes part in the next launches
   int* d_nonfinite = nullptr;    // [B] raised by the assemble kernels when a stamped value is NaN / Inf
+  int* d_cold = nullptr;         // [B] 1 = the instance's DC solve is a cold start: initjct (armed per launch) applies to it (solve.jl:615-625: iszero(u0))
   // LU
   bool analyzed = false;
   cadnip::LUProgram lu;

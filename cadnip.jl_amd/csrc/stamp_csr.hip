@@ -64,7 +64,7 @@ struct LdsOut {
 
 struct CsrStampArgs {
   const int* nodes; const int* ipar; const double* par; const double* wave;
-  const double* u; const double* t; const int* active;
+  const double* u; const double* t; const int* active; const int* cold;
   double *G, *C, *b, *limit_w; int* nonfinite;
   const unsigned char* diag_flag; const double* gshunt; const double* srcFact;
   const int* step_ptr; const int* step_info; const uint4* tgt_rec;   // [n_chunks + 1] step ranges, per step class | new-level flag << 8, STEP_W records (16 B each) per step (build_stamp_plan)
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(64) k_stamp_csr(CsrStampArgs a) {
   }
   SC_POINT(0);
   {
-    DevCtx d{a.nodes, a.ipar, a.par + (size_t)inst_c * a.n_par * a.count, a.wave, a.count, dev < a.count ? dev : a.count - 1, a.t[inst_c], a.mode, a.initjct};
+    DevCtx d{a.nodes, a.ipar, a.par + (size_t)inst_c * a.n_par * a.count, a.wave, a.count, dev < a.count ? dev : a.count - 1, a.t[inst_c], a.mode, (a.initjct && a.cold[inst_c]) ? 1 : 0};
     LdsOut s{tile, tile + (size_t)a.n_g * a.cs, tile + (size_t)(a.n_g + a.n_c) * a.cs, a.cs, ldev, valid};
     const double* u = a.u_lds ? u_tile + (size_t)(ii < a.ipw ? ii : 0) * a.n : a.u + (size_t)inst_c * a.n;
     double* lw = valid ? a.limit_w + (size_t)inst_c * a.n : nullptr;
@@ -469,7 +469,7 @@ static int launch_stamp_csr_t(CadnipHandle* h, DeviceBlock& b) {
   while (ipw > 1 && (size_t)ipw * tile_words * 8 > 64 * 1024) --ipw;
   const int u_lds = (size_t)ipw * h->n * 8 <= 16 * 1024 ? 1 : 0;
   const size_t shmem = ((size_t)ipw * tile_words + 3 * (size_t)ipw + (u_lds ? (size_t)ipw * h->n : 0)) * 8;   // tiles (staged slots + tree scratch), per-instance scalars, u
-  CsrStampArgs a{b.d_nodes, b.d_ipar, b.d_par, h->d_wave, h->d_u, h->d_t, h->d_active, h->d_G, h->d_C, h->d_b, h->d_limit_w, h->d_nonfinite,
+  CsrStampArgs a{b.d_nodes, b.d_ipar, b.d_par, h->d_wave, h->d_u, h->d_t, h->d_active, h->d_cold, h->d_G, h->d_C, h->d_b, h->d_limit_w, h->d_nonfinite,
                  h->d_diag_flag, h->d_gshunt, h->d_srcfact, b.d_sp_tptr, b.d_sp_info, b.d_sp_rec,
                  h->B, b.count, h->n, h->nnz, b.n_par, b.n_g, b.n_c, b.n_b, b.sp_cs, b.sp_chunks, ipw, lpd, h->spec.mode, h->initjct,
                  (TYPE == CADNIP_DEV_MOS1 || TYPE == CADNIP_DEV_VA) ? 1 : 0, b.sp_levels, b.sp_scratch, u_lds};

@@ -68,7 +68,7 @@ class SpecC(C.Structure):
 
 class DCOptsC(C.Structure):
     _fields_ = [("abstol", C.c_double), ("maxiters", C.c_int32), ("use_pcnr", C.c_int32), ("cold_start", C.c_int32),
-                ("use_stepping", C.c_int32), ("fused", C.c_int32)]
+                ("use_stepping", C.c_int32), ("fused", C.c_int32), ("participate", _I)]
 
 
 class TranOptsC(C.Structure):
@@ -305,11 +305,13 @@ class Handle:
 
     # -- drivers -------------------------------------------------------------------------------
     def dc_run(self, u0=None, abstol=1e-10, maxiters=100, use_pcnr=True, cold_start=True, use_stepping=True,
-               raise_on_fail=False, fused=False):
+               raise_on_fail=False, fused=False, participate=None):
+        """``participate``: boolean mask [B]; instances with False sit the run out (u unchanged, converged False)."""
         u = self._bn(0.0 if u0 is None else u0).copy()
         conv = np.zeros(self.B, dtype=np.int32)
         st = RunStatsC()
-        o = DCOptsC(abstol, maxiters, int(use_pcnr), int(cold_start), int(use_stepping), int(fused))
+        pm = None if participate is None else np.ascontiguousarray(np.asarray(participate, dtype=bool).astype(np.int32))
+        o = DCOptsC(abstol, maxiters, int(use_pcnr), int(cold_start), int(use_stepping), int(fused), None if pm is None else _ip(pm))
         rc = self.lib.cadnip_dc_run(self.h, C.byref(o), _dp(u), _ip(conv), C.byref(st))
         if rc not in (OK, NOCONV) or (rc == NOCONV and raise_on_fail):
             _check(rc, "cadnip_dc_run")

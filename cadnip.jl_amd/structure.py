@@ -112,6 +112,21 @@ class Structure:
     def nnz(self):
         return int(self.colidx.shape[0])
 
+    def signature(self):
+        """hash of everything a device handle is built from except parameter values: two sweep points with equal signatures
+        can share one resident batch"""
+        import hashlib
+        h = hashlib.sha1()
+        h.update(repr((self.n, self.n_nodes, self.n_currents, self.n_charges, self.n_limits, self.ns_g, self.ns_c, self.ns_b,
+                       tuple(self.node_names), tuple(self.current_names), tuple(self.charge_names), tuple(self.limit_names))).encode())
+        for a in (self.rowptr, self.colidx, self.g_ptr, self.g_slots, self.c_ptr, self.c_slots, self.b_ptr, self.b_slots):
+            h.update(np.ascontiguousarray(a, dtype=np.int64).tobytes())
+        for b in self.blocks:
+            h.update(repr((b.type, b.count, b.n_par, b.n_g, b.n_c, b.n_b)).encode())
+            h.update(np.ascontiguousarray(b.nodes, dtype=np.int64).tobytes())
+            h.update(np.ascontiguousarray(b.ipar, dtype=np.int64).tobytes())
+        return h.hexdigest()
+
     def index_of(self, name):
         """sol[:name] lookup order nodes -> currents -> charges -> limits (build.jl:421-457)."""
         if name in self.node_names:

@@ -192,6 +192,9 @@ typedef struct {
   int32_t use_stepping;   /* gshunt / source stepping fallbacks solve.jl:909-925 */
   int32_t fused;          /* non-zero: the first attempt (PCNR / Newton at the handle's spec) runs in the fused kernel
                              (csrc/fused2.hip, DC mode); the fallback homotopies always use the per-op kernels */
+  const int32_t* participate; /* [B] or NULL (= everyone): instances with 0 sit the run out -- their u is left as it is and they
+                             report converged = 0.  dc!(cs) continuation solves a sweep in stages (sweeps.jl:511-532): the
+                             points of a stage start from converged neighbours of the earlier stages */
 } CadnipDCOpts;
 
 typedef struct {

@@ -1,0 +1,73 @@
+"""GPU: dc!(CircuitSweep) with continuation (sweeps.jl:489-532) and sweeps that cross a structural boundary."""
+import numpy as np
+import pytest
+
+import cadnip_jl_amd as cj
+from cadnip_jl_amd import api
+from oracle import mna_ref as M
+from oracle.netlist_ref import make_builder
+
+pytestmark = pytest.mark.gpu
+
+
+def _diode_chain():
+    """test/sweep.jl:318-329: v1 - 1k - three diodes (is = 1e-14, n = 1) to ground, the source swept"""
+    c = cj.Circuit("diode_chain")
+    c.V("v1", "in", "0", dc=cj.Param("vsrc"))
+    c.R("r1", "in", "n1", 1e3)
+    c.D("d1", "n1", "n2", Is=1e-14)
+    c.D("d2", "n2", "n3", Is=1e-14)
+    c.D("d3", "n3", "0", Is=1e-14)
+    return c
+
+
+def test_dc_sweep_continuation_lands_where_cold_solves_land():
+    """test/sweep.jl:332-357: 40 points vsrc = 0.5:0.5:20; continuation changes the path Newton takes, not where it lands
+    (n1 to deftol, I_v1 to 1e-6 relative), every point converges, n1 clamps near three junction drops and grows
+    monotonically; and the warm-started sweep costs fewer Newton iterations than 40 cold solves."""
+    mc = api.MNACircuit(_diode_chain(), {"vsrc": 1.0})
+    sweep = api.Sweep(vsrc=list(np.arange(0.5, 20.25, 0.5)))
+    cs = api.CircuitSweep(mc, sweep)
+    warm = api.dc(cs)
+    cold = api.dc(cs, continuation=False)
+    assert len(warm) == len(cold) == 40 and all(s.converged for _, s in warm) and all(s.converged for _, s in cold)
+    for (pw, sw), (pc, sc) in zip(warm, cold):
+        assert pw == pc
+        assert abs(sw["n1"] - sc["n1"]) <= 1e-7
+        assert sw["I_v1"] == pytest.approx(sc["I_v1"], rel=1e-6)
+    v_n1 = np.array([s["n1"] for _, s in warm])
+    assert np.all(np.diff(v_n1) > 0) and 1.8 < v_n1[-1] < 2.4                # test/sweep.jl:347-357
+    # the oracle's serial continuation (sweeps.jl:511-532 restated) lands on the same points
+    for k in (0, 7, 39):
+        b = make_builder(_diode_chain().to_dicts({"vsrc": sweep.values[k]}))
+        assert M.dc(b)["n1"] == pytest.approx(warm[k]["n1"], abs=1e-7)
+    # iteration counts: the staged warm starts against cold starts of the same batch
+    sim = api.BatchSimulator(api.MNACircuit(_diode_chain(), {"vsrc": 1.0}, api.MNASpec(mode="dcop")), cs.points())
+    try:
+        _, cw, sw_ = sim.dc_continuation()
+        _, cc, sc_ = sim.dc()
+        assert np.all(cw) and np.all(cc) and sw_["stages"] == 7 and sw_["cold_points"] == 1
+        assert sw_["newton_iters"] < sc_["newton_iters"], (sw_, sc_)
+    finally:
+        sim.close()
+
+
+def test_sweep_across_a_structural_boundary_is_split_by_structure():
+    """rd swept through 0: the instances with rd = 0 have no internal drain node (mos1.va:716-721).  Round 1 refused such a
+    sweep; now every structure class is its own batch and each point equals its stand-alone solve."""
+    c = cj.Circuit("rd sweep")
+    c.V("vd", "dd", "0", dc=2.0)
+    c.R("rl", "dd", "d", 1e3)
+    c.V("vg", "g", "0", dc=cj.Param("vg"))
+    c.MOS1("m1", "d", "g", "0", "0", dict(type=1, vto=0.7, kp=100e-6, rd=cj.Param("rd")), w=10e-6, l=1e-6)
+    mc = api.MNACircuit(c, {"rd": 0.0, "vg": 1.5})
+    sweep = api.ProductSweep(api.Sweep(vg=[1.0, 1.5, 2.0]), api.Sweep(rd=[0.0, 50.0, 0.0, 200.0]))
+    res = api.dc(api.CircuitSweep(mc, sweep))
+    assert len(res) == 12 and all(s.converged for _, s in res)
+    for pt, sol in res:
+        has_int = "m1_sp_mos1_d_int" in sol.node_names
+        assert has_int == (pt["rd"] != 0.0)
+        ref = M.dc(make_builder(c.to_dicts(pt)))
+        assert sol["d"] == pytest.approx(ref["d"], abs=1e-8) and sol["I_vd"] == pytest.approx(ref["I_vd"], rel=1e-7)
+        if has_int:
+            assert sol["m1_sp_mos1_d_int"] == pytest.approx(ref["m1_sp_mos1_d_int"], abs=1e-8)

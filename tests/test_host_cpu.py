@@ -693,3 +693,32 @@ def test_c6288_deck_flattens_and_orders_at_scale():
     prog = hip.host_lu_analyze(st.n, st.rowptr, st.colidx, vals, sample=True)
     assert sorted(prog["rperm"].tolist()) == list(range(st.n)) and sorted(prog["cperm"].tolist()) == list(range(st.n))
     assert len(prog["col"]) < 1.2 * st.nnz
+
+
+def test_staged_continuation_order_and_structure_classes():
+    """dc!(cs) continuation as batch stages (api.continuation_stages): every index exactly once, each stage's points lie midway
+    between solved ones, seeds prefer the converged point below; and a sweep that moves a model parameter across a structural
+    boundary (rd = 0 collapses sp_mos1's internal drain node, mos1.va:716-721) is split into one class per structure."""
+    from cadnip_jl_amd import api
+    for n in (1, 2, 3, 7, 40, 64, 1000):
+        stages = api.continuation_stages(n)
+        flat = [i for st in stages for i in st]
+        assert sorted(flat) == list(range(n)) and stages[0] == [0] and len(stages) <= 2 + int(np.ceil(np.log2(max(n, 1))))
+        solved = {0}
+        for st in stages[1:]:
+            for i in st:
+                assert any(j < i for j in solved)                 # a solved neighbour below exists (the reference's direction)
+            solved |= set(st)
+    assert api.seed_for(5, [0, 4, 8]) == 4 and api.seed_for(2, [4, 8]) == 4 and api.seed_for(3, []) is None
+    c = cj.Circuit("rd sweep")
+    c.V("vd", "d", "0", dc=2.0)
+    c.V("vg", "g", "0", dc=cj.Param("vg"))
+    c.MOS1("m1", "d", "g", "0", "0", dict(type=1, vto=0.7, kp=100e-6, rd=cj.Param("rd")), w=10e-6, l=1e-6)
+    mc = api.MNACircuit(c, {"rd": 0.0, "vg": 1.5})
+    pts = list(api.ProductSweep(api.Sweep(vg=[1.0, 1.5, 2.0]), api.Sweep(rd=[0.0, 10.0, 0.0, 20.0])))
+    classes = api.structure_classes(mc, pts)
+    assert len(classes) == 2
+    (i0, st0), (i1, st1) = classes
+    assert sorted(i0 + i1) == list(range(12)) and all(pts[i]["rd"] == 0.0 for i in i0) and all(pts[i]["rd"] != 0.0 for i in i1)
+    assert st1.n == st0.n + 1 and "m1_sp_mos1_d_int" in st1.node_names and "m1_sp_mos1_d_int" not in st0.node_names
+    assert st0.signature() != st1.signature() and st0.signature() == cj.discover(c, {"rd": 0.0, "vg": 7.0}).signature()
