@@ -168,12 +168,14 @@ class SweepResult:
 # solutions
 # ------------------------------------------------------------------------------------------------
 class DCSolution:
-    """solve.jl:156-166."""
+    """solve.jl:156-166; name lookup in the reference's order -- nodes, currents, charges, limits, then device terminal
+    currents ``i_<device>_<terminal>`` and operating-point variables ``<device>_<var>`` (solve.jl:234-250, test/opinfo.jl)."""
 
-    def __init__(self, st: Structure, x, converged):
+    def __init__(self, st: Structure, x, converged, op=None):
         self.st = st
         self.x = np.asarray(x)
         self.converged = bool(converged)
+        self.op = dict(op or {})
         self.node_names = st.node_names
         self.current_names = st.current_names
         self.charge_names = st.charge_names
@@ -181,7 +183,24 @@ class DCSolution:
         self.n_nodes = st.n_nodes
 
     def __getitem__(self, name):
-        return float(self.x[self.st.index_of(name)])
+        try:
+            return float(self.x[self.st.index_of(name)])
+        except KeyError:
+            if name in self.op:
+                return self.op[name]
+            raise
+
+    def terminal_currents(self):
+        return {k: v for k, v in self.op.items() if k.startswith("i_")}
+
+    def op_vars(self):
+        return {k: v for k, v in self.op.items() if not k.startswith("i_")}
+
+    def keys(self):
+        return list(self.st.node_names) + list(self.st.current_names) + list(self.op)
+
+    def __contains__(self, name):
+        return name in self.op or name in self.st.node_names or name in self.st.current_names
 
 
 class TranSolution:
@@ -310,6 +329,16 @@ class BatchSimulator:
             self.analyze()
         return self.h.dc_run(u0, abstol=abstol, maxiters=maxiters, use_pcnr=True, cold_start=(u0 is None) if cold_start is None else cold_start,
                              fused=fused, participate=participate)
+
+    def operating_points(self, u, mode="dcop"):
+        """Terminal currents and op variables of every instance at the states ``u`` (opinfo.py): one restamp with the
+        per-device contributions read back."""
+        from . import opinfo
+        self.h.set_spec(mode=mode)
+        self.h.set_u(u)
+        Sg, Sc, Sb = self.h.get_contributions()
+        packed = pack_params(self.st, self.mc.circuit, self.params, self.temps, self.B, gmin=self.mc.spec.gmin, tnom_c=self.mc.spec.tnom)
+        return [opinfo.operating_point(self.st, np.asarray(u)[i], Sg[i], Sb[i], packed, i) for i in range(self.B)]
 
     def dc_continuation(self, abstol=1e-10, maxiters=100, mode="dcop", fused=False):
         """dc!(cs; continuation=true) (sweeps.jl:489-532) for a resident batch.  The reference walks the sweep serially and
@@ -452,8 +481,9 @@ def dc(target, u0=None, device=0, continuation=True):
             sim = BatchSimulator(mc, [pts[i] for i in idx], device, st=st)
             try:
                 u, conv, _ = sim.dc_continuation() if continuation else sim.dc()
+                ops = sim.operating_points(u)
                 for k, i in enumerate(idx):
-                    sols[i] = DCSolution(sim.st, u[k], conv[k])
+                    sols[i] = DCSolution(sim.st, u[k], conv[k], ops[k])
             finally:
                 sim.close()
         return SweepResult(pts, sols)
@@ -461,7 +491,7 @@ def dc(target, u0=None, device=0, continuation=True):
     sim = BatchSimulator(mc, None, device)
     try:
         u, conv, _ = sim.dc(u0=u0)
-        return DCSolution(sim.st, u[0], conv[0])
+        return DCSolution(sim.st, u[0], conv[0], sim.operating_points(u)[0])
     finally:
         sim.close()
 

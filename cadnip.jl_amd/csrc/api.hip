@@ -1,5 +1,6 @@
 // api.hip -- the C ABI of include/cadnip_hip.h (everything except the two host drivers).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdio.h>
 #include <string.h>
 #include <string>
@@ -325,6 +326,23 @@ int cadnip_get_GCb(CadnipHandle* h, double* G_ref_nz, double* C_ref_nz, double* 
   }
   HIP_TRY(hipStreamSynchronize(h->stream));
   return CADNIP_OK;
+}
+
+// Operating-point read-out (context.jl:1200-1342: terminal currents, op variables): the per-device contributions of one
+// restamp at the handle's current state, [B][ns_g + ns_c + ns_b] in the slot layout of CadnipStructure (slot (k, dev) of
+// a block at base + k * count + dev).  The stamping kernels keep these in LDS; here they write them out once.
+int cadnip_get_contributions(CadnipHandle* h, double* slots_host) {
+  if (!h || !slots_host) return CADNIP_BADARG;
+  const size_t cnt = (size_t)h->B * h->ns;
+  HIP_TRY(hipMalloc((void**)&h->d_dump, std::max<size_t>(cnt, 1) * sizeof(double)));
+  int rc = CADNIP_OK;
+  if (hipMemsetAsync(h->d_dump, 0, cnt * sizeof(double), h->stream) != hipSuccess) rc = CADNIP_HIPERROR;
+  if (!rc) rc = launch_rebuild(h);
+  if (!rc && hipMemcpyAsync(slots_host, h->d_dump, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = CADNIP_HIPERROR;
+  if (hipStreamSynchronize(h->stream) != hipSuccess) rc = CADNIP_HIPERROR;
+  (void)hipFree(h->d_dump);
+  h->d_dump = nullptr;
+  return rc;
 }
 
 int cadnip_analyze(CadnipHandle* h, int32_t sample_instance) {

@@ -95,6 +95,7 @@ struct CadnipHandle {
   unsigned char* d_diag_flag = nullptr;   // [nnz] 1 where the entry is G[i,i] of a voltage node
   int* d_long_rows = nullptr;   // rows with more than LONG_LIST entries (kernels.hip: k_residual_long)
   int n_long_rows = 0;
+  double* d_dump = nullptr;     // non-null only inside cadnip_get_contributions: [B][ns] staged contributions (stamp_csr.hip)
   unsigned* d_prep = nullptr;   // words the stamping kernels do not store themselves (stamp_csr.hip: k_stamp_prep)
   int n_prep = 0, n_prep_atomic = 0;   // the first n_prep_atomic words are rewritten before every restamp
   bool prep_stale = true;              // unstamped node diagonals may still hold a gshunt of an earlier restamp

@@ -70,6 +70,8 @@ struct CsrStampArgs {
   const int* step_ptr; const int* step_info; const uint4* tgt_rec;   // [n_chunks + 1] step ranges, per step class | new-level flag << 8, STEP_W records (16 B each) per step (build_stamp_plan)
   int B, count, n, nnz, n_par, n_g, n_c, n_b, cs, n_chunks, ipw, lpd, mode, initjct, zero_first, n_levels, n_scratch;
   int u_lds;   // the unknowns of the tile's instances are staged in LDS (small circuits): node voltages are then LDS reads
+  double* dump; int ns, dump_g, dump_c, dump_b;   // operating-point read-out only (cadnip_get_contributions): the staged per-device
+                                                    // contributions written out as [B][ns], slot (k, dev) of array A at A_base + k * count + dev
 
 };
 
@@ -172,6 +174,12 @@ __global__ void __launch_bounds__(64) k_stamp_csr(CsrStampArgs a) {
     else if (TYPE == CADNIP_DEV_VA) stamp_va(d, u, s, lw);
   }
   CADNIP_WAVE_SYNC();
+  if (a.dump && valid && side == 0) {
+    double* D = a.dump + (size_t)inst * a.ns;
+    for (int k = 0; k < a.n_g; ++k) D[a.dump_g + k * a.count + dev] = tile[k * a.cs + ldev];
+    for (int k = 0; k < a.n_c; ++k) D[a.dump_c + k * a.count + dev] = tile[(a.n_g + k) * a.cs + ldev];
+    for (int k = 0; k < a.n_b; ++k) D[a.dump_b + k * a.count + dev] = tile[(a.n_g + a.n_c + k) * a.cs + ldev];
+  }
   SC_POINT(1);
   // ---- segmented reduction: one target per lane and step, contributions summed in COO order out of LDS.  A target is
   // one 16-byte record (destination, count, up to five staging offsets inline); RED_U records per lane are requested
@@ -472,7 +480,8 @@ static int launch_stamp_csr_t(CadnipHandle* h, DeviceBlock& b) {
   CsrStampArgs a{b.d_nodes, b.d_ipar, b.d_par, h->d_wave, h->d_u, h->d_t, h->d_active, h->d_cold, h->d_G, h->d_C, h->d_b, h->d_limit_w, h->d_nonfinite,
                  h->d_diag_flag, h->d_gshunt, h->d_srcfact, b.d_sp_tptr, b.d_sp_info, b.d_sp_rec,
                  h->B, b.count, h->n, h->nnz, b.n_par, b.n_g, b.n_c, b.n_b, b.sp_cs, b.sp_chunks, ipw, lpd, h->spec.mode, h->initjct,
-                 (TYPE == CADNIP_DEV_MOS1 || TYPE == CADNIP_DEV_VA) ? 1 : 0, b.sp_levels, b.sp_scratch, u_lds};
+                 (TYPE == CADNIP_DEV_MOS1 || TYPE == CADNIP_DEV_VA) ? 1 : 0, b.sp_levels, b.sp_scratch, u_lds,
+                 h->d_dump, h->ns, b.g_base, h->ns_g + b.c_base, h->ns_g + h->ns_c + b.b_base};
   if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_stamp_csr<TYPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   const unsigned grid = (unsigned)b.sp_chunks * (unsigned)((h->B + ipw - 1) / ipw);
   hipLaunchKernelGGL(k_stamp_csr<TYPE>, dim3(grid), dim3(64), shmem, h->stream, a);

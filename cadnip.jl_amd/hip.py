@@ -20,7 +20,7 @@ STATUS_NAMES = {0: "CADNIP_OK", 1: "CADNIP_BADARG", 2: "CADNIP_SINGULAR", 3: "CA
 # every symbol declared in include/cadnip_hip.h
 EXPORTS = [
     "cadnip_create", "cadnip_destroy", "cadnip_set_params", "cadnip_set_spec", "cadnip_set_initjct",
-    "cadnip_rebuild", "cadnip_residual", "cadnip_jacobian", "cadnip_ode_rhs", "cadnip_ode_jacobian", "cadnip_get_GCb", "cadnip_analyze",
+    "cadnip_rebuild", "cadnip_residual", "cadnip_jacobian", "cadnip_ode_rhs", "cadnip_ode_jacobian", "cadnip_get_GCb", "cadnip_get_contributions", "cadnip_analyze",
     "cadnip_analyze_values", "cadnip_factor", "cadnip_solve", "cadnip_lu_stats", "cadnip_dc_run",
     "cadnip_dc_log_size", "cadnip_dc_log_get", "cadnip_tran_run", "cadnip_tran_state", "cadnip_dev_ptr", "cadnip_stream", "cadnip_set_u", "cadnip_get_u", "cadnip_get_flags",
     "cadnip_sync", "cadnip_debug_copy", "cadnip_debug_stamp_time", "cadnip_profile_enable", "cadnip_profile_read", "cadnip_version",
@@ -279,6 +279,14 @@ class Handle:
         lw = np.empty((B, max(st.n_limits, 1)))
         _check(self.lib.cadnip_get_GCb(self.h, _dp(G), _dp(Cm), _dp(b), _dp(lw)), "cadnip_get_GCb")
         return G, Cm, b, lw[:, :st.n_limits]
+
+    def get_contributions(self):
+        """Per-device contributions of one restamp at the current state: (S_g [B, ns_g], S_c [B, ns_c], S_b [B, ns_b])."""
+        st = self.st
+        ns = st.ns_g + st.ns_c + st.ns_b
+        S = np.zeros((self.B, max(ns, 1)))
+        _check(self.lib.cadnip_get_contributions(self.h, _dp(S)), "cadnip_get_contributions")
+        return S[:, :st.ns_g], S[:, st.ns_g:st.ns_g + st.ns_c], S[:, st.ns_g + st.ns_c:ns]
 
     # -- LU ----------------------------------------------------------------------------------
     def analyze(self, sample_instance=0):

@@ -106,6 +106,7 @@ class Structure:
     n_coo_g: int = 0
     n_coo_c: int = 0
     n_coo_b: int = 0
+    opinfo: list = field(default_factory=list)     # per device: terminals, local rows per terminal, local stamp program (opinfo.py)
     mos1_vdep: tuple = (False, False, False, False)
 
     @property
@@ -515,6 +516,7 @@ def discover(circuit: Circuit, params: Dict[str, float]) -> Structure:
     vdep = detect_mos1_vdep(circuit, params)
     va_vdep = detect_va_vdep(circuit, params)
     pending_bsrc = []   # (ipar list, tokens): programs are encoded once every node has its index
+    opinfo = []
     recs = []   # (stream, seq-order implicit, type, dev_in_block, local_slot, row_typed, col_typed)
     for di, dev in enumerate(circuit.devices):
         ty = dev.type
@@ -597,6 +599,20 @@ def discover(circuit: Circuit, params: Dict[str, float]) -> Structure:
             prog = mod.program(vd)
         d_in_block = len(per_type[ty])
         per_type[ty].append((di, nodes, ipar))
+        # operating-point channel (context.jl:1200-1342): the device's terminals and, per terminal, the local KCL rows whose
+        # contributions flow into it (an internal node collapsed onto a terminal feeds that terminal)
+        if ty == "MOS1":
+            terms, groups = ("d", "g", "s", "b"), [[0] + ([4] if sc_d else []), [1], [2] + ([5] if sc_s else []), [3]]
+        elif ty.startswith("VA:"):
+            terms = tuple(p.lower() for p in mod.ports)
+            groups = [[t] + [k for k in alias if alias[k] == t] for t in range(len(mod.ports))]
+        elif ty == "D":
+            terms, groups = ("a", "c"), [[0], [1]]
+        elif ty == "SMOS":
+            terms, groups = ("d", "g", "s"), [[0], [1], [2]]
+        else:
+            terms, groups = ("p", "n"), [[0], [1]]
+        opinfo.append({"name": dev.name, "type": ty, "dev": d_in_block, "nodes": list(nodes), "prog": list(prog), "terminals": terms, "groups": groups})
         for (stream, k, rl, cl) in prog:
             row = nodes[rl]
             col = nodes[cl] if cl is not None else None
@@ -681,7 +697,7 @@ def discover(circuit: Circuit, params: Dict[str, float]) -> Structure:
         wave_data=np.array(wave_data, dtype=np.float64), ns_g=ns_g, ns_c=ns_c, ns_b=ns_b,
         g_ptr=g_ptr, g_slots=g_slots, c_ptr=c_ptr, c_slots=c_slots, b_ptr=b_ptr, b_slots=b_slots,
         diag_nz=diag, limit_init=np.array(A.limit_init, dtype=np.float64), breakpoints=breakpoints,
-        n_coo_g=len(coo["G"]), n_coo_c=len(coo["C"]), n_coo_b=len(coo["b"]), mos1_vdep=vdep)
+        n_coo_g=len(coo["G"]), n_coo_c=len(coo["C"]), n_coo_b=len(coo["b"]), mos1_vdep=vdep, opinfo=opinfo)
 
 
 def pack_params(st: Structure, circuit: Circuit, params: Dict[str, np.ndarray], temp_c, B: int,

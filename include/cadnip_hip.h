@@ -162,6 +162,10 @@ int cadnip_jacobian(CadnipHandle* h, const double* gamma_host, double* J_ref_nz_
  * cadnip_get_GCb's C.  u_host NULL = reuse the stamps of the last rebuild. */
 int cadnip_ode_rhs(CadnipHandle* h, const double* u_host, const double* t_host, double* du_host);
 int cadnip_ode_jacobian(CadnipHandle* h, const double* u_host, const double* t_host, double* J_ref_nz_host);
+/* operating-point read-out: the per-device contributions of one restamp at the handle's current u / t,
+ * [B][ns_g + ns_c + ns_b] in CadnipStructure's slot layout (G slots, then C, then b; slot (k, dev) of a block at
+ * base + k * count + dev).  Terminal currents and small-signal variables are sums over them (context.jl:1200-1342). */
+int cadnip_get_contributions(CadnipHandle* h, double* slots_host);
 /* parity / debug read-back in the reference's CSC nzval order (any pointer may be NULL) */
 int cadnip_get_GCb(CadnipHandle* h, double* G_ref_nz, double* C_ref_nz, double* b, double* limit_w);
 
