@@ -35,7 +35,7 @@ def main():
             "lds_active_share_of_cu_busy": l["SQ_LDS_IDX_ACTIVE"]["total"] / l["SQ_BUSY_CU_CYCLES"]["total"],
             "bank_conflict_share_of_lds_active": l["SQ_LDS_BANK_CONFLICT"]["total"] / l["SQ_LDS_IDX_ACTIVE"]["total"],
             "same_address_conflict_share_of_lds_active": l["SQ_LDS_ADDR_CONFLICT"]["total"] / l["SQ_LDS_IDX_ACTIVE"]["total"]}
-    json.dump(out, open("profiles/%s_pmc_summary.json" % tag, "w"), indent=1)
+    json.dump(out, open("%s_pmc_summary.json" % (tag if "/" in tag else "profiles/" + tag), "w"), indent=1)
     print(json.dumps(out["fused2_newton"], indent=1))
 
 
