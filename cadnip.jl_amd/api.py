@@ -251,6 +251,24 @@ def clip_sample(J, headroom=1e6):
 class BatchSimulator:
     """One structure, B resident sweep instances on one GPU."""
 
+    @classmethod
+    def from_packed(cls, st: Structure, packed, spec: Optional[MNASpec] = None, device: int = 0, vscale: float = 1.0):
+        """A simulator from a ready structure and packed per-instance parameter blocks (``pack_params`` output, one array
+        [B, n_par, count] per block) -- e.g. loaded with ``structure.load_structure`` on a machine that holds the library's generated
+        model code but not the model's Verilog-A source."""
+        from . import hip
+        self = cls.__new__(cls)
+        spec = spec or MNASpec()
+        self.mc, self.points, self.st = None, None, st
+        self.B = int(np.asarray(packed[0]).shape[0])
+        self.params, self.temps = {}, np.full(self.B, spec.temp)
+        self._vscale = float(vscale)
+        self.h = hip.Handle(st, self.B, device)
+        self.h.set_params([np.ascontiguousarray(p, dtype=np.float64) for p in packed])
+        self.h.set_spec(mode=spec.mode if spec.mode in ("dcop", "tran", "tranop") else "tran", gmin=spec.gmin, gshunt=spec.gshunt, srcFact=spec.srcFact)
+        self._analyzed = False
+        return self
+
     def __init__(self, mc: MNACircuit, points: Optional[List[Dict[str, Any]]] = None, device: int = 0, st: Optional[Structure] = None):
         from . import hip
         self.mc = mc
@@ -279,6 +297,8 @@ class BatchSimulator:
         self.h.close()
 
     def vscale(self):
+        if self.mc is None:
+            return self._vscale
         v = [abs(float(np.max(np.abs(self.params[k])))) for k in self.params] + [1.0]
         for d in self.mc.circuit.devices:
             if d.type == "V":

@@ -220,7 +220,7 @@ int dc_newton(CadnipHandle* h, double abstol, int maxiters, int use_pcnr, int co
   int saved_initjct = h->initjct;
   h->initjct = (cold_start && a.use_pcnr) ? 1 : 0;   // armed for the first stamping only (solve.jl:624,632)
   int rc = CADNIP_OK;
-  if (fused && h->analyzed && !h->homotopy && h->spec.gshunt == 0.0 && h->spec.srcFact >= 1.0 && fused2_fits(h)) {
+  if (fused && h->analyzed && !h->homotopy && h->spec.gshunt == 0.0 && h->spec.srcFact >= 1.0 && !h->va_ext && fused2_fits(h)) {
     // the whole Newton loop of every instance in the fused kernel; the host only looks at the running count
     TranArgs ta{};
     ta.u = h->d_u; ta.limit_w = h->d_limit_w; ta.status = d->status; ta.cnt = d->cnt; ta.active = h->d_active; ta.flags = h->d_flags;
@@ -522,7 +522,7 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
              o->t0, o->t1, o->reltol, h0, hmin, hmax, o->newton_tol > 0 ? o->newton_tol : 1e-3,
              o->max_newton > 0 ? o->max_newton : 10, o->max_order > 0 ? o->max_order : 2, o->use_pcnr};
   if (!h->analyzed) return CADNIP_NOTREADY;              // the symbolic LU phase (cadnip_analyze*) comes first
-  const bool use_fused = o->fused && fused2_fits(h);     // a circuit too large for the LDS-resident kernel runs on the per-op kernels
+  const bool use_fused = o->fused && !h->va_ext && fused2_fits(h);   // (external generated models exist in the per-op stamping kernel only)     // a circuit too large for the LDS-resident kernel runs on the per-op kernels
   struct ModeGuard { CadnipHandle* h; int saved; ~ModeGuard() { h->spec.mode = saved; } } mode_guard{h, h->spec.mode};
   h->spec.mode = 1;   // :tran (restored on every exit path)
   hipLaunchKernelGGL(k_tran_init, dim3(h->B), dim3(64), 0, h->stream, a);

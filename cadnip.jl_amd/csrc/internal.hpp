@@ -132,6 +132,7 @@ struct CadnipHandle {
   bool f2_blk_dirty = true;
   int f2_n_blk = 0, f2_rc_blk = -1;
   bool f2_direct = false;     // devices emit their residuals directly: no J*u pass (off: CADNIP_F2_NODIRECT=1)
+  bool va_ext = false;        // the circuit uses an external generated model (va_generated_ext.hpp): not compiled into the fused kernel
   bool f2_lean = false;       // only device types of the lean kernel variant (fused2.hip: dispatch_stamp2)
   int f2_src_blk = -1;        // first independent-source block of the fused block list
   int n_cu = 0;

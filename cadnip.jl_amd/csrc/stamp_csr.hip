@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <vector>
+#define CADNIP_VA_WITH_EXT   // this translation unit carries the external generated models too (va_generated_ext.hpp)
 #include "devices.hpp"
 #include "internal.hpp"
 #include "tran_ctrl.hpp"   // CADNIP_WAVE_SYNC

@@ -108,6 +108,31 @@ template <int N, int B, class Out> __device__ __forceinline__ void va_emit_limit
   s.G(g0 + 2, 1.0);
 }
 
+// An executed potential contribution V(p,n) <+ 0 with its branch current I (local unknown `ui`; vasim.jl:2363-2393): KCL columns
+// G[p,I] = 1, G[n,I] = -1, the constraint row G[I,p] = 1, G[I,n] = -1 with its (zero) partials -dV/dV_k in every node column --
+// the reference stamps them, so they are part of the pattern -- and b[I] = 0.  g0: first G slot of the short (VAModule.g_short),
+// bk: its b slot.  `on`: the statement executes for this instance with two distinct unknowns behind p and n.
+template <int N, class Out>
+__device__ __forceinline__ void va_emit_short(const double* u, const Out& s, const double (&Vf)[N], const int* nd, int ui, int pl, int nl, int g0, int bk, bool on) {
+  if (!on) return;
+  s.G(g0, 1.0);
+  s.G(g0 + 1, -1.0);
+  s.G(g0 + 2, 1.0);
+  s.G(g0 + 3, -1.0);
+  if constexpr (!Out::DIRECT) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) s.G(g0 + 4 + k, 0.0);
+    s.B(bk, 0.0);
+  }
+  if constexpr (Out::DIRECT) {
+    const int ni = nd[ui];
+    const double cur = u[ni];
+    s.Rn(pl < 0 ? -1 : nd[pl], cur);
+    s.Rn(nl < 0 ? -1 : nd[nl], -cur);
+    s.Rn(ni, (pl < 0 ? 0.0 : Vf[pl]) - (nl < 0 ? 0.0 : Vf[nl]));
+  }
+}
+
 // One branch (p, n) of a generated module: I = resistive current (value + d/dV_k), Q = charge (value + d/dV_k), both
 // already scaled by the multiplicity factor.  Slot layout: VAModule.shape / .program (cadnip.jl_amd/va/frontend.py).
 // Both reactive forms are written; the circuit's pattern holds the one the host's voltage-dependence detection chose, the

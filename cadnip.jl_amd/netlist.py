@@ -301,6 +301,10 @@ def read_spice(text, models=None, includes=None, sweep=(), title=""):
                     if float(kv.get("level", "1")) != 1.0:
                         raise ValueError("only level-1 MOSFET cards (sp_mos1) have a GPU device: %r" % line)
                     card["type"] = 1 if kind_m == "nmos" else -1
+                elif kind_m in va_modules:
+                    # .model <name> <verilog-a module> k=v ...: a card of a generated module (test/mna/psp103_integration.jl:44:
+                    # ".model nch psp103va type=1"); instances merge their own parameters over it
+                    card["__va__"] = va_modules[kind_m].name
                 elif kind_m != "d":
                     raise ValueError("unsupported .model type %r" % pos[1])
                 models[pos[0].lower()] = card
@@ -343,8 +347,21 @@ def read_spice(text, models=None, includes=None, sweep=(), title=""):
             if card is None:
                 raise KeyError("diode model %r is not in `models`" % toks[3])
             others.append(("D", name, (sc.node(toks[1]), sc.node(toks[2])), {"card": card}))
-        elif kind in "mx":
+        elif kind in "mxn":
             pos, kv = _split_params(toks[1:])
+            va_card = models.get(pos[-1].lower()) if pos else None
+            if kind in "mn" and isinstance(va_card, dict) and "__va__" in va_card:
+                # Mname / Nname nets... card [k=v]: instance of a Verilog-A module through a .model card (N: the OSDI element letter
+                # of ngspice decks, benchmarks/vacask/ring/cedarsim/models.inc:4)
+                mod = va_modules[va_card["__va__"].lower()]
+                if len(pos) - 1 != len(mod.ports):
+                    raise ValueError("%s: %d nets for the %d ports of %s" % (head, len(pos) - 1, len(mod.ports), mod.name))
+                inst = {k: v for k, v in va_card.items() if k != "__va__"}
+                inst.update({k: sc.val(v) for k, v in kv.items() if k != "m"})
+                others.append(("VA", name, tuple(sc.node(t) for t in pos[:-1]), {"module": mod.name, "inst": inst, "m": sc.val(kv["m"]) if "m" in kv else 1.0}))
+                return
+            if kind == "n":
+                raise ValueError("N element without a Verilog-A model card: %r" % line)
             sub = subckts.get(pos[-1].lower()) if kind == "x" and pos else None
             if sub is not None:
                 if depth > 32:

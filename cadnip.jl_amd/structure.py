@@ -161,6 +161,46 @@ class Structure:
         return tol
 
 
+_ST_ARRAYS = ("rowptr", "colidx", "to_ref_nz", "ref_colptr", "ref_rowval", "wave_data", "g_ptr", "g_slots", "c_ptr", "c_slots", "b_ptr", "b_slots",
+              "diag_nz", "limit_init")
+_ST_SCALARS = ("n", "n_nodes", "n_currents", "n_charges", "n_limits", "ns_g", "ns_c", "ns_b", "n_coo_g", "n_coo_c", "n_coo_b")
+
+
+def save_structure(st: Structure, path, **extra):
+    """Structure -> one .npz (arrays as they are, names / blocks / operating-point table as JSON); ``extra``: further arrays to
+    keep beside it (packed parameters, fixture states).  A structure discovered where a model's Verilog-A source is at hand can
+    then drive the GPU path where it is not (the library carries the generated code, not the source)."""
+    import json
+    meta = {k: int(getattr(st, k)) for k in _ST_SCALARS}
+    meta.update(node_names=st.node_names, current_names=st.current_names, charge_names=st.charge_names, limit_names=st.limit_names,
+                breakpoints=st.breakpoints, opinfo=st.opinfo, mos1_vdep=list(st.mos1_vdep),
+                blocks=[dict(type=b.type, count=b.count, dev_index=list(map(int, b.dev_index)), g_base=b.g_base, c_base=b.c_base, b_base=b.b_base,
+                             n_g=b.n_g, n_c=b.n_c, n_b=b.n_b, n_par=b.n_par) for b in st.blocks])
+    arrays = {k: np.asarray(getattr(st, k)) for k in _ST_ARRAYS}
+    for i, b in enumerate(st.blocks):
+        arrays["blk%d_nodes" % i] = b.nodes
+        arrays["blk%d_ipar" % i] = b.ipar
+    arrays.update({"x_" + k: np.asarray(v) for k, v in extra.items()})
+    np.savez_compressed(path, meta=np.frombuffer(json.dumps(meta, default=lambda o: o.tolist() if hasattr(o, "tolist") else list(o)).encode(), dtype=np.uint8), **arrays)
+
+
+def load_structure(path):
+    """-> (Structure, extra arrays) as written by save_structure."""
+    import json
+    z = np.load(path, allow_pickle=False)
+    meta = json.loads(bytes(z["meta"]).decode())
+    blocks = [Block(b["type"], b["count"], b["dev_index"], z["blk%d_nodes" % i], z["blk%d_ipar" % i], b["g_base"], b["c_base"], b["b_base"],
+                    b["n_g"], b["n_c"], b["n_b"], b["n_par"]) for i, b in enumerate(meta["blocks"])]
+
+    def tup(o):     # JSON turns the tuples of the operating-point programs into lists
+        return tuple(tup(x) for x in o) if isinstance(o, list) else o
+    opinfo = [dict(d, prog=[tup(r) for r in d["prog"]], terminals=tuple(d["terminals"]), nodes=[tup(x) for x in d["nodes"]]) for d in meta["opinfo"]]
+    st = Structure(blocks=blocks, node_names=meta["node_names"], current_names=meta["current_names"], charge_names=meta["charge_names"],
+                   limit_names=meta["limit_names"], breakpoints=[tuple(b) for b in meta["breakpoints"]], opinfo=opinfo, mos1_vdep=tuple(meta["mos1_vdep"]),
+                   **{k: meta[k] for k in _ST_SCALARS}, **{k: z[k] for k in _ST_ARRAYS})
+    return st, {k[2:]: z[k] for k in z.files if k.startswith("x_")}
+
+
 # local stamp programs: (stream, local_slot, row_local, col_local); order = the reference's
 # stamp order inside each stamp! method (devices.jl line numbers in include/cadnip_hip.h)
 def _prog_conductance(p, n, k0=0):
@@ -380,6 +420,24 @@ def detect_mos1_vdep(circuit: Circuit, params: Dict[str, float], seed: int = 0xD
     return tuple(is_vdep)
 
 
+_inst_cache: Dict[tuple, tuple] = {}
+
+
+def va_instance(mod, dev, params):
+    """(parameter values, alias map, shorts_on, active branches) of one Verilog-A instance for parameter set ``params``
+    (va/host_eval.py: instance_structure); cached per (module, given parameter values): a deck instantiates few distinct cards."""
+    given = {k: float(np.asarray(resolve(v, params)).flat[0]) for k, v in dev.model.items()}
+    key = (mod.name, id(mod), tuple(sorted(given.items())))
+    hit = _inst_cache.get(key)
+    if hit is None:
+        par = va.host_eval.defaults(mod, given)
+        hit = (par,) + tuple(mod.instance_structure(par, set(dev.model)))
+        if len(_inst_cache) > 4096:
+            _inst_cache.clear()
+        _inst_cache[key] = hit
+    return hit
+
+
 def detect_va_vdep(circuit: Circuit, params: Dict[str, float], seed: int = 0xDEADBEEF):
     """Per Verilog-A module in the circuit: which reactive branches use a charge unknown.  Emulates the reference's
     detection run (build_with_detection, solve.jl:1793-1822) pass by pass: five builder passes, the first at x = 0, pass
@@ -423,7 +481,8 @@ def detect_va_vdep(circuit: Circuit, params: Dict[str, float], seed: int = 0xDEA
             n_m1q += sum(m1v)
         elif ty.startswith("VA:"):
             mod = va.get(ty[3:])[1]
-            alias = mod.aliases(va.host_eval.defaults(mod, {k: float(np.asarray(resolve(v, params)).flat[0]) for k, v in d.model.items()}), set(d.model))
+            _, alias, shorts_on, _ = va_instance(mod, d, params)
+            n_cur += sum(shorts_on)
             ext = [A.node(nm) for nm in d.nodes]
             loc = list(ext) + [None] * mod.n_internal
             for k in range(len(mod.ports), mod.n_nodes):
@@ -471,7 +530,7 @@ def detect_va_vdep(circuit: Circuit, params: Dict[str, float], seed: int = 0xDEA
             if not ty.startswith("VA:"):
                 continue
             mod = va.get(ty[3:])[1]
-            par = va.host_eval.defaults(mod, {k: float(np.asarray(resolve(v, params)).flat[0]) for k, v in d.model.items()})
+            par, _, shorts_on, active = va_instance(mod, d, params)
             idx = [A.node(nm) for nm in d.nodes] + internal[d.name]
             seen_nodes.update(A.node_names[t[1]] for t in internal[d.name] if t != GND)
             V = [0.0 if t == GND else xat(t[1]) for t in idx]
@@ -479,11 +538,12 @@ def detect_va_vdep(circuit: Circuit, params: Dict[str, float], seed: int = 0xDEA
             for l in range(len(mod.limit_branches)):
                 lim_sf += 1
                 vold.append(xat(len(seen_nodes) + cur_sf + q_sf + lim_sf - 1))
+            cur_sf += sum(shorts_on)            # V(a,b) <+ 0 with a branch current: allocated while the body runs (vasim.jl:2365)
             mf = float(np.asarray(resolve(d.params["m"], params)).flat[0])
             vals = va.host_eval.evaluate(mod, V, par, 27.0 + 273.15, mf, 1e-12, vold=vold, given=set(d.model))
             flags, pos = [], 0
             for b, (pn, nn) in enumerate(mod.branches):
-                if not mod.reactive[b]:
+                if not mod.reactive[b] or not active[b]:
                     flags.append(False)
                     continue
                 Vb = (V[pn] if pn >= 0 else 0.0) - (V[nn] if nn >= 0 else 0.0)
@@ -580,7 +640,7 @@ def discover(circuit: Circuit, params: Dict[str, float]) -> Structure:
                 raise ValueError("%s: %d nets for the %d ports of %s" % (dev.name, len(dev.nodes), len(mod.ports), mod.name))
             # internal nodes, then one charge unknown per voltage-dependent reactive branch, allocated in branch order as
             # the branches are stamped (vasim.jl:3533-3564, 3433-3472)
-            alias = mod.aliases(va.host_eval.defaults(mod, {k: float(np.asarray(resolve(v, params)).flat[0]) for k, v in dev.model.items()}), set(dev.model))
+            _, alias, shorts_on, active = va_instance(mod, dev, params)
             for k in range(len(mod.ports), mod.n_nodes):     # a collapsed internal node is its neighbour's unknown (vasim.jl:3533-3564)
                 if k in alias and alias[k] < 0:
                     nodes.append(GND)                         # V(a) <+ 0: the internal node is ground
@@ -595,8 +655,11 @@ def discover(circuit: Circuit, params: Dict[str, float]) -> Structure:
                 nodes.append(A.charge(nm) if (mod.reactive[b] and vd[b]) else GND)
             for (p, n) in mod.limit_branches:      # one limit unknown per $limit probe branch, init 0 (vasim.jl:3110-3138)
                 nodes.append(A.limit("%s_%s_lim_%s_%s" % (dev.name, mod.name, mod.nodes[p] if p >= 0 else "0", mod.nodes[n] if n >= 0 else "0"), 0.0))
-            ipar = [mid, sum((1 << b) for b in range(len(mod.branches)) if mod.reactive[b] and vd[b])]
-            prog = mod.program(vd)
+            for j, si in enumerate(mod.vshorts):   # the branch current of an executed V(a,b) <+ 0 (vasim.jl:2365: I_V_<p>_<n>)
+                a_, b_ = mod.shorts[si][0], mod.shorts[si][1]
+                nodes.append(A.current("%s_I_V_%s_%s" % (dev.name, mod.nodes[a_], mod.nodes[b_] if b_ >= 0 else "0")) if shorts_on[j] else GND)
+            ipar = [mid, sum((1 << b) for b in range(len(mod.branches)) if mod.reactive[b] and vd[b]), sum((1 << j) for j in range(len(mod.vshorts)) if shorts_on[j])]
+            prog = mod.program(vd, active, shorts_on)
         d_in_block = len(per_type[ty])
         per_type[ty].append((di, nodes, ipar))
         # operating-point channel (context.jl:1200-1342): the device's terminals and, per terminal, the local KCL rows whose

@@ -256,6 +256,9 @@ class VAModule:
     limit_branches: List[Tuple[int, int]] = field(default_factory=list)   # probe branches of the $limit sites, first-use order
     limit_sites: List[int] = field(default_factory=list)              # per $limit call site (evaluation order): its limit branch
     shorts: List[tuple] = field(default_factory=list)                 # V(a,b) <+ 0: (a, b, [(static condition, wanted truth)])
+    vshorts: List[int] = field(default_factory=list)                  # indices into `shorts` of the statements that are NOT a node alias: a short
+                                                                      # that executes owns a branch-current unknown (see short_is_alias)
+    branch_guarded: List[bool] = field(default_factory=list)          # per branch: every contribution sits under parameter-decided conditions only
     local_init: List[tuple] = field(default_factory=list)             # module-scope `real x = expr`: (name, expr) in declaration order
     aliasparams: Dict[str, str] = field(default_factory=dict)         # aliasparam alias = parameter
     param_kind: Dict[str, str] = field(default_factory=dict)          # parameter -> "real" | "integer" | "string"
@@ -276,6 +279,18 @@ class VAModule:
     def n_sites(self):
         return len(self.limit_sites)
 
+    def short_is_alias(self, i):
+        """The reference aliases an internal node to a *terminal* only for the pattern ``if (cond) V(int, ext) <+ 0`` at the top
+        level of the analog block (detect_short_circuits, vasim.jl:2723-2818: the if-branch of a top-level conditional, one net
+        internal, the other a port).  Every other executed ``V(a,b) <+ 0`` -- an else-branch as in PSP103's CollapsableR macro, a
+        pair of internal nets -- is a potential contribution with its own branch current (vasim.jl:2311-2395).  ``V(a) <+ 0``
+        (internal net to ground) keeps this build's alias-to-ground treatment."""
+        a, b, guards = self.shorts[i][:3]
+        np_ = len(self.ports)
+        if b < 0:
+            return True
+        return len(guards) == 1 and guards[0][1] is True and ((a >= np_) != (b >= np_))
+
     def aliases(self, par, given=None):
         """Node collapse of one instance: internal node index -> the node it is merged into (-1 = ground), for the
         ``V(a,b) <+ 0`` / ``V(a) <+ 0`` statements whose conditions -- decided by the parameters, possibly through
@@ -283,6 +298,12 @@ class VAModule:
         of the parameters the instance sets explicitly, for $param_given)."""
         from .host_eval import collapsed_nodes
         return collapsed_nodes(self, par, given)
+
+    def instance_structure(self, par, given=None):
+        """(alias map, per `vshorts` entry: the statement executes for this instance, per branch: it is stamped) -- see
+        host_eval.instance_structure."""
+        from .host_eval import instance_structure
+        return instance_structure(self, par, given)
 
     # ---- stamp layout (structure.py / hipgen.py / oracle agree on it) ------------------------------------------
     # local unknowns: nodes 0..N-1, then one charge unknown per branch (ground when the branch has none), then one limit
@@ -297,9 +318,15 @@ class VAModule:
         if self.uses_given:
             n_par += len(self.params)       # + one $param_given flag per parameter
         n_par += len(self.string_tests)     # + one flag per (string parameter == literal) test
-        return (N + B + L, 2 * N * B + (N + 1) * B + 3 * L, 2 * B + 2 * N * B, 3 * B, n_par, 2)
+        NV = len(self.vshorts)
+        # short currents: local unknown N + B + L + j;  G slots g_short(j) + {0: (p,I), 1: (n,I), 2: (I,p), 3: (I,n), 4 + k: (I,k)};  b slot 3B + j
+        return (N + B + L + NV, 2 * N * B + (N + 1) * B + 3 * L + (4 + N) * NV, 2 * B + 2 * N * B, 3 * B + NV, n_par, 3)
 
-    def program(self, vdep):
+    def g_short(self, j):
+        N, B, L = self.n_nodes, len(self.branches), len(self.limit_branches)
+        return 2 * N * B + (N + 1) * B + 3 * L + (4 + N) * j
+
+    def program(self, vdep, active=None, shorts_on=None):
         """(stream, local slot, local row, local col) in the reference's stamp order (vasim.jl:3374-3521): per branch the
         resistive Jacobian, then the reactive part in charge-state or linear form, then the equivalent currents."""
         N, B = self.n_nodes, len(self.branches)
@@ -311,7 +338,27 @@ class VAModule:
                 prog.append(("G", g0 + 1, ul, p))
             if n >= 0:
                 prog.append(("G", g0 + 2, ul, n))
+        # executed V(a,b) <+ 0 statements with a branch current (vasim.jl:2363-2393: stamped where the statement stands, i.e.
+        # while the body runs, before the collected branches): KCL columns, the constraint row with its (zero) partials, b
+        for j, si in enumerate(self.vshorts):
+            if shorts_on is None or not shorts_on[j]:
+                continue
+            p, n = self.shorts[si][0], self.shorts[si][1]
+            ui, g0 = N + B + len(self.limit_branches) + j, self.g_short(j)
+            if p >= 0:
+                prog.append(("G", g0, p, ui))
+            if n >= 0:
+                prog.append(("G", g0 + 1, n, ui))
+            if p >= 0:
+                prog.append(("G", g0 + 2, ui, p))
+            if n >= 0:
+                prog.append(("G", g0 + 3, ui, n))
+            for k in range(N):
+                prog.append(("G", g0 + 4 + k, ui, k))
+            prog.append(("b", 3 * B + j, ui, None))
         for b, (p, n) in enumerate(self.branches):
+            if active is not None and not active[b]:
+                continue          # every contribution of the branch sits in a conditional this instance does not take (inline stamps, vasim.jl:2397-2470)
             for k in range(N):
                 if p >= 0:
                     prog.append(("G", 2 * N * b + 2 * k, p, k))
@@ -1011,7 +1058,7 @@ def _analyse(m: VAModule):
                 for c, _ in guards:
                     if not is_static(c):
                         raise VAError("%s: V(%s,%s) <+ 0 under a condition that is not decided by the parameters" % (m.name, s[1], s[2]))
-                m.shorts.append((a, b, list(guards)))
+                m.shorts.append((a, b, list(guards), s))
             elif s[0] == "block":
                 short_walk(s[1], guards)
             elif s[0] == "if":
@@ -1022,6 +1069,8 @@ def _analyse(m: VAModule):
                     if inner[0] == "short":
                         raise VAError("%s: V(%s,%s) <+ 0 inside a case / loop statement" % (m.name, inner[1], inner[2]))
     short_walk(m.body, [])
+    m.vshorts = [i for i in range(len(m.shorts)) if not m.short_is_alias(i)]
+
 
     # ---- $limit call sites: numbered in source order; top level of the analog block only (vasim.jl:1278-1279)
     def sites(e, allowed):
@@ -1224,6 +1273,23 @@ def _analyse(m: VAModule):
             raise VAError("%s: I(%s,%s) is read in an expression and the branch carries a contribution: branch-current "
                           "unknowns are not supported" % (m.name, m.nodes[br[0]] if br[0] >= 0 else "gnd", m.nodes[br[1]] if br[1] >= 0 else "gnd"))
     m.var_is_dual, m.var_is_reactive = dual, react
+    # ---- branches whose every contribution stands under parameter-decided conditions: the reference stamps such contributions
+    # inline, where and when the statement executes (vasim.jl:2270-2470), so an instance that never takes them has no stamps
+    guarded = [True] * len(m.branches)
+
+    def contrib_walk(stmts, under):          # under: "top" (no enclosing conditional), "static" (parameter-decided ones only), "dyn"
+        for s in stmts:
+            if s[0] == "contrib":
+                if s[3][0] != "noise" and under != "static":
+                    guarded[m.branches.index((node(s[1]), node(s[2])))] = False
+            elif s[0] == "block":
+                contrib_walk(s[1], under)
+            elif s[0] == "if":
+                contrib_walk([s[2], s[3]], "dyn" if (under == "dyn" or not is_static(s[1])) else "static")
+            elif s[0] in ("case", "for", "while"):
+                contrib_walk([x for x in _walk([s]) if x[0] == "contrib"], "dyn")
+    contrib_walk(m.body, "top")
+    m.branch_guarded = guarded
     m.reactive = [False] * len(m.branches)
     for s in _walk(m.body):
         if s[0] == "contrib" and not only_noise(s[3]) and is_react(s[3]):

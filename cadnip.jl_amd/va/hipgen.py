@@ -241,7 +241,13 @@ class _Gen:
                 if q:
                     self.lines.append("%sbr%d_q = br%d_q + %s;" % (pad, b, b, q))
             elif s[0] == "short":
-                self.lines.append("%s// V(%s,%s) <+ 0: the two nets are one unknown for this instance (collapsed at structure discovery)" % (pad, s[1], s[2]))
+                j = next((jj for jj, si in enumerate(m.vshorts) if m.shorts[si][3] is s), -1)
+                if j < 0:
+                    self.lines.append("%s// V(%s,%s) <+ 0: the two nets are one unknown for this instance (collapsed at structure discovery)" % (pad, s[1], s[2]))
+                else:
+                    a, b = m.shorts[m.vshorts[j]][0], m.shorts[m.vshorts[j]][1]
+                    self.lines.append("%sva_emit_short<N>(u, s, Vf, nd, N + B + NL + %d, %d, %d, %d, %d, ((smask >> %d) & 1) != 0);   // V(%s,%s) <+ 0 with a branch current"
+                                      % (pad, j, a, b, m.g_short(j), 3 * len(m.branches) + j, j, s[1], s[2]))
             elif s[0] == "block":
                 self.stmts(s[1], ind)
             elif s[0] == "if":
@@ -296,9 +302,12 @@ def generate_function(m):
     L.append("__device__ inline void stamp_va_%s(const Ctx& d, const double* u, const Out& s, double* lw) {" % m.name)
     L.append("  constexpr int N = %d, B = %d, S = %d, NL = %d;   // nodes, branches, $limit sites, limit unknowns" % (N, B, S, NL))
     L.append("  typedef Dual<N + S> T;")
-    L.append("  int nd[N + B + NL];")
+    L.append("  constexpr int NV = %d;   // V(a,b) <+ 0 statements that own a branch current" % len(m.vshorts))
+    L.append("  int nd[N + B + NL + NV];")
     L.append("#pragma unroll")
-    L.append("  for (int k = 0; k < N + B + NL; ++k) nd[k] = node_of(d, k);")
+    L.append("  for (int k = 0; k < N + B + NL + NV; ++k) nd[k] = node_of(d, k);")
+    if m.vshorts:
+        L.append("  const int smask = d.ipar[2 * d.count + d.dev];   // bit j: short j executes for this instance")
     L.append("  double Vf[N];")
     L.append("#pragma unroll")
     L.append("  for (int k = 0; k < N; ++k) Vf[k] = volt(u, nd[k]);")
@@ -339,9 +348,13 @@ def generate_function(m):
 
 
 def generate_header(modules):
-    """The whole va_generated.hpp: one function per module, the dispatcher and the host-side shape table."""
+    """The whole va_generated.hpp: one function per built-in module, the dispatcher and the host-side shape table.  The modules
+    whose sources are not part of this repository (va.EXTERNAL) live in va_generated_ext.hpp (generate_ext_header), which this
+    header includes: their model ids follow the built-in ones."""
     out = ["// GENERATED by cadnip.jl_amd/va/hipgen.py from the Verilog-A sources listed below -- do not edit.",
            "// Included by devices.hpp (device code) and api.hip (shape table).", "#pragma once", ""]
+    out.append("#define CADNIP_VA_NBUILTIN %d" % len(modules))
+    out.append('#include "va_generated_ext.hpp"   // CADNIP_VA_NEXT, CADNIP_VA_EXT_DISPATCH, CADNIP_VA_EXT_SHAPES (+ device code under CADNIP_VA_WITH_EXT)')
     out.append("#ifdef CADNIP_VA_DEVICE_CODE   // set by va_runtime.hpp (device translation units); api.hip takes the shape table only")
     out.append("namespace cadnip {")
     for m in modules:
@@ -353,6 +366,9 @@ def generate_header(modules):
     out.append("  switch (d.ipar[0 * d.count + d.dev]) {")
     for i, m in enumerate(modules):
         out.append("    case %d: stamp_va_%s(d, u, s, lw); break;" % (i, m.name))
+    out.append("#ifdef CADNIP_VA_WITH_EXT   // only the per-op stamping kernel carries the large external models (stamp_csr.hip)")
+    out.append("    CADNIP_VA_EXT_DISPATCH")
+    out.append("#endif")
     out.append("    default: break;")
     out.append("  }")
     out.append("}")
@@ -360,17 +376,41 @@ def generate_header(modules):
     out.append("#endif")
     out.append("")
     out.append("// n_nodes (local unknowns), n_g, n_c, n_b, n_par, n_ipar per generated model: what cadnip_create checks a block against")
-    out.append("#define CADNIP_VA_NMODELS %d" % len(modules))
-    out.append("static const struct { const char* name; int n_nodes, n_g, n_c, n_b, n_par, n_ipar; } CADNIP_VA_SHAPES[%d] = {" % max(1, len(modules)))
+    out.append("#define CADNIP_VA_NMODELS (CADNIP_VA_NBUILTIN + CADNIP_VA_NEXT)")
+    out.append("static const struct { const char* name; int n_nodes, n_g, n_c, n_b, n_par, n_ipar; } CADNIP_VA_SHAPES[CADNIP_VA_NMODELS > 0 ? CADNIP_VA_NMODELS : 1] = {")
     for m in modules:
         out.append('  {"%s", %d, %d, %d, %d, %d, %d},' % ((m.name,) + m.shape()))
-    if not modules:
-        out.append('  {"", 0, 0, 0, 0, 0, 0},')
+    out.append("  CADNIP_VA_EXT_SHAPES")
     out.append("};")
     return "\n".join(out) + "\n"
 
 
+def generate_ext_header(modules):
+    """va_generated_ext.hpp: the stamp functions of the external models (the reference's PSP103: its source is third-party
+    text inside the reference and is not copied -- this generated header is what the repository keeps, regenerated by
+    csrc/build.sh whenever the source is present).  Device code only under CADNIP_VA_WITH_EXT: these functions are thousands of
+    statements long and belong to the per-op stamping kernel only; circuits that use them never run in the fused kernel."""
+    out = ["// GENERATED by cadnip.jl_amd/va/hipgen.py from %s -- do not edit." % (", ".join(m.name for m in modules) or "(no external model)"),
+           "// Included by va_generated.hpp.", "#pragma once", ""]
+    out.append("#define CADNIP_VA_NEXT %d" % len(modules))
+    out.append("#define CADNIP_VA_EXT_SHAPES " + " ".join('{"%s", %d, %d, %d, %d, %d, %d},' % ((m.name,) + m.shape()) for m in modules))
+    out.append("#define CADNIP_VA_EXT_DISPATCH " + " ".join("case CADNIP_VA_NBUILTIN + %d: stamp_va_%s(d, u, s, lw); break;" % (i, m.name) for i, m in enumerate(modules)))
+    out.append("#if defined(CADNIP_VA_DEVICE_CODE) && defined(CADNIP_VA_WITH_EXT)")
+    out.append("namespace cadnip {")
+    for m in modules:
+        out.append(generate_function(m))
+        out.append("")
+    out.append("}  // namespace cadnip")
+    out.append("#endif")
+    return "\n".join(out) + "\n"
+
+
 def main(argv):
+    """hipgen.py a.va b.va ...        -> va_generated.hpp on stdout
+       hipgen.py --ext x.va y.va ...  -> va_generated_ext.hpp on stdout"""
+    if argv and argv[0] == "--ext":
+        sys.stdout.write(generate_ext_header([parse_file(fn) for fn in argv[1:]]))
+        return
     mods = [parse_file(fn) for fn in argv]
     sys.stdout.write(generate_header(mods))
 

@@ -46,11 +46,12 @@ def _q(x):
 
 
 def evaluate(m, V, par, temp_k=300.15, mfactor=1.0, gmin=1e-12, vold=None, initjct=0, given=None, mode="tran", simparams=None,
-             on_short=None):
+             on_short=None, on_contrib=None):
     """Branch values of module ``m`` at node voltages ``V`` (list over m.nodes): ``[(I_b, q_b)]`` per branch, before the
     multiplicity factor.  ``par``: parameter name -> number (all of them; see ``defaults``); ``vold``: the value of the
     limit unknown of every $limit probe branch (zeros when omitted); ``given``: the parameters the instance sets explicitly
-    ($param_given; default: all of ``par``); ``on_short(a, b)``: called for every V(a,b) <+ 0 that executes."""
+    ($param_given; default: all of ``par``); ``on_short(a, b, stmt)``: called for every V(a,b) <+ 0 that executes; ``on_contrib(branch)``: for every
+    executed current contribution."""
     given = set(par) if given is None else {g for g in given}
     for al, target in m.aliasparams.items():
         if al in given:
@@ -174,6 +175,8 @@ def evaluate(m, V, par, temp_k=300.15, mfactor=1.0, gmin=1e-12, vold=None, initj
             if k == "assign":
                 store(s[1], ev(s[2]))
             elif k == "contrib":
+                if on_contrib is not None and s[3][0] != "noise":
+                    on_contrib(m.branches.index((m.node_index(s[1]), m.node_index(s[2]))))
                 if s[3][0] == "noise":
                     continue
                 b = m.branches.index((m.node_index(s[1]), m.node_index(s[2])))
@@ -215,7 +218,7 @@ def evaluate(m, V, par, temp_k=300.15, mfactor=1.0, gmin=1e-12, vold=None, initj
                 raise VAError("%s: %s %s" % (m.name, s[1], s[2]))
             elif k == "short":
                 if on_short is not None:
-                    on_short(m.node_index(s[1]), m.node_index(s[2]))
+                    on_short(m.node_index(s[1]), m.node_index(s[2]), s)
 
     for name, ie in m.local_init:                               # module-scope initialisers, in declaration order
         env[name] = ev(ie)
@@ -223,18 +226,31 @@ def evaluate(m, V, par, temp_k=300.15, mfactor=1.0, gmin=1e-12, vold=None, initj
     return [(a.r, a.q) for a in acc]
 
 
-def collapsed_nodes(m, par, given=None, temp_k=300.15, mfactor=1.0, gmin=1e-12):
-    """internal node -> the node it is merged into (-1 = ground) for this instance: the V(a,b) <+ 0 statements that execute in
-    one evaluation at zero bias (their conditions are decided by the parameters: frontend._analyse)."""
+def instance_structure(m, par, given=None, temp_k=300.15, mfactor=1.0, gmin=1e-12):
+    """What one evaluation at zero bias says about the structure of this instance (conditions decided by the parameters):
+
+    * alias: internal node -> the node it is merged into (-1 = ground), for the executed V(a,b) <+ 0 statements of the alias
+      kind (VAModule.short_is_alias: the reference's detect_short_circuits pattern, vasim.jl:2723-2818);
+    * shorts_on[j]: the j-th statement of ``m.vshorts`` executes -- a potential contribution V(a,b) <+ 0 that owns a branch
+      current (vasim.jl:2311-2395; skipped when both nets are one unknown already);
+    * active[b]: branch b is stamped -- always, unless every contribution of it sits under parameter-decided conditions and
+      none of them executes (the reference stamps such contributions inline, vasim.jl:2397-2470)."""
     np_ = len(m.ports)
     out = {}
+    kind = {id(m.shorts[i][3]): (m.vshorts.index(i) if i in m.vshorts else -1) for i in range(len(m.shorts))}
+    shorts_on = [False] * len(m.vshorts)
+    touched = [False] * len(m.branches)
 
     def root(i):
         while i in out and i >= 0:
             i = out[i]
         return i
 
-    def on_short(a, b):
+    def on_short(a, b, stmt):
+        j = kind.get(id(stmt), -1)
+        if j >= 0:
+            shorts_on[j] = True
+            return
         a, b = root(a), root(b)
         if a == b:
             return
@@ -244,11 +260,25 @@ def collapsed_nodes(m, par, given=None, temp_k=300.15, mfactor=1.0, gmin=1e-12):
             out[b] = a
         else:
             raise VAError("%s: V(%s,%s) <+ 0 between two terminals needs a branch current (not supported)" % (m.name, m.nodes[a], m.nodes[b]))
+
+    def on_contrib(b):
+        touched[b] = True
     try:
-        evaluate(m, [0.0] * m.n_nodes, par, temp_k, mfactor, gmin, given=given, on_short=on_short)
+        evaluate(m, [0.0] * m.n_nodes, par, temp_k, mfactor, gmin, given=given, on_short=on_short, on_contrib=on_contrib)
     except (ValueError, ZeroDivisionError, OverflowError):
         pass                    # a zero-bias probe may leave the model's domain after the collapse statements (setup section) ran
-    return {k: root(k) for k in out}
+    alias = {k: root(k) for k in out}
+    for j, si in enumerate(m.vshorts):           # both nets already one unknown: nothing to stamp (vasim.jl:2364 `if p != n`)
+        a, b = m.shorts[si][0], m.shorts[si][1]
+        if shorts_on[j] and alias.get(a, a) == alias.get(b, b):
+            shorts_on[j] = False
+    active = [touched[b] or not m.branch_guarded[b] for b in range(len(m.branches))]
+    return alias, shorts_on, active
+
+
+def collapsed_nodes(m, par, given=None, temp_k=300.15, mfactor=1.0, gmin=1e-12):
+    """internal node -> the node it is merged into (-1 = ground) for this instance (see instance_structure)."""
+    return instance_structure(m, par, given, temp_k, mfactor, gmin)[0]
 
 
 def static_eval(e, par, temp_k=300.15, mfactor=1.0, gmin=1e-12):

@@ -111,10 +111,11 @@ class VAFatal(RuntimeError):
     pass
 
 
-def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False, given=None, spec=None, on_short=None):
+def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False, given=None, spec=None, on_short=None, touched=None):
     """Branch contributions of ``mod`` on dual node voltages ``Vd``: one Dual / CDual / float per branch.
     ``limit_site(j, vnew_dual, fn)`` implements a $limit call site (stamp_va); ``given``: the parameters the instance sets
-    explicitly ($param_given); ``on_short(a, b)``: called for every executed V(a,b) <+ 0."""
+    explicitly ($param_given); ``on_short(a, b, stmt)``: called for every executed V(a,b) <+ 0; ``touched``: a list that
+    receives True at the index of every branch a current contribution executes for."""
     given = set(par) if given is None else set(given)
     for al, target in mod.aliasparams.items():
         if al in given:
@@ -245,6 +246,8 @@ def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False
                 if s[3][0] == "noise":
                     continue
                 b = mod.branches.index((mod.node_index(s[1]), mod.node_index(s[2])))
+                if touched is not None:
+                    touched[b] = True
                 acc[b] = acc[b] + ev(s[3])
             elif k == "block":
                 run(s[1])
@@ -282,12 +285,23 @@ def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False
                 raise VAFatal("%s: %s %s" % (mod.name, s[1], s[2]))
             elif k == "short":
                 if on_short is not None:
-                    on_short(mod.node_index(s[1]), mod.node_index(s[2]))
+                    on_short(mod.node_index(s[1]), mod.node_index(s[2]), s)
 
     for name, ie in mod.local_init:                             # module-scope initialisers, in declaration order
         env[name] = ev(ie)
     run(mod.body)
     return acc
+
+
+def short_aliases_a_terminal(mod, stmt):
+    """detect_short_circuits (vasim.jl:2723-2818): only ``V(int, ext) <+ 0`` in the if-branch of a top-level conditional aliases
+    the internal node to the terminal.  Every other two-net V(a,b) <+ 0 is a potential contribution with a branch current
+    (vasim.jl:2311-2395).  (The one-net form V(a) <+ 0 stays this build's alias to ground.)"""
+    a, b, guards = next(x[:3] for x in mod.shorts if x[3] is stmt)
+    np_ = len(mod.ports)
+    if b < 0:
+        return True
+    return len(guards) == 1 and guards[0][1] is True and ((a >= np_) != (b >= np_))
 
 
 def collapsed_nodes(mod, par, given, spec, mfactor=1.0, gmin=1e-12):
@@ -302,7 +316,9 @@ def collapsed_nodes(mod, par, given, spec, mfactor=1.0, gmin=1e-12):
             i = out[i]
         return i
 
-    def on_short(a, b):
+    def on_short(a, b, stmt):
+        if not short_aliases_a_terminal(mod, stmt):
+            return
         a, b = root(a), root(b)
         if a == b:
             return
@@ -362,9 +378,29 @@ def stamp_va(ctx, mod, ext_nodes, x, par, spec, instance, mfactor=1.0, gmin=None
         pl, nl = mod.limit_branches[mod.limit_sites[j]]
         return (Vf[pl] if pl >= 0 else 0.0) - (Vf[nl] if nl >= 0 else 0.0) - limw[j]
 
+    def on_short(a, b, stmt):
+        """An executed V(a,b) <+ 0 that is not a terminal alias: stamped where it stands, with its own branch current
+        (vasim.jl:2363-2393): KCL columns, the constraint row and its (zero) partials in every node column, b = 0."""
+        if short_aliases_a_terminal(mod, stmt):
+            return
+        p_node, n_node = (node[a] if a >= 0 else 0), (node[b] if b >= 0 else 0)
+        if p_node == n_node:
+            return
+        iv = ctx.alloc_current("%s_I_V_%s_%s" % (instance, mod.nodes[a], mod.nodes[b] if b >= 0 else "0"))
+        ctx.stamp_G(p_node, iv, 1.0)
+        ctx.stamp_G(n_node, iv, -1.0)
+        ctx.stamp_G(iv, p_node, 1.0)
+        ctx.stamp_G(iv, n_node, -1.0)
+        for k in range(N):
+            ctx.stamp_G(iv, node[k], -0.0)
+        ctx.stamp_b(iv, 0.0)
+
     temp_k = float(getattr(spec, "temp", 27.0)) + 273.15
-    Ibr = evaluate(mod, Vd, par, temp_k, mfactor, spec.gmin if gmin is None else gmin, limit_site, ctx.initjct, given, spec)
+    touched = [False] * len(mod.branches)
+    Ibr = evaluate(mod, Vd, par, temp_k, mfactor, spec.gmin if gmin is None else gmin, limit_site, ctx.initjct, given, spec, on_short, touched)
     for b, (pl, nl) in enumerate(mod.branches):
+        if mod.branch_guarded[b] and not touched[b]:
+            continue          # contributions inside conditionals are stamped inline, when they execute (vasim.jl:2397-2470): none did
         p_node = node[pl] if pl >= 0 else 0
         n_node = node[nl] if nl >= 0 else 0
         I_branch = mfactor * Ibr[b]

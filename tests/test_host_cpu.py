@@ -603,7 +603,7 @@ def test_verilog_a_front_end_and_generator():
     assert (m.name, m.ports, m.nodes) == ("tst", ["a", "b", "c"], ["a", "b", "c", "x"]) and list(m.params) == ["g", "cq", "k"]
     assert m.branches == [(0, 3), (3, 1), (2, -1)] and m.reactive == [True, False, True]
     assert m.var_is_dual == {"v": True, "i": True, "q": True, "w": False} and not any(m.var_is_reactive.values())
-    assert m.shape() == (4 + 3, 2 * 4 * 3 + 5 * 3, 2 * 3 + 2 * 4 * 3, 9, 3 + 3, 2)
+    assert m.shape() == (4 + 3, 2 * 4 * 3 + 5 * 3, 2 * 3 + 2 * 4 * 3, 9, 3 + 3, 3)      # (third ipar row: which V(a,b) <+ 0 statements execute)
     par = va.host_eval.defaults(m, {"G": 2e-3})
     assert par == {"g": 2e-3, "cq": 2e-12, "k": 4e-3}
     with pytest.raises(va.VAError):
@@ -617,7 +617,7 @@ def test_verilog_a_front_end_and_generator():
     assert "double v_w = 0.0;" in text and "T v_q = 0.0;" in text            # w never sees a voltage: stays a double
     assert "va_emit_branch<N, S, B, true>(d, u, s, Vf, ld, nd, 0, 0, 3," in text and "va_emit_branch<N, S, B, true>(d, u, s, Vf, ld, nd, 2, 2, -1," in text
     hdr = hipgen.generate_header([m])
-    assert '{"tst", 7, 39, 30, 9, 6, 2}' in hdr and "case 0: stamp_va_tst(d, u, s, lw); break;" in hdr
+    assert '{"tst", 7, 39, 30, 9, 6, 3}' in hdr and "case 0: stamp_va_tst(d, u, s, lw); break;" in hdr
     # a local that carries ddt(): the reactive part follows it through assignments, sums and scaling
     m2 = va.parse_module("module r(p, n); electrical p, n; parameter real c = 1p; real t1, t2;"
                          " analog begin t1 = ddt(c * V(p, n)); t2 = 2.0 * t1 + V(p, n) * 1m; I(p, n) <+ -t2 / 4.0; end endmodule")
@@ -637,7 +637,7 @@ def test_verilog_a_front_end_and_generator():
         I(a, c) <+ 1m * v1 * v3 + twice(V(e));  I(e) <+ 2m * v2;
       end endmodule""")
     assert m3.limit_branches == [(0, 1), (2, -1)] and m3.limit_sites == [0, 1, 0] and list(m3.functions) == ["clip", "twice"]
-    assert m3.shape() == (3 + 2 + 2, 2 * 3 * 2 + 4 * 2 + 3 * 2, 2 * 2 + 2 * 3 * 2, 6, 3, 2)
+    assert m3.shape() == (3 + 2 + 2, 2 * 3 * 2 + 4 * 2 + 3 * 2, 2 * 2 + 2 * 3 * 2, 6, 3, 3)
     assert m3.program([False, False])[:5] == [("G", 20, 5, 5), ("G", 21, 5, 0), ("G", 22, 5, 1), ("G", 23, 6, 6), ("G", 24, 6, 2)]
     (ia, _), (ie, _) = va.host_eval.evaluate(m3, [1.0, 0.2, 0.7], {}, vold=[0.5, 0.1])
     assert ia == pytest.approx(1e-3 * 0.6 * 0.8 + 2.0 * 0.7) and ie == pytest.approx(2e-3 * 0.3)      # clipped at vold + k; twice() clips at 1.0

@@ -1,0 +1,70 @@
+"""PSP103 (BASELINE.json config 5) on the CPU side: the committed fixtures tests/golden/psp103_*.npz are what
+tools/make_psp103_fixtures.py produces from the reference's model text today, the structure carries the numbers the reference
+documents, and the oracle passes the reference's own PSP103 tests.  Needs the model source (/root/reference or CADNIP_VA_PATH);
+the fixture-only checks run everywhere."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from cadnip_jl_amd import structure as S, va
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+HAVE_SOURCE = va.external_source(*va.EXTERNAL[0][1:]) is not None
+needs_source = pytest.mark.skipif(not HAVE_SOURCE, reason="psp103.va is not at hand (no reference checkout, CADNIP_VA_PATH unset)")
+
+
+def test_ring_fixture_carries_the_reference_layout():
+    """doc/ring_oscillator_investigation.md:22-26: 371 unknowns, C with 1296 stored entries; 8 internal nodes per device with
+    hierarchical names (test/mna/psp103_integration.jl:160-172); one branch current per executed V(a,b) <+ 0 of the model's
+    CollapsableR macro (vasim.jl:2311-2395) and 5 charge unknowns per device make up the rest: 10 + 1 + 18 (8 + 7 + 5) = 371."""
+    st, x = S.load_structure(os.path.join(GOLD, "psp103_ring.npz"))
+    assert (st.n, st.n_nodes, st.n_currents, st.n_charges, st.n_limits) == (371, 154, 127, 90, 0)
+    assert int((np.diff(st.c_ptr) > 0).sum()) == 1296
+    internal = [nm for nm in st.node_names if "PSP103VA" in nm]
+    assert len(internal) == 18 * 8 and len(set(internal)) == len(internal)
+    for inst in ("xu1_xmn_nm", "xu1_xmp_nm", "xu9_xmn_nm", "xu9_xmp_nm"):
+        assert sum(nm.startswith(inst + "_PSP103VA_") for nm in internal) == 8
+    assert st.current_names[0] == "I_vdd" and st.current_names[1] == "xu1_xmp_nm_I_V_G_GP" and len(st.current_names) == 1 + 18 * 7
+    assert x["U"].shape == (5, 371) and x["G"].shape == (5, st.nnz) and np.isfinite(x["G"]).all() and np.isfinite(x["b"]).all()
+    blk = next(b for b in st.blocks if b.type == "VA:PSP103VA")
+    assert blk.count == 18 and np.all(blk.ipar[0] == len(va.MODEL_FILES)) and np.all(blk.ipar[2] == 0x7F)
+
+
+@needs_source
+@pytest.mark.parametrize("name", ["nmos_defaults", "nmos_card", "ring"])
+def test_committed_fixtures_are_current(name):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_psp103_fixtures as mk
+    st, extra = mk.build(name)
+    st0, x0 = S.load_structure(os.path.join(GOLD, "psp103_%s.npz" % name))
+    assert st.signature() == st0.signature()
+    for k in ("U", "G", "C", "b"):
+        assert np.array_equal(extra[k], x0[k]), k
+    for i in range(int(x0["n_packed"][0])):
+        assert np.array_equal(extra["packed%d" % i], x0["packed%d" % i])
+
+
+@needs_source
+def test_oracle_passes_the_reference_psp103_dc_tests():
+    """test/mna/psp103_integration.jl:40-122 on the oracle: V(d) = 1.2, V(g) = 0.6, |Id| in (100 uA, 1 mA) with the default card
+    and in (10 uA, 10 mA) with the partial VACASK card."""
+    for name, lo, hi in (("nmos_defaults", 100e-6, 1e-3), ("nmos_card", 10e-6, 10e-3)):
+        st, x = S.load_structure(os.path.join(GOLD, "psp103_%s.npz" % name))
+        u = x["dc_x"]
+        assert abs(u[st.index_of("d")] - 1.2) < 1e-6 and abs(u[st.index_of("g")] - 0.6) < 1e-6
+        assert lo < abs(u[st.index_of("I_Vds")]) < hi
+        assert sum("PSP103VA" in nm for nm in st.node_names) == 8
+
+
+@needs_source
+def test_generated_external_header_is_current():
+    """csrc/va_generated_ext.hpp (committed: the library must build where the model source is absent) is what the generator
+    writes from the source today."""
+    from cadnip_jl_amd.va import hipgen, frontend
+    mods = [frontend.parse_file(va.external_source(fn, sd)) for _, fn, sd in va.EXTERNAL]
+    want = hipgen.generate_ext_header(mods)
+    have = open(os.path.join(ROOT, "cadnip.jl_amd", "csrc", "va_generated_ext.hpp")).read()
+    assert have == want

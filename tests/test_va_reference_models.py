@@ -164,6 +164,8 @@ def _device_compile(header_text, tmp_path, opt="-O1"):
     for h in ("devices.hpp", "va_runtime.hpp"):
         os.symlink(os.path.join(root, "cadnip.jl_amd", "csrc", h), src / h)
     (src / "va_generated.hpp").write_text(header_text)
+    from cadnip_jl_amd.va import hipgen
+    (src / "va_generated_ext.hpp").write_text(hipgen.generate_ext_header([]))     # no external model beside the ones under test
     (src / "tu.hip").write_text('#include <hip/hip_runtime.h>\n#include "devices.hpp"\nusing namespace cadnip;\n'
                                 "__global__ void k_tu(DevCtx d, const double* u, double* S, double* lw) {\n"
                                 "  SlotOut s{S, S + 100000, S + 200000, d.count, d.dev};\n  stamp_va(d, u, s, lw);\n}\n")

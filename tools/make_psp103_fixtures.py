@@ -1,0 +1,110 @@
+"""Golden fixtures for BASELINE.json's config 5 (PSP103 ring oscillator) and the reference's PSP103 DC tests.
+
+PSP103's Verilog-A source is third-party text inside the reference (models/PSPModels.jl/va) and is not copied into this
+repository, so it is absent on the GPU box.  What travels instead -- written by this script, run in the build container where
+/root/reference exists -- is DATA:
+
+  tests/golden/psp103_<case>.npz     the discovered structure (cadnip_jl_amd.structure.save_structure), the packed
+                                     per-instance parameter blocks, K states u with the ORACLE's G, C, b at each of them
+                                     (oracle/va_ref.py interpreting the model text on the oracle's own duals through
+                                     oracle/mna_ref.py's literal fast_rebuild!), and for the DC cases the oracle's DC solution.
+
+Cases: `nmos_defaults`, `nmos_card` -- test/mna/psp103_integration.jl:40-122 (the reference asserts |Id| in (100 uA, 1 mA) and
+(10 uA, 10 mA)); `ring` -- benchmarks/vacask/ring/cedarsim/runme.sp + models.inc (kept as data fixtures psp103_ring.sp /
+psp103_models.inc), n = 371 (doc/ring_oscillator_investigation.md:22).
+
+    python tools/make_psp103_fixtures.py            (needs /root/reference or CADNIP_VA_PATH)
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import cadnip_jl_amd as cj                                   # noqa: E402
+from cadnip_jl_amd import netlist, structure as S            # noqa: E402
+from oracle import mna_ref as M                              # noqa: E402
+from oracle.netlist_ref import make_builder                  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+NMOS_DEFAULTS = """* PSP103VA NMOS IV test with defaults
+.model nch psp103va type=1
+M1 d g 0 0 nch W=10u L=1u
+Vds d 0 DC 1.2
+Vgs g 0 DC 0.6
+"""
+# test/mna/psp103_integration.jl:67-106: a subset of the VACASK card
+NMOS_CARD = """* PSP103VA with full model parameters
+.model nch psp103va type=1 tr=27.0 vfbo=-1.1 vfbl=0 vfbw=0 stvfbo=5.0e-4 toxo=1.5e-9 epsroxo=3.9 nsubo=3.0e+23 nsubw=0 wseg=1.5e-10
++ npck=1.0e+24 npckw=0 wsegp=0.9e-8 lpck=5.5e-8 lpckw=0 fol1=2.0e-2 fol2=5.0e-6 facneffaco=0.8 gfacnudo=0.1 npo=1.5e+26 npl=10.0e-18
++ cto=5.0e-15 ctl=4.0e-2 ctlexp=0.6 toxovo=1.5e-9 toxovdo=2.0e-9 lov=10.0e-9 lovd=0 wot=0 thesato=0.5 mueo=0.5 mue=0.5
+M1 d g 0 0 nch W=10u L=1u
+Vds d 0 DC 1.2
+Vgs g 0 DC 0.6
+"""
+
+
+def ring_deck():
+    deck = open(os.path.join(GOLD, "psp103_ring.sp")).read()
+    inc = open(os.path.join(GOLD, "psp103_models.inc")).read()
+    return '.include "models.inc"\n' + deck.split("\n", 1)[1], {"models.inc": inc}     # (the first line is the title)
+
+
+def cases():
+    return {"nmos_defaults": (NMOS_DEFAULTS, {}, "dcop"), "nmos_card": (NMOS_CARD, {}, "dcop"), "ring": ring_deck() + ("tran",)}
+
+
+def states(st, K, seed, vmax):
+    """K probe states: zero, then random node voltages in [-0.1, 1.1] vmax, small branch currents, charges of either sign."""
+    rng = np.random.default_rng(seed)
+    U = np.zeros((K, st.n))
+    a, b, c = st.n_nodes, st.n_nodes + st.n_currents, st.n_nodes + st.n_currents + st.n_charges
+    for k in range(1, K):
+        U[k, :a] = (rng.random(a) * 1.2 - 0.1) * vmax
+        U[k, a:b] = (rng.random(b - a) - 0.5) * 1e-3
+        U[k, b:c] = (rng.random(c - b) - 0.5) * 1e-2
+    return U
+
+
+def build(name, K=5):
+    deck, includes, mode = cases()[name]
+    circ, _ = netlist.read_spice(deck, includes=includes)
+    st = cj.discover(circ, {})
+    packed = cj.pack_params(st, circ, {}, np.array([27.0]), 1, gmin=1e-12)
+    bld = make_builder(circ.to_dicts({}))
+    spec = M.MNASpec(mode=mode, temp=27.0)
+    ctx = M.build_with_detection(bld, {}, spec)
+    cs = M.compile_structure(bld, {}, spec, ctx=ctx)
+    ws = M.create_workspace(cs, ctx=ctx)
+    assert (st.n, st.node_names, st.current_names, st.charge_names) == (cs.n, ctx.node_names, ctx.current_names, ctx.charge_names)
+    assert np.array_equal(st.ref_colptr, cs.colptr) and np.array_equal(st.ref_rowval, cs.rowval)
+    U = states(st, K, 20261004, 1.2)
+    T = np.array([0.0, 0.0, 1.5e-9, 3e-9, 7e-9][:K])
+    Gs, Cs, bs = [], [], []
+    for u, t in zip(U, T):
+        M.fast_rebuild(ws, u, float(t))
+        Gs.append(cs.G.data.copy()); Cs.append(cs.C.data.copy()); bs.append(ws.dctx.b.copy())
+    extra = dict(U=U, T=T, G=np.array(Gs), C=np.array(Cs), b=np.array(bs), mode=np.frombuffer(mode.encode(), dtype=np.uint8),
+                 n_packed=np.array([len(packed)]))
+    for i, p in enumerate(packed):
+        extra["packed%d" % i] = p
+    if mode == "dcop":
+        sol = M.solve_dc(bld, {}, spec)
+        assert sol.converged
+        extra["dc_x"] = np.asarray(sol.x, dtype=float)
+    return st, extra
+
+
+def main():
+    for name in cases():
+        st, extra = build(name)
+        path = os.path.join(GOLD, "psp103_%s.npz" % name)
+        S.save_structure(st, path, **extra)
+        print("%-14s n = %d (nodes %d, currents %d, charges %d)  nnz %d  ->  %s (%.1f KB)" % (
+            name, st.n, st.n_nodes, st.n_currents, st.n_charges, st.nnz, os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()
