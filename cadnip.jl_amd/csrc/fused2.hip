@@ -85,6 +85,22 @@ static bool f2_prepare(CadnipHandle* h, F2Tables& T, const std::vector<int>& g_p
   }
   for (int s = 0; s < h->ns_g; ++s) if (gs[s] < 0) gs[s] = trash0 + lane_g[s];
   for (int s = 0; s < h->ns_b; ++s) if (br[s] < 0) br[s] = trash0 + lane_b[s];
+  // ---- the linear-solve sections first: the per-op program LU (lu_f2.hip) stages only this prefix of the table in LDS
+  T.begin(S_ENT); for (u64 wv : G.lanes) T.add64(wv);
+  T.begin(S_TERM); for (unsigned t : G.terms) T.add32(t);
+  T.begin(S_LEV); for (u64 wv : G.passes) T.add64(wv);
+  T.add64(0); T.add64(0);   // two empty passes: the kernel reads pass descriptors two ahead
+  std::vector<int> qoff(n);
+  for (int j = 0; j < n; ++j) qoff[j] = y0 + qinv[j];
+  T.begin(S_QINV); T.add16(qoff);
+  {
+    std::vector<int> rowoff(n);                       // unknown index -> rhs word of its row (direct residuals, devices.hpp Rn)
+    for (int i = 0; i < n; ++i) rowoff[i] = y0 + pinv[i];
+    T.begin(S_ROWOF); T.add16(rowoff);
+  }
+  T.begin(S_LOADPOS); T.add16(dst);                 // csr entry -> W word: the per-op program LU loads J = G + gamma C through it
+  while (T.data.size() & 3) T.data.push_back(0);   // the work arrays behind the staged prefix stay 16-byte aligned
+  h->f2_lu_len = (int)T.data.size();
   T.begin(S_GPOS); T.add16(gs);
   T.begin(S_CDESC);
   for (int s = 0; s < h->ns_c; ++s) {
@@ -104,19 +120,6 @@ static bool f2_prepare(CadnipHandle* h, F2Tables& T, const std::vector<int>& g_p
     for (int i = 0; i < n; ++i) for (int e = h->h_rowptr[i]; e < h->h_rowptr[i + 1]; ++e) row_of[e] = i;
     for (auto& oe : order) { const int e = oe.second; T.add64(pack4(dst[e], y0 + pinv[row_of[e]], h->h_colidx[e], 0)); }
   }
-  T.begin(S_ENT); for (u64 wv : G.lanes) T.add64(wv);
-  T.begin(S_TERM); for (unsigned t : G.terms) T.add32(t);
-  T.begin(S_LEV); for (u64 wv : G.passes) T.add64(wv);
-  T.add64(0); T.add64(0);   // two empty passes: the kernel reads pass descriptors two ahead
-  std::vector<int> qoff(n);
-  for (int j = 0; j < n; ++j) qoff[j] = y0 + qinv[j];
-  T.begin(S_QINV); T.add16(qoff);
-  {
-    std::vector<int> rowoff(n);                       // unknown index -> rhs word of its row (direct residuals, devices.hpp Rn)
-    for (int i = 0; i < n; ++i) rowoff[i] = y0 + pinv[i];
-    T.begin(S_ROWOF); T.add16(rowoff);
-  }
-  T.begin(S_LOADPOS); T.add16(dst);                 // csr entry -> W word: the per-op program LU loads J = G + gamma C through it
   T.begin(S_NODES);
   h->f2_nodes_off.clear();
   {
@@ -156,6 +159,8 @@ static int fused2_tables(CadnipHandle* h) {
   h->f2_blk_dirty = true;
   return CADNIP_OK;
 }
+
+bool fused2_tables_ready(CadnipHandle* h) { return fused2_tables(h) == CADNIP_OK; }
 
 // Does one instance of this circuit (tables + work array) fit into a CU's LDS?  The drivers fall back to the per-op
 // kernels (still on the GPU) when it does not, or when the tables cannot address it.

@@ -62,6 +62,7 @@ struct DeviceBlock {
   int g_base, c_base, b_base, n_g, n_c, n_b;
   int* d_nodes = nullptr;
   std::vector<int> h_nodes;  // host copy (the fused kernel keeps an int16 copy in LDS)
+  bool va_tl = false;        // generated external model: evaluated with one derivative direction per lane (stamp_csr.hip)
   bool mos1_plain = false;   // sp_mos1 block: every instance has gd = gs = OxideCap = 0 (set by cadnip_set_params)
   int* d_ipar = nullptr;
   double* d_par = nullptr;   // [B][n_par][count]
@@ -132,6 +133,7 @@ struct CadnipHandle {
   bool f2_blk_dirty = true;
   int f2_n_blk = 0, f2_rc_blk = -1;
   bool f2_direct = false;     // devices emit their residuals directly: no J*u pass (off: CADNIP_F2_NODIRECT=1)
+  int f2_lu_len = 0;          // 32-bit words of the table's linear-solve prefix (entry program, permutations, load map)
   bool va_ext = false;        // the circuit uses an external generated model (va_generated_ext.hpp): not compiled into the fused kernel
   bool f2_lean = false;       // only device types of the lean kernel variant (fused2.hip: dispatch_stamp2)
   int f2_src_blk = -1;        // first independent-source block of the fused block list
@@ -165,6 +167,7 @@ int launch_calib_copy(CadnipHandle* h, long n, int reps);
 int launch_negate(CadnipHandle* h, double* d_x, long n);
 struct TranArgs;                                                          // tran_ctrl.hpp
 int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds); // fused2.hip
+bool fused2_tables_ready(CadnipHandle* h);                                 // the packed tables exist (built on demand)
 bool fused2_fits(CadnipHandle* h);                                        // false: circuit too large for the LDS-resident kernel
 int launch_fused2_dc(CadnipHandle* h, const TranArgs& t, int rounds, double abstol, int maxiters, int use_pcnr, int mode, int initjct, int* d_dcstate);
 struct ProfScope {

@@ -5,7 +5,7 @@
 // sharing ONE copy of the program tables in LDS -- the first per-op LU (k_lu, kernels.hip) fetched every level's indices
 // from global memory behind three dependent loads and took 52 us for the DFF at B = 1024.
 // k_lu remains for what this program cannot do: factor-only / solve-only (the callback ABI's cadnip_factor /
-// cadnip_solve keep the factors in HBM) and circuits whose tables do not fit (fused2_fits).
+// cadnip_solve keep the factors in HBM) and circuits whose program does not fit.
 #include <hip/hip_runtime.h>
 #include "fused2_kernel.hpp"
 
@@ -114,13 +114,13 @@ __global__ void __launch_bounds__(64 * WPB) k_lu_f2(LuF2Args f) {
 
 // 0 = done with the program kernel; 1 = not applicable (the caller falls back to k_lu); < 0 never
 int launch_factor_solve_f2(CadnipHandle* h, const double* d_rhs, double* d_x) {
-  if (!h->analyzed || !fused2_fits(h)) return 1;
+  if (!h->analyzed || !fused2_tables_ready(h)) return 1;   // (only the linear-solve prefix of the tables has to fit: checked below)
   ProfScope ps(h, "lu_factor_solve");
   LuF2Args f;
-  f.tab = h->d_f2tab; for (int i = 0; i < S_NSEC; ++i) f.off[i] = h->f2off[i]; f.tab_len = h->f2len;
+  f.tab = h->d_f2tab; for (int i = 0; i < S_NSEC; ++i) f.off[i] = h->f2off[i]; f.tab_len = h->f2_lu_len;
   f.G = h->d_G; f.C = h->d_C; f.gamma = h->d_gamma; f.rhs = d_rhs; f.x = d_x; f.active = h->d_active; f.flags = h->d_flags;
   f.B = h->B; f.n = h->n; f.nnz = h->nnz; f.lu_words = h->f2_lu_words; f.n_pre = h->f2_n_pre; f.n_post = h->f2_n_post; f.nc = h->f2_nc; f.dn0 = h->f2_dn0;
-  const size_t tab_dbl = (size_t)h->f2len / 2, per = (size_t)h->f2_lu_words + h->n + F2_TRASH;
+  const size_t tab_dbl = (size_t)h->f2_lu_len / 2, per = (size_t)h->f2_lu_words + h->n + F2_TRASH;
   int wpb = 8;
   while (wpb > 1 && ((tab_dbl + wpb * per) * 8 > 160 * 1024 || h->B < 256 * wpb / 2)) wpb >>= 1;
   const size_t shmem = (tab_dbl + wpb * per) * 8;

@@ -24,8 +24,9 @@ def _lit(x):
 
 
 class _Gen:
-    def __init__(self, m, func=None):
+    def __init__(self, m, func=None, tl=False):
         self.m = m
+        self.tl = tl           # tangent-lane variant: T = Dual<1>, the lane's direction is `dir` (va_runtime.hpp)
         self.lines = []
         self.pre = []          # definitions of $limit sites: emitted in front of the statement that uses them
         self.func = func       # name of the analog function being generated: every variable has the template type X
@@ -60,7 +61,7 @@ class _Gen:
         if k == "ddx":
             c, t, _ = self.g(e[1])
             a = m.node_index(e[2])
-            return ("va_ddx(%s, %d)" % (c, a)) if (t and a >= 0) else "0.0", False, None
+            return ("va_ddx%s(%s, %d)" % ("_tl" if self.tl else "", c, a)) if (t and a >= 0) else "0.0", False, None
         if k == "var":
             if self.func:
                 return "f_" + e[1], True, None
@@ -78,7 +79,10 @@ class _Gen:
             self.pre.append("const double lim_w%d = %s<double>(%s, sys);" % (j, self.fname(e[3]), args))
             self.pre.append("if (lw) lw[nd[N + B + %d]] = lim_w%d;" % (lb, j))
             self.pre.append("ld[%d] = va_val(%s) - lim_w%d;" % (j, probe, j))
-            self.pre.append("const T site%d = va_site(%s, lim_w%d, N + %d);" % (j, probe, j, j))
+            if self.tl:
+                self.pre.append("const T site%d = va_site_tl(%s, lim_w%d, dir == N + %d);" % (j, probe, j, j))
+            else:
+                self.pre.append("const T site%d = va_site(%s, lim_w%d, N + %d);" % (j, probe, j, j))
             return "site%d" % j, True, None
         if k == "V":
             a, b = m.node_index(e[1]), m.node_index(e[2])
@@ -246,8 +250,8 @@ class _Gen:
                     self.lines.append("%s// V(%s,%s) <+ 0: the two nets are one unknown for this instance (collapsed at structure discovery)" % (pad, s[1], s[2]))
                 else:
                     a, b = m.shorts[m.vshorts[j]][0], m.shorts[m.vshorts[j]][1]
-                    self.lines.append("%sva_emit_short<N>(u, s, Vf, nd, N + B + NL + %d, %d, %d, %d, %d, ((smask >> %d) & 1) != 0);   // V(%s,%s) <+ 0 with a branch current"
-                                      % (pad, j, a, b, m.g_short(j), 3 * len(m.branches) + j, j, s[1], s[2]))
+                    self.lines.append("%sva_emit_short<N>(u, s, Vf, nd, N + B + NL + %d, %d, %d, %d, %d, ((smask >> %d) & 1) != 0%s);   // V(%s,%s) <+ 0 with a branch current"
+                                      % (pad, j, a, b, m.g_short(j), 3 * len(m.branches) + j, j, " && dir == 0" if self.tl else "", s[1], s[2]))
             elif s[0] == "block":
                 self.stmts(s[1], ind)
             elif s[0] == "if":
@@ -289,9 +293,13 @@ def generate_analog_functions(m):
     return "\n".join(out + defs)
 
 
-def generate_function(m):
+def generate_function(m, tl=False):
+    """tl: the tangent-lane variant ``stamp_va_<module>_tl(d, u, s, lw, dir)`` -- one derivative direction per lane, 16 lanes per
+    device (va_runtime.hpp); the statements are the same text on Dual<1>."""
     N, B, NP, S, NL = m.n_nodes, len(m.branches), len(m.params), m.n_sites, len(m.limit_branches)
-    g = _Gen(m)
+    if tl and N + S > 16:
+        raise VAError("%s: %d derivative directions do not fit the 16 lanes of a device group" % (m.name, N + S))
+    g = _Gen(m, tl=tl)
     L = g.lines
     if m.functions:
         L.append(generate_analog_functions(m))
@@ -299,9 +307,12 @@ def generate_function(m):
         m.name, ", ".join(m.nodes), NP, ", ".join("(%s,%s)%s" % (m.nodes[p] if p >= 0 else "gnd", m.nodes[n] if n >= 0 else "gnd",
                                                                " reactive" if r else "") for (p, n), r in zip(m.branches, m.reactive))))
     L.append("template <class Ctx, class Out>")
-    L.append("__device__ inline void stamp_va_%s(const Ctx& d, const double* u, const Out& s, double* lw) {" % m.name)
+    if tl:
+        L.append("__device__ inline void stamp_va_%s_tl(const Ctx& d, const double* u, const Out& s, double* lw, const int dir) {" % m.name)
+    else:
+        L.append("__device__ inline void stamp_va_%s(const Ctx& d, const double* u, const Out& s, double* lw) {" % m.name)
     L.append("  constexpr int N = %d, B = %d, S = %d, NL = %d;   // nodes, branches, $limit sites, limit unknowns" % (N, B, S, NL))
-    L.append("  typedef Dual<N + S> T;")
+    L.append("  typedef Dual<%s> T;" % ("1" if tl else "N + S"))
     L.append("  constexpr int NV = %d;   // V(a,b) <+ 0 statements that own a branch current" % len(m.vshorts))
     L.append("  int nd[N + B + NL + NV];")
     L.append("#pragma unroll")
@@ -312,7 +323,10 @@ def generate_function(m):
     L.append("#pragma unroll")
     L.append("  for (int k = 0; k < N; ++k) Vf[k] = volt(u, nd[k]);")
     for k in range(N):
-        L.append("  const T V%d = T::seed(Vf[%d], %d);   // V(%s)" % (k, k, k, m.nodes[k]))
+        if tl:
+            L.append("  const T V%d = va_seed_tl(Vf[%d], dir == %d);   // V(%s)" % (k, k, k, m.nodes[k]))
+        else:
+            L.append("  const T V%d = T::seed(Vf[%d], %d);   // V(%s)" % (k, k, k, m.nodes[k]))
     for i, p in enumerate(m.params):
         if m.param_kind.get(p) == "string":
             continue
@@ -327,7 +341,7 @@ def generate_function(m):
     for lb, (p, n) in enumerate(m.limit_branches):
         L.append("  const double vold%d = u[nd[N + B + %d]];   // limit unknown of probe branch (%s,%s)" % (
             lb, lb, m.nodes[p] if p >= 0 else "gnd", m.nodes[n] if n >= 0 else "gnd"))
-        L.append("  va_emit_limit_rows<N, B>(s, %d);" % lb)
+        L.append("  %sva_emit_limit_rows<N, B>(s, %d);" % ("if (dir == 0) " if tl else "", lb))
     for v in m.locals_:
         L.append("  %s v_%s = 0.0;" % ("T" if m.var_is_dual[v] else "double", v))
         if m.var_is_reactive[v]:
@@ -336,6 +350,17 @@ def generate_function(m):
         L.append("  T br%d_r = 0.0, br%d_q = 0.0;" % (b, b))
     g.stmts([("assign", nm, ie) for nm, ie in m.local_init], 1)       # module-scope initialisers, in declaration order
     g.stmts(m.body, 1)
+    if tl:
+        L.append("  // this lane's weight in the equivalent currents: -V_dir for a node direction, V(probe) - w for a $limit site, 0 when idle")
+        L.append("  double wgt = 0.0;")
+        for k in range(N):
+            L.append("  if (dir == %d) wgt = -Vf[%d];" % (k, k))
+        for j in range(S):
+            L.append("  if (dir == N + %d) wgt = ld[%d];" % (j, j))
+        for b, ((p, n), r) in enumerate(zip(m.branches, m.reactive)):
+            L.append("  va_emit_branch_tl<N, S, B, %s>(s, %d, sys.mf * br%d_r, sys.mf * br%d_q, wgt, dir);" % ("true" if r else "false", b, b, b))
+        L.append("}")
+        return "\n".join(L)
     L.append("  const int vdep = d.ipar[1 * d.count + d.dev];   // bit b: branch b uses a charge unknown")
     for b, ((p, n), r) in enumerate(zip(m.branches, m.reactive)):
         L.append("  va_emit_branch<N, S, B, %s>(d, u, s, Vf, ld, nd, %d, %d, %d, sys.mf * br%d_r, sys.mf * br%d_q, ((vdep >> %d) & 1) != 0);"
@@ -354,7 +379,7 @@ def generate_header(modules):
     out = ["// GENERATED by cadnip.jl_amd/va/hipgen.py from the Verilog-A sources listed below -- do not edit.",
            "// Included by devices.hpp (device code) and api.hip (shape table).", "#pragma once", ""]
     out.append("#define CADNIP_VA_NBUILTIN %d" % len(modules))
-    out.append('#include "va_generated_ext.hpp"   // CADNIP_VA_NEXT, CADNIP_VA_EXT_DISPATCH, CADNIP_VA_EXT_SHAPES (+ device code under CADNIP_VA_WITH_EXT)')
+    out.append('#include "va_generated_ext.hpp"   // CADNIP_VA_NEXT, CADNIP_VA_EXT_DISPATCH_TL, CADNIP_VA_EXT_SHAPES (+ device code under CADNIP_VA_WITH_EXT)')
     out.append("#ifdef CADNIP_VA_DEVICE_CODE   // set by va_runtime.hpp (device translation units); api.hip takes the shape table only")
     out.append("namespace cadnip {")
     for m in modules:
@@ -366,12 +391,19 @@ def generate_header(modules):
     out.append("  switch (d.ipar[0 * d.count + d.dev]) {")
     for i, m in enumerate(modules):
         out.append("    case %d: stamp_va_%s(d, u, s, lw); break;" % (i, m.name))
-    out.append("#ifdef CADNIP_VA_WITH_EXT   // only the per-op stamping kernel carries the large external models (stamp_csr.hip)")
-    out.append("    CADNIP_VA_EXT_DISPATCH")
-    out.append("#endif")
     out.append("    default: break;")
     out.append("  }")
     out.append("}")
+    out.append("#ifdef CADNIP_VA_WITH_EXT   // only the per-op stamping kernel carries the large external models (stamp_csr.hip)")
+    out.append("// external models: lane `dir` of the device's 16-lane group computes the partial of direction `dir`")
+    out.append("template <class Ctx, class Out>")
+    out.append("__device__ inline void stamp_va_tl(const Ctx& d, const double* u, const Out& s, double* lw, const int dir) {")
+    out.append("  switch (d.ipar[0 * d.count + d.dev]) {")
+    out.append("    CADNIP_VA_EXT_DISPATCH_TL")
+    out.append("    default: break;")
+    out.append("  }")
+    out.append("}")
+    out.append("#endif")
     out.append("}  // namespace cadnip")
     out.append("#endif")
     out.append("")
@@ -394,11 +426,12 @@ def generate_ext_header(modules):
            "// Included by va_generated.hpp.", "#pragma once", ""]
     out.append("#define CADNIP_VA_NEXT %d" % len(modules))
     out.append("#define CADNIP_VA_EXT_SHAPES " + " ".join('{"%s", %d, %d, %d, %d, %d, %d},' % ((m.name,) + m.shape()) for m in modules))
-    out.append("#define CADNIP_VA_EXT_DISPATCH " + " ".join("case CADNIP_VA_NBUILTIN + %d: stamp_va_%s(d, u, s, lw); break;" % (i, m.name) for i, m in enumerate(modules)))
+    out.append("// evaluated with one derivative direction per lane, 16 lanes per device (va_runtime.hpp: tangent lanes)")
+    out.append("#define CADNIP_VA_EXT_DISPATCH_TL " + " ".join("case CADNIP_VA_NBUILTIN + %d: stamp_va_%s_tl(d, u, s, lw, dir); break;" % (i, m.name) for i, m in enumerate(modules)))
     out.append("#if defined(CADNIP_VA_DEVICE_CODE) && defined(CADNIP_VA_WITH_EXT)")
     out.append("namespace cadnip {")
     for m in modules:
-        out.append(generate_function(m))
+        out.append(generate_function(m, tl=True))
         out.append("")
     out.append("}  // namespace cadnip")
     out.append("#endif")
