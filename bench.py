@@ -429,6 +429,7 @@ def run(args, rank, world, local_rank, dist, dev, sync, reduce_max, reduce_sum, 
                 sk["traffic_GBps"] = round(live["stamp"]["hbm_bytes_per_launch"] / (sk["avg_us"] * 1e3), 1)
             extras["stamp_kernel"] = sk
             extras.update(single_and_callback(circ, local_rank, args))
+            extras["psp103_ring"] = psp103_ring_leg(local_rank)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args, circ, sim, pts, save_t)
@@ -448,6 +449,38 @@ def run(args, rank, world, local_rank, dist, dev, sync, reduce_max, reduce_sum, 
         result.update(extras)
     sim.close()
     return result
+
+
+def psp103_ring_leg(device):
+    """BASELINE.json config 5 beside the headline number: the reference's 9-stage PSP103 ring oscillator (n = 371, generated PSP103 evaluated
+    on tangent lanes, per-op path), a 20 ns slice of its 1 us run with the reference's tolerances (runme.jl:66), alone and as 256 supply
+    corners.  Structure and parameters come from the committed fixture (the model source is not on the GPU box)."""
+    from cadnip_jl_amd import api, structure as S
+    from cadnip_jl_amd.structure import expand_breakpoints
+    out = {"workload": "benchmarks/vacask/ring: 9 stages, 18 PSP103 devices, n = 371; CedarTranOp start, 20 ns slice, dtmax 50 ps, abstol 1e-4, reltol 1e-2",
+           "reference_us_per_iter": 1376.0, "vacask_us_per_iter": 27.8, "reference_source": "doc/ring_oscillator_investigation.md:299-313"}
+    try:
+        st, x = S.load_structure(os.path.join(ROOT, "tests", "golden", "psp103_ring.npz"))
+        for B in (1, 256):
+            packed = [np.repeat(x["packed%d" % i], B, axis=0) for i in range(int(x["n_packed"][0]))]
+            vb = next(i for i, b in enumerate(st.blocks) if b.type == "V")
+            packed[vb][:, 0, 0] = np.linspace(1.1, 1.3, B) if B > 1 else 1.2
+            sim = api.BatchSimulator.from_packed(st, packed, api.MNASpec(mode="tran", temp=27.0), device=device, vscale=1.2)
+            try:
+                sim.analyze()
+                u, conv, _ = sim.dc(abstol=1e-9, mode="tranop")
+                sim.h.set_spec(mode="tran")
+                t1 = 20e-9
+                _, _, stats = sim.h.tran_run(0.0, t1, st.state_abstol(vntol=1e-4, iabstol=1e-7, chgtol=1e-4), 1e-2, breaks=expand_breakpoints(st.breakpoints, (0.0, t1)),
+                                             save_t=np.array([t1]), obs=[st.index_of("1")], hmax=50e-12, fused=0)
+            finally:
+                sim.close()
+            out["B%d" % B] = {"newton_iters": int(stats["newton_iters"]), "wall_s": round(stats["wall_seconds"], 3), "failed": int(stats["n_failed"]) + int((~conv).sum()),
+                              "us_per_instance_iter": round(1e6 * stats["wall_seconds"] / max(stats["newton_iters"], 1), 3),
+                              "us_per_newton_round": round(1e6 * stats["wall_seconds"] / max(stats["launches"], 1), 1)}
+    except Exception as e:       # the headline line must not depend on this leg
+        out["error"] = "%s: %s" % (type(e).__name__, e)
+    return out
 
 
 def single_and_callback(circ, device, args):

@@ -144,6 +144,109 @@ end
 make_gpu_dae_residual() = (resid, du, u, ws::GPUEvalWorkspace, t) -> fast_residual!(resid, du, u, ws, t)
 make_gpu_dae_jacobian() = (J, du, u, ws::GPUEvalWorkspace, gamma, t) -> fast_jacobian!(J, du, u, ws, gamma, t)
 
+# ---- walking CompiledStructure into CadnipStructure (SURVEY.md section 8f-1) --------------------------------------------
+# What the library needs beyond the matrices is, per device, WHICH stamp of the builder pass lands WHERE.  The reference
+# already has that in positional form: the k-th stamp_G! call of a builder pass writes nzval[cs.G_coo_to_idx[k]]
+# (src/mna/value_only.jl:395-421, src/mna/precompile.jl:75-124), stamp_C! likewise, and the k-th deferred b stamp goes to row
+# cs.b_deferred_resolved[k] (direct b stamps: the row itself).  A device table row says how many stamps its stamp! method
+# issues and in which local order (`program`: the same fixed per-type programs as cadnip.jl_amd/structure.py PROGRAMS, i.e.
+# the statement order of src/mna/devices.jl / the generated stamp! of src/vasim.jl:3319-3521), so one walk over the table in
+# builder order splits the three positional streams into (block, local slot, device) -> target.
+
+"One instance of the flattened netlist: type id (include/cadnip_hip.h CadnipDeviceType), resolved local unknown indices
+(0-based, -1 = ground), integer parameters, and its stamp program: (stream, local slot, local row, local col) with stream
+:G / :C / :b in the order the stamp! method issues them; stamps into ground are NOT listed (the reference skips them before
+the positional counter, value_only.jl:395-397)."
+struct DeviceRow
+    type::Int32
+    nodes::Vector{Int32}
+    ipar::Vector{Int32}
+    program::Vector{Tuple{Symbol,Int32,Int32,Int32}}
+    shape::NTuple{6,Int32}            # n_nodes, n_g, n_c, n_b, n_par, n_ipar of the type (CADNIP_VA_SHAPES for generated modules)
+end
+
+"""
+    export_structure(cs::MNA.CompiledStructure, ctx::MNA.MNAContext, table::Vector{DeviceRow}; n_instances=1, device=0)
+
+`cs`, `ctx` as `compile_structure` leaves them (precompile.jl:312-443); `table` in builder order.  Returns the
+`GPUEvalWorkspace` whose CSR pattern, `to_ref_nz` permutation and per-nz gather lists reproduce `cs.G` / `cs.C` / `b`
+addition for addition (COO order), so `nonzeros(J)` comes back in `cs.G`'s own nzval order.
+"""
+function export_structure(cs, ctx, table::Vector{DeviceRow}; n_instances=1, device=0)
+    n = cs.n; G = cs.G
+    colptr, rowval = G.colptr, G.rowval                       # cs.C shares the pattern (precompile.jl:413-421)
+    nnz_ = length(rowval)
+    # CSC -> CSR with the permutation back to the reference's nzval order
+    rowcount = zeros(Int32, n + 1)
+    for r in rowval; rowcount[r + 1] += 1; end
+    rowptr = cumsum(rowcount)                                  # 0-based row pointer
+    fill_ = copy(rowptr[1:n]); colidx = zeros(Int32, nnz_); to_ref = zeros(Int32, nnz_); csr_of = zeros(Int32, nnz_)
+    for j in 1:n, p in colptr[j]:(colptr[j + 1] - 1)
+        r = rowval[p]; e = (fill_[r] += 1)
+        colidx[e] = j - 1; to_ref[e] = p - 1; csr_of[p] = e - 1
+    end
+    # blocks: instances grouped by type in order of first appearance (one kernel per device type)
+    order = unique(Int32[d.type for d in table])
+    members = Dict(t => findall(d -> d.type == t, table) for t in order)
+    gb = cb = bb = Int32(0); bases = Dict{Int32,NTuple{3,Int32}}()
+    blocks = CadnipDeviceBlock[]; keep = Any[]
+    for t in order
+        idx = members[t]; sh = table[idx[1]].shape; cnt = Int32(length(idx))
+        nodes = Int32[table[i].nodes[k] for k in 1:sh[1], i in idx] |> permutedims |> vec        # [n_local][count]
+        ipar = Int32[get(table[i].ipar, k, 0) for k in 1:max(sh[6], 1), i in idx] |> permutedims |> vec
+        push!(keep, nodes, ipar)
+        bases[t] = (gb, cb, bb)
+        push!(blocks, CadnipDeviceBlock(t, cnt, sh[1], pointer(nodes), sh[6], pointer(ipar), sh[5], gb, cb, bb, sh[2], sh[3], sh[4]))
+        gb += sh[2] * cnt; cb += sh[3] * cnt; bb += sh[4] * cnt
+    end
+    # one walk over the builder order: positional streams -> per-target slot lists, COO order preserved
+    g_lists = [Int32[] for _ in 1:nnz_]; c_lists = [Int32[] for _ in 1:nnz_]; b_lists = [Int32[] for _ in 1:n]
+    kg = kc = kb = 0
+    seen = Dict(t => 0 for t in order)
+    for d in table
+        dev = seen[d.type]; seen[d.type] += 1
+        cnt = length(members[d.type]); (g0, c0, b0) = bases[d.type]
+        for (stream, slot, lrow, lcol) in d.program
+            if stream === :G
+                kg += 1; push!(g_lists[csr_of[cs.G_coo_to_idx[kg]] + 1], g0 + slot * cnt + dev)
+            elseif stream === :C
+                kc += 1; push!(c_lists[csr_of[cs.C_coo_to_idx[kc]] + 1], c0 + slot * cnt + dev)
+            else
+                kb += 1; push!(b_lists[d.nodes[lrow + 1] + 1], b0 + slot * cnt + dev)     # resolved row of the stamp (deferred ones: cs.b_deferred_resolved)
+            end
+        end
+    end
+    (kg == cs.G_n_coo && kc == cs.C_n_coo) || error("device table does not account for every stamp of the builder pass ($kg/$(cs.G_n_coo) G, $kc/$(cs.C_n_coo) C)")
+    flat(ls) = (Int32[0; cumsum(length.(ls))], reduce(vcat, ls; init=Int32[]))
+    (g_ptr, g_slots), (c_ptr, c_slots), (b_ptr, b_slots) = flat(g_lists), flat(c_lists), flat(b_lists)
+    diag = Int32[(e = findfirst(==(i - 1), view(colidx, rowptr[i] + 1:rowptr[i + 1])); e === nothing ? -1 : rowptr[i] + e - 1) for i in 1:n]
+    ws = export_structure(n, cs.n_nodes, cs.n_currents, ctx.n_charges, cs.n_limits, Int32.(rowptr), colidx, to_ref, blocks, Float64[],
+                          (gb, cb, bb), g_ptr, g_slots, c_ptr, c_slots, b_ptr, b_slots, diag, Vector{Float64}(cs.limit_init);
+                          n_instances=n_instances, device=device)
+    append!(ws.keep, keep)
+    return ws
+end
+
+# ---- the GPU LU behind LinearSolve.jl: what `KLUFactorization()` is to src/mna/solve.jl:612-613 and to DFBDF / FBDF's `linsolve` ----
+# (Sundials' IDA takes its linear solver by name, src/sweeps.jl:600; a Julia host that wants the GPU factorisation inside IDA
+# wraps the same three calls in a SUNLinearSolver through Sundials.jl's `LinSolHandle` -- setup = factor!, solve = solve!.)
+#
+#   using LinearSolve
+#   struct CadnipLU <: LinearSolve.SciMLLinearSolveAlgorithm; ws::GPUEvalWorkspace; end
+#   LinearSolve.init_cacheval(alg::CadnipLU, A, b, u, Pl, Pr, maxiters, abstol, reltol, verbose, assumptions) = (analyze!(alg.ws); alg.ws)
+#   function SciMLBase.solve!(cache::LinearSolve.LinearCache, alg::CadnipLU; kwargs...)
+#       ws = cache.cacheval
+#       if cache.isfresh                      # a new Jacobian was written into cache.A by fast_jacobian!: it is already on the device
+#           factor!(ws); cache.isfresh = false
+#       end
+#       solve!(cache.u, ws, cache.b)
+#       return SciMLBase.build_linear_solution(alg, cache.u, nothing, cache)
+#   end
+#
+# The Jacobian never travels: fast_jacobian! leaves J = G + gamma C on the device (the nzval copy it returns is for the host's
+# own use), factor! refactors it with the stored pivot sequence (klu_refactor semantics; CADNIP_SINGULAR -> SingularException,
+# which the reference's callers catch: src/mna/solve.jl:887-897), solve! runs the two triangular sweeps.
+
 Base.close(ws::GPUEvalWorkspace) = (ccall((:cadnip_destroy, LIB), Cvoid, (Ptr{Cvoid},), ws.handle); ws.handle = C_NULL; nothing)
 
 end # module
