@@ -516,6 +516,94 @@ def dc(target, u0=None, device=0, continuation=True):
         sim.close()
 
 
+class ACSol:
+    """ac!'s result (src/ac.jl:75-82): the system linearised at the DC point -- G (with gmin on the voltage-node diagonals), C, the
+    excitation b_ac -- plus the DC solution and the frequency grid in hertz.  ``sol[name]`` is the complex response of a node
+    voltage or a branch current over the grid (ac.jl name-based access); ``freqresp(name, omegas)`` evaluates at angular
+    frequencies (ac.jl:185-215); ``magnitude_db`` / ``phase_deg`` as in ac.jl:228-273."""
+
+    def __init__(self, st, G, C, b_ac, dc_x, freqs):
+        self.st, self.G, self.C, self.b_ac, self.dc_x, self.freqs = st, G, C, b_ac, dc_x, np.asarray(freqs, dtype=float)
+        self._cache = {}
+
+    def _solve(self, omegas):
+        key = tuple(np.asarray(omegas, dtype=float))
+        if key not in self._cache:
+            self._cache[key] = np.array([np.linalg.solve(self.G + 1j * w * self.C, self.b_ac) for w in key]) if len(key) else np.zeros((0, self.st.n), complex)
+        return self._cache[key]
+
+    def freqresp(self, name, omegas):
+        return self._solve(omegas)[:, self.st.index_of(name)]
+
+    def __getitem__(self, name):
+        return self.freqresp(name, 2.0 * np.pi * self.freqs)
+
+    def magnitude_db(self, name, freqs=None):
+        r = self[name] if freqs is None else self.freqresp(name, 2.0 * np.pi * np.asarray(freqs, dtype=float))
+        return 20.0 * np.log10(np.abs(r))
+
+    def phase_deg(self, name, freqs=None):
+        r = self[name] if freqs is None else self.freqresp(name, 2.0 * np.pi * np.asarray(freqs, dtype=float))
+        return np.degrees(np.angle(r))
+
+
+def acdec(points_per_decade, fstart, fstop):
+    """SPICE ``.ac dec``: logarithmic grid with ``points_per_decade`` points per decade from fstart to fstop (hertz)."""
+    n = int(np.floor(np.log10(fstop / fstart) * points_per_decade + 1e-9)) + 1
+    return fstart * 10.0 ** (np.arange(n) / points_per_decade)
+
+
+def rhs_ac(st, circuit, params):
+    """get_rhs_ac (build.jl:169-190): V sources stamp their ``ac`` value on their branch row (devices.jl:659), I sources +ac into p
+    and -ac into n (devices.jl:728-729)."""
+    from .circuit import resolve
+    b = np.zeros(st.n, dtype=complex)
+    for d in circuit.devices:
+        if d.type not in ("V", "I"):
+            continue
+        ac = complex(resolve(d.params.get("ac", 0.0), params))
+        if ac == 0:
+            continue
+        if d.type == "V":
+            b[st.index_of("I_" + d.name)] += ac
+        else:
+            for nm, sgn in ((d.nodes[0], 1.0), (d.nodes[1], -1.0)):
+                if nm not in ("0", "gnd", "gnd!"):
+                    b[st.index_of(nm)] += sgn * ac
+    return b
+
+
+def ac(target, freqs=(), gmin=1e-12, device=0):
+    """ac!(circuit, freqs; gmin) -- src/ac.jl:113-170.  The DC operating point and the restamp at it run on the GPU (cadnip_dc_run,
+    cadnip_rebuild: the linearisation IS the stamping); G gets ``gmin`` on the voltage-node diagonals (assemble_G(ctx; gshunt=gmin),
+    ac.jl:127).  The frequency sweep is the reference's own dense ``(jw C + G)^-1 b_ac`` on the host: n is a circuit's size, not a
+    batch dimension.  A CircuitSweep returns one ACSol per point (one resident batch per structure class)."""
+    import scipy.sparse as sp
+    sweep = isinstance(target, CircuitSweep)
+    mc0 = target.circuit if sweep else target
+    mc = MNACircuit(mc0.circuit, mc0.params, MNASpec(temp=mc0.spec.temp, mode="dcop", gmin=mc0.spec.gmin))
+    pts = target.points() if sweep else [{}]
+    sols = [None] * len(pts)
+    for idx, st in structure_classes(mc, pts) if sweep else [(list(range(1)), None)]:
+        sim = BatchSimulator(mc, [pts[i] for i in idx] if sweep else None, device, st=st)
+        try:
+            st = sim.st
+            u, conv, _ = sim.dc()
+            if not np.all(conv):
+                raise RuntimeError("ac: the DC operating point did not converge for %d point(s)" % int((~conv).sum()))
+            sim.h.rebuild(u, 0.0)
+            G, C, _, _ = sim.h.get_GCb()
+            for k, i in enumerate(idx):
+                dense = lambda nz: sp.csc_matrix((nz, st.ref_rowval, st.ref_colptr), shape=(st.n, st.n)).toarray()
+                Gd, Cd = dense(G[k]), dense(C[k])
+                Gd[np.arange(st.n_nodes), np.arange(st.n_nodes)] += gmin
+                p_i = {kk: float(v[k]) for kk, v in sim.params.items()}
+                sols[i] = ACSol(st, Gd, Cd, rhs_ac(st, mc.circuit, p_i), u[k].copy(), freqs)
+        finally:
+            sim.close()
+    return SweepResult(pts, sols) if sweep else sols[0]
+
+
 def tran(target, tspan, abstol=1e-10, reltol=1e-8, saveat=None, device=0, **kw):
     """tran!(circuit, tspan) / tran!(cs::CircuitSweep, tspan) -- sweeps.jl:588-665, 692-707."""
     tspan = (float(tspan[0]), float(tspan[1]))

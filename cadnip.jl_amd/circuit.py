@@ -53,11 +53,12 @@ class Circuit:
     def L(self, name, p, n, l):
         return self._add("L", name, (p, n), {"l": l})
 
-    def V(self, name, p, n, dc=0.0, wave=None, scale=1.0):
-        return self._add("V", name, (p, n), {"dc": dc, "scale": scale}, wave=wave)
+    def V(self, name, p, n, dc=0.0, wave=None, scale=1.0, ac=0.0):
+        """``ac``: small-signal excitation (complex: magnitude and phase), stamped into b_ac only (devices.jl:659)."""
+        return self._add("V", name, (p, n), {"dc": dc, "scale": scale, "ac": ac}, wave=wave)
 
-    def I(self, name, p, n, dc=0.0, wave=None, scale=1.0):
-        return self._add("I", name, (p, n), {"dc": dc, "scale": scale}, wave=wave)
+    def I(self, name, p, n, dc=0.0, wave=None, scale=1.0, ac=0.0):
+        return self._add("I", name, (p, n), {"dc": dc, "scale": scale, "ac": ac}, wave=wave)
 
     def E(self, name, op, on, ip, in_, gain):
         return self._add("E", name, (op, on, ip, in_), {"gain": gain})

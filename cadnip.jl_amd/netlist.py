@@ -335,9 +335,22 @@ def read_spice(text, models=None, includes=None, sweep=(), title=""):
                     dc = args[0]
                 rest = rest[:m.start()] + rest[m.end():]
             rt = [t for t in rest.split() if t.lower() != "dc"]
+            ac = 0.0
+            low = [t.lower() for t in rt]
+            if "ac" in low:      # AC mag [phase in degrees]  (test/ac.jl:21, 101-108)
+                k = low.index("ac")
+                vals = []
+                for t in rt[k + 1:k + 3]:
+                    try:
+                        vals.append(float(sc.val(t)))
+                    except (ValueError, KeyError):
+                        break
+                mag = vals[0] if vals else 1.0
+                ac = mag * complex(math.cos(math.radians(vals[1])), math.sin(math.radians(vals[1]))) if len(vals) > 1 else mag
+                rt = rt[:k] + rt[k + 1 + len(vals):]
             if rt:
                 dc = sc.val(rt[0])
-            (sources if kind == "v" else others).append((kind.upper(), name, (p, n), {"dc": dc, "wave": wave}))
+            (sources if kind == "v" else others).append((kind.upper(), name, (p, n), {"dc": dc, "wave": wave, "ac": ac}))
         elif kind in "rcl":
             others.append((kind.upper(), name, (sc.node(toks[1]), sc.node(toks[2])), {"value": sc.val(toks[3])}))
         elif kind in "eg":
@@ -413,9 +426,9 @@ def read_spice(text, models=None, includes=None, sweep=(), title=""):
     c = Circuit(title)
     for ty, name, nodes, a in sources + others:
         if ty == "V":
-            c.V(name, nodes[0], nodes[1], dc=a["dc"], wave=a["wave"])
+            c.V(name, nodes[0], nodes[1], dc=a["dc"], wave=a["wave"], ac=a.get("ac", 0.0))
         elif ty == "I":
-            c.I(name, nodes[0], nodes[1], dc=a["dc"], wave=a["wave"])
+            c.I(name, nodes[0], nodes[1], dc=a["dc"], wave=a["wave"], ac=a.get("ac", 0.0))
         elif ty == "R":
             c.R(name, nodes[0], nodes[1], a["value"])
         elif ty == "C":
