@@ -85,6 +85,19 @@ int cadnip_create(const CadnipStructure* s, int32_t n_instances, int32_t device,
   CREATE_TRY(dev_upload(&h->d_c_slots, s->c_slots, (size_t)s->c_ptr[s->nnz]));
   CREATE_TRY(dev_upload(&h->d_b_ptr, s->b_ptr, (size_t)s->n + 1));
   CREATE_TRY(dev_upload(&h->d_b_slots, s->b_slots, (size_t)s->b_ptr[s->n]));
+  {
+    // the device-local unknowns (charges, limits) and which of them carry a constant-1 diagonal (one G stamp, no C stamp on their own
+    // diagonal entry): the symbolic phase marks such pivots `unit` -- nothing divides by them.  CADNIP_LU_NOLEAF=1 switches that off,
+    // CADNIP_LU_LEAF_FIRST=1 additionally pivots them before everything else (diagnostics).
+    h->leaf_unit_ok.assign(s->n, 0);
+    const int q0 = s->n_nodes + s->n_currents, l0 = s->n - s->n_limits;
+    for (int i = q0; i < s->n; ++i)
+      for (int e = s->rowptr[i]; e < s->rowptr[i + 1]; ++e)
+        if (s->colidx[e] == i) h->leaf_unit_ok[i] = (s->g_ptr[e + 1] - s->g_ptr[e] == 1 && s->c_ptr[e + 1] == s->c_ptr[e]) ? 1 : 0;
+    if (!getenv("CADNIP_LU_NOLEAF") && q0 >= 0 && q0 <= l0 && l0 <= s->n && s->n_charges == l0 - q0) {
+      h->leaves.q_begin = q0; h->leaves.lim_begin = l0; h->leaves.unit_ok = h->leaf_unit_ok.data(); h->leaves.first = getenv("CADNIP_LU_LEAF_FIRST") != nullptr;
+    }
+  }
   std::vector<unsigned char> dflag(s->nnz, 0);
   for (int i = 0; i < s->n_nodes; ++i) { int p = s->diag_nz[i]; if (p >= 0 && p < s->nnz) dflag[p] = 1; }
   CREATE_TRY(dev_upload(&h->d_diag_flag, dflag.data(), dflag.size()));
@@ -195,6 +208,7 @@ void cadnip_destroy(CadnipHandle* h) {
   }
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->d_f2queue) (void)hipFree(h->d_f2queue);
+  if (h->d_f2_lufac) (void)hipFree(h->d_f2_lufac);
   if (h->d_f2blk) (void)hipFree(h->d_f2blk);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -352,7 +366,7 @@ int cadnip_analyze(CadnipHandle* h, int32_t sample_instance) {
   HIP_TRY(hipMemcpyAsync(vals.data(), h->d_J + (size_t)sample_instance * h->nnz, (size_t)h->nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   std::string err;
-  int rc = lu_analyze(h->n, h->h_rowptr, h->h_colidx, vals, 1e-3, false, h->lu, err);
+  int rc = lu_analyze(h->n, h->h_rowptr, h->h_colidx, vals, 1e-3, false, h->lu, err, h->leaves.q_begin >= 0 ? &h->leaves : nullptr);
   if (rc) { fprintf(stderr, "[cadnip_hip] analyze: %s\n", err.c_str()); return rc; }
   return upload_lu(h);
 }
@@ -361,7 +375,7 @@ int cadnip_analyze_values(CadnipHandle* h, const double* J_csr_host) {
   if (!h || !J_csr_host) return CADNIP_BADARG;
   std::vector<double> vals(J_csr_host, J_csr_host + h->nnz);
   std::string err;
-  int rc = lu_analyze(h->n, h->h_rowptr, h->h_colidx, vals, 1e-3, true, h->lu, err);
+  int rc = lu_analyze(h->n, h->h_rowptr, h->h_colidx, vals, 1e-3, true, h->lu, err, h->leaves.q_begin >= 0 ? &h->leaves : nullptr);
   if (rc) { fprintf(stderr, "[cadnip_hip] analyze: %s\n", err.c_str()); return rc; }
   return upload_lu(h);
 }
@@ -380,12 +394,17 @@ static const std::vector<int>* host_lu_array(const CadnipHostLU* lu, int which) 
   return nullptr;
 }
 int cadnip_host_lu_analyze(int32_t n, const int32_t* rowptr, const int32_t* colidx, const double* vals, double pivot_tol, int32_t sample, CadnipHostLU** out) {
+  return cadnip_host_lu_analyze_leaves(n, rowptr, colidx, vals, pivot_tol, sample, -1, -1, nullptr, out);
+}
+int cadnip_host_lu_analyze_leaves(int32_t n, const int32_t* rowptr, const int32_t* colidx, const double* vals, double pivot_tol, int32_t sample,
+                                  int32_t q_begin, int32_t lim_begin, const uint8_t* unit_ok, CadnipHostLU** out) {
   if (n <= 0 || !rowptr || !colidx || !vals || !out) return CADNIP_BADARG;
   CadnipHostLU* lu = new CadnipHostLU();
   std::vector<int> rp(rowptr, rowptr + n + 1), ci(colidx, colidx + rowptr[n]);
   std::vector<double> v(vals, vals + rowptr[n]);
   std::string err;
-  int rc = lu_analyze(n, rp, ci, v, pivot_tol, sample != 0, lu->p, err);
+  cadnip::LULeaves lv; lv.q_begin = q_begin; lv.lim_begin = lim_begin; lv.unit_ok = unit_ok; lv.first = getenv("CADNIP_LU_LEAF_FIRST") != nullptr;
+  int rc = lu_analyze(n, rp, ci, v, pivot_tol, sample != 0, lu->p, err, q_begin >= 0 ? &lv : nullptr);
   if (rc) { delete lu; return rc; }
   *out = lu;
   return CADNIP_OK;

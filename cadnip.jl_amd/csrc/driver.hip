@@ -34,6 +34,7 @@ struct Driver {
   double *t = nullptr, *h = nullptr, *hprev = nullptr, *hpp = nullptr;
   int *nhist = nullptr, *order = nullptr, *k = nullptr, *status = nullptr, *bp_idx = nullptr, *save_idx = nullptr, *dcstate = nullptr, *action = nullptr;
   long long* cnt = nullptr;   // [B][4]
+  double *mn_a0f = nullptr, *mn_ss = nullptr, *mn_dnp = nullptr; int* mn_flags = nullptr;   // Newton mode 1 (tran_ctrl.hpp)
   double *u0 = nullptr, *u1 = nullptr, *u2 = nullptr, *up = nullptr, *beta = nullptr;
   double *atol = nullptr, *emask = nullptr, *breaks = nullptr, *save_t = nullptr, *out = nullptr;
   int* obs = nullptr;
@@ -58,6 +59,7 @@ int ensure_driver(CadnipHandle* h) {
   TRY(dalloc(&d->nhist, B)); TRY(dalloc(&d->order, B)); TRY(dalloc(&d->k, B)); TRY(dalloc(&d->status, B));
   TRY(dalloc(&d->bp_idx, B)); TRY(dalloc(&d->save_idx, B)); TRY(dalloc(&d->dcstate, B)); TRY(dalloc(&d->action, B));
   TRY(dalloc(&d->cnt, B * 4));
+  TRY(dalloc(&d->mn_a0f, B)); TRY(dalloc(&d->mn_ss, B)); TRY(dalloc(&d->mn_dnp, B)); TRY(dalloc(&d->mn_flags, B));
   TRY(dalloc(&d->u0, B * n)); TRY(dalloc(&d->u1, B * n)); TRY(dalloc(&d->u2, B * n)); TRY(dalloc(&d->up, B * n)); TRY(dalloc(&d->beta, B * n));
   TRY(dalloc(&d->atol, n)); TRY(dalloc(&d->emask, n)); TRY(dalloc(&d->nactive, 2)); TRY(dalloc(&d->part, B));
   return CADNIP_OK;
@@ -90,6 +92,7 @@ __global__ void __launch_bounds__(64) k_tran_init(TranArgs a) {
   s.nhist = 1; s.ord = 1; s.k = 0; s.status = 0; s.bp = bp; s.si = si;
   s.c_newton = s.c_accept = s.c_reject = s.c_fail = 0;
   s.t_break = next_break(a, bp); s.t_save = next_save(a, si);
+  s.a0f = 0.0; s.ss = 20.0; s.dnp = 0.0; s.dsc = 1.0; s.mflags = MN_NEED;
   GlobalVecs v(a, inst);
   prepare_step(a, v, s, tid, a.t0, a.h0, 1, a.h0, a.h0);
   store_state(a, inst, tid, s);
@@ -287,7 +290,8 @@ void cadnip_driver_free(CadnipHandle* h) {
   if (!h || !h->drv) return;
   Driver* d = h->drv;
   void* ptrs[] = {d->t, d->h, d->hprev, d->hpp, d->nhist, d->order, d->k, d->status, d->bp_idx, d->save_idx, d->dcstate, d->action, d->cnt,
-                  d->u0, d->u1, d->u2, d->up, d->beta, d->atol, d->emask, d->breaks, d->save_t, d->out, d->obs, d->nactive, d->part};
+                  d->u0, d->u1, d->u2, d->up, d->beta, d->atol, d->emask, d->breaks, d->save_t, d->out, d->obs, d->nactive, d->part,
+                  d->mn_a0f, d->mn_ss, d->mn_dnp, d->mn_flags};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete d;
   h->drv = nullptr;
@@ -520,9 +524,11 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
              d->u0, d->u1, d->u2, d->up, d->beta, d->atol, d->emask, d->breaks, d->save_t, d->obs, d->out, d->nactive,
              h->B, h->n, h->n_limits, o->n_break, o->n_save, n_obs, n_err,
              o->t0, o->t1, o->reltol, h0, hmin, hmax, o->newton_tol > 0 ? o->newton_tol : 1e-3,
-             o->max_newton > 0 ? o->max_newton : 10, o->max_order > 0 ? o->max_order : 2, o->use_pcnr};
+             o->max_newton > 0 ? o->max_newton : 10, o->max_order > 0 ? o->max_order : 2, o->use_pcnr,
+             o->newton_mode ? 1 : 0, d->mn_a0f, d->mn_ss, d->mn_dnp, d->mn_flags};
   if (!h->analyzed) return CADNIP_NOTREADY;              // the symbolic LU phase (cadnip_analyze*) comes first
   const bool use_fused = o->fused && !h->va_ext && fused2_fits(h);   // (external generated models exist in the per-op stamping kernel only)     // a circuit too large for the LDS-resident kernel runs on the per-op kernels
+  if (o->newton_mode && !use_fused) return CADNIP_BADARG;   // Jacobian reuse lives in the fused kernel (tran_ctrl.hpp)
   struct ModeGuard { CadnipHandle* h; int saved; ~ModeGuard() { h->spec.mode = saved; } } mode_guard{h, h->spec.mode};
   h->spec.mode = 1;   // :tran (restored on every exit path)
   hipLaunchKernelGGL(k_tran_init, dim3(h->B), dim3(64), 0, h->stream, a);

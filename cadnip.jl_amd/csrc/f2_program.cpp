@@ -96,6 +96,7 @@ bool f2_build_program(const LUProgram& P, int n, int nc, F2Program& G) {
     const int* it = std::lower_bound(b, e, j);
     return (it != e && *it == j) ? (int)(it - &P.lu_col[0]) : -1;
   };
+  auto unit = [&](int k) { return !P.unit.empty() && P.unit[k] != 0; };   // pivot k is the stamped constant 1 (symbolic.cpp: leaf phase)
   std::vector<int> lev(P.nnz_lu, -1);        // level at which a sparse entry is final (-1: as assembled)
   std::vector<F2Ent> pre, post;
   for (int i = 0; i < n; ++i)
@@ -111,7 +112,7 @@ bool f2_build_program(const LUProgram& P, int n, int nc, F2Program& G) {
         x.a.push_back(G.posW[pl]); x.b.push_back(G.posW[pu]);
         x.lvl = std::max(x.lvl, std::max(lev[pl], lev[pu]));
       }
-      if (j < i) { x.dg = G.posW[P.lu_diag[j]]; x.lvl = std::max(x.lvl, lev[P.lu_diag[j]]); }
+      if (j < i && !unit(j)) { x.dg = G.posW[P.lu_diag[j]]; x.lvl = std::max(x.lvl, lev[P.lu_diag[j]]); }   // L entry / pivot (a constant-1 pivot divides nothing)
       if (x.a.empty() && x.dg < 0) continue;
       x.lvl += 1;
       lev[p] = x.lvl;
@@ -148,17 +149,37 @@ bool f2_build_program(const LUProgram& P, int n, int nc, F2Program& G) {
   }
   std::vector<int> xlev(n, -1);
   for (int i = cs0 - 1; i >= 0; --i) {
-    F2Ent x; x.pos = y0 + i; x.dg = G.posW[P.lu_diag[i]]; x.lvl = -1;
+    F2Ent x; x.pos = y0 + i; x.dg = unit(i) ? -1 : G.posW[P.lu_diag[i]]; x.lvl = -1;
     for (int pu = P.lu_diag[i] + 1; pu < P.lu_rowptr[i + 1]; ++pu) {
       const int j = P.lu_col[pu];
       x.a.push_back(G.posW[pu]); x.b.push_back(y0 + j);
       if (j < cs0) x.lvl = std::max(x.lvl, xlev[j]);
     }
+    if (x.a.empty() && x.dg < 0) continue;     // x_i = y_i: nothing to do (xlev stays -1: final as forward substitution left it)
     x.lvl += 1;
     xlev[i] = x.lvl;
     post.push_back(std::move(x));
   }
-  if (!f2_emit_passes(pre, G, G.n_pre) || !f2_emit_passes(post, G, G.n_post)) return false;
+  // forward substitution on KEPT factors (Newton mode 1, a round that does not refactor): the y recurrences alone; every L entry is
+  // final, so a row's level is one more than the deepest y it reads
+  std::vector<F2Ent> fwd;
+  {
+    std::vector<int> fl(n, -1);
+    for (int i = 0; i < n; ++i) {
+      F2Ent x; x.pos = y0 + i; x.dg = -1; x.lvl = -1;
+      for (int pl = P.lu_rowptr[i]; pl < P.lu_diag[i]; ++pl) {
+        const int k = P.lu_col[pl];
+        if (k >= cs0) break;
+        x.a.push_back(G.posW[pl]); x.b.push_back(y0 + k);
+        x.lvl = std::max(x.lvl, fl[k]);
+      }
+      if (x.a.empty()) continue;
+      x.lvl += 1;
+      fl[i] = x.lvl;
+      fwd.push_back(std::move(x));
+    }
+  }
+  if (!f2_emit_passes(pre, G, G.n_pre) || !f2_emit_passes(post, G, G.n_post) || !f2_emit_passes(fwd, G, G.n_fwd)) return false;
   G.terms.push_back(0);   // a lane without terms still prefetches term[t0]
   if (G.terms.size() >= 65535) return false;
   // wave cycles measured on the DFF (tools/trace_fused2.py): ~950 per pass; dense solve 2.7 k at nc = 8, 4.3 k at nc = 12

@@ -62,7 +62,7 @@ static bool f2_prepare(CadnipHandle* h, F2Tables& T, const std::vector<int>& g_p
   }
   const int y0 = G.lu_words, trash0 = G.lu_words + n;                 // W offsets
   if (trash0 + F2_TRASH >= 65535) return false;
-  h->f2_lu_words = G.lu_words; h->f2_nc = G.nc; h->f2_dn0 = G.dn0; h->f2_n_pre = G.n_pre; h->f2_n_post = G.n_post;
+  h->f2_lu_words = G.lu_words; h->f2_nc = G.nc; h->f2_dn0 = G.dn0; h->f2_n_pre = G.n_pre; h->f2_n_post = G.n_post; h->f2_n_fwd = G.n_fwd;
   std::vector<int> pinv(n), qinv(n);
   for (int k = 0; k < n; ++k) { pinv[P.rperm[k]] = k; qinv[P.cperm[k]] = k; }
   std::vector<int> dst(h->nnz, 0);
@@ -222,7 +222,21 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
   for (int i = 0; i < S_NSEC; ++i) f.off[i] = h->f2off[i];
   f.tab_len = h->f2len;
   f.n = h->n; f.nnz = h->nnz; f.nnz_lu = h->f2_lu_words;
-  f.n_pre = h->f2_n_pre; f.n_post = h->f2_n_post; f.nc = h->f2_nc; f.dn0 = h->f2_dn0;
+  f.n_pre = h->f2_n_pre; f.n_post = h->f2_n_post; f.nc = h->f2_nc; f.dn0 = h->f2_dn0; f.n_fwd = h->f2_n_fwd;
+  f.lufac = nullptr;
+  if (!dc && t.newton_mode) {
+    // IDA-style Jacobian reuse exists in the lean direct-residual variant (fused2_kernel.hpp); the kept factors of instances that
+    // are not resident live in HBM
+    if (!(h->f2_direct && h->f2_lean)) return CADNIP_BADARG;
+    const size_t need = (size_t)h->B * h->f2_lu_words;
+    if (need > h->f2_lufac_cap) {
+      if (h->d_f2_lufac) (void)hipFree(h->d_f2_lufac);
+      h->d_f2_lufac = nullptr; h->f2_lufac_cap = 0;
+      HIP_TRY(hipMalloc((void**)&h->d_f2_lufac, need * sizeof(double)));
+      h->f2_lufac_cap = need;
+    }
+    f.lufac = h->d_f2_lufac;
+  }
   f.rounds = rounds; f.B = h->B; f.t = t; f.cold = h->d_cold;
   f.dc_abstol = 0; f.dc_maxiters = 0; f.dc_pcnr = 0; f.dc_mode = 1; f.dc_initjct = 0; f.dcstate = nullptr;
   if (dc) { f.dc_abstol = dc->abstol; f.dc_maxiters = dc->maxiters; f.dc_pcnr = dc->use_pcnr; f.dc_mode = dc->mode; f.dc_initjct = dc->initjct; f.dcstate = dc->dcstate; }

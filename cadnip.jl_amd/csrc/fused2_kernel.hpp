@@ -47,6 +47,8 @@ struct F2Args {
   int tab_len;               // 32-bit words (even)
   int n, nnz, nnz_lu, rounds, B;   // nnz_lu: words of W before the rhs (sparse L\U entries + dense core block)
   int n_pre, n_post, nc, dn0;       // passes before / after the dense core solve, core size, first word of the core block
+  int n_fwd;                        // Newton mode 1: passes of the forward substitution alone (kept factors), behind the pre / post passes
+  double* lufac;                    // [B][nnz_lu] kept factors of the instances that are not resident (between launches / while queued)
   // DC mode (k_fused2<WPB, true>): PCNR / plain Newton on G u = b (driver.hip: k_dc_check, k_dc_update)
   double dc_abstol; int dc_maxiters, dc_pcnr, dc_mode, dc_initjct; int* dcstate;
   const int* cold;           // [B] DC mode: 1 = the instance starts cold (initjct applies to it), driver.hip: k_dc_init
@@ -72,6 +74,7 @@ struct TranStateView {
   long long* cnt;
   const double *breaks, *save_t;
   int n_break, n_save;
+  int newton_mode; double *mn_a0f, *mn_ss, *mn_dnp; int* mn_flags;
 };
 __device__ __forceinline__ TranStateView state_view() {
   const F2ArgsK p = kargs();
@@ -79,6 +82,7 @@ __device__ __forceinline__ TranStateView state_view() {
   v.t = p->t.t; v.h = p->t.h; v.hprev = p->t.hprev; v.hpp = p->t.hpp; v.tcur = p->t.tcur; v.gamma = p->t.gamma;
   v.nhist = p->t.nhist; v.order = p->t.order; v.k = p->t.k; v.status = p->t.status; v.bp_idx = p->t.bp_idx; v.save_idx = p->t.save_idx;
   v.active = p->t.active; v.cnt = p->t.cnt; v.breaks = p->t.breaks; v.save_t = p->t.save_t; v.n_break = p->t.n_break; v.n_save = p->t.n_save;
+  v.newton_mode = p->t.newton_mode; v.mn_a0f = p->t.mn_a0f; v.mn_ss = p->t.mn_ss; v.mn_dnp = p->t.mn_dnp; v.mn_flags = p->t.mn_flags;
   return v;
 }
 
@@ -86,9 +90,12 @@ __device__ __forceinline__ TranStateView state_view() {
 // GUARD: a lane whose `sink` is non-zero (no device behind it) sends every stamp to that trash word instead.
 // DIRECT: the residual comes from the devices (Rn, devices.hpp) -- b stamps and the C*beta terms are dropped here and
 // the kernel skips its J*u product.
-template <bool GUARD, bool DIRECT_>
+// JAC = false: a round on kept factors (Newton mode 1) -- the matrix stamps G / C are no-ops, so everything the devices compute only
+// for them (the partial derivatives) is dead code to the compiler; the residual stamps remain.
+template <bool GUARD, bool DIRECT_, bool JAC = true>
 struct AccumOutT {
   static constexpr bool DIRECT = DIRECT_;
+  static_assert(JAC || DIRECT_, "a residual-only pass needs the direct residuals");
   double* W; const double* betas; double a0;
   const u16* gpos; const u64* cdesc; const u16* brow;   // already offset to this device block
   int count, dev;
@@ -101,10 +108,12 @@ struct AccumOutT {
     atomicAdd(&W[tg(node < 0 ? trash : (unsigned)rowof[node])], v);
   }
   __device__ __forceinline__ void G(int k, double v) const {
+    if (!JAC) return;
     if (__builtin_constant_p(v) && v == 0.0) return;     // structurally zero stamps cost nothing
     atomicAdd(&W[tg(gpos[k * count + dev])], v);
   }
   __device__ __forceinline__ void C(int k, double v) const {
+    if (!JAC) return;
     if (__builtin_constant_p(v) && v == 0.0) return;
     const u64 d = cdesc[k * count + dev];
     atomicAdd(&W[tg((unsigned)d & 0xFFFFu)], a0 * v);
@@ -117,6 +126,7 @@ struct AccumOutT {
   // batch forms: all table reads of the batch are issued before its first atomic, so a batch costs one LDS
   // round trip plus the atomics' issue slots instead of one dependent read -> atomic chain per stamp
   template <int N> __device__ __forceinline__ void Gv(int k0, const double (&v)[N]) const {
+    if (!JAC) return;
     unsigned p[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) p[i] = gpos[(k0 + i) * count + dev];
@@ -124,6 +134,7 @@ struct AccumOutT {
     for (int i = 0; i < N; ++i) if (!(__builtin_constant_p(v[i]) && v[i] == 0.0)) atomicAdd(&W[tg(p[i])], v[i]);
   }
   template <int N> __device__ __forceinline__ void Gk(const int (&k)[N], const double (&v)[N]) const {
+    if (!JAC) return;
     unsigned p[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) p[i] = gpos[k[i] * count + dev];
@@ -131,6 +142,7 @@ struct AccumOutT {
     for (int i = 0; i < N; ++i) atomicAdd(&W[tg(p[i])], v[i]);
   }
   template <int N> __device__ __forceinline__ void Cv(int k0, const double (&v)[N]) const {
+    if (!JAC) return;
     u64 d[N];
     double bt[N];
 #pragma unroll
@@ -265,21 +277,26 @@ struct FusedVecs {
 // The core of the linear system: the Schur complement of the last NC pivots (accumulated in W by the entry program), one
 // row per lane, eliminated and solved in registers.  Pivot rows are broadcast with v_readlane; no LDS traffic and no fences
 // inside.  Static pivot order like the rest of the factorisation; a zero / non-finite pivot raises `bad`.
-template <int NC>
-__device__ __forceinline__ void dense_core_solve(double* W, int dn0, int yc0, int lane, int& bad) {
+// MODE 0: eliminate and solve; `keep` writes the factors back (multipliers below the diagonal, U on and above it) for later
+// MODE 1 calls, which only carry the right-hand side through them (Newton mode 1: a round on kept factors).
+template <int NC, int MODE>
+__device__ __forceinline__ void dense_core_solve(double* W, int dn0, int yc0, int lane, int& bad, bool keep) {
   const int row = lane < NC ? lane : 0;
-  const double* S = W + dn0 + row * NC;
+  double* S = W + dn0 + row * NC;
   double A[NC], rp[NC], bc = W[yc0 + row];
 #pragma unroll
   for (int j = 0; j < NC; ++j) A[j] = S[j];
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
     const double pkk = readlane_f64(A[k], k);
-    if (pkk == 0.0 || !isfinite(pkk)) bad = 1;
+    if (MODE == 0 && (pkk == 0.0 || !isfinite(pkk))) bad = 1;
     rp[k] = fast_div(1.0, pkk);
-    const double m = lane > k ? A[k] * rp[k] : 0.0;       // rows up to k keep their (final) U rows
+    const double m = lane > k ? (MODE == 0 ? A[k] * rp[k] : A[k]) : 0.0;       // rows up to k keep their (final) U rows
+    if (MODE == 0) {
 #pragma unroll
-    for (int j = k + 1; j < NC; ++j) A[j] = fma(-m, readlane_f64(A[j], k), A[j]);
+      for (int j = k + 1; j < NC; ++j) A[j] = fma(-m, readlane_f64(A[j], k), A[j]);
+      if (lane > k) A[k] = m;
+    }
     bc = fma(-m, readlane_f64(bc, k), bc);
   }
 #pragma unroll
@@ -287,7 +304,13 @@ __device__ __forceinline__ void dense_core_solve(double* W, int dn0, int yc0, in
     const double xk = readlane_f64(bc * rp[k], k);         // lane k holds the reduced rhs of row k
     bc = lane == k ? xk : (lane < k ? fma(-A[k], xk, bc) : bc);
   }
-  if (lane < NC) W[yc0 + lane] = bc;
+  if (lane < NC) {
+    W[yc0 + lane] = bc;
+    if (MODE == 0 && keep) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j) S[j] = A[j];
+    }
+  }
 }
 
 // VAR: 0 = direct residuals, lean device set; 1 = direct residuals, every device type; 2 = assembled residual
@@ -405,6 +428,12 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
     const double *ug = ka->t.u + vo, *betag = ka->t.beta + vo;
     for (int i = lane0; i < n; i += 64) { us[i] = ug[i]; betas[i] = DC ? 0.0 : betag[i]; }
   }
+  // Newton mode 1: the factors this instance kept when it last left a wave
+  const bool mn = !DC && LEAN && a.newton_mode != 0;     // (lean variant only: the host refuses the mode otherwise, fused2.hip)
+  if (mn && (st.mflags & MN_VALID)) {
+    const double* src = kargs()->lufac + (size_t)inst * f.nnz_lu;
+    for (int i = lane0; i < f.nnz_lu; i += 64) W[i] = src[i];
+  }
   // DC state of this instance: settle flag of the PCNR loop (solve.jl:640-657), Newton solves done in this launch
   int dc_state = 0, dc_iters = 0, dc_first = 0;
   if (DC) { dc_state = __builtin_amdgcn_readfirstlane(kargs()->dcstate[inst]); dc_first = f.dc_initjct && __builtin_amdgcn_readfirstlane(kargs()->cold[inst]); }
@@ -425,7 +454,20 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     CADNIP_TRACE_POINT(17);
-    for (int i = lane; i < (nW >> 1); i += 64) ((double2*)W)[i] = make_double2(0.0, 0.0);   // nW is even (f2_program.cpp), W 16-byte aligned
+    // Newton mode 1: does this round refactor (IDA's lsetup conditions, tran_ctrl.hpp)?  Otherwise the factors in W stay and only
+    // the right-hand side (and the trash words) are cleared.
+    bool refresh = true;
+    if (mn) {
+      refresh = (st.mflags & MN_NEED) || !(st.mflags & MN_VALID) ||
+                (st.k == 0 && (st.a0 < 0.6 * st.a0f || st.a0 * 0.6 > st.a0f || (st.mflags >> MN_SINCE_SHIFT) >= 20));
+      if (refresh) { st.a0f = st.a0; st.ss = 20.0; st.mflags = MN_VALID | MN_JCUR; st.dsc = 1.0; }
+      else st.dsc = st.a0 == st.a0f ? 1.0 : 2.0 / (1.0 + st.a0 / st.a0f);
+    }
+    if (refresh) {
+      for (int i = lane; i < (nW >> 1); i += 64) ((double2*)W)[i] = make_double2(0.0, 0.0);   // nW is even (f2_program.cpp), W 16-byte aligned
+    } else {
+      for (int i = f.nnz_lu + lane; i < nW; i += 64) W[i] = 0.0;
+    }
     CADNIP_WAVE_SYNC();
     CADNIP_TRACE_POINT(0);
     // ---- stamp: accumulate J (at LU positions) and the C*beta - b part of the residual
@@ -453,8 +495,10 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          atomicAdd(&W[rc_gp[q][0] & 0xFFFFu], jv[q]); atomicAdd(&W[rc_gp[q][0] >> 16], -jv[q]);
-          atomicAdd(&W[rc_gp[q][1] & 0xFFFFu], -jv[q]); atomicAdd(&W[rc_gp[q][1] >> 16], jv[q]);
+          if (refresh) {
+            atomicAdd(&W[rc_gp[q][0] & 0xFFFFu], jv[q]); atomicAdd(&W[rc_gp[q][0] >> 16], -jv[q]);
+            atomicAdd(&W[rc_gp[q][1] & 0xFFFFu], -jv[q]); atomicAdd(&W[rc_gp[q][1] >> 16], jv[q]);
+          }
           atomicAdd(&W[rc_row[q] & 0xFFFFu], cur[q]); atomicAdd(&W[rc_row[q] >> 16], -cur[q]);
         }
       }
@@ -469,8 +513,10 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
         if (src_type == CADNIP_DEV_VSOURCE) {
           // branch rows / columns +-1 (devices.hpp: branch4); KCL rows carry u[I], the branch row V(p) - V(n) - v
           const double ui = at(src_nd[1]), vd = at(src_nd[0] & 0xFFFFu) - at(src_nd[0] >> 16) - src_val;
-          atomicAdd(&W[src_gp[0] & 0xFFFFu], 1.0); atomicAdd(&W[src_gp[0] >> 16], -1.0);
-          atomicAdd(&W[src_gp[1] & 0xFFFFu], 1.0); atomicAdd(&W[src_gp[1] >> 16], -1.0);
+          if (refresh) {
+            atomicAdd(&W[src_gp[0] & 0xFFFFu], 1.0); atomicAdd(&W[src_gp[0] >> 16], -1.0);
+            atomicAdd(&W[src_gp[1] & 0xFFFFu], 1.0); atomicAdd(&W[src_gp[1] >> 16], -1.0);
+          }
           atomicAdd(&W[src_row[0] & 0xFFFFu], ui); atomicAdd(&W[src_row[0] >> 16], -ui);
           atomicAdd(&W[src_row[1]], vd);
         } else {
@@ -523,15 +569,25 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
           const int dv = d0 + (lane >> 1);
           const bool valid = dv < B.count;
           LdsCtx d{nodes + B.nodes_off, B.ipar, par, f.wave, B.count, valid ? dv : B.count - 1, tcur, dmode, dinit};
-          AccumOutT<true, DIRECT> s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, d.dev, valid ? 0u : trash_w, us, rowof, trash_w};
-          stamp_mos1_pair(d, us, s, lw, side, valid);
+          if (LEAN && !DC && !refresh) {       // round on kept factors: residuals only
+            AccumOutT<true, DIRECT, !LEAN || DC> s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, d.dev, valid ? 0u : trash_w, us, rowof, trash_w};
+            stamp_mos1_pair(d, us, s, lw, side, valid);
+          } else {
+            AccumOutT<true, DIRECT> s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, d.dev, valid ? 0u : trash_w, us, rowof, trash_w};
+            stamp_mos1_pair(d, us, s, lw, side, valid);
+          }
         }
         dev0 = B.count;
       }
       for (int dev = dev0; dev < B.count; dev += 64) {
         LdsCtx d{nodes + B.nodes_off, B.ipar, par, f.wave, B.count, dev, tcur, dmode, dinit};
-        AccumOutT<false, DIRECT> s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev, 0u, us, rowof, trash_w};
-        dispatch_stamp2<LEAN>(B.type, d, us, s, lw);
+        if (LEAN && !DC && !refresh) {
+          AccumOutT<false, DIRECT, !LEAN || DC> s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev, 0u, us, rowof, trash_w};
+          dispatch_stamp2<LEAN>(B.type, d, us, s, lw);
+        } else {
+          AccumOutT<false, DIRECT> s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev, 0u, us, rowof, trash_w};
+          dispatch_stamp2<LEAN>(B.type, d, us, s, lw);
+        }
       }
       CADNIP_TRACE_POINT(8 + bi);
     }
@@ -636,13 +692,20 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
         D = Dn; T0 = T0n; pd = pd1; pd1 = pd2;
       }
     };
-    run_passes(0, f.n_pre);
+    if (refresh) run_passes(0, f.n_pre);
+    else run_passes(f.n_pre + f.n_post, f.n_fwd);          // kept factors: the forward substitution alone
     CADNIP_TRACE_POINT(4);
     if (f.nc > 0) {
       const int yc0 = f.nnz_lu + n - f.nc;
-      if (f.nc == 8) dense_core_solve<8>(W, f.dn0, yc0, lane, bad);
-      else if (f.nc == 12) dense_core_solve<12>(W, f.dn0, yc0, lane, bad);
-      else dense_core_solve<F2_NCMAX>(W, f.dn0, yc0, lane, bad);
+      if (refresh) {
+        if (f.nc == 8) dense_core_solve<8, 0>(W, f.dn0, yc0, lane, bad, mn);
+        else if (f.nc == 12) dense_core_solve<12, 0>(W, f.dn0, yc0, lane, bad, mn);
+        else dense_core_solve<F2_NCMAX, 0>(W, f.dn0, yc0, lane, bad, mn);
+      } else if (LEAN && !DC) {
+        if (f.nc == 8) dense_core_solve<8, 1>(W, f.dn0, yc0, lane, bad, false);
+        else if (f.nc == 12) dense_core_solve<12, 1>(W, f.dn0, yc0, lane, bad, false);
+        else dense_core_solve<F2_NCMAX, 1>(W, f.dn0, yc0, lane, bad, false);
+      }
       CADNIP_WAVE_SYNC();
     }
     CADNIP_TRACE_POINT(5);
@@ -680,6 +743,10 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
       double *betag = ka->t.beta + vo, *dug = ka->t.du + vo;
       const double a0 = st.a0;
       for (int i = lane0; i < n; i += 64) { double x = us[i], b = betas[i]; ug[i] = x; betag[i] = b; dug[i] = a0 * x + b; }
+      if (mn && (st.mflags & MN_VALID) && st.status == 0) {    // the factors travel with the instance
+        double* dst = ka->lufac + (size_t)inst * f.nnz_lu;
+        for (int i = lane0; i < f.nnz_lu; i += 64) dst[i] = W[i];
+      }
       vec.store_history(n, lane0);
       store_state(state_view(), inst, lane0, st);
     }

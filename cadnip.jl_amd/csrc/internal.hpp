@@ -27,6 +27,7 @@ void set_last_error(const char* what, hipError_t e);
 struct LUProgram {
   int n = 0;
   std::vector<int> rperm, cperm;       // pivot k uses original row rperm[k], column cperm[k]
+  std::vector<char> unit;              // pivot k is the stamped constant 1 (a charge / limit row's own diagonal): no division by it
   int nnz_lu = 0;
   // LU stored row-major in permuted indices; row i occupies [lu_rowptr[i], lu_rowptr[i+1]) with sorted columns
   std::vector<int> lu_rowptr, lu_col, lu_diag;   // lu_diag[i] = position of U(i,i)
@@ -39,6 +40,10 @@ struct LUProgram {
   std::vector<int> fwd_rows, fwd_lev_ptr, bwd_rows, bwd_lev_ptr;
 };
 
+// device-local unknowns for the leaf-first pivot order (symbolic.cpp): charges [q_begin, lim_begin), limits [lim_begin, n);
+// unit_ok[i]: the diagonal of unknown i is one constant stamp (no C part, a single G slot)
+struct LULeaves { int q_begin = -1, lim_begin = -1; const unsigned char* unit_ok = nullptr; bool first = false; };   // first: pivot the leaves before everything else (diagnostic, CADNIP_LU_LEAF_FIRST=1)
+
 static inline unsigned long long pack4(unsigned a, unsigned b, unsigned c, unsigned d) {
   return (unsigned long long)(a & 0xFFFFu) | ((unsigned long long)(b & 0xFFFFu) << 16) | ((unsigned long long)(c & 0xFFFFu) << 32) | ((unsigned long long)(d & 0xFFFFu) << 48);
 }
@@ -49,7 +54,7 @@ struct F2Program {
   std::vector<int> posW;                   // LU pattern position -> W offset
   std::vector<unsigned long long> lanes, passes;          // lane descriptors, pass descriptors (pre-dense passes, then post-dense)
   std::vector<unsigned> terms;
-  int n_pre = 0, n_post = 0;
+  int n_pre = 0, n_post = 0, n_fwd = 0;    // (n_fwd: forward substitution alone, on kept factors: behind the other two lists)
   double cost = 0;                         // issue-slot estimate used to choose nc
 };
 
@@ -125,7 +130,8 @@ struct CadnipHandle {
   unsigned int* d_f2tab = nullptr;
   int f2off[16] = {0};      // section offsets in 32-bit words
   int f2len = 0;            // 32-bit words
-  int f2_lu_words = 0, f2_nc = 0, f2_dn0 = 0, f2_n_pre = 0, f2_n_post = 0;   // linear-solve program of the fused kernel
+  int f2_lu_words = 0, f2_nc = 0, f2_dn0 = 0, f2_n_pre = 0, f2_n_post = 0, f2_n_fwd = 0;
+  double* d_f2_lufac = nullptr; size_t f2_lufac_cap = 0;   // Newton mode 1: kept factors of the non-resident instances [B][f2_lu_words]   // linear-solve program of the fused kernel
   std::vector<int> f2_nodes_off;   // per device block: offset (int16 units) of its node table inside the NODES section
   bool fused2_dirty = true;
   int* d_f2queue = nullptr;   // fused kernel: dynamic instance queue
@@ -133,6 +139,8 @@ struct CadnipHandle {
   bool f2_blk_dirty = true;
   int f2_n_blk = 0, f2_rc_blk = -1;
   bool f2_direct = false;     // devices emit their residuals directly: no J*u pass (off: CADNIP_F2_NODIRECT=1)
+  std::vector<unsigned char> leaf_unit_ok;   // per unknown: its diagonal is one constant G stamp, no C stamp (leaf-first pivot order, symbolic.cpp)
+  cadnip::LULeaves leaves;    // charge / limit ranges of the unknown layout [V | I | q | lim]
   int f2_lu_len = 0;          // 32-bit words of the table's linear-solve prefix (entry program, permutations, load map)
   bool va_ext = false;        // the circuit uses an external generated model (va_generated_ext.hpp): not compiled into the fused kernel
   bool f2_lean = false;       // only device types of the lean kernel variant (fused2.hip: dispatch_stamp2)
@@ -151,7 +159,7 @@ struct CadnipHandle {
 namespace cadnip {
 // symbolic.cpp
 int lu_analyze(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, const std::vector<double>& vals,
-               double pivot_tol, bool sample, LUProgram& out, std::string& err);
+               double pivot_tol, bool sample, LUProgram& out, std::string& err, const LULeaves* leaves = nullptr);
 // kernels.hip launchers (all asynchronous on h->stream)
 int launch_rebuild(CadnipHandle* h);                       // stamp_csr.hip: one stamp + reduce kernel per device type at (d_u, d_t)
 int build_stamp_plan(CadnipHandle* h, const CadnipStructure* s);   // stamp_csr.hip, once per structure

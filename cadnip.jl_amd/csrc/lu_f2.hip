@@ -101,9 +101,9 @@ __global__ void __launch_bounds__(64 * WPB) k_lu_f2(LuF2Args f) {
   run_passes(0, f.n_pre);
   if (f.nc > 0) {
     const int yc0 = f.lu_words + n - f.nc;
-    if (f.nc == 8) dense_core_solve<8>(W, f.dn0, yc0, lane, bad);
-    else if (f.nc == 12) dense_core_solve<12>(W, f.dn0, yc0, lane, bad);
-    else dense_core_solve<F2_NCMAX>(W, f.dn0, yc0, lane, bad);
+    if (f.nc == 8) dense_core_solve<8, 0>(W, f.dn0, yc0, lane, bad, false);
+    else if (f.nc == 12) dense_core_solve<12, 0>(W, f.dn0, yc0, lane, bad, false);
+    else dense_core_solve<F2_NCMAX, 0>(W, f.dn0, yc0, lane, bad, false);
     CADNIP_WAVE_SYNC();
   }
   run_passes(f.n_pre, f.n_post);

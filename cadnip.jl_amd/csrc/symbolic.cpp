@@ -29,22 +29,30 @@ static const int LU_EXHAUSTIVE_MAX = 4096;   // unknowns up to which every remai
 static const int LU_SEARCH_ROWS = 12;        // beyond: candidates come from this many shortest rows
 
 static int lu_analyze_mode(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, const std::vector<double>& vals,
-                           double pivot_tol, bool magnitudes, LUProgram& out, std::string& err);
+                           double pivot_tol, bool magnitudes, const LULeaves* leaves, LUProgram& out, std::string& err);
 
 // The pivot search eliminates numerically on the sample.  A sample assembled from several operating points is not
 // the Jacobian of any one state, so cancellation in it can fake a singular matrix (two nodes tied by the same huge
 // sampled conductance).  When the signed elimination fails, the search is repeated on magnitudes
 // (|a_ij| + |l_ik u_kj|, no cancellation): a structurally non-singular pattern then always yields an order.
 // `sample` = vals is such a composite; for the Jacobian of one state a singular result is reported as is.
+// `leaves` (optional): the unknowns from leaves->q_begin on are charge states, from leaves->lim_begin on limit variables -- the
+// device-local unknowns of Cadnip's formulation (contrib.jl:356-375 charge rows q - 1e12 Q(V) = 0, vasim.jl:3110-3138 tracking rows
+// u_l - V(probe) = 0).  Their diagonal is a stamped constant 1, their rows and columns touch only their own device's unknowns, and they
+// do not touch each other except charge rows reading limit columns.  They are therefore pivoted FIRST, on their own diagonals -- limits,
+// then charges: no fill (every update lands on an entry the device stamps anyway), dependency depth two, and what remains for the
+// Markowitz search is the node / branch-current system (DFF: 25 of 235 unknowns; c6288: 5 124 of 75 908).  A leaf whose diagonal fails
+// the threshold test (or is missing) is left to the general search.  `unit[k]` marks pivots whose value is the constant 1 (structure says
+// one constant stamp, the sample says exactly 1.0): entries divided by them need no division.
 int lu_analyze(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, const std::vector<double>& vals,
-               double pivot_tol, bool sample, LUProgram& out, std::string& err) {
+               double pivot_tol, bool sample, LUProgram& out, std::string& err, const LULeaves* leaves) {
   // The program is built aside and moved into `out` only on success: a failed analysis (a singular re-pivot victim,
   // driver.hip) must leave the caller's previous program -- and the device arrays uploaded from it -- usable.
   LUProgram fresh;
-  int rc = lu_analyze_mode(n, rowptr, colidx, vals, pivot_tol, false, fresh, err);
+  int rc = lu_analyze_mode(n, rowptr, colidx, vals, pivot_tol, false, leaves, fresh, err);
   if (rc == CADNIP_SINGULAR && sample) {
     std::string err2;
-    int rc2 = lu_analyze_mode(n, rowptr, colidx, vals, pivot_tol, true, fresh, err2);
+    int rc2 = lu_analyze_mode(n, rowptr, colidx, vals, pivot_tol, true, leaves, fresh, err2);
     if (rc2 == CADNIP_OK) { err.clear(); rc = rc2; }
   }
   if (rc == CADNIP_OK) out = std::move(fresh);
@@ -52,9 +60,21 @@ int lu_analyze(int n, const std::vector<int>& rowptr, const std::vector<int>& co
 }
 
 static int lu_analyze_mode(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, const std::vector<double>& vals,
-                           double pivot_tol, bool magnitudes, LUProgram& out, std::string& err) {
+                           double pivot_tol, bool magnitudes, const LULeaves* leaves, LUProgram& out, std::string& err) {
   out = LUProgram();
   out.n = n;
+  out.unit.assign(n, 0);
+  // leaf unknowns in the order they are tried: limits, then charges
+  std::vector<int> leaf_order;
+  const bool have_leaves = leaves && leaves->q_begin >= 0 && leaves->q_begin <= leaves->lim_begin && leaves->lim_begin <= n;
+  std::vector<char> unit_cand(n, 0);          // pivot k sits on a leaf's own diagonal whose stamped value is the constant 1
+  std::vector<double> diag0(n, 0.0);          // the sample's diagonal before any elimination
+  for (int i = 0; i < n; ++i) for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) if (colidx[p] == i) diag0[i] = vals[p];
+  if (have_leaves && leaves->first) {
+    for (int i = leaves->lim_begin; i < n; ++i) leaf_order.push_back(i);
+    for (int i = leaves->q_begin; i < leaves->lim_begin; ++i) leaf_order.push_back(i);
+  }
+  size_t leaf_next = 0;
   std::vector<std::map<int, double>> rows(n);
   std::vector<std::set<int>> cols(n);
   for (int i = 0; i < n; ++i)
@@ -82,12 +102,25 @@ static int lu_analyze_mode(int n, const std::vector<int>& rowptr, const std::vec
     bool bdiag = false;
     double brel = 0;
     cand.clear();
-    if (restricted) {
+    // ---- leaf phase: the next device-local unknown whose own diagonal passes the threshold test
+    while (leaf_next < leaf_order.size() && bi < 0) {
+      const int i = leaf_order[leaf_next++];
+      if (rdone[i]) continue;
+      auto it = rows[i].find(i);
+      if (it == rows[i].end()) continue;
+      const double av = std::fabs(it->second);
+      if (!(av > 0.0) || !std::isfinite(av)) continue;
+      double m = 0;
+      for (int ii : cols[i]) m = std::max(m, std::fabs(rows[ii][i]));
+      if (av < pivot_tol * m) continue;
+      bi = bj = i;
+    }
+    if (bi < 0 && restricted) {
       // the shortest rows; keep going while nothing acceptable was found (threshold test) -- done below by widening
       for (auto it = by_len.begin(); it != by_len.end() && (int)cand.size() < LU_SEARCH_ROWS; ++it) cand.push_back(it->second);
     }
-    const int n_scan = restricted ? (int)cand.size() : n;
-    for (int ci = 0; ci < n_scan || (restricted && bi < 0 && ci < (int)by_len.size()); ++ci) {
+    const int n_scan = bi >= 0 ? 0 : restricted ? (int)cand.size() : n;
+    for (int ci = 0; ci < n_scan || (n_scan > 0 && restricted && bi < 0 && ci < (int)by_len.size()); ++ci) {
       if (restricted && ci >= (int)cand.size()) {      // widen: nothing passed the threshold among the shortest rows
         cand.clear();
         for (auto& pr : by_len) cand.push_back(pr.second);
@@ -121,6 +154,7 @@ static int lu_analyze_mode(int n, const std::vector<int>& rowptr, const std::vec
     if (bi < 0) { err = "matrix is singular at pivot step " + std::to_string(k); return CADNIP_SINGULAR; }
     out.rperm[k] = bi;
     out.cperm[k] = bj;
+    if (have_leaves && bi == bj && bi >= leaves->q_begin && leaves->unit_ok && leaves->unit_ok[bi] && diag0[bi] == 1.0) unit_cand[k] = 1;
     double piv = rows[bi][bj];
     std::vector<int> lrows;
     for (int i : cols[bj]) if (i != bi) lrows.push_back(i);
@@ -187,13 +221,15 @@ static int lu_analyze_mode(int n, const std::vector<int>& rowptr, const std::vec
   std::vector<int> level(out.nnz_lu, 0);
   struct Ent { int pos, diag, lvl; std::vector<int> a, b; };
   std::vector<Ent> ents;
+  // a candidate pivot IS the constant 1 if, besides, no elimination step updates its diagonal entry (no term in its recurrence):
+  // decided here, row by row -- row j's diagonal is complete before any later row divides by it
   for (int i = 0; i < n; ++i) {
     int r0 = out.lu_rowptr[i], r1 = out.lu_rowptr[i + 1], dp = out.lu_diag[i];
     for (int p = r0; p < r1; ++p) {
       int j = out.lu_col[p];
       Ent e;
       e.pos = p;
-      e.diag = (j < i) ? out.lu_diag[j] : -1;
+      e.diag = (j < i && !out.unit[j]) ? out.lu_diag[j] : -1;     // L entry: divided by its pivot, unless that is the constant 1
       int lvl = 0;
       for (int pl = r0; pl < dp; ++pl) {       // L(i,k), k ascending
         int kk = out.lu_col[pl];
@@ -204,6 +240,7 @@ static int lu_analyze_mode(int n, const std::vector<int>& rowptr, const std::vec
         e.b.push_back(it->second);
         lvl = std::max(lvl, std::max(level[pl], level[it->second]) + 1);
       }
+      if (j == i) out.unit[i] = (unit_cand[i] && e.a.empty()) ? 1 : 0;
       if (e.diag >= 0) lvl = std::max(lvl, level[e.diag] + 1);
       level[p] = lvl;
       e.lvl = lvl;

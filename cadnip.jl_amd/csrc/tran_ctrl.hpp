@@ -71,13 +71,27 @@ struct TranArgs {
   int B, n, n_limits, n_break, n_save, n_obs, n_err;
   double t0, t1, reltol, h0, hmin, hmax, newton_tol;
   int max_newton, max_order, use_pcnr;
+  // Newton mode 1 = the nonlinear iteration as IDA runs it (the reference's integrator, sweeps.jl:600): the Jacobian is refactored
+  // only on a "setup" -- first round, a0 outside [0.6, 1 / 0.6] of its value at the last one (IDA's XRATE window), 20 steps without one, or a failed iteration on
+  // a stale one, which is then repeated at the same step -- the rounds between solve with the kept factors (residual-only device
+  // pass); the update is scaled by 2 / (1 + a0 / a0_setup) on a stale Jacobian; convergence is IDA's rate test
+  // ss * ||delta|| <= 0.33 with ss = rate / (1 - rate) carried from round to round and reset to 20 at a setup (ida.c: IDANls /
+  // IDANewtonIter; the rate is taken between successive updates).  Fused kernel and CPU port only.  Per-instance state:
+  int newton_mode;
+  double *mn_a0f, *mn_ss, *mn_dnp; int* mn_flags;
 };
+#define MN_NEED 1     // the next round must refactor
+#define MN_JCUR 2     // a refactorisation happened in this step attempt
+#define MN_VALID 4    // kept factors exist (in the wave's LDS work array, or saved to HBM between launches)
+#define MN_SINCE_SHIFT 8   // accepted steps since the last refactorisation
 
 struct StepState {
   double t, h, hprev, hpp, tn, a0;   // accepted time, step in flight, the two previous steps, t + h, BDF leading coefficient
   int nhist, ord, k, status, bp, si; // history depth, order, Newton counter, 0 running / 1 done / <0 failed, next breakpoint / save index
   int c_newton, c_accept, c_reject, c_fail;   // counter increments since load
   double t_break, t_save;                     // breaks[bp] / save_t[si], +inf past the end: derived, refreshed when bp / si move
+  double a0f, ss, dnp, dsc;                   // Newton mode 1: a0 of the kept factors, rate constant, previous update norm; scale of this round's update
+  int mflags;
 };
 template <class A> __device__ __forceinline__ double next_break(const A& a, int bp) { return bp < a.n_break ? a.breaks[bp] : __builtin_inf(); }
 template <class A> __device__ __forceinline__ double next_save(const A& a, int si) { return si < a.n_save ? a.save_t[si] : __builtin_inf(); }
@@ -94,6 +108,8 @@ __device__ __forceinline__ void make_uniform(StepState& s) {
   s.status = __builtin_amdgcn_readfirstlane(s.status); s.bp = __builtin_amdgcn_readfirstlane(s.bp); s.si = __builtin_amdgcn_readfirstlane(s.si);
   s.c_newton = __builtin_amdgcn_readfirstlane(s.c_newton); s.c_accept = __builtin_amdgcn_readfirstlane(s.c_accept);
   s.c_reject = __builtin_amdgcn_readfirstlane(s.c_reject); s.c_fail = __builtin_amdgcn_readfirstlane(s.c_fail);
+  s.a0f = uniform_f64(s.a0f); s.ss = uniform_f64(s.ss); s.dnp = uniform_f64(s.dnp); s.dsc = uniform_f64(s.dsc);
+  s.mflags = __builtin_amdgcn_readfirstlane(s.mflags);
 }
 
 // A: TranArgs, or a view with the same member names (the fused kernel fetches these rarely used pointers on demand)
@@ -103,6 +119,8 @@ template <class A> __device__ inline StepState load_state(const A& a, int inst) 
   s.nhist = a.nhist[inst]; s.ord = a.order[inst]; s.k = a.k[inst]; s.status = a.status[inst]; s.bp = a.bp_idx[inst]; s.si = a.save_idx[inst];
   s.c_newton = s.c_accept = s.c_reject = s.c_fail = 0;
   s.t_break = next_break(a, s.bp); s.t_save = next_save(a, s.si);
+  s.a0f = 0.0; s.ss = 20.0; s.dnp = 0.0; s.dsc = 1.0; s.mflags = MN_NEED;
+  if (a.newton_mode) { s.a0f = a.mn_a0f[inst]; s.ss = a.mn_ss[inst]; s.dnp = a.mn_dnp[inst]; s.mflags = a.mn_flags[inst]; }
   return s;
 }
 template <class A> __device__ inline void store_state(const A& a, int inst, int tid, const StepState& s) {
@@ -110,6 +128,7 @@ template <class A> __device__ inline void store_state(const A& a, int inst, int 
   a.t[inst] = s.t; a.h[inst] = s.h; a.hprev[inst] = s.hprev; a.hpp[inst] = s.hpp; a.tcur[inst] = s.tn; a.gamma[inst] = s.a0;
   a.nhist[inst] = s.nhist; a.order[inst] = s.ord; a.k[inst] = s.k; a.status[inst] = s.status; a.bp_idx[inst] = s.bp; a.save_idx[inst] = s.si;
   a.active[inst] = s.status == 0 ? 1 : 0;
+  if (a.newton_mode) { a.mn_a0f[inst] = s.a0f; a.mn_ss[inst] = s.ss; a.mn_dnp[inst] = s.dnp; a.mn_flags[inst] = s.mflags; }
   long long* c = a.cnt + (size_t)inst * 4;
   c[0] += s.c_newton; c[1] += s.c_accept; c[2] += s.c_reject; c[3] += s.c_fail;
 }
@@ -209,6 +228,7 @@ __device__ inline void prepare_step(const TranArgs& a, V& v, StepState& s, int t
     });
   }
   s.h = h; s.ord = ord; s.k = 0; s.tn = tn; s.a0 = a0;
+  s.mflags &= ~MN_JCUR;          // a new step attempt: no refactorisation in it yet
 }
 
 template <class V>
@@ -246,7 +266,7 @@ __device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, i
   double s1 = 0.0, s2 = 0.0;
   each_elem<V>(n, tid, [&](int i, int k) {
     const double x0 = v.h0(i, k), at = v.atol_of(a, i, k), upv = v.hp(i, k), em = v.emask_of(a, i, k);
-    double d = v.get_delta(i);
+    double d = v.get_delta(i) * s.dsc;
     double un = v.get_u(i) - d;
     if (!isfinite(d)) bad = 1;
     double w = fast_div(1.0, at + a.reltol * fabs(x0));
@@ -261,7 +281,19 @@ __device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, i
   const double dnorm = sqrt(s1 / n);
   CADNIP_TRACE_POINT(30);
   s.c_newton += 1;
-  const bool conv = !bad && dnorm < a.newton_tol;
+  bool conv = !bad && dnorm < a.newton_tol, diverge = false;
+  if (a.newton_mode) {
+    conv = false;
+    if (!bad) {
+      if (s.k == 0) conv = dnorm <= 0.33e-4;
+      else {
+        const double rate = s.dnp > 0.0 ? dnorm / s.dnp : 0.0;
+        if (rate > 0.9) diverge = true; else s.ss = rate / (1.0 - rate);
+      }
+      if (!diverge && s.ss * dnorm <= 0.33) conv = true;
+      s.dnp = dnorm;
+    }
+  }
   if (conv) {
     double errn = 0.0;
     bool accept = true;
@@ -297,6 +329,7 @@ __device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, i
       hnext = fmin(hnext, a.hmax);
       s.t = tn; s.hpp = hprev; s.hprev = h; s.nhist = nh_new;
       s.c_accept += 1;
+      s.mflags += 1 << MN_SINCE_SHIFT;
       CADNIP_TRACE_POINT(31);
       if (tn >= a.t1) { s.status = 1; return; }
       if (hnext < a.hmin) hnext = a.hmin;
@@ -313,7 +346,12 @@ __device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, i
       prepare_step(a, v, s, tid, s.t, hn, s.nhist, hprev, hpp);
     }
   } else {
-    if (bad || s.k + 1 >= a.max_newton) {
+    if (a.newton_mode && (bad || diverge || s.k + 1 >= a.max_newton) && !(s.mflags & MN_JCUR)) {
+      // the iteration failed on a stale Jacobian: same step again, refactored first (IDA: IDA_NLS recoverable with callSetup)
+      s.mflags |= MN_NEED;
+      CADNIP_WAVE_SYNC();
+      prepare_step(a, v, s, tid, s.t, h, s.nhist, hprev, hpp);
+    } else if (bad || diverge || s.k + 1 >= a.max_newton) {
       double hn = 0.25 * h;
       s.c_fail += 1;
       if (hn < a.hmin) { s.status = -2; return; }

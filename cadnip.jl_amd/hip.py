@@ -24,7 +24,7 @@ EXPORTS = [
     "cadnip_analyze_values", "cadnip_factor", "cadnip_solve", "cadnip_lu_stats", "cadnip_dc_run",
     "cadnip_dc_log_size", "cadnip_dc_log_get", "cadnip_tran_run", "cadnip_tran_state", "cadnip_dev_ptr", "cadnip_stream", "cadnip_set_u", "cadnip_get_u", "cadnip_get_flags",
     "cadnip_sync", "cadnip_debug_copy", "cadnip_debug_stamp_time", "cadnip_profile_enable", "cadnip_profile_read", "cadnip_version",
-    "cadnip_host_lu_analyze", "cadnip_host_lu_size", "cadnip_host_lu_get", "cadnip_host_lu_free",
+    "cadnip_host_lu_analyze", "cadnip_host_lu_analyze_leaves", "cadnip_host_lu_size", "cadnip_host_lu_get", "cadnip_host_lu_free",
     "cadnip_host_f2_build", "cadnip_host_f2_size", "cadnip_host_f2_get", "cadnip_host_f2_free",
 ]
 
@@ -76,7 +76,7 @@ class TranOptsC(C.Structure):
                 ("hmin", C.c_double), ("hmax", C.c_double), ("max_newton", C.c_int32), ("max_order", C.c_int32),
                 ("use_pcnr", C.c_int32), ("newton_tol", C.c_double), ("n_break", C.c_int32), ("breaks", _D),
                 ("n_save", C.c_int32), ("save_t", _D), ("n_obs", C.c_int32), ("obs", _I),
-                ("max_iterations", C.c_int64), ("fused", C.c_int32)]
+                ("max_iterations", C.c_int64), ("fused", C.c_int32), ("newton_mode", C.c_int32)]
 
 
 class RunStatsC(C.Structure):
@@ -335,7 +335,7 @@ class Handle:
 
     def tran_run(self, t0, t1, abstol, reltol=1e-4, breaks=(), save_t=(), obs=None, h0=0.0, hmin=0.0, hmax=0.0,
                  max_newton=10, max_order=2, use_pcnr=False, newton_tol=1e-3, max_iterations=0, fused=False,
-                 err_mask="differential"):
+                 err_mask="differential", newton_mode=0):
         at = np.ascontiguousarray(np.broadcast_to(np.asarray(abstol, dtype=np.float64), (self.st.n,)))
         if isinstance(err_mask, str):
             em = self.st.differential_mask() if err_mask == "differential" else np.ones(self.st.n)
@@ -351,7 +351,7 @@ class Handle:
         st = RunStatsC()
         o = TranOptsC(t0, t1, reltol, _dp(at), _dp(em), h0, hmin, hmax, max_newton, max_order, int(use_pcnr), newton_tol,
                       br.size, _dp(br) if br.size else None, sv.size, _dp(sv) if sv.size else None,
-                      ob.size, _ip(ob) if ob.size else None, max_iterations, int(fused))  # fused: 0 = one kernel per op, non-zero = fused Newton kernel
+                      ob.size, _ip(ob) if ob.size else None, max_iterations, int(fused), int(newton_mode))  # fused: 0 = one kernel per op, non-zero = fused Newton kernel
         rc = self.lib.cadnip_tran_run(self.h, C.byref(o), _dp(out), per.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(st))
         if rc not in (OK, NOCONV):
             _check(rc, "cadnip_tran_run")
@@ -402,15 +402,32 @@ LU_ARRAYS = ("rperm", "cperm", "rowptr", "col", "diag", "load_src", "load_dst", 
 F2_ARRAYS = (("posW", np.int32), ("lanes", np.uint64), ("passes", np.uint64), ("terms", np.uint32), ("meta", np.int32))
 
 
-def host_lu_analyze(n, rowptr, colidx, vals, pivot_tol=1e-3, sample=False, f2_nc=None):
-    """Host-only symbolic phase (no GPU needed): returns the LU program as a dict of int32 arrays."""
+def leaves_of(st):
+    """(q_begin, lim_begin, unit_ok) of a Structure: the leaf-first pivot order a handle built from it uses (csrc/api.hip: cadnip_create)."""
+    q0, l0 = st.n_nodes + st.n_currents, st.n - st.n_limits
+    ok = np.zeros(st.n, dtype=np.uint8)
+    rows = np.repeat(np.arange(st.n), np.diff(st.rowptr))
+    for e in np.flatnonzero((rows == np.asarray(st.colidx)) & (rows >= q0)):
+        ok[rows[e]] = 1 if (st.g_ptr[e + 1] - st.g_ptr[e] == 1 and st.c_ptr[e + 1] == st.c_ptr[e]) else 0
+    return q0, l0, ok
+
+
+def host_lu_analyze(n, rowptr, colidx, vals, pivot_tol=1e-3, sample=False, f2_nc=None, leaves=None):
+    """Host-only symbolic phase (no GPU needed): returns the LU program as a dict of int32 arrays.  ``leaves``: ``leaves_of(st)`` for
+    the pivot order of a handle (device-local unknowns first), None for the plain Markowitz search."""
     lib = load_library()
     rp = np.ascontiguousarray(rowptr, dtype=np.int32)
     ci = np.ascontiguousarray(colidx, dtype=np.int32)
     v = np.ascontiguousarray(vals, dtype=np.float64)
     p = C.c_void_p()
-    _check(lib.cadnip_host_lu_analyze(C.c_int32(n), _ip(rp), _ip(ci), _dp(v), C.c_double(pivot_tol), C.c_int32(int(sample)), C.byref(p)),
-           "cadnip_host_lu_analyze")
+    if leaves is None or os.environ.get("CADNIP_LU_NOLEAF"):
+        _check(lib.cadnip_host_lu_analyze(C.c_int32(n), _ip(rp), _ip(ci), _dp(v), C.c_double(pivot_tol), C.c_int32(int(sample)), C.byref(p)),
+               "cadnip_host_lu_analyze")
+    else:
+        ok = np.ascontiguousarray(leaves[2], dtype=np.uint8)
+        _check(lib.cadnip_host_lu_analyze_leaves(C.c_int32(n), _ip(rp), _ip(ci), _dp(v), C.c_double(pivot_tol), C.c_int32(int(sample)),
+                                                 C.c_int32(int(leaves[0])), C.c_int32(int(leaves[1])), ok.ctypes.data_as(C.c_void_p), C.byref(p)),
+               "cadnip_host_lu_analyze_leaves")
     out = {}
     try:
         for k, nm in enumerate(LU_ARRAYS):

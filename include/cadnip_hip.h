@@ -220,6 +220,10 @@ typedef struct {
   int32_t n_obs;   const int32_t* obs;   /* unknown indices to record; n_obs = 0 -> all n */
   int64_t max_iterations;   /* safety bound on lock-step Newton launches */
   int32_t fused;            /* non-zero = fused per-instance Newton kernel (csrc/fused2.hip), 0 = one kernel per op */
+  int32_t newton_mode;      /* 0 = full Newton, converged when the weighted update norm < newton_tol (every round restamps and refactors);
+                               1 = the nonlinear iteration as IDA runs it (the reference's integrator, src/sweeps.jl:600): refactor on a setup
+                               only (first round, a0 outside [0.6, 1/0.6] of its last setup value, 20 steps, failure on a stale Jacobian), kept factors in between, rate-based
+                               convergence test ss ||delta|| <= 0.33.  Fused kernel only (CADNIP_BADARG otherwise) */
 } CadnipTranOpts;
 
 typedef struct {
@@ -277,6 +281,11 @@ typedef enum { CADNIP_LU_RPERM = 0, CADNIP_LU_CPERM, CADNIP_LU_ROWPTR, CADNIP_LU
 /* sample != 0: `vals` is a composite magnitude sample (as cadnip_analyze_values takes), not one state's Jacobian: a
  * numerically singular sample is re-analysed on magnitudes instead of being reported (csrc/symbolic.cpp) */
 int cadnip_host_lu_analyze(int32_t n, const int32_t* rowptr, const int32_t* colidx, const double* vals, double pivot_tol, int32_t sample, CadnipHostLU** out);
+/* ... with the leaf-first pivot order a handle uses (csrc/symbolic.cpp): unknowns [q_begin, lim_begin) are charge states, [lim_begin, n)
+ * limit variables (the reference's layout [V | I | q | lim], src/mna/context.jl); unit_ok[i] != 0: the diagonal of unknown i is one
+ * constant stamp.  q_begin < 0: plain Markowitz search (as cadnip_host_lu_analyze). */
+int cadnip_host_lu_analyze_leaves(int32_t n, const int32_t* rowptr, const int32_t* colidx, const double* vals, double pivot_tol, int32_t sample,
+                                  int32_t q_begin, int32_t lim_begin, const uint8_t* unit_ok, CadnipHostLU** out);
 int32_t cadnip_host_lu_size(const CadnipHostLU* lu, int32_t which);
 int cadnip_host_lu_get(const CadnipHostLU* lu, int32_t which, int32_t* dst);
 void cadnip_host_lu_free(CadnipHostLU* lu);

@@ -377,7 +377,10 @@ void residual(const Port& P, const double* u, const double* du, double* r) {   /
 }
 
 // numeric refactor with the fixed pivot sequence + solve; returns false on a zero / non-finite pivot
-bool factor_solve(Port& P, double gamma, const double* rhs, double* x) {
+bool lu_solve_kept(Port& P, const double* rhs, double* x);
+bool lu_factor(Port& P, double gamma);
+bool factor_solve(Port& P, double gamma, const double* rhs, double* x) { return lu_factor(P, gamma) && lu_solve_kept(P, rhs, x); }
+bool lu_factor(Port& P, double gamma) {
   LU& L = P.lu;
   std::fill(L.v.begin(), L.v.end(), 0.0);
   for (int k = 0; k < P.nnz; ++k) L.v[L.load_dst[k]] = P.G[k] + gamma * P.C[k];
@@ -390,6 +393,12 @@ bool factor_solve(Port& P, double gamma, const double* rhs, double* x) {
   }
   const int n = P.n;
   for (int i = 0; i < n; ++i) { double d = L.v[L.diag[i]]; if (d == 0.0 || !std::isfinite(d)) return false; }
+  return true;
+}
+// the two triangular sweeps on the factors lu_factor left (klu_solve after klu_refactor; Newton mode 1 keeps them over several rounds)
+bool lu_solve_kept(Port& P, const double* rhs, double* x) {
+  LU& L = P.lu;
+  const int n = P.n;
   for (int i = 0; i < n; ++i) L.y[i] = rhs[L.rperm[i]];
   for (int i = 0; i < n; ++i) { double acc = L.y[i]; for (int p = L.rowptr[i]; p < L.diag[i]; ++p) acc -= L.v[p] * L.y[L.col[p]]; L.y[i] = acc; }
   for (int i = n - 1; i >= 0; --i) { double acc = L.y[i]; for (int p = L.diag[i] + 1; p < L.rowptr[i + 1]; ++p) acc -= L.v[p] * L.y[L.col[p]]; L.y[i] = acc / L.v[L.diag[i]]; }
@@ -479,6 +488,7 @@ int port_dc(void* p, double* u, double abstol, int maxiters, int use_pcnr, int c
 struct TranOpts {
   double t0, t1, reltol; const double* abstol; const double* err_mask; double h0, hmin, hmax; int max_newton, max_order, use_pcnr; double newton_tol;
   int n_break; const double* breaks; int n_save; const double* save_t; int n_obs; const int* obs;
+  int newton_mode;   // 1 = IDA's nonlinear iteration: Jacobian reuse + rate test (cadnip.jl_amd/csrc/tran_ctrl.hpp, the same policy statement for statement)
 };
 struct TranStats { int64_t newton_iters, accepted, rejected, newton_failures; int status; double wall_seconds; };
 
@@ -512,16 +522,27 @@ int port_tran(void* p, double* u_io, const TranOpts* o, double* out, TranStats* 
     }
     h = hh; k = 0;
   };
-  prepare(t, h, nhist, hprev, hpp);
+  // Newton mode 1 (tran_ctrl.hpp): kept factors, their a0, the rate constant, the previous update norm, flags
+  const int mode = o->newton_mode;
+  double a0f = 0.0, ss = 20.0, dnp = 0.0; bool need = true, jcur = false, valid = false; int since = 0;
+  auto prepare0 = prepare;
+  auto prepare_attempt = [&](double tt, double hh, int nh, double hp, double hq) { prepare0(tt, hh, nh, hp, hq); jcur = false; };
+  prepare_attempt(t, h, nhist, hprev, hpp);
   while (status == 0) {
     dbg = dbg_env && tn >= dbg_from;
     rebuild(P, u.data(), tn);
     residual(P, u.data(), du.data(), r.data());
-    bool ok = factor_solve(P, a0, r.data(), delta.data());
+    bool refresh = true; double dsc = 1.0;
+    if (mode) {
+      refresh = need || !valid || (k == 0 && (a0 < 0.6 * a0f || a0 * 0.6 > a0f || since >= 20));
+      if (refresh) { a0f = a0; ss = 20.0; need = false; valid = true; jcur = true; since = 0; }
+      else dsc = a0 == a0f ? 1.0 : 2.0 / (1.0 + a0 / a0f);
+    }
+    bool ok = refresh ? factor_solve(P, a0, r.data(), delta.data()) : lu_solve_kept(P, r.data(), delta.data());
     S.newton_iters += 1;
     double s1 = 0, s2 = 0; bool bad = !ok;
     for (int i = 0; i < n; ++i) {
-      double d = delta[i], un = u[i] - d; if (!std::isfinite(d)) bad = true;
+      double d = delta[i] * dsc, un = u[i] - d; if (!std::isfinite(d)) bad = true;
       double w = 1.0 / (o->abstol[i] + o->reltol * std::fabs(u0[i])); s1 += (d * w) * (d * w);
       double e = un - up[i], w2 = emask[i] / (o->abstol[i] + o->reltol * std::max(std::fabs(u0[i]), std::fabs(un))); s2 += (e * w2) * (e * w2);
       u[i] = un;
@@ -538,7 +559,17 @@ int port_tran(void* p, double* u_io, const TranOpts* o, double* out, TranStats* 
         double hdr[4] = {tn, h, a0, (double)n}; fwrite(hdr, 8, 4, f); fwrite(u.data(), 8, n, f); fwrite(beta.data(), 8, n, f); fclose(f);
       }
     }
-    if (!bad && dnorm < ntol) {
+    bool conv = !bad && dnorm < ntol, diverge = false;
+    if (mode) {
+      conv = false;
+      if (!bad) {
+        if (k == 0) conv = dnorm <= 0.33e-4;
+        else { const double rate = dnp > 0.0 ? dnorm / dnp : 0.0; if (rate > 0.9) diverge = true; else ss = rate / (1.0 - rate); }
+        if (!diverge && ss * dnorm <= 0.33) conv = true;
+        dnp = dnorm;
+      }
+    }
+    if (conv) {
       double errn = 0; bool accept = true;
       if (nhist >= 2 && n_err > 0) {
         double errc; if (ord == 1) errc = h / (h + hprev); else { double w = h / hprev; errc = ((1.0 + w) * h / (1.0 + 2.0 * w)) / (h + hprev + hpp); }
@@ -562,22 +593,25 @@ int port_tran(void* p, double* u_io, const TranOpts* o, double* out, TranStats* 
         double new_hprev = h, new_hpp = hprev;
         if (landed) { ++bp; nh_new = 1; double tstop = o->t1; if (bp < o->n_break && o->breaks[bp] < tstop) tstop = o->breaks[bp]; hnext = 0.1 * std::min(h, tstop - tn); }
         hnext = std::min(hnext, hmax);
-        t = tn; hprev = new_hprev; hpp = new_hpp; nhist = nh_new; S.accepted += 1;
+        t = tn; hprev = new_hprev; hpp = new_hpp; nhist = nh_new; S.accepted += 1; since += 1;
         if (trace_t && ntrace < trace_cap) trace_t[ntrace++] = t;
         if (tn >= o->t1) { status = 1; break; }
         if (hnext < hmin) hnext = hmin;
-        prepare(t, hnext, nhist, hprev, hpp);
+        prepare_attempt(t, hnext, nhist, hprev, hpp);
       } else {
         double fac = 0.9 * std::pow(errn, -1.0 / (ord + 1)); fac = std::min(0.9, std::max(0.1, fac));
         double hn = h * fac; S.rejected += 1;
         if (hn < hmin) { status = -1; break; }
-        prepare(t, hn, nhist, hprev, hpp);
+        prepare_attempt(t, hn, nhist, hprev, hpp);
       }
     } else {
-      if (bad || k + 1 >= maxn) {
+      if (mode && (bad || diverge || k + 1 >= maxn) && !jcur) {
+        need = true;                                   // failed on a stale Jacobian: the same step again, refactored first
+        prepare_attempt(t, h, nhist, hprev, hpp);
+      } else if (bad || diverge || k + 1 >= maxn) {
         double hn = 0.25 * h; S.newton_failures += 1;
         if (hn < hmin) { status = -2; break; }
-        prepare(t, hn, nhist, hprev, hpp);
+        prepare_attempt(t, hn, nhist, hprev, hpp);
       } else {
         if (o->use_pcnr && L > 0) for (int i = n - L; i < n; ++i) u[i] = P.limit_w[i];
         for (int i = 0; i < n; ++i) du[i] = a0 * u[i] + beta[i];

@@ -26,7 +26,7 @@ class StubHandle:
     def set_spec(self, **kw):
         pass
 
-    def tran_run(self, t0, t1, atol, reltol, breaks=(), save_t=(), obs=None, fused=0):
+    def tran_run(self, t0, t1, atol, reltol, breaks=(), save_t=(), obs=None, fused=0, newton_mode=0):
         CALLS.append("tran")
         time.sleep(0.01)
         out = np.full((self.B, len(save_t), len(obs)), float(dist.get_rank()))
@@ -69,13 +69,13 @@ def main():
         return float(t.item()) if isinstance(x, float) else int(t.item())
 
     args = types.SimpleNamespace(steps=2, warmup=1, instances=64, total_instances=96, fused=2, no_cpu_baseline=True, no_live_pmc=True,
-                                 no_extras=True, cpu_sample=8)
+                                 no_extras=True, cpu_sample=8, newton_mode=1)
     res = bench.run(args, rank, world, rank, dist, None, sync=lambda: None, reduce_max=lambda x: allreduce(x, "max"),
                     reduce_sum=lambda x: allreduce(x, "sum"), simulator=StubSim)
     dist.barrier()
     dist.destroy_process_group()
-    # weak: (1 warmup + 2 timed) steps; strong: (1 + 2); rank 0: + 1 profiled step without a gather
-    assert CALLS.count("tran") == 6 + (1 if rank == 0 else 0), CALLS
+    # weak: (1 warmup + 2 timed) steps; strong: (1 + 2); rank 0: + 1 profiled step and 2 full-Newton comparison steps, none of them gathering
+    assert CALLS.count("tran") == 6 + (3 if rank == 0 else 0), CALLS
     if rank == 0:
         assert res["n_gpus"] == world and res["config"]["instances_total"] == 64 * world
         assert res["config"]["newton_iters_per_step"] == 110 * 64 * world                  # SUM over ranks

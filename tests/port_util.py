@@ -34,6 +34,6 @@ def analyze_port(st, port, vscale, gamma=1e9, seed=1234, n_samples=6):
         G, C, b, lw = port.rebuild(u, 0.0)
         port.set_spec(initjct=0)
         acc = np.maximum(acc, api.clip_sample(G + gamma * C)[0])
-    prog = hip.host_lu_analyze(st.n, st.rowptr, st.colidx, acc, sample=True)
+    prog = hip.host_lu_analyze(st.n, st.rowptr, st.colidx, acc, sample=True, leaves=hip.leaves_of(st))   # the pivot order a handle uses
     port.set_lu(prog)
     return prog

@@ -30,6 +30,9 @@ def test_bench_line_contract(capsys):
     assert s["bound"] == "hbm" and s["B"] == 8192 and 0.0 < s["frac"] <= 1.0 and abs(s["frac"] - s["achieved_GBps"] / 8000.0) < 1e-3
     assert d["strong_1024"]["instances_total"] == 64 and d["strong_1024"]["value"] > 0
     assert d["single_instance_us_per_iter"] > 0 and d["callback_us_per_iter"] > 0
+    assert d["config"]["newton_mode"] == 1 and d["full_newton"]["newton_iters_per_step"] > d["config"]["newton_iters_per_step"]
+    p = d["psp103_ring"]
+    assert "error" not in p and p["B1"]["failed"] == 0 and p["B256"]["failed"] == 0 and p["B256"]["us_per_instance_iter"] < p["B1"]["us_per_instance_iter"] < 1376.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and "sample" in c
 

@@ -247,3 +247,52 @@ def test_dff_monte_carlo_variant_matches_port():
         assert rst["status"] == 1
         assert abs(per[i, 0] - rst["newton_iters"]) <= 0.01 * rst["newton_iters"], (i, per[i], rst)
         assert np.max(np.abs(out[i] - ref) / np.maximum(np.abs(ref), 1.0)) <= REL_TOL, i
+
+
+def test_dff_transient_newton_mode_1_matches_port():
+    """Newton mode 1 -- Jacobian reuse and the rate-based convergence test as IDA runs them (tran_ctrl.hpp) -- in the fused kernel
+    against the port's statement-for-statement mirror: the same policy must take the same path (counts within 1 %, as for full
+    Newton in the fused kernel) and land on the same waveforms (1e-9); it needs fewer refactorisations than Newton rounds."""
+    circ = bm.dff_circuit()
+    points = [{}, {"vdd": 4.5, "temp": 125.0}, {"vdd": 5.5, "temp": -40.0}]
+    sim = api.BatchSimulator(api.MNACircuit(circ, {"vdd": 5.0}), points)
+    st = sim.st
+    sim.analyze()
+    u0, conv, _ = sim.dc(abstol=1e-9, mode="tranop")
+    assert np.all(conv)
+    ts = np.linspace(0.0, 7e-7, 141)
+    obs = list(range(st.n_nodes))
+    sim.h.set_spec(mode="tran")
+    breaks = expand_breakpoints(st.breakpoints, bm.DFF_TSPAN)
+    atol = st.state_abstol(**ABSTOL)
+    out, per, stats = sim.h.tran_run(0.0, 7e-7, atol, 1e-4, breaks=breaks, save_t=ts, obs=obs, fused=2, newton_mode=1)
+    assert stats["n_failed"] == 0
+    out0, per0, stats0 = None, None, None
+    u0b, _, _ = sim.dc(abstol=1e-9, mode="tranop")
+    sim.h.set_spec(mode="tran")
+    out0, per0, stats0 = sim.h.tran_run(0.0, 7e-7, atol, 1e-4, breaks=breaks, save_t=ts, obs=obs, fused=2, newton_mode=0)
+    # same circuit behaviour as full Newton, to the integrator's tolerance (different iterates, same solution)
+    assert np.max(np.abs(out - out0)) < 2e-2 * 5.0 and np.max(np.abs(out[:, -1] - out0[:, -1])) < 1e-3
+    for i, pt in enumerate(points):
+        pst, port = make_port(circ, {"vdd": pt.get("vdd", 5.0)}, pt.get("temp", 27.0), "tran")
+        analyze_port(pst, port, sim.vscale())
+        ref, uf, rst, _ = port.tran(u0[i], 0.0, 7e-7, atol, 1e-4, breaks=breaks, save_t=ts, obs=obs, err_mask=pst.differential_mask(),
+                                    use_pcnr=False, newton_mode=1)
+        port.close()
+        assert rst["status"] == 1
+        assert abs(per[i, 0] - rst["newton_iters"]) <= 0.01 * rst["newton_iters"], (pt, per[i], rst)
+        err = np.max(np.abs(out[i] - ref) / np.maximum(np.abs(ref), 1.0))
+        assert err <= REL_TOL, (pt, err)
+    print("newton iterations mode 1:", per[:, 0], " mode 0:", per0[:, 0], " steps:", per[:, 1], per0[:, 1])
+    sim.close()
+
+
+def test_newton_mode_1_needs_the_fused_kernel():
+    circ = tc.ALL_STAMP["inverter"][0]()
+    sim = api.BatchSimulator(api.MNACircuit(circ, tc.ALL_STAMP["inverter"][1]), None)
+    sim.analyze()
+    sim.dc(abstol=1e-9, mode="tranop")
+    sim.h.set_spec(mode="tran")
+    with pytest.raises(Exception):
+        sim.h.tran_run(0.0, 1e-8, sim.st.state_abstol(**ABSTOL), 1e-4, save_t=[1e-8], fused=0, newton_mode=1)
+    sim.close()
