@@ -490,7 +490,7 @@ struct TranOpts {
   int n_break; const double* breaks; int n_save; const double* save_t; int n_obs; const int* obs;
   int newton_mode;   // 1 = IDA's nonlinear iteration: Jacobian reuse + rate test (cadnip.jl_amd/csrc/tran_ctrl.hpp, the same policy statement for statement)
 };
-struct TranStats { int64_t newton_iters, accepted, rejected, newton_failures; int status; double wall_seconds; };
+struct TranStats { int64_t newton_iters, accepted, rejected, newton_failures; int status; double wall_seconds; int64_t refactorisations; };
 
 // the transient driver of cadnip.jl_amd/csrc/driver.hip, one instance, sequential
 int port_tran(void* p, double* u_io, const TranOpts* o, double* out, TranStats* st, double* trace_t, int trace_cap, int* trace_n) {
@@ -506,7 +506,7 @@ int port_tran(void* p, double* u_io, const TranOpts* o, double* out, TranStats* 
   int savedmode = P.mode; P.mode = 1;
   while (bp < o->n_break && o->breaks[bp] <= o->t0) ++bp;
   while (si < o->n_save && o->save_t[si] <= o->t0) { for (int j = 0; j < n_obs; ++j) out[(size_t)si * n_obs + j] = u[o->n_obs > 0 ? o->obs[j] : j]; ++si; }
-  TranStats S{0, 0, 0, 0, 0, 0.0}; int ntrace = 0;
+  TranStats S{0, 0, 0, 0, 0, 0.0, 0}; int ntrace = 0;
   const char* dbg_env = getenv("PORT_DEBUG"); const double dbg_from = dbg_env ? atof(dbg_env) : 0.0; bool dbg = false;
   auto prepare = [&](double tt, double hh, int nh, double hp, double hq) {
     double tstop = o->t1; if (bp < o->n_break && o->breaks[bp] < tstop) tstop = o->breaks[bp];
@@ -539,6 +539,7 @@ int port_tran(void* p, double* u_io, const TranOpts* o, double* out, TranStats* 
       else dsc = a0 == a0f ? 1.0 : 2.0 / (1.0 + a0 / a0f);
     }
     bool ok = refresh ? factor_solve(P, a0, r.data(), delta.data()) : lu_solve_kept(P, r.data(), delta.data());
+    S.refactorisations += refresh ? 1 : 0;
     S.newton_iters += 1;
     double s1 = 0, s2 = 0; bool bad = !ok;
     for (int i = 0; i < n; ++i) {

@@ -36,7 +36,7 @@ class TranOptsC(C.Structure):
 
 class TranStatsC(C.Structure):
     _fields_ = [("newton_iters", C.c_int64), ("accepted", C.c_int64), ("rejected", C.c_int64),
-                ("newton_failures", C.c_int64), ("status", C.c_int32), ("wall_seconds", C.c_double)]
+                ("newton_failures", C.c_int64), ("status", C.c_int32), ("wall_seconds", C.c_double), ("refactorisations", C.c_int64)]
 
 
 _lib = None
