@@ -20,12 +20,23 @@ template <int N> __device__ __forceinline__ Dual<N> va_chain(const Dual<N>& a, d
   for (int i = 0; i < N; ++i) r.p[i] = a.p[i] * df;
   return r;
 }
+// The expensive elementary functions (software fp64: exp ~40 instructions, log ~50, pow ~170) behind one name each.  PSP103 has ~500 call
+// sites and its tangent-lane stamp function is 157 k vector instructions of straight-line code (1.2 MB) that every wave streams through the
+// instruction cache once; calling these instead of inlining them was tried in the translation unit that carries it and lost.
+#ifdef CADNIP_VA_WITH_EXT
+#define VA_MATH_FN static __device__ __forceinline__   // (called, not inlined: measured 7 % slower -- the call sequences cost more than the instruction fetches they save)
+#else
+#define VA_MATH_FN __device__ __forceinline__
+#endif
+VA_MATH_FN double va_m_exp(double x) { return exp(x); }
+VA_MATH_FN double va_m_log(double x) { return log(x); }
+VA_MATH_FN double va_m_pow(double a, double b) { return pow(a, b); }
 #define VA_UNARY(name, fexpr, dfexpr)                                                                     \
   __device__ __forceinline__ double va_##name(double x) { return fexpr; }                                 \
   template <int N> __device__ __forceinline__ Dual<N> va_##name(const Dual<N>& a) {                        \
     const double x = a.v; const double f = fexpr; (void)f; return va_chain(a, f, dfexpr); }
-VA_UNARY(exp, exp(x), f)
-VA_UNARY(ln, log(x), 1.0 / x)
+VA_UNARY(exp, va_m_exp(x), f)
+VA_UNARY(ln, va_m_log(x), 1.0 / x)
 VA_UNARY(log, log10(x), 1.0 / (x * 2.302585092994046))
 VA_UNARY(sqrt, sqrt(x), 0.5 / f)
 VA_UNARY(tanh, tanh(x), 1.0 - f * f)
@@ -41,7 +52,7 @@ VA_UNARY(asinh, asinh(x), 1.0 / sqrt(x * x + 1.0))
 VA_UNARY(acosh, acosh(x), 1.0 / sqrt(x * x - 1.0))
 VA_UNARY(atanh, atanh(x), 1.0 / (1.0 - x * x))
 // limexp: exp below 80, its tangent above (the usual SPICE continuation)
-VA_UNARY(limexp, (x < 80.0 ? exp(x) : exp(80.0) * (1.0 + x - 80.0)), (x < 80.0 ? f : exp(80.0)))
+VA_UNARY(limexp, (x < 80.0 ? va_m_exp(x) : 5.54062238439351e+34 * (1.0 + x - 80.0)), (x < 80.0 ? f : 5.54062238439351e+34))
 #undef VA_UNARY
 // piecewise constant functions: plain numbers
 template <class X> __device__ __forceinline__ double va_floor(const X& x) { return floor(va_val(x)); }
@@ -54,17 +65,39 @@ __device__ __forceinline__ double va_abs(double x) { return fabs(x); }
 template <int N> __device__ __forceinline__ Dual<N> va_abs(const Dual<N>& a) { return a.v >= 0.0 ? a : -a; }
 
 // two-argument functions: every double / dual combination
-__device__ __forceinline__ double va_pow(double a, double b) { return pow(a, b); }
+// pow: the exponents compact models use are mostly parameters with simple values (JUNCAP's grading coefficients default to 1/2,
+// mobility exponents to 1 or 2).  A software fp64 pow is ~170 instructions on this ISA, a square root ~20: the common exponents take
+// their closed forms (exact or within the same ulp as pow), everything else goes to pow.  The derivative of a^b with respect to a is
+// b f / a -- one division instead of a second pow (b a^(b-1) when a = 0).
+__device__ __forceinline__ double va_pow(double a, double b) {
+  if (b == 0.5) return sqrt(a);
+  if (b == 1.0) return a;
+  if (b == 2.0) return a * a;
+  if (b == -1.0) return 1.0 / a;
+  if (b == -0.5) return 1.0 / sqrt(a);
+  if (b == 0.0) return 1.0;
+  if (b == 1.5) return a * sqrt(a);
+  if (b == 3.0) return a * a * a;
+  return va_m_pow(a, b);
+}
+__device__ __forceinline__ double va_dpow(double a, double b, double f) {   // d(a^b)/da given f = a^b
+  if (b == 0.0) return 0.0;
+  return a != 0.0 ? b * f / a : b * va_pow(a, b - 1.0);
+}
 template <int N> __device__ __forceinline__ Dual<N> va_pow(const Dual<N>& a, double b) {
-  const double f = pow(a.v, b);
-  return va_chain(a, f, b == 0.0 ? 0.0 : b * pow(a.v, b - 1.0));
+  const double f = va_pow(a.v, b);
+  return va_chain(a, f, va_dpow(a.v, b, f));
 }
 template <int N> __device__ __forceinline__ Dual<N> va_pow(double a, const Dual<N>& b) {
-  const double f = pow(a, b.v);
-  return va_chain(b, f, f * log(a));
+  const double f = va_pow(a, b.v);
+  return va_chain(b, f, f * va_m_log(a));
 }
 template <int N> __device__ __forceinline__ Dual<N> va_pow(const Dual<N>& a, const Dual<N>& b) {
-  const double f = pow(a.v, b.v), da = b.v == 0.0 ? 0.0 : b.v * pow(a.v, b.v - 1.0), db = f * log(a.v);
+  const double f = va_pow(a.v, b.v), da = va_dpow(a.v, b.v, f);
+  bool bdep = false;
+#pragma unroll
+  for (int i = 0; i < N; ++i) bdep = bdep || b.p[i] != 0.0;
+  const double db = bdep ? f * log(a.v) : 0.0;             // (the exponent is usually a parameter carried in a dual: no log then)
   Dual<N> r; r.v = f;
 #pragma unroll
   for (int i = 0; i < N; ++i) r.p[i] = a.p[i] * da + (b.p[i] != 0.0 ? b.p[i] * db : 0.0);
