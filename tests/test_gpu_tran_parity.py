@@ -145,8 +145,10 @@ def test_fused_kernel_matches_per_op_path(name):
     assert abs(int(got[0][1][0]) - int(got[1][1][0])) <= max(3, 0.02 * got[0][1][0]), (name, got[0][1], got[1][1])
 
 
-def test_full_size_corner_sweep_properties():
-    """BASELINE.json config 4 at full size (32 Vdd x 32 temperature corners of the DFF transient, one resident batch)
+@pytest.mark.parametrize("newton_mode", [0, 1])
+def test_full_size_corner_sweep_properties(newton_mode):
+    """(both Newton modes of the fused kernel: full Newton, and IDA's Jacobian reuse with factors that travel with the instances)
+    BASELINE.json config 4 at full size (32 Vdd x 32 temperature corners of the DFF transient, one resident batch)
     checked through size-independent properties: every instance finishes; the race-free logic pins hold at every corner;
     an instance's result does not depend on the batch it runs in (bitwise: nothing crosses instances, and the in-kernel
     instance queue hands out whole instances); the sweep is invariant under permutation of the points."""
@@ -158,7 +160,7 @@ def test_full_size_corner_sweep_properties():
     def run(points):
         sim = api.BatchSimulator(api.MNACircuit(circ, {"vdd": 5.0}), points)
         st = sim.st
-        out, per, stats = sim.tran(bm.DFF_TSPAN, st.state_abstol(**ABSTOL), 1e-4, ts, obs=[st.index_of("Q"), st.index_of("Q_neg")], fused=1)
+        out, per, stats = sim.tran(bm.DFF_TSPAN, st.state_abstol(**ABSTOL), 1e-4, ts, obs=[st.index_of("Q"), st.index_of("Q_neg")], fused=1, newton_mode=newton_mode)
         sim.close()
         return out, per, stats
 
