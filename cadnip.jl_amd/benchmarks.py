@@ -112,6 +112,27 @@ def dff_circuit(mc_vto=None, mc_kp=None, meyer=False, generated=False):
     return c
 
 
+def dff_circuit_bsim4(vdd=None):
+    """The same flip-flop with the reference's own BSIM4 text: every MOSFET an instance of ``sp_bsim4v8`` (models/VADistillerModels.jl/va/
+    bsim4v8.va through the generator, csrc/va_generated_ext.hpp) on its default card -- SURVEY.md section 8d's secondary model for config 3
+    ("bsim4v8 defaults level=14"; the gf180 PDK cards are not in the reference).  Only type and W / L are given; the model's own intrinsic
+    and overlap charges load the nodes (no lumped gate capacitors).  ``vdd``: a number fixes the supply (no sweep parameter)."""
+    c = Circuit("gf180 dffnq_4 test bench (sp_bsim4v8, default card)")
+    v = Param("vdd") if vdd is None else float(vdd)
+    amp = Param("vdd", scale=1.0 / 5.0) if vdd is None else float(vdd) / 5.0
+    c.V("VVDD", "VDD", "0", dc=v)
+    c.V("VVSS", "VSS", "0", dc=0.0)
+    c.V("VQ", "Q", "Q_tmp", dc=0.0)
+    c.V("VNW", "VNW", "VDD", dc=0.0)
+    c.V("VPW", "VPW", "VSS", dc=0.0)
+    c.V("VCLKN", "CLKN", "0", dc=(Param("vdd", scale=CLKN_PWL[1][0] / 5.0) if vdd is None else CLKN_PWL[1][0] * amp), wave=("pwl",) + CLKN_PWL, scale=amp)
+    c.V("VD", "D", "0", dc=(Param("vdd", scale=D_PWL[1][0] / 5.0) if vdd is None else D_PWL[1][0] * amp), wave=("pwl",) + D_PWL, scale=amp)
+    for (nm, d, g, s, b, W, L) in DFF_FETS:
+        c.VA("X_" + nm, "sp_bsim4v8", (d, g, s, b), type=1.0 if nm.startswith("tn") else -1.0, w=W, l=L)
+    c.C("CQ", "Q_tmp", "0", 1.7205e-13)
+    return c
+
+
 def inverter_circuit():
     """Single CMOS inverter transient of benchmarks/inverter_performance_bench.jl
     (benchmark_common.jl:82-105): nfet W=0.36u L=0.6u, pfet W=0.495u L=0.5u, VDD = 5 V, CQ = 1 fF,

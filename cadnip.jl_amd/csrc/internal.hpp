@@ -67,7 +67,7 @@ struct DeviceBlock {
   int g_base, c_base, b_base, n_g, n_c, n_b;
   int* d_nodes = nullptr;
   std::vector<int> h_nodes;  // host copy (the fused kernel keeps an int16 copy in LDS)
-  bool va_tl = false;        // generated external model: evaluated with one derivative direction per lane (stamp_csr.hip)
+  int va_tl = 0;             // generated external model: lanes per device when evaluated with one derivative direction per lane (16 / 32; stamp_csr.hip)
   bool mos1_plain = false;   // sp_mos1 block: every instance has gd = gs = OxideCap = 0 (set by cadnip_set_params)
   int* d_ipar = nullptr;
   double* d_par = nullptr;   // [B][n_par][count]

@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(64) k_stamp_csr(CsrStampArgs a) {
     else if (TYPE == CADNIP_DEV_BVSOURCE) stamp_bvsource(d, u, s, lw);
     else if (TYPE == CADNIP_DEV_BISOURCE) stamp_bisource(d, u, s, lw);
     else if (TYPE == CADNIP_DEV_VA) {
-      if (a.lpd == VA_TL_LANES) stamp_va_tl(d, u, s, lw, side);   // external model: lane `side` of the device's group carries direction `side`
+      if (a.lpd >= VA_TL_LANES) stamp_va_tl(d, u, s, lw, side);   // external model: lane `side` of the device's group carries direction `side`
       else stamp_va(d, u, s, lw);
     }
   }
@@ -318,7 +318,7 @@ int build_stamp_plan(CadnipHandle* h, const CadnipStructure* s) {
     if (b.count == 0) continue;
     const int nslots = b.n_g + b.n_c + b.n_b;
     int cs = b.type == CADNIP_DEV_MOS1 ? 32 : 64;                       // sp_mos1: room for two lanes per device
-    if (b.type == CADNIP_DEV_VA && b.va_tl) cs = 64 / VA_TL_LANES;      // external models: 16 direction lanes per device (va_runtime.hpp)
+    if (b.type == CADNIP_DEV_VA && b.va_tl) cs = 64 / b.va_tl;           // external models: 16 or 32 direction lanes per device (va_runtime.hpp)
     while (cs > 1 && (size_t)cs * nslots * 8 > 96 * 1024) cs >>= 1;     // big generated models: smaller chunks
     if ((size_t)cs * nslots > 65535) return CADNIP_BADARG;              // 16-bit staging offsets
     if (b.count <= cs) { b.sp_cs = b.count; b.sp_chunks = 1; }
@@ -475,7 +475,7 @@ template <int TYPE>
 static int launch_stamp_csr_t(CadnipHandle* h, DeviceBlock& b) {
   const int nslots = b.n_g + b.n_c + b.n_b;
   const bool pair = TYPE == CADNIP_DEV_MOS1 && b.mos1_plain;
-  const int lpd = pair ? 2 : (TYPE == CADNIP_DEV_VA && b.va_tl) ? VA_TL_LANES : 1;
+  const int lpd = pair ? 2 : (TYPE == CADNIP_DEV_VA && b.va_tl) ? b.va_tl : 1;
   int ipw = 1;
   if (b.sp_chunks == 1) ipw = std::min(8, std::max(1, 64 / (b.count * lpd)));   // (a wave reduces its instances one after the other: few per wave)
   const size_t tile_words = (size_t)nslots * b.sp_cs + b.sp_scratch;

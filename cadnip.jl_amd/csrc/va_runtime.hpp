@@ -227,41 +227,43 @@ __device__ __forceinline__ void va_emit_branch(const Ctx& d, const double* u, co
 // (the equivalent current I - sum_k dI/dV_k V_k) are DPP row sums (tran_ctrl.hpp: group_sum16); a lane writes the stamps of its
 // own node column.  Per-op stamping kernel only (stamp_csr.hip); the summation order of the equivalent currents differs from
 // the reference's left-to-right sum, i.e. results agree with the oracle to rounding, not bit for bit.
-#define VA_TL_LANES 16
+#define VA_TL_LANES 16          // lanes per device: 16 (one DPP row) for models with up to 16 directions, 32 (two rows) up to 32
 __device__ __forceinline__ Dual<1> va_seed_tl(double x, bool mine) { Dual<1> r; r.v = x; r.p[0] = mine ? 1.0 : 0.0; return r; }
 __device__ __forceinline__ Dual<1> va_site_tl(const Dual<1>& probe, double w, bool mine) { Dual<1> r = probe; r.v = w; if (mine) r.p[0] = 1.0; return r; }
 // ddx(expr, V(node k)): the partial held by lane k of this device's group
-__device__ __forceinline__ double va_ddx_tl(double, int) { return 0.0; }
-__device__ __forceinline__ double va_ddx_tl(const Dual<1>& a, int k) { return __shfl(a.p[0], (int)((__lane_id() & ~(VA_TL_LANES - 1)) + k)); }
+template <int LANES> __device__ __forceinline__ double va_ddx_tl(double, int) { return 0.0; }
+template <int LANES> __device__ __forceinline__ double va_ddx_tl(const Dual<1>& a, int k) { return __shfl(a.p[0], (int)((__lane_id() & ~(LANES - 1)) + k)); }
 template <int CTRL> __device__ __forceinline__ double dpp_row_f64(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
-// sum over the 16 lanes of a DPP row (= one device's direction lanes), result in every lane; all lanes of the wave must be active
-__device__ __forceinline__ double va_group_sum(double v) {
+// sum over one device's direction lanes -- the 16 lanes of a DPP row, or two neighbouring rows -- result in every lane; all lanes of the
+// wave must be active
+template <int LANES> __device__ __forceinline__ double va_group_sum(double v) {
   v += dpp_row_f64<0xB1>(v);    // quad_perm [1,0,3,2]
   v += dpp_row_f64<0x4E>(v);    // quad_perm [2,3,0,1]
   v += dpp_row_f64<0x141>(v);   // row_half_mirror
   v += dpp_row_f64<0x140>(v);   // row_mirror
+  if (LANES == 32) v += __shfl_xor(v, 16);
   return v;
 }
 
 // wgt: this direction's weight in  X - sum_k dX/dV_k V_k + sum_j dX/dsite_j (V(probe_j) - w_j):  -V_dir for a node direction,
 // V(probe_j) - w_j for $limit site j, 0 for an idle lane (the generated function computes it once, after the body)
-template <int N, int S, int B, bool REACTIVE, class Out>
+template <int N, int S, int B, bool REACTIVE, int LANES, class Out>
 __device__ __forceinline__ void va_emit_branch_tl(const Out& s, int b, const Dual<1>& I, const Dual<1>& Q, double wgt, int dir) {
   static_assert(!Out::DIRECT, "tangent-lane stamping exists for the per-op path only");
   const double CS = CADNIP_CHARGE_SCALE;
   const bool node_dir = dir < N;
-  const double Ieq = I.v + va_group_sum(I.p[0] * wgt);
+  const double Ieq = I.v + va_group_sum<LANES>(I.p[0] * wgt);
   if (node_dir) {
     s.G(2 * N * b + 2 * dir, I.p[0]);
     s.G(2 * N * b + 2 * dir + 1, -I.p[0]);
   }
   if (REACTIVE) {
-    const double bq = Q.v + va_group_sum(Q.p[0] * wgt);
+    const double bq = Q.v + va_group_sum<LANES>(Q.p[0] * wgt);
     if (node_dir) {
       s.G(2 * N * B + (N + 1) * b + 1 + dir, -CS * Q.p[0]);
       s.C(2 * B + 2 * N * b + 2 * dir, Q.p[0]);

@@ -14,7 +14,8 @@ MODEL_FILES = ("va_resistor.va", "va_capacitor.va", "va_diode.va", "va_sqmos.va"
 # their generated stamp functions (csrc/va_generated_ext.hpp, model ids after the built-in ones); the host side -- structure
 # discovery, parameter defaults -- needs the source itself and looks for it in $CADNIP_VA_PATH (os.pathsep-separated directories)
 # and then in the reference checkout.  (module name, file name, directories below the reference root)
-EXTERNAL = (("PSP103VA", "psp103.va", ("models/PSPModels.jl/va",)),)
+EXTERNAL = (("PSP103VA", "psp103.va", ("models/PSPModels.jl/va",)),
+            ("sp_bsim4v8", "bsim4v8.va", ("models/VADistillerModels.jl/va",)))
 REFERENCE_ROOT = "/root/reference"
 
 _cache = {}

@@ -61,7 +61,7 @@ class _Gen:
         if k == "ddx":
             c, t, _ = self.g(e[1])
             a = m.node_index(e[2])
-            return ("va_ddx%s(%s, %d)" % ("_tl" if self.tl else "", c, a)) if (t and a >= 0) else "0.0", False, None
+            return ("va_ddx%s(%s, %d)" % (("_tl<%d>" % tl_lanes(m)) if self.tl else "", c, a)) if (t and a >= 0) else "0.0", False, None
         if k == "var":
             if self.func:
                 return "f_" + e[1], True, None
@@ -293,12 +293,18 @@ def generate_analog_functions(m):
     return "\n".join(out + defs)
 
 
+def tl_lanes(m):
+    """lanes per device of the tangent-lane variant: one DPP row when the directions (nodes + $limit sites) fit it, else two"""
+    return 16 if m.n_nodes + m.n_sites <= 16 else 32
+
+
 def generate_function(m, tl=False):
     """tl: the tangent-lane variant ``stamp_va_<module>_tl(d, u, s, lw, dir)`` -- one derivative direction per lane, 16 lanes per
     device (va_runtime.hpp); the statements are the same text on Dual<1>."""
     N, B, NP, S, NL = m.n_nodes, len(m.branches), len(m.params), m.n_sites, len(m.limit_branches)
-    if tl and N + S > 16:
-        raise VAError("%s: %d derivative directions do not fit the 16 lanes of a device group" % (m.name, N + S))
+    if tl and N + S > 32:
+        raise VAError("%s: %d derivative directions do not fit the 32 lanes of a device group" % (m.name, N + S))
+    lanes = tl_lanes(m)
     g = _Gen(m, tl=tl)
     L = g.lines
     if m.functions:
@@ -358,7 +364,7 @@ def generate_function(m, tl=False):
         for j in range(S):
             L.append("  if (dir == N + %d) wgt = ld[%d];" % (j, j))
         for b, ((p, n), r) in enumerate(zip(m.branches, m.reactive)):
-            L.append("  va_emit_branch_tl<N, S, B, %s>(s, %d, sys.mf * br%d_r, sys.mf * br%d_q, wgt, dir);" % ("true" if r else "false", b, b, b))
+            L.append("  va_emit_branch_tl<N, S, B, %s, %d>(s, %d, sys.mf * br%d_r, sys.mf * br%d_q, wgt, dir);" % ("true" if r else "false", lanes, b, b, b))
         L.append("}")
         return "\n".join(L)
     L.append("  const int vdep = d.ipar[1 * d.count + d.dev];   // bit b: branch b uses a charge unknown")
@@ -426,7 +432,8 @@ def generate_ext_header(modules):
            "// Included by va_generated.hpp.", "#pragma once", ""]
     out.append("#define CADNIP_VA_NEXT %d" % len(modules))
     out.append("#define CADNIP_VA_EXT_SHAPES " + " ".join('{"%s", %d, %d, %d, %d, %d, %d},' % ((m.name,) + m.shape()) for m in modules))
-    out.append("// evaluated with one derivative direction per lane, 16 lanes per device (va_runtime.hpp: tangent lanes)")
+    out.append("// evaluated with one derivative direction per lane, 16 or 32 lanes per device (va_runtime.hpp: tangent lanes)")
+    out.append("#define CADNIP_VA_EXT_TL_LANES " + " ".join("%d," % tl_lanes(m) for m in modules))
     out.append("#define CADNIP_VA_EXT_DISPATCH_TL " + " ".join("case CADNIP_VA_NBUILTIN + %d: stamp_va_%s_tl(d, u, s, lw, dir); break;" % (i, m.name) for i, m in enumerate(modules)))
     out.append("#if defined(CADNIP_VA_DEVICE_CODE) && defined(CADNIP_VA_WITH_EXT)")
     out.append("namespace cadnip {")

@@ -218,6 +218,12 @@ def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False
                 return float(getattr(spec, "time", 0.0)) if spec is not None else 0.0
             return simparam(e)
         op, l, r = e[1], ev(e[2]), ev(e[3])
+        if isinstance(l, str) or isinstance(r, str):          # string parameters compare as strings (bsim4v8: version == "4.8.3")
+            if op == "==":
+                return float(str(l) == str(r))
+            if op == "!=":
+                return float(str(l) != str(r))
+            raise ValueError("%s: operator %s on a string" % (mod.name, op))
         if op == "+":
             return l + r
         if op == "-":

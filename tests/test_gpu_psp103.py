@@ -21,7 +21,7 @@ RTOL = 1e-11     # stamped values relative to the largest entry of their array: 
 
 
 def _load(name):
-    st, x = S.load_structure(os.path.join(GOLD, "psp103_%s.npz" % name))
+    st, x = S.load_structure(os.path.join(GOLD, "%s%s.npz" % ("" if name.startswith("bsim4") else "psp103_", name)))
     packed = [x["packed%d" % i] for i in range(int(x["n_packed"][0]))]
     return st, x, packed, bytes(x["mode"]).decode()
 
@@ -34,8 +34,9 @@ def _sim(name, mode=None, B=1):
     return st, x, sim
 
 
-@pytest.mark.parametrize("name", ["nmos_defaults", "nmos_card", "ring"])
+@pytest.mark.parametrize("name", ["nmos_defaults", "nmos_card", "ring", "bsim4_nmos", "bsim4_dff"])
 def test_psp103_stamps_match_the_oracle(name):
+    """(bsim4_*: the reference's bsim4v8.va -- 13 nodes + 18 $limit sites = 31 derivative directions on 32 lanes per device)"""
     st, x, sim = _sim(name)
     h = sim.h
     worst = 0.0
@@ -98,3 +99,38 @@ def test_psp103_ring_oscillates():
     assert max(periods) / min(periods) < 1.02, periods
     print("ring period %.3f ns, %d Newton iterations, %d accepted / %d rejected steps" % (
         np.mean(periods) * 1e9, stats["newton_iters"], stats["steps_accepted"], stats["steps_rejected"]))
+
+
+def test_bsim4v8_dc_matches_the_oracle():
+    """One sp_bsim4v8 NMOS on its default card (W = 1 u, L = 0.5 u, Vgs = 0.8, Vds = 1.2): the GPU's PCNR DC solve -- nine $limit
+    unknowns, two branch currents of executed V(a,b) <+ 0 statements, two surviving internal nodes -- lands on the oracle's solution."""
+    st, x, sim = _sim("bsim4_nmos", mode="dcop")
+    assert (st.n, st.n_nodes, st.n_currents, st.n_charges, st.n_limits) == (20, 4, 4, 3, 9)
+    u, conv, stats = sim.dc(abstol=1e-10, mode="dcop")
+    sim.close()
+    assert conv[0], stats
+    ref = x["dc_x"]
+    Id = u[0, st.index_of("I_Vds")]
+    assert 50e-6 < abs(Id) < 500e-6 and abs(Id - ref[st.index_of("I_Vds")]) <= 1e-8 * abs(Id)
+    assert np.max(np.abs(u[0, :st.n_nodes] - ref[:st.n_nodes])) < 1e-9
+
+
+def test_dff_with_the_reference_bsim4v8_text_latches():
+    """SURVEY.md section 8d's secondary model for config 3: the gf180 flip-flop netlist with every MOSFET an sp_bsim4v8 instance on the
+    default card, Vdd = 1.8 V (n = 535: 78 nodes, 67 branch currents, 120 charge states, 270 limit unknowns).  DC start and the
+    0-700 ns transient on the per-op path; the logic pins that do not depend on the D / CLKN race (test/gf180_dff.jl:29-33): Q = 0 at
+    150 and 250 ns, Q = Vdd at 700 ns, Q_neg its complement."""
+    st, x, sim = _sim("bsim4_dff", mode="tran")
+    sim.analyze()
+    u, conv, _ = sim.dc(abstol=1e-9, mode="tranop")
+    assert conv[0]
+    ts = np.array([150e-9, 250e-9, 700e-9])
+    sim.h.set_spec(mode="tran")
+    out, per, stats = sim.h.tran_run(0.0, 7e-7, st.state_abstol(vntol=1e-6, iabstol=1e-9, chgtol=1e-6), 1e-4,
+                                     breaks=expand_breakpoints(st.breakpoints, (0.0, 7e-7)), save_t=ts, obs=[st.index_of("Q"), st.index_of("Q_neg")], fused=0)
+    sim.close()
+    assert stats["n_failed"] == 0, stats
+    q, qn = out[0, :, 0], out[0, :, 1]
+    assert abs(q[0]) < 0.02 and abs(q[1]) < 0.02 and abs(q[2] - 1.8) < 0.02, q
+    assert abs(qn[2]) < 0.02 and abs(qn[0] - 1.8) < 0.02, qn
+    print("bsim4v8 DFF: %d Newton iterations, %d accepted / %d rejected steps, %.2f s" % (stats["newton_iters"], stats["steps_accepted"], stats["steps_rejected"], stats["wall_seconds"]))

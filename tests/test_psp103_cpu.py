@@ -12,7 +12,7 @@ from cadnip_jl_amd import structure as S, va
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
-HAVE_SOURCE = va.external_source(*va.EXTERNAL[0][1:]) is not None
+HAVE_SOURCE = all(va.external_source(fn, sd) is not None for _, fn, sd in va.EXTERNAL)
 needs_source = pytest.mark.skipif(not HAVE_SOURCE, reason="psp103.va is not at hand (no reference checkout, CADNIP_VA_PATH unset)")
 
 
@@ -34,12 +34,12 @@ def test_ring_fixture_carries_the_reference_layout():
 
 
 @needs_source
-@pytest.mark.parametrize("name", ["nmos_defaults", "nmos_card", "ring"])
+@pytest.mark.parametrize("name", ["nmos_defaults", "nmos_card", "ring", "bsim4_nmos", "bsim4_dff"])
 def test_committed_fixtures_are_current(name):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_psp103_fixtures as mk
     st, extra = mk.build(name)
-    st0, x0 = S.load_structure(os.path.join(GOLD, "psp103_%s.npz" % name))
+    st0, x0 = S.load_structure(os.path.join(GOLD, "%s%s.npz" % ("" if name.startswith("bsim4") else "psp103_", name)))
     assert st.signature() == st0.signature()
     for k in ("U", "G", "C", "b"):
         assert np.array_equal(extra[k], x0[k]), k
@@ -68,3 +68,16 @@ def test_generated_external_header_is_current():
     want = hipgen.generate_ext_header(mods)
     have = open(os.path.join(ROOT, "cadnip.jl_amd", "csrc", "va_generated_ext.hpp")).read()
     assert have == want
+
+
+def test_bsim4_dff_fixture_layout():
+    """The flip-flop on the reference's bsim4v8.va (default card): 30 devices, each with 2 surviving internal nodes, 2 branch currents of
+    executed V(a,b) <+ 0 statements, 4 charge states and 9 $limit unknowns; 31 derivative directions -> 32 lanes per device."""
+    st, x = S.load_structure(os.path.join(GOLD, "bsim4_dff.npz"))
+    assert (st.n, st.n_nodes, st.n_currents, st.n_charges, st.n_limits) == (535, 18 + 60, 7 + 60, 120, 270)
+    blk = next(b for b in st.blocks if b.type == "VA:sp_bsim4v8")
+    assert blk.count == 30 and np.all(blk.ipar[0] == len(va.MODEL_FILES) + 1)
+    if HAVE_SOURCE:
+        from cadnip_jl_amd.va import hipgen
+        m = va.get("sp_bsim4v8")[1]
+        assert (m.n_nodes, m.n_sites, hipgen.tl_lanes(m)) == (13, 18, 32) and hipgen.tl_lanes(va.get("PSP103VA")[1]) == 16
