@@ -20,6 +20,7 @@
 // several tiles of the SAME kernel -- a boundary between tiles, e.g. a supply rail fed by every chunk of a large circuit --
 // is accumulated with a global fp64 atomic, on a word that k_stamp_prep has pre-set when no earlier kernel stores it.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
 #include <vector>
@@ -489,6 +490,8 @@ static int launch_stamp_csr_t(CadnipHandle* h, DeviceBlock& b) {
                  h->d_dump, h->ns, b.g_base, h->ns_g + b.c_base, h->ns_g + h->ns_c + b.b_base};
   if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_stamp_csr<TYPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   const unsigned grid = (unsigned)b.sp_chunks * (unsigned)((h->B + ipw - 1) / ipw);
+  if (getenv("CADNIP_SC_DEBUG")) fprintf(stderr, "[cadnip stamp] type %d count %d cs %d chunks %d ipw %d lpd %d nslots %d scratch %d tile_words %zu shmem %zu grid %u steps %d levels %d\n",
+                                         TYPE, b.count, b.sp_cs, b.sp_chunks, ipw, lpd, nslots, b.sp_scratch, tile_words, shmem, grid, 0, b.sp_levels);
   hipLaunchKernelGGL(k_stamp_csr<TYPE>, dim3(grid), dim3(64), shmem, h->stream, a);
   return CADNIP_OK;
 }

@@ -333,16 +333,30 @@ def generate_function(m, tl=False):
             L.append("  const T V%d = va_seed_tl(Vf[%d], dir == %d);   // V(%s)" % (k, k, k, m.nodes[k]))
         else:
             L.append("  const T V%d = T::seed(Vf[%d], %d);   // V(%s)" % (k, k, k, m.nodes[k]))
+    # parameters: small modules read them once, up front.  A large external model (782 parameters for PSP103) would keep hundreds of
+    # them alive from the top of the function to their uses -- the first build spilled 638 doubles to scratch memory and reloaded each
+    # at its use, one exposed memory latency apiece (80 % of the wave's time was s_waitcnt) -- so there every reference loads its
+    # parameter where it stands (macros, undefined again behind the function).
+    macros = []
     for i, p in enumerate(m.params):
         if m.param_kind.get(p) == "string":
             continue
-        L.append("  const double p_%s = par_of(d, %d);" % (p, i))
+        if tl:
+            macros.append(("p_%s" % p, "par_of(d, %d)" % i))
+        else:
+            L.append("  const double p_%s = par_of(d, %d);" % (p, i))
     L.append("  const VaSys sys{par_of(d, %d), par_of(d, %d), par_of(d, %d), d.initjct ? 1.0 : 0.0, d.mode, d.t};   // $temperature, $mfactor, gmin, initjct, analysis(), $abstime" % (NP, NP + 1, NP + 2))
     if m.uses_given:
         for i, p in enumerate(m.params):
-            L.append("  const double g_%s = par_of(d, %d);   // $param_given(%s)" % (p, NP + 3 + i, p))
+            if tl:
+                macros.append(("g_%s" % p, "par_of(d, %d)" % (NP + 3 + i)))
+            else:
+                L.append("  const double g_%s = par_of(d, %d);   // $param_given(%s)" % (p, NP + 3 + i, p))
     for i, (p, lit) in enumerate(m.string_tests):
-        L.append("  const double st_%d = par_of(d, %d);   // %s == \"%s\"" % (i, NP + 3 + (NP if m.uses_given else 0) + i, p, lit))
+        if tl:
+            macros.append(("st_%d" % i, "par_of(d, %d)" % (NP + 3 + (NP if m.uses_given else 0) + i)))
+        else:
+            L.append("  const double st_%d = par_of(d, %d);   // %s == \"%s\"" % (i, NP + 3 + (NP if m.uses_given else 0) + i, p, lit))
     L.append("  double ld[S > 0 ? S : 1] = {0.0};    // per $limit site: V(probe) - w, the lim_rhs delta (vasim.jl:2957-2966)")
     for lb, (p, n) in enumerate(m.limit_branches):
         L.append("  const double vold%d = u[nd[N + B + %d]];   // limit unknown of probe branch (%s,%s)" % (
@@ -366,7 +380,8 @@ def generate_function(m, tl=False):
         for b, ((p, n), r) in enumerate(zip(m.branches, m.reactive)):
             L.append("  va_emit_branch_tl<N, S, B, %s, %d>(s, %d, sys.mf * br%d_r, sys.mf * br%d_q, wgt, dir);" % ("true" if r else "false", lanes, b, b, b))
         L.append("}")
-        return "\n".join(L)
+        k = next(i for i, l in enumerate(L) if l.startswith("template <class Ctx, class Out>"))
+        return "\n".join(L[:k] + ["#define %s %s" % mc for mc in macros] + L[k:] + ["#undef %s" % mc[0] for mc in macros])
     L.append("  const int vdep = d.ipar[1 * d.count + d.dev];   // bit b: branch b uses a charge unknown")
     for b, ((p, n), r) in enumerate(zip(m.branches, m.reactive)):
         L.append("  va_emit_branch<N, S, B, %s>(d, u, s, Vf, ld, nd, %d, %d, %d, sys.mf * br%d_r, sys.mf * br%d_q, ((vdep >> %d) & 1) != 0);"
