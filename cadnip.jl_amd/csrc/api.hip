@@ -163,7 +163,7 @@ int cadnip_create(const CadnipStructure* s, int32_t n_instances, int32_t device,
         ok = b.n_nodes == sh.n_nodes && b.n_g == sh.n_g && b.n_c == sh.n_c && b.n_b == sh.n_b && b.n_par == sh.n_par;
       }
       if (!ok) { cadnip_destroy(h); return CADNIP_BADARG; }
-      if (id >= CADNIP_VA_NBUILTIN) { static const int tl_lanes[] = {CADNIP_VA_EXT_TL_LANES 0}; h->va_ext = true; b.va_tl = tl_lanes[id - CADNIP_VA_NBUILTIN]; }   // a large external model (PSP103): per-op kernels only (fused2_fits)
+      if (id >= CADNIP_VA_NBUILTIN) { static const int tl_lanes[] = {CADNIP_VA_EXT_TL_LANES 0}, n_cache[] = {CADNIP_VA_EXT_NCACHE 0}; h->va_ext = true; b.va_tl = tl_lanes[id - CADNIP_VA_NBUILTIN]; b.n_cache = n_cache[id - CADNIP_VA_NBUILTIN]; }   // a large external model (PSP103): per-op kernels only (fused2_fits)
     }
     b.h_nodes.assign(sb.nodes, sb.nodes + (size_t)b.n_nodes * b.count);
     h->blocks.push_back(b);                      // registered first: a failing upload below is cleaned up by cadnip_destroy
@@ -171,6 +171,7 @@ int cadnip_create(const CadnipStructure* s, int32_t n_instances, int32_t device,
     CREATE_TRY(dev_upload(&hb.d_nodes, sb.nodes, (size_t)b.n_nodes * b.count));
     CREATE_TRY(dev_upload(&hb.d_ipar, sb.ipar, (size_t)(b.n_ipar > 0 ? b.n_ipar : 1) * b.count));
     CREATE_TRY(dev_alloc(&hb.d_par, (size_t)h->B * b.n_par * b.count));
+    if (b.n_cache > 0) CREATE_TRY(dev_alloc(&hb.d_cache, (size_t)h->B * b.n_cache * b.count));
   }
   size_t B = h->B, n = h->n, nnz = h->nnz;
   CREATE_TRY(dev_alloc(&h->d_u, B * n)); CREATE_TRY(dev_alloc(&h->d_du, B * n)); CREATE_TRY(dev_alloc(&h->d_t, B)); CREATE_TRY(dev_alloc(&h->d_gamma, B));
@@ -203,7 +204,7 @@ void cadnip_destroy(CadnipHandle* h) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->d_f2tab) (void)hipFree(h->d_f2tab);
   for (auto& b : h->blocks) {
-    void* bp[] = {b.d_nodes, b.d_ipar, b.d_par, b.d_sp_tptr, b.d_sp_info, b.d_sp_rec};
+    void* bp[] = {b.d_nodes, b.d_ipar, b.d_par, b.d_sp_tptr, b.d_sp_info, b.d_sp_rec, b.d_cache};
     for (void* p : bp) if (p) (void)hipFree(p);
   }
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
@@ -234,6 +235,11 @@ int cadnip_set_params(CadnipHandle* h, int32_t block, const double* par_host) {
     b.mos1_plain = plain;
   }
   h->f2_blk_dirty = true;
+  if (b.n_cache > 0) {       // generated external model: its bias-independent statements run now, once for this parameter set
+    int rc = cadnip::launch_va_setup(h, b);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
   return CADNIP_OK;
 }
 

@@ -54,6 +54,7 @@ template <class NodeT> struct DevCtxT {
   double t;
   int mode;                        // 0 dcop, 1 tran, 2 tranop
   int initjct;
+  const double* __restrict__ cache = nullptr;   // generated external models: [n_cache][count] values of this instance's setup pass (va_generated_ext.hpp)
 };
 typedef DevCtxT<int> DevCtx;
 
@@ -92,6 +93,7 @@ struct SlotOut {
 
 template <class Ctx> __device__ __forceinline__ int node_of(const Ctx& d, int k) { return d.nodes[k * d.count + d.dev]; }
 template <class Ctx> __device__ __forceinline__ double par_of(const Ctx& d, int k) { return d.par[k * d.count + d.dev]; }
+template <class Ctx> __device__ __forceinline__ double va_cache(const Ctx& d, int k) { return d.cache[k * d.count + d.dev]; }
 __device__ __forceinline__ double volt(const double* u, int node) { return node < 0 ? 0.0 : u[node]; }
 
 // ------------------------------------------------------------------------------------------

@@ -67,6 +67,7 @@ struct DeviceBlock {
   int g_base, c_base, b_base, n_g, n_c, n_b;
   int* d_nodes = nullptr;
   std::vector<int> h_nodes;  // host copy (the fused kernel keeps an int16 copy in LDS)
+  double* d_cache = nullptr; int n_cache = 0;   // generated external model: [B][n_cache][count] results of its setup pass (bias-independent statements)
   int va_tl = 0;             // generated external model: lanes per device when evaluated with one derivative direction per lane (16 / 32; stamp_csr.hip)
   bool mos1_plain = false;   // sp_mos1 block: every instance has gd = gs = OxideCap = 0 (set by cadnip_set_params)
   int* d_ipar = nullptr;
@@ -175,6 +176,7 @@ int launch_calib_copy(CadnipHandle* h, long n, int reps);
 int launch_negate(CadnipHandle* h, double* d_x, long n);
 struct TranArgs;                                                          // tran_ctrl.hpp
 int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds); // fused2.hip
+int launch_va_setup(CadnipHandle* h, DeviceBlock& b);                        // stamp_csr.hip: the setup pass of a generated external model's block
 bool fused2_tables_ready(CadnipHandle* h);                                 // the packed tables exist (built on demand)
 bool fused2_fits(CadnipHandle* h);                                        // false: circuit too large for the LDS-resident kernel
 int launch_fused2_dc(CadnipHandle* h, const TranArgs& t, int rounds, double abstol, int maxiters, int use_pcnr, int mode, int initjct, int* d_dcstate);

@@ -72,6 +72,7 @@ struct CsrStampArgs {
   const int* step_ptr; const int* step_info; const uint4* tgt_rec;   // [n_chunks + 1] step ranges, per step class | new-level flag << 8, STEP_W records (16 B each) per step (build_stamp_plan)
   int B, count, n, nnz, n_par, n_g, n_c, n_b, cs, n_chunks, ipw, lpd, mode, initjct, zero_first, n_levels, n_scratch;
   int u_lds;   // the unknowns of the tile's instances are staged in LDS (small circuits): node voltages are then LDS reads
+  const double* cache; int n_cache;                 // generated external models: setup-pass results [B][n_cache][count] (k_va_setup)
   double* dump; int ns, dump_g, dump_c, dump_b;   // operating-point read-out only (cadnip_get_contributions): the staged per-device
                                                     // contributions written out as [B][ns], slot (k, dev) of array A at A_base + k * count + dev
 
@@ -151,7 +152,8 @@ __global__ void __launch_bounds__(64) k_stamp_csr(CsrStampArgs a) {
   }
   SC_POINT(0);
   {
-    DevCtx d{a.nodes, a.ipar, a.par + (size_t)inst_c * a.n_par * a.count, a.wave, a.count, dev < a.count ? dev : a.count - 1, a.t[inst_c], a.mode, (a.initjct && a.cold[inst_c]) ? 1 : 0};
+    DevCtx d{a.nodes, a.ipar, a.par + (size_t)inst_c * a.n_par * a.count, a.wave, a.count, dev < a.count ? dev : a.count - 1, a.t[inst_c], a.mode, (a.initjct && a.cold[inst_c]) ? 1 : 0,
+             a.cache ? a.cache + (size_t)inst_c * a.n_cache * a.count : nullptr};
     LdsOut s{tile, tile + (size_t)a.n_g * a.cs, tile + (size_t)(a.n_g + a.n_c) * a.cs, a.cs, ldev, valid};
     const double* u = a.u_lds ? u_tile + (size_t)(ii < a.ipw ? ii : 0) * a.n : a.u + (size_t)inst_c * a.n;
     double* lw = valid ? a.limit_w + (size_t)inst_c * a.n : nullptr;
@@ -472,6 +474,25 @@ int build_stamp_plan(CadnipHandle* h, const CadnipStructure* s) {
   return CADNIP_OK;
 }
 
+// Setup pass of a generated external model (va_generated_ext.hpp: setup_va_<module>): every bias-independent statement of the module,
+// one thread per (instance, device), whenever the block's parameters change (cadnip_set_params).  What the per-call stamp function
+// reads of it lies in the block's cache [B][n_cache][count].
+__global__ void __launch_bounds__(64) k_va_setup(const int* nodes, const int* ipar, const double* par, const double* wave, double* cache, int B, int count, int n_par, int n_cache, int mode) {
+  const int idx = blockIdx.x * 64 + threadIdx.x;
+  if (idx >= B * count) return;
+  const int inst = idx / count, dev = idx - inst * count;
+  DevCtx d{nodes, ipar, par + (size_t)inst * n_par * count, wave, count, dev, 0.0, mode, 0, nullptr};
+  setup_va(d, cache + (size_t)inst * n_cache * count + dev, count);
+}
+
+int launch_va_setup(CadnipHandle* h, DeviceBlock& b) {
+  if (b.n_cache <= 0 || !b.d_cache) return CADNIP_OK;
+  const int total = h->B * b.count;
+  hipLaunchKernelGGL(k_va_setup, dim3((total + 63) / 64), dim3(64), 0, h->stream, b.d_nodes, b.d_ipar, b.d_par, h->d_wave, b.d_cache, h->B, b.count, b.n_par, b.n_cache, h->spec.mode);
+  HIP_TRY(hipGetLastError());
+  return CADNIP_OK;
+}
+
 template <int TYPE>
 static int launch_stamp_csr_t(CadnipHandle* h, DeviceBlock& b) {
   const int nslots = b.n_g + b.n_c + b.n_b;
@@ -487,7 +508,7 @@ static int launch_stamp_csr_t(CadnipHandle* h, DeviceBlock& b) {
                  h->d_diag_flag, h->d_gshunt, h->d_srcfact, b.d_sp_tptr, b.d_sp_info, b.d_sp_rec,
                  h->B, b.count, h->n, h->nnz, b.n_par, b.n_g, b.n_c, b.n_b, b.sp_cs, b.sp_chunks, ipw, lpd, h->spec.mode, h->initjct,
                  (TYPE == CADNIP_DEV_MOS1 || TYPE == CADNIP_DEV_VA) ? 1 : 0, b.sp_levels, b.sp_scratch, u_lds,
-                 h->d_dump, h->ns, b.g_base, h->ns_g + b.c_base, h->ns_g + h->ns_c + b.b_base};
+                 b.d_cache, b.n_cache, h->d_dump, h->ns, b.g_base, h->ns_g + b.c_base, h->ns_g + h->ns_c + b.b_base};
   if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_stamp_csr<TYPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   const unsigned grid = (unsigned)b.sp_chunks * (unsigned)((h->B + ipw - 1) / ipw);
   if (getenv("CADNIP_SC_DEBUG")) fprintf(stderr, "[cadnip stamp] type %d count %d cs %d chunks %d ipw %d lpd %d nslots %d scratch %d tile_words %zu shmem %zu grid %u steps %d levels %d\n",

@@ -265,6 +265,8 @@ class VAModule:
     func_dirs: Dict[str, list] = field(default_factory=dict)          # analog function -> direction of every argument ("in" | "out" | "inout")
     uses_given: bool = False                                          # the module asks $param_given(...): instances carry one flag per parameter
     string_tests: List[tuple] = field(default_factory=list)           # (string parameter, literal) pairs the module compares: one host-evaluated flag each
+    hoist_vars: set = field(default_factory=set)                      # bias-independent locals computed once per parameter set (_hoist_analysis)
+    cache_vars: List[str] = field(default_factory=list)               # ... those the per-call code reads: the per-device cache layout
     source: str = ""
 
     @property
@@ -1316,7 +1318,110 @@ def _analyse(m: VAModule):
     m.uses_given = any(has_given(e) for body in bodies for st in _walk(body) for e in ([st] if st[0] == "callstmt" else _subexprs(st))) \
         or any(has_given(ie) for _, ie in m.local_init)
     m.is_dual, m.is_react, m.node_index = is_dual, is_react, node
+    m.expr_is_static = lambda e: not expr_dyn(e)
+    _hoist_analysis(m)
     return m
+
+
+def _hoist_analysis(m):
+    """Which bias-independent locals can be computed once per parameter set instead of once per stamp call (the reference re-evaluates the
+    whole analog block per call; OSDI compilers split model / instance setup from eval the same way).
+    ``m.hoist_vars``: static locals whose every write precedes, in program order, every read -- their value at any read is their final
+    value -- and that are written neither in a loop nor through an output argument.  ``m.cache_vars``: those of them that anything remaining
+    in the per-call code reads (ordered: the layout of the per-device cache).  Temporaries that are reused (read before a later write)
+    stay in the per-call code."""
+    pos = [0]
+    first_read, last_write, barred = {}, {}, set()
+
+    def reads(e, acc):
+        if not isinstance(e, tuple) or not e:
+            return
+        if e[0] == "var":
+            acc.add(e[1])
+        for sub in e[1:]:
+            for a in (sub if isinstance(sub, list) else [sub]):
+                if isinstance(a, tuple):
+                    reads(a, acc)
+
+    def note_reads(exprs, p):
+        acc = set()
+        for e in exprs:
+            reads(e, acc)
+        for v in acc:
+            first_read.setdefault(v, p)
+
+    def walk(stmts, loop):
+        for s in stmts:
+            pos[0] += 1
+            p, k = pos[0], s[0]
+            if k == "assign":
+                note_reads([s[2]], p)
+                last_write[s[1]] = p
+                if loop:
+                    barred.add(s[1])
+            elif k == "contrib":
+                note_reads([s[3]], p)
+            elif k == "block":
+                walk(s[1], loop)
+            elif k == "if":
+                note_reads([s[1]], p)
+                walk([s[2], s[3]], loop)
+            elif k == "case":
+                note_reads([s[1]] + [v for vals, _ in s[2] if vals is not None for v in vals], p)
+                walk([body for _, body in s[2]], loop)
+            elif k == "while":
+                note_reads([s[1]], p)
+                walk([s[2]], True)
+            elif k == "for":
+                walk([s[1]], True)
+                note_reads([s[2]], p)
+                walk([s[4], s[3]], True)
+            elif k == "callstmt":
+                note_reads(s[2], p)
+                for a, d in zip(s[2], m.func_dirs.get(s[1]) or []):
+                    if d != "in" and a[0] == "var":
+                        barred.add(a[1])
+    for nm, ie in m.local_init:
+        pos[0] += 1
+        note_reads([ie], pos[0])
+        last_write[nm] = pos[0]
+    walk(m.body, False)
+    H = {v for v in m.locals_ if m.var_is_static.get(v) and v in last_write and v not in barred
+         and (v not in first_read or last_write[v] < first_read[v])}
+    # a hoisted variable may only be computed from parameters, system constants and other hoisted variables ... or from static
+    # temporaries, which the setup pass computes as well (it runs every static statement): nothing to check.  What the per-call code
+    # still reads:
+    used = set()
+
+    def stay(stmts):
+        for s in stmts:
+            k = s[0]
+            if k == "assign":
+                if s[1] not in H:
+                    reads(s[2], used)
+            elif k == "contrib":
+                reads(s[3], used)
+            elif k == "block":
+                stay(s[1])
+            elif k == "if":
+                reads(s[1], used)
+                stay([s[2], s[3]])
+            elif k == "case":
+                reads(s[1], used)
+                for vals, body in s[2]:
+                    for v in (vals or []):
+                        reads(v, used)
+                    stay([body])
+            elif k == "while":
+                reads(s[1], used); stay([s[2]])
+            elif k == "for":
+                stay([s[1]]); reads(s[2], used); stay([s[4], s[3]])
+            elif k == "callstmt":
+                for a in s[2]:
+                    reads(a, used)
+    stay(m.body)
+    m.hoist_vars = H
+    m.cache_vars = [v for v in m.locals_ if v in H and v in used]
 
 
 def parse_file(path, defines=None) -> VAModule:

@@ -27,6 +27,7 @@ class _Gen:
     def __init__(self, m, func=None, tl=False):
         self.m = m
         self.tl = tl           # tangent-lane variant: T = Dual<1>, the lane's direction is `dir` (va_runtime.hpp)
+        self.phase = "all"     # "setup": bias-independent statements only; "eval": without the assignments to hoisted variables
         self.lines = []
         self.pre = []          # definitions of $limit sites: emitted in front of the statement that uses them
         self.func = func       # name of the analog function being generated: every variable has the template type X
@@ -190,6 +191,21 @@ class _Gen:
     def stmts(self, body, ind):
         m, pad = self.m, "  " * ind
         for s in body:
+            if self.phase == "setup":
+                if s[0] in ("contrib", "short", "fatal"):
+                    continue
+                if s[0] == "assign" and not m.var_is_static.get(s[1], False):
+                    continue
+                if s[0] == "callstmt" and not all(m.expr_is_static(a) for a in s[2]):
+                    continue
+                if s[0] in ("if", "while") and not m.expr_is_static(s[1]):
+                    continue
+                if s[0] == "case" and not m.expr_is_static(s[1]):
+                    continue
+                if s[0] == "for" and not m.expr_is_static(s[2]):
+                    continue
+            elif self.phase == "eval" and s[0] == "assign" and s[1] in m.hoist_vars:
+                continue
             if s[0] == "callstmt":
                 c = self.call(s[1], s[2])[0]
                 self.flush(pad)
@@ -298,7 +314,7 @@ def tl_lanes(m):
     return 16 if m.n_nodes + m.n_sites <= 16 else 32
 
 
-def generate_function(m, tl=False):
+def generate_function(m, tl=False, with_functions=True):
     """tl: the tangent-lane variant ``stamp_va_<module>_tl(d, u, s, lw, dir)`` -- one derivative direction per lane, 16 lanes per
     device (va_runtime.hpp); the statements are the same text on Dual<1>."""
     N, B, NP, S, NL = m.n_nodes, len(m.branches), len(m.params), m.n_sites, len(m.limit_branches)
@@ -306,8 +322,11 @@ def generate_function(m, tl=False):
         raise VAError("%s: %d derivative directions do not fit the 32 lanes of a device group" % (m.name, N + S))
     lanes = tl_lanes(m)
     g = _Gen(m, tl=tl)
+    hoist = tl and bool(m.cache_vars)        # the external models run a setup pass once per parameter set (generate_setup)
+    if hoist:
+        g.phase = "eval"
     L = g.lines
-    if m.functions:
+    if m.functions and with_functions:
         L.append(generate_analog_functions(m))
     L.append("// module %s: nodes (%s), %d parameter(s), branches %s" % (
         m.name, ", ".join(m.nodes), NP, ", ".join("(%s,%s)%s" % (m.nodes[p] if p >= 0 else "gnd", m.nodes[n] if n >= 0 else "gnd",
@@ -363,6 +382,10 @@ def generate_function(m, tl=False):
             lb, lb, m.nodes[p] if p >= 0 else "gnd", m.nodes[n] if n >= 0 else "gnd"))
         L.append("  %sva_emit_limit_rows<N, B>(s, %d);" % ("if (dir == 0) " if tl else "", lb))
     for v in m.locals_:
+        if hoist and v in m.hoist_vars:
+            if v in m.cache_vars:
+                macros.append(("v_%s" % v, "va_cache(d, %d)" % m.cache_vars.index(v)))
+            continue                                    # computed by the setup pass; read from the per-device cache where used
         L.append("  %s v_%s = 0.0;" % ("T" if m.var_is_dual[v] else "double", v))
         if m.var_is_reactive[v]:
             L.append("  T v_%s_q = 0.0;" % v)
@@ -393,6 +416,37 @@ def generate_function(m, tl=False):
     return "\n".join(L)
 
 
+def generate_setup(m):
+    """``setup_va_<module>(d, cache, stride)``: every bias-independent statement of the module, once per (instance, device) and parameter
+    set; writes the hoisted variables the per-call code reads (VAModule.cache_vars) to ``cache[k * stride]``."""
+    NP = len(m.params)
+    g = _Gen(m)
+    g.phase = "setup"
+    L = g.lines
+    macros = []
+    for i, p in enumerate(m.params):
+        if m.param_kind.get(p) != "string":
+            macros.append(("p_%s" % p, "par_of(d, %d)" % i))
+    if m.uses_given:
+        for i, p in enumerate(m.params):
+            macros.append(("g_%s" % p, "par_of(d, %d)" % (NP + 3 + i)))
+    for i, (p, lit) in enumerate(m.string_tests):
+        macros.append(("st_%d" % i, "par_of(d, %d)" % (NP + 3 + (NP if m.uses_given else 0) + i)))
+    L.append("template <class Ctx>")
+    L.append("__device__ inline void setup_va_%s(const Ctx& d, double* cache, const int stride) {" % m.name)
+    L.append("  typedef double T;")
+    L.append("  const VaSys sys{par_of(d, %d), par_of(d, %d), par_of(d, %d), 0.0, d.mode, 0.0};" % (NP, NP + 1, NP + 2))
+    for v in m.locals_:
+        if m.var_is_static.get(v, False):
+            L.append("  double v_%s = 0.0;" % v)
+    g.stmts([("assign", nm, ie) for nm, ie in m.local_init if m.var_is_static.get(nm, False)], 1)
+    g.stmts(m.body, 1)
+    for k, v in enumerate(m.cache_vars):
+        L.append("  cache[%d * stride] = v_%s;" % (k, v))
+    L.append("}")
+    return "\n".join(["#define %s %s" % mc for mc in macros] + L + ["#undef %s" % mc[0] for mc in macros])
+
+
 def generate_header(modules):
     """The whole va_generated.hpp: one function per built-in module, the dispatcher and the host-side shape table.  The modules
     whose sources are not part of this repository (va.EXTERNAL) live in va_generated_ext.hpp (generate_ext_header), which this
@@ -416,6 +470,14 @@ def generate_header(modules):
     out.append("  }")
     out.append("}")
     out.append("#ifdef CADNIP_VA_WITH_EXT   // only the per-op stamping kernel carries the large external models (stamp_csr.hip)")
+    out.append("// external models: the bias-independent statements, once per parameter set (one thread per device)")
+    out.append("template <class Ctx>")
+    out.append("__device__ inline void setup_va(const Ctx& d, double* cache, const int stride) {")
+    out.append("  switch (d.ipar[0 * d.count + d.dev]) {")
+    out.append("    CADNIP_VA_EXT_DISPATCH_SETUP")
+    out.append("    default: break;")
+    out.append("  }")
+    out.append("}")
     out.append("// external models: lane `dir` of the device's 16-lane group computes the partial of direction `dir`")
     out.append("template <class Ctx, class Out>")
     out.append("__device__ inline void stamp_va_tl(const Ctx& d, const double* u, const Out& s, double* lw, const int dir) {")
@@ -450,10 +512,17 @@ def generate_ext_header(modules):
     out.append("// evaluated with one derivative direction per lane, 16 or 32 lanes per device (va_runtime.hpp: tangent lanes)")
     out.append("#define CADNIP_VA_EXT_TL_LANES " + " ".join("%d," % tl_lanes(m) for m in modules))
     out.append("#define CADNIP_VA_EXT_DISPATCH_TL " + " ".join("case CADNIP_VA_NBUILTIN + %d: stamp_va_%s_tl(d, u, s, lw, dir); break;" % (i, m.name) for i, m in enumerate(modules)))
+    out.append("// doubles per device that the setup pass leaves for the per-call code (VAModule.cache_vars)")
+    out.append("#define CADNIP_VA_EXT_NCACHE " + " ".join("%d," % len(m.cache_vars) for m in modules))
+    out.append("#define CADNIP_VA_EXT_DISPATCH_SETUP " + " ".join("case CADNIP_VA_NBUILTIN + %d: setup_va_%s(d, cache, stride); break;" % (i, m.name) for i, m in enumerate(modules)))
     out.append("#if defined(CADNIP_VA_DEVICE_CODE) && defined(CADNIP_VA_WITH_EXT)")
     out.append("namespace cadnip {")
     for m in modules:
-        out.append(generate_function(m, tl=True))
+        if m.functions:
+            out.append(generate_analog_functions(m))
+        out.append(generate_setup(m))
+        out.append("")
+        out.append(generate_function(m, tl=True, with_functions=False))
         out.append("")
     out.append("}  // namespace cadnip")
     out.append("#endif")
