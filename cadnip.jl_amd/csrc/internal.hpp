@@ -143,6 +143,7 @@ struct CadnipHandle {
   std::vector<unsigned char> leaf_unit_ok;   // per unknown: its diagonal is one constant G stamp, no C stamp (leaf-first pivot order, symbolic.cpp)
   cadnip::LULeaves leaves;    // charge / limit ranges of the unknown layout [V | I | q | lim]
   int f2_lu_len = 0;          // 32-bit words of the table's linear-solve prefix (entry program, permutations, load map)
+  int n_cu_hint() const { return n_cu > 0 ? n_cu : 256; }   // compute units of the device (queried by the first fused launch; MI355X: 256)
   bool va_ext = false;        // the circuit uses an external generated model (va_generated_ext.hpp): not compiled into the fused kernel
   bool f2_lean = false;       // only device types of the lean kernel variant (fused2.hip: dispatch_stamp2)
   int f2_src_blk = -1;        // first independent-source block of the fused block list

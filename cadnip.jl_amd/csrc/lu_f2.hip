@@ -112,6 +112,92 @@ __global__ void __launch_bounds__(64 * WPB) k_lu_f2(LuF2Args f) {
   if (wave_any(bad) && lane == 0) atomicOr(&f.flags[inst], 1);
 }
 
+// Few instances (a single transient, a handful of corners): one wave per instance leaves the chip empty and walks the passes one after
+// the other -- the ring oscillator of BASELINE.json's config 5 (n = 371) has 105 of them in 46 dependency levels.  Here WPI waves share
+// one instance: the passes of a level are dealt round-robin to the waves (they touch different entries and read only earlier levels), a
+// workgroup barrier closes the level, the dense core is wave 0's.  No software pipeline: with so few waves the kernel is latency-bound anyway.
+template <int WPI>
+__global__ void __launch_bounds__(64 * WPI) k_lu_f2_mw(LuF2Args f) {
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), n = f.n;
+  {
+    const uint2* src = (const uint2*)f.tab;
+    uint2* dst = (uint2*)sm;
+    for (int i = tid; i < f.tab_len / 2; i += 64 * WPI) dst[i] = src[i];
+  }
+  const int inst = blockIdx.x;
+  if (inst >= f.B || !f.active[inst]) return;                 // (uniform over the workgroup: nobody is left waiting at a barrier)
+  const unsigned* tab = (const unsigned*)sm;
+  const int nW = f.lu_words + n + F2_TRASH;
+  double* W = sm + f.tab_len / 2;
+  const u16* loadpos = (const u16*)(tab + f.off[S_LOADPOS]);
+  const u64* laned = (const u64*)(tab + f.off[S_ENT]);
+  const unsigned* term = tab + f.off[S_TERM];
+  typedef const __attribute__((address_space(4))) u64* PassPtr;
+  const PassPtr passd = (PassPtr)(const u64*)(f.tab + f.off[S_LEV]);
+  const u16* qinv = (const u16*)(tab + f.off[S_QINV]);
+  const u16* rowof = (const u16*)(tab + f.off[S_ROWOF]);
+  for (int i = tid; i < (nW >> 1); i += 64 * WPI) ((double2*)W)[i] = make_double2(0.0, 0.0);
+  __syncthreads();
+  {
+    const double* G = f.G + (size_t)inst * f.nnz;
+    const double* C = f.C + (size_t)inst * f.nnz;
+    const double gam = f.gamma[inst];
+    for (int e = tid; e < f.nnz; e += 64 * WPI) W[loadpos[e]] = G[e] + gam * C[e];
+    const double* rhs = f.rhs + (size_t)inst * n;
+    for (int i = tid; i < n; i += 64 * WPI) W[rowof[i]] = rhs[i];
+  }
+  __syncthreads();
+  int bad = 0;
+  auto run_passes = [&](const int p_first, const int p_count) {
+    int in_level = 0;
+    for (int pi = p_first; pi < p_first + p_count; ++pi) {
+      const u64 pd = passd[pi];
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pd), hi = __builtin_amdgcn_readfirstlane((unsigned)(pd >> 32));
+      const int T = hi & 0x7F, maxlg = (hi >> 8) & 7, hasdiv = (hi >> 11) & 1, fence = (hi >> 12) & 1;
+      if (in_level % WPI == w && T > 0) {
+        const bool act = lane < T;
+        const u64 D = laned[lo + (act ? lane : T - 1)];
+        const unsigned pos = (unsigned)D & 0xFFFFu, dg = (unsigned)(D >> 16) & 0xFFFFu, t0 = (unsigned)(D >> 32) & 0xFFFFu;
+        const unsigned dhi = (unsigned)(D >> 48);
+        const int nt = act ? (int)(dhi & 0xFFu) : 0, lg = (dhi >> 8) & 7;
+        const bool leader = act && ((dhi >> 12) & 1u);
+        const double acc0 = W[pos];
+        double piv = W[dg == NOPOS ? pos : dg];
+        double part = 0.0;
+        for (int t = 0; t < nt; ++t) { const unsigned tm = term[t0 + t]; part = fma(W[tm & 0xFFFFu], W[tm >> 16], part); }
+        if (maxlg >= 1) { const double o = dpp_f64<0xB1>(part); part += lg >= 1 ? o : 0.0; }
+        if (maxlg >= 2) { const double o = dpp_f64<0x4E>(part); part += lg >= 2 ? o : 0.0; }
+        if (maxlg >= 3) { const double o = dpp_f64<0x141>(part); part += lg >= 3 ? o : 0.0; }
+        if (maxlg >= 4) { const double o = dpp_f64<0x140>(part); part += lg >= 4 ? o : 0.0; }
+        double acc = acc0 - part;
+        if (hasdiv) {
+          if (dg == NOPOS) piv = 1.0;
+          else if (act && (piv == 0.0 || !isfinite(piv))) bad = 1;
+          acc = fast_div(acc, piv);
+        }
+        if (leader) W[pos] = acc;
+      }
+      ++in_level;
+      if (fence) { __syncthreads(); in_level = 0; }
+    }
+  };
+  run_passes(0, f.n_pre);
+  if (f.nc > 0) {
+    if (w == 0) {
+      const int yc0 = f.lu_words + n - f.nc;
+      if (f.nc == 8) dense_core_solve<8, 0>(W, f.dn0, yc0, lane, bad, false);
+      else if (f.nc == 12) dense_core_solve<12, 0>(W, f.dn0, yc0, lane, bad, false);
+      else dense_core_solve<F2_NCMAX, 0>(W, f.dn0, yc0, lane, bad, false);
+    }
+    __syncthreads();
+  }
+  run_passes(f.n_pre, f.n_post);
+  double* x = f.x + (size_t)inst * n;
+  for (int i = tid; i < n; i += 64 * WPI) { const double v = W[qinv[i]]; if (!isfinite(v)) bad = 1; x[i] = v; }
+  if (wave_any(bad) && lane == 0) atomicOr(&f.flags[inst], 1);
+}
+
 // 0 = done with the program kernel; 1 = not applicable (the caller falls back to k_lu); < 0 never
 int launch_factor_solve_f2(CadnipHandle* h, const double* d_rhs, double* d_x) {
   if (!h->analyzed || !fused2_tables_ready(h)) return 1;   // (only the linear-solve prefix of the tables has to fit: checked below)
@@ -121,6 +207,18 @@ int launch_factor_solve_f2(CadnipHandle* h, const double* d_rhs, double* d_x) {
   f.G = h->d_G; f.C = h->d_C; f.gamma = h->d_gamma; f.rhs = d_rhs; f.x = d_x; f.active = h->d_active; f.flags = h->d_flags;
   f.B = h->B; f.n = h->n; f.nnz = h->nnz; f.lu_words = h->f2_lu_words; f.n_pre = h->f2_n_pre; f.n_post = h->f2_n_post; f.nc = h->f2_nc; f.dn0 = h->f2_dn0;
   const size_t tab_dbl = (size_t)h->f2_lu_len / 2, per = (size_t)h->f2_lu_words + h->n + F2_TRASH;
+  // a few instances of a circuit with many passes: several waves per instance (k_lu_f2_mw).  CADNIP_LU_WPI forces 1 / 4 (diagnostic)
+  {
+    const char* e = getenv("CADNIP_LU_WPI");
+    const int wpi = e ? atoi(e) : (h->B * 4 <= h->n_cu_hint() && h->f2_n_pre + h->f2_n_post >= 32 ? 4 : 1);
+    const size_t shmem_mw = (tab_dbl + per) * 8;
+    if (wpi == 4 && shmem_mw <= 160 * 1024) {
+      if (shmem_mw > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_lu_f2_mw<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_mw));
+      hipLaunchKernelGGL(k_lu_f2_mw<4>, dim3(h->B), dim3(256), shmem_mw, h->stream, f);
+      HIP_TRY(hipGetLastError());
+      return CADNIP_OK;
+    }
+  }
   int wpb = 8;
   while (wpb > 1 && ((tab_dbl + wpb * per) * 8 > 160 * 1024 || h->B < 256 * wpb / 2)) wpb >>= 1;
   const size_t shmem = (tab_dbl + wpb * per) * 8;
