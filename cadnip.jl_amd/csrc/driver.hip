@@ -324,9 +324,9 @@ int cadnip_dc_run(CadnipHandle* h, const CadnipDCOpts* o, double* u_host, int32_
   const size_t B = h->B, n = h->n;
   auto w0 = std::chrono::steady_clock::now();
   d->dc_log.clear();
-  HIP_TRY(hipMemcpyAsync(h->d_u, u_host, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   // the symbolic phase needs one numeric Jacobian: stamp once at the start point
   if (!h->analyzed) {
+    HIP_TRY(hipMemcpyAsync(h->d_u, u_host, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     std::vector<int> ones(B, 1);
     HIP_TRY(hipMemcpyAsync(h->d_active, ones.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_gamma, 0, B * sizeof(double), h->stream));
@@ -348,22 +348,26 @@ int cadnip_dc_run(CadnipHandle* h, const CadnipDCOpts* o, double* u_host, int32_
     CadnipHandle* h;
     ~HomotopyGuard() { (void)upload_homotopy(h, nullptr, nullptr); }
   } guard{h};
-  const std::vector<double> start(u_host, u_host + B * n);
-  std::vector<double> U(start), R(B * n);          // per-instance start state of the next run / states after the last run
+  // per-instance start state of the next run / states after the last run.  `start` and `U` are built only when the first run leaves
+  // someone unsolved: the usual case -- everybody converges in stage 0 -- moves the state once up and once down, nothing more
+  std::vector<double> start, U, R(B * n);
   std::vector<int> fin(B, 0), status(B), part(B, 1), out_of_run(B, 0);
   if (o->participate)
     for (size_t i = 0; i < B; ++i) if (!o->participate[i]) { part[i] = 0; out_of_run[i] = 1; fin[i] = 1; }   // (fin: no stage picks them up)
   std::vector<long long> cnt(B * 4);
   std::vector<double> gsh(B, h->spec.gshunt), sfc(B, h->spec.srcFact);
   long long iters = 0;
+  bool direct = false;
   // one Newton run of the instances in `part`, each from U[i] with its own (gsh[i], sfc[i]); results in status / R / cnt
   auto run = [&](int use_pcnr, int cold_start, int fused, int stage, const std::vector<double>& rung) -> int {
-    HIP_TRY(hipMemcpyAsync(h->d_u, U.data(), B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_u, U.empty() ? u_host : U.data(), B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(d->part, part.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
     TRY(upload_homotopy(h, gsh.data(), sfc.data()));
     TRY(dc_newton(h, o->abstol, o->maxiters, use_pcnr, cold_start, nullptr, fused, d->part));
     HIP_TRY(hipMemcpy(status.data(), d->status, B * sizeof(int), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(R.data(), h->d_u, B * n * sizeof(double), hipMemcpyDeviceToHost));
+    direct = stage == 0 && !o->participate;
+    for (size_t i = 0; i < B && direct; ++i) direct = status[i] == 1;
+    HIP_TRY(hipMemcpy(direct ? u_host : R.data(), h->d_u, B * n * sizeof(double), hipMemcpyDeviceToHost));   // direct: the first run solved everybody -- straight to the caller
     HIP_TRY(hipMemcpy(cnt.data(), d->cnt, B * 4 * sizeof(long long), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < B; ++i)
       if (part[i]) { iters += cnt[i * 4]; d->dc_log.push_back({(int)i, stage, rung[i], status[i] == 1 ? 1 : 0, cnt[i * 4]}); }
@@ -374,6 +378,17 @@ int cadnip_dc_run(CadnipHandle* h, const CadnipDCOpts* o, double* u_host, int32_
   const std::vector<double> none(B, 0.0);
   // ---- stage 0: PCNR (or plain Newton) from the caller's start point
   TRY(run(o->use_pcnr, o->cold_start, o->fused, 0, none));
+  if (direct) {
+    // everybody converged in the first run: the device holds the solutions already, the caller's array has them too
+    if (converged_host) for (size_t i = 0; i < B; ++i) converged_host[i] = 1;
+    std::vector<int> ones(B, 1);
+    HIP_TRY(hipMemcpy(h->d_cold, ones.data(), B * sizeof(int), hipMemcpyHostToDevice));      // (d_active: dc_newton left every instance active)
+    HIP_TRY(hipMemcpy(h->d_active, ones.data(), B * sizeof(int), hipMemcpyHostToDevice));
+    if (st) { memset(st, 0, sizeof(*st)); st->newton_iters = iters; st->n_failed = 0; st->wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count(); }
+    return CADNIP_OK;
+  }
+  start.assign(u_host, u_host + B * n);
+  U = start;
   for (size_t i = 0; i < B; ++i) if (part[i]) { take(i); if (status[i] == 1) fin[i] = 1; }
   // ---- stage 1: plain Newton from the caller's start point, for those PCNR did not solve
   if (n_open() && o->use_pcnr && h->n_limits > 0) {
