@@ -211,7 +211,7 @@ def read_spice(text, models=None, includes=None, sweep=(), title=""):
 
     sources, others = [], []
     from . import va
-    va_modules = {nm.lower(): m for nm, (_, m) in va.registry().items()}
+    va_names = va.module_names()          # lower-case name -> module name; a module is parsed when a card or an instance uses it
 
     class Scope:
         def __init__(self, prefix="", nmap=None, params=None, parent=None):
@@ -301,10 +301,10 @@ def read_spice(text, models=None, includes=None, sweep=(), title=""):
                     if float(kv.get("level", "1")) != 1.0:
                         raise ValueError("only level-1 MOSFET cards (sp_mos1) have a GPU device: %r" % line)
                     card["type"] = 1 if kind_m == "nmos" else -1
-                elif kind_m in va_modules:
+                elif kind_m in va_names:
                     # .model <name> <verilog-a module> k=v ...: a card of a generated module (test/mna/psp103_integration.jl:44:
                     # ".model nch psp103va type=1"); instances merge their own parameters over it
-                    card["__va__"] = va_modules[kind_m].name
+                    card["__va__"] = va_names[kind_m]
                 elif kind_m != "d":
                     raise ValueError("unsupported .model type %r" % pos[1])
                 models[pos[0].lower()] = card
@@ -366,7 +366,7 @@ def read_spice(text, models=None, includes=None, sweep=(), title=""):
             if kind in "mn" and isinstance(va_card, dict) and "__va__" in va_card:
                 # Mname / Nname nets... card [k=v]: instance of a Verilog-A module through a .model card (N: the OSDI element letter
                 # of ngspice decks, benchmarks/vacask/ring/cedarsim/models.inc:4)
-                mod = va_modules[va_card["__va__"].lower()]
+                mod = va.get(va_card["__va__"])[1]
                 if len(pos) - 1 != len(mod.ports):
                     raise ValueError("%s: %d nets for the %d ports of %s" % (head, len(pos) - 1, len(mod.ports), mod.name))
                 inst = {k: v for k, v in va_card.items() if k != "__va__"}
@@ -392,9 +392,9 @@ def read_spice(text, models=None, includes=None, sweep=(), title=""):
                 for body_line in sub["body"]:
                     handle(body_line, inner, depth + 1)
                 return
-            if kind == "x" and pos and pos[-1].lower() in va_modules:
+            if kind == "x" and pos and pos[-1].lower() in va_names:
                 # instance of a Verilog-A module that is compiled into the library (cadnip.jl_amd/va)
-                mod = va_modules[pos[-1].lower()]
+                mod = va.get(va_names[pos[-1].lower()])[1]
                 if len(pos) - 1 != len(mod.ports):
                     raise ValueError("%s: %d nets for the %d ports of %s" % (head, len(pos) - 1, len(mod.ports), mod.name))
                 inst = {k: sc.val(v) for k, v in kv.items() if k != "m"}

@@ -30,29 +30,64 @@ def external_source(fn, subdirs):
     return None
 
 
-def registry():
-    """name -> (model id, VAModule): the built-in modules, then the external ones whose source is found."""
+def _builtin():
     if not _cache:
-        from .frontend import parse_file
         for i, fn in enumerate(MODEL_FILES):
             m = parse_module(open(os.path.join(MODEL_DIR, fn)).read(), MODEL_DIR)
             _cache[m.name] = (i, m)
-        for j, (name, fn, subdirs) in enumerate(EXTERNAL):
-            p = external_source(fn, subdirs)
-            if p is not None:
-                m = parse_file(p)
-                if m.name != name:
-                    raise VAError("%s defines module %s, expected %s" % (p, m.name, name))
-                _cache[m.name] = (len(MODEL_FILES) + j, m)
     return _cache
+
+
+def _external(name):
+    """(model id, VAModule) of an external model, parsed on first use (PSP103 / bsim4v8: seconds); None when its source is not at hand."""
+    if name not in _ext_cache:
+        from .frontend import parse_file
+        j = next(k for k, e in enumerate(EXTERNAL) if e[0] == name)
+        p = external_source(EXTERNAL[j][1], EXTERNAL[j][2])
+        if p is None:
+            _ext_cache[name] = None
+        else:
+            m = parse_file(p)
+            if m.name != name:
+                raise VAError("%s defines module %s, expected %s" % (p, m.name, name))
+            _ext_cache[name] = (len(MODEL_FILES) + j, m)
+    return _ext_cache[name]
+
+
+_ext_cache = {}
+
+
+def module_names():
+    """lower-case name -> module name of everything a deck may instantiate: the built-in modules and the external models whose
+    source is found (they are parsed only when used: ``get``)."""
+    out = {nm.lower(): nm for nm in _builtin()}
+    for name, fn, subdirs in EXTERNAL:
+        if external_source(fn, subdirs) is not None:
+            out[name.lower()] = name
+    return out
+
+
+def registry():
+    """name -> (model id, VAModule): the built-in modules, then the external ones whose source is found (parses all of them)."""
+    out = dict(_builtin())
+    for name, _, _ in EXTERNAL:
+        e = _external(name)
+        if e is not None:
+            out[name] = e
+    return out
 
 
 def get(name):
     try:
-        return registry()[name]
+        if name in _builtin():
+            return _builtin()[name]
+        e = _external(name) if any(x[0] == name for x in EXTERNAL) else None
+        if e is None:
+            raise KeyError(name)
+        return e
     except KeyError:
         ext = [e for e in EXTERNAL if e[0] == name]
         if ext:
             raise VAError("the library carries %s, but its Verilog-A source %s was not found (set CADNIP_VA_PATH to its directory): the host "
                           "side needs it for structure discovery and parameter defaults" % (name, ext[0][1])) from None
-        raise VAError("no Verilog-A module %r is compiled into the library (have: %s)" % (name, ", ".join(registry()))) from None
+        raise VAError("no Verilog-A module %r is compiled into the library (have: %s)" % (name, ", ".join(module_names().values()))) from None
