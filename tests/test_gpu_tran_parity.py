@@ -16,12 +16,12 @@ REL_TOL = 1e-9
 ABSTOL = dict(vntol=1e-6, iabstol=1e-9, chgtol=1e-6)
 
 
-def _port_run(circ, params, temp, u0, ts, obs, vscale):
+def _port_run(circ, params, temp, u0, ts, obs, vscale, newton_mode=0):
     st, port = make_port(circ, params, temp, "tran")
     analyze_port(st, port, vscale)
     breaks = expand_breakpoints(st.breakpoints, bm.DFF_TSPAN)
     out, uf, stats, _ = port.tran(u0, bm.DFF_TSPAN[0], bm.DFF_TSPAN[1], st.state_abstol(**ABSTOL), 1e-4, breaks=breaks, save_t=ts,
-                                  obs=obs, err_mask=st.differential_mask(), use_pcnr=False)
+                                  obs=obs, err_mask=st.differential_mask(), use_pcnr=False, newton_mode=newton_mode)
     port.close()
     return out, stats
 
@@ -180,8 +180,9 @@ def test_full_size_corner_sweep_properties(newton_mode):
     assert np.array_equal(out_p, out[perm]) and np.array_equal(per_p[:, :4], per[perm][:, :4])
 
 
+@pytest.mark.parametrize("newton_mode", [0, 1])
 @pytest.mark.parametrize("B", [70, 300, 700])
-def test_inverter_sweep_batch_sizes(B):
+def test_inverter_sweep_batch_sizes(B, newton_mode):
     """Batch sizes that select the 1-, 2- and 4-instance-per-workgroup variants of the fused kernel (and, with the small
     LDS footprint of this circuit, several workgroups per CU): every instance equals its single-instance run bit for bit."""
     circ = bm.inverter_circuit()
@@ -192,7 +193,7 @@ def test_inverter_sweep_batch_sizes(B):
     def run(points):
         sim = api.BatchSimulator(api.MNACircuit(circ, {"vdd": 5.0}), points)
         st = sim.st
-        out, per, stats = sim.tran((0.0, 4e-7), st.state_abstol(**ABSTOL), 1e-4, ts, obs=[st.index_of("Q")], fused=1)
+        out, per, stats = sim.tran((0.0, 4e-7), st.state_abstol(**ABSTOL), 1e-4, ts, obs=[st.index_of("Q")], fused=1, newton_mode=newton_mode)
         sim.close()
         assert stats["n_failed"] == 0
         return out, per
@@ -222,8 +223,9 @@ def test_circuit_too_large_for_the_fused_kernel_runs_per_op():
     assert 0.0 < res[0][0][0, 1, 0] <= 1.0 + 1e-6
 
 
-def test_dff_monte_carlo_variant_matches_port():
-    """SURVEY.md 8d config 4, Monte-Carlo variant: threshold shift ~ N(0, 0.02^2) V and kp factor ~ N(1, 0.03^2) per
+@pytest.mark.parametrize("newton_mode", [0, 1])
+def test_dff_monte_carlo_variant_matches_port(newton_mode):
+    """(in both Newton modes) SURVEY.md 8d config 4, Monte-Carlo variant: threshold shift ~ N(0, 0.02^2) V and kp factor ~ N(1, 0.03^2) per
     instance from numpy.random.default_rng(0xDEADBEEF), every instance at nominal supply.  All 64 samples finish with
     the race-free logic pins; three of them are checked against the CPU port at the 1e-9 bar."""
     circ = bm.dff_circuit(mc_vto="dvto", mc_kp="kpf")
@@ -238,14 +240,14 @@ def test_dff_monte_carlo_variant_matches_port():
     obs = [st.index_of("Q"), st.index_of("Q_neg")]
     sim.h.set_spec(mode="tran")
     breaks = expand_breakpoints(st.breakpoints, bm.DFF_TSPAN)
-    out, per, stats = sim.h.tran_run(0.0, 7e-7, st.state_abstol(**ABSTOL), 1e-4, breaks=breaks, save_t=ts, obs=obs, fused=1)
+    out, per, stats = sim.h.tran_run(0.0, 7e-7, st.state_abstol(**ABSTOL), 1e-4, breaks=breaks, save_t=ts, obs=obs, fused=1, newton_mode=newton_mode)
     vs = sim.vscale()
     sim.close()
     assert stats["n_failed"] == 0
     assert np.all(np.abs(out[:, 0, 0]) < 0.05) and np.all(np.abs(out[:, 1, 0]) < 0.05) and np.all(np.abs(out[:, 2, 0] - 5.0) < 0.05)
     assert len({int(x) for x in per[:, 0]}) > 8          # the samples really differ: different Newton counts
     for i in (0, 17, 63):
-        ref, rst = _port_run(circ, pts[i], 27.0, u0[i], ts, obs, vs)
+        ref, rst = _port_run(circ, pts[i], 27.0, u0[i], ts, obs, vs, newton_mode=newton_mode)
         assert rst["status"] == 1
         assert abs(per[i, 0] - rst["newton_iters"]) <= 0.01 * rst["newton_iters"], (i, per[i], rst)
         assert np.max(np.abs(out[i] - ref) / np.maximum(np.abs(ref), 1.0)) <= REL_TOL, i
