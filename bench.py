@@ -472,7 +472,7 @@ def psp103_ring_leg(device):
     corners.  Structure and parameters come from the committed fixture (the model source is not on the GPU box)."""
     from cadnip_jl_amd import api, structure as S
     from cadnip_jl_amd.structure import expand_breakpoints
-    out = {"workload": "benchmarks/vacask/ring: 9 stages, 18 PSP103 devices, n = 371; CedarTranOp start, 20 ns slice, dtmax 50 ps, abstol 1e-4, reltol 1e-2",
+    out = {"workload": "benchmarks/vacask/ring: 9 stages, 18 PSP103 devices, n = 371; CedarTranOp start, 20 ns slice, dtmax 50 ps, abstol 1e-4, reltol 1e-2, IDA's convergence test (newton_mode 1; the per-op path refactors every round)",
            "reference_us_per_iter": 1376.0, "vacask_us_per_iter": 27.8, "reference_source": "doc/ring_oscillator_investigation.md:299-313"}
     try:
         st, x = S.load_structure(os.path.join(ROOT, "tests", "golden", "psp103_ring.npz"))
@@ -487,7 +487,7 @@ def psp103_ring_leg(device):
                 sim.h.set_spec(mode="tran")
                 t1 = 20e-9
                 _, _, stats = sim.h.tran_run(0.0, t1, st.state_abstol(vntol=1e-4, iabstol=1e-7, chgtol=1e-4), 1e-2, breaks=expand_breakpoints(st.breakpoints, (0.0, t1)),
-                                             save_t=np.array([t1]), obs=[st.index_of("1")], hmax=50e-12, fused=0)
+                                             save_t=np.array([t1]), obs=[st.index_of("1")], hmax=50e-12, fused=0, newton_mode=1)
             finally:
                 sim.close()
             out["B%d" % B] = {"newton_iters": int(stats["newton_iters"]), "wall_s": round(stats["wall_seconds"], 3), "failed": int(stats["n_failed"]) + int((~conv).sum()),

@@ -106,6 +106,16 @@ __global__ void __launch_bounds__(64) k_tran_update(TranArgs a) {
   CADNIP_WAVE_SYNC();
   if (tid == 0) a.flags[inst] = 0;
   GlobalVecs v(a, inst);
+  if (a.newton_mode) {
+    // per-op path: every round restamps and refactors (the factors live in LDS for the length of one k_lu_f2 launch), so the Jacobian is
+    // always current -- a failed iteration halves the step at once, nothing is scaled.  The rate constant follows the same events as in
+    // the fused kernel (reset to 20 where that one would refactor: first round, a0 outside IDA's window, 20 steps), so both paths accept
+    // iterates by the same rule.  oracle/cpu_port.cpp mirrors this as newton_mode 2.
+    const bool setup = !(s.mflags & MN_VALID) || (s.k == 0 && (s.a0 < 0.6 * s.a0f || s.a0 * 0.6 > s.a0f || (s.mflags >> MN_SINCE_SHIFT) >= 20));
+    if (setup) { s.a0f = s.a0; s.ss = 20.0; s.mflags = MN_VALID | MN_JCUR; }
+    else s.mflags |= MN_JCUR;
+    s.dsc = 1.0;
+  }
   tran_update_body(a, v, s, inst, tid, bad);
   store_state(a, inst, tid, s);
 }
@@ -543,7 +553,6 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
              o->newton_mode ? 1 : 0, d->mn_a0f, d->mn_ss, d->mn_dnp, d->mn_flags};
   if (!h->analyzed) return CADNIP_NOTREADY;              // the symbolic LU phase (cadnip_analyze*) comes first
   const bool use_fused = o->fused && !h->va_ext && fused2_fits(h);   // (external generated models exist in the per-op stamping kernel only)     // a circuit too large for the LDS-resident kernel runs on the per-op kernels
-  if (o->newton_mode && !use_fused) return CADNIP_BADARG;   // Jacobian reuse lives in the fused kernel (tran_ctrl.hpp)
   struct ModeGuard { CadnipHandle* h; int saved; ~ModeGuard() { h->spec.mode = saved; } } mode_guard{h, h->spec.mode};
   h->spec.mode = 1;   // :tran (restored on every exit path)
   hipLaunchKernelGGL(k_tran_init, dim3(h->B), dim3(64), 0, h->stream, a);

@@ -223,7 +223,8 @@ typedef struct {
   int32_t newton_mode;      /* 0 = full Newton, converged when the weighted update norm < newton_tol (every round restamps and refactors);
                                1 = the nonlinear iteration as IDA runs it (the reference's integrator, src/sweeps.jl:600): refactor on a setup
                                only (first round, a0 outside [0.6, 1/0.6] of its last setup value, 20 steps, failure on a stale Jacobian), kept factors in between, rate-based
-                               convergence test ss ||delta|| <= 0.33.  Fused kernel only (CADNIP_BADARG otherwise) */
+                               convergence test ss ||delta|| <= 0.33.  The fused kernel keeps the factors; the per-op kernels refactor every round (their
+                               factors live in LDS for one launch) and take the convergence test only */
 } CadnipTranOpts;
 
 typedef struct {

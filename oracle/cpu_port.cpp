@@ -488,7 +488,8 @@ int port_dc(void* p, double* u, double abstol, int maxiters, int use_pcnr, int c
 struct TranOpts {
   double t0, t1, reltol; const double* abstol; const double* err_mask; double h0, hmin, hmax; int max_newton, max_order, use_pcnr; double newton_tol;
   int n_break; const double* breaks; int n_save; const double* save_t; int n_obs; const int* obs;
-  int newton_mode;   // 1 = IDA's nonlinear iteration: Jacobian reuse + rate test (cadnip.jl_amd/csrc/tran_ctrl.hpp, the same policy statement for statement)
+  int newton_mode;   // 1 = IDA's nonlinear iteration: Jacobian reuse + rate test (cadnip.jl_amd/csrc/tran_ctrl.hpp, the same policy statement for statement);
+                     // 2 = the same test with a refactorisation every round (what the per-op GPU path does with newton_mode 1)
 };
 struct TranStats { int64_t newton_iters, accepted, rejected, newton_failures; int status; double wall_seconds; int64_t refactorisations; };
 
@@ -536,7 +537,8 @@ int port_tran(void* p, double* u_io, const TranOpts* o, double* out, TranStats* 
     if (mode) {
       refresh = need || !valid || (k == 0 && (a0 < 0.6 * a0f || a0 * 0.6 > a0f || since >= 20));
       if (refresh) { a0f = a0; ss = 20.0; need = false; valid = true; jcur = true; since = 0; }
-      else dsc = a0 == a0f ? 1.0 : 2.0 / (1.0 + a0 / a0f);
+      if (mode == 2) { refresh = true; jcur = true; }        // the per-op GPU path: same events for the rate constant, but it refactors every round
+      if (!refresh) dsc = a0 == a0f ? 1.0 : 2.0 / (1.0 + a0 / a0f);
     }
     bool ok = refresh ? factor_solve(P, a0, r.data(), delta.data()) : lu_solve_kept(P, r.data(), delta.data());
     S.refactorisations += refresh ? 1 : 0;

@@ -291,12 +291,31 @@ def test_dff_transient_newton_mode_1_matches_port():
     sim.close()
 
 
-def test_newton_mode_1_needs_the_fused_kernel():
-    circ = tc.ALL_STAMP["inverter"][0]()
-    sim = api.BatchSimulator(api.MNACircuit(circ, tc.ALL_STAMP["inverter"][1]), None)
+def test_newton_mode_1_on_the_per_op_path_matches_port_mode_2():
+    """The per-op kernels refactor every round; with newton_mode 1 they take IDA's convergence test only.  The port's newton_mode 2 is
+    that policy: identical Newton / step / reject counts (the per-op path sums in the reference's order, like the port) and 1e-9."""
+    circ = bm.dff_circuit()
+    points = [{}, {"vdd": 4.6, "temp": 100.0}]
+    sim = api.BatchSimulator(api.MNACircuit(circ, {"vdd": 5.0}), points)
+    st = sim.st
     sim.analyze()
-    sim.dc(abstol=1e-9, mode="tranop")
+    u0, conv, _ = sim.dc(abstol=1e-9, mode="tranop")
+    assert np.all(conv)
+    ts = np.linspace(0.0, 7e-7, 71)
+    obs = list(range(st.n_nodes))
     sim.h.set_spec(mode="tran")
-    with pytest.raises(Exception):
-        sim.h.tran_run(0.0, 1e-8, sim.st.state_abstol(**ABSTOL), 1e-4, save_t=[1e-8], fused=0, newton_mode=1)
+    breaks = expand_breakpoints(st.breakpoints, bm.DFF_TSPAN)
+    atol = st.state_abstol(**ABSTOL)
+    out, per, stats = sim.h.tran_run(0.0, 7e-7, atol, 1e-4, breaks=breaks, save_t=ts, obs=obs, fused=0, newton_mode=1)
+    assert stats["n_failed"] == 0
+    for i, pt in enumerate(points):
+        pst, port = make_port(circ, {"vdd": pt.get("vdd", 5.0)}, pt.get("temp", 27.0), "tran")
+        analyze_port(pst, port, sim.vscale())
+        ref, uf, rst, _ = port.tran(u0[i], 0.0, 7e-7, atol, 1e-4, breaks=breaks, save_t=ts, obs=obs, err_mask=pst.differential_mask(),
+                                    use_pcnr=False, newton_mode=2)
+        port.close()
+        assert rst["status"] == 1 and rst["refactorisations"] == rst["newton_iters"]
+        assert (per[i, 0], per[i, 1], per[i, 2]) == (rst["newton_iters"], rst["accepted"], rst["rejected"]), (pt, per[i], rst)
+        assert np.max(np.abs(out[i] - ref) / np.maximum(np.abs(ref), 1.0)) <= REL_TOL
+    assert per[0, 0] < 2500          # 3 891 with the fixed update tolerance of mode 0
     sim.close()

@@ -21,7 +21,7 @@ from cadnip_jl_amd import api, structure as S                     # noqa: E402
 from cadnip_jl_amd.structure import expand_breakpoints            # noqa: E402
 
 
-def run(B, tspan, reltol, vntol=1e-6, vdd_lo=1.1, vdd_hi=1.3):
+def run(B, tspan, reltol, vntol=1e-6, newton_mode=1, vdd_lo=1.1, vdd_hi=1.3):
     st, x = S.load_structure(os.path.join(ROOT, "tests", "golden", "psp103_ring.npz"))
     packed = [np.repeat(x["packed%d" % i], B, axis=0) for i in range(int(x["n_packed"][0]))]
     vb = next(i for i, b in enumerate(st.blocks) if b.type == "V")
@@ -37,7 +37,7 @@ def run(B, tspan, reltol, vntol=1e-6, vdd_lo=1.1, vdd_hi=1.3):
     sim.h.set_spec(mode="tran")
     t0 = time.time()
     out, per, stats = sim.h.tran_run(0.0, tspan, st.state_abstol(vntol=vntol, iabstol=1e-3 * vntol, chgtol=vntol), reltol,
-                                     breaks=expand_breakpoints(st.breakpoints, (0.0, tspan)), save_t=ts, obs=[st.index_of("1")], hmax=50e-12, fused=0)
+                                     breaks=expand_breakpoints(st.breakpoints, (0.0, tspan)), save_t=ts, obs=[st.index_of("1")], hmax=50e-12, fused=0, newton_mode=newton_mode)
     wall = time.time() - t0
     sim.close()
     v = out[:, :, 0]
@@ -48,9 +48,9 @@ def run(B, tspan, reltol, vntol=1e-6, vdd_lo=1.1, vdd_hi=1.3):
         up = np.flatnonzero((w[:-1] < 0.5 * vdd[i]) & (w[1:] >= 0.5 * vdd[i]))
         per_ns.append(np.mean(np.diff(ts[late][up])) * 1e9 if len(up) > 2 else float("nan"))
     it = stats["newton_iters"]
-    print("B = %4d  tspan %.0f ns  reltol %g vntol %g: DC %.2f s (%d iterations), transient %.2f s, %d Newton iterations (%d accepted / %d rejected steps, "
+    print("B = %4d  tspan %.0f ns  reltol %g vntol %g newton_mode %d: DC %.2f s (%d iterations), transient %.2f s, %d Newton iterations (%d accepted / %d rejected steps, "
           "%d failed instances) -> %.1f us per Newton round of the batch, %.2f us per instance-iteration; period %.3f ns at %.2f V%s" % (
-              B, tspan * 1e9, reltol, vntol, t_dc, dcs["newton_iters"], wall, it, stats["steps_accepted"], stats["steps_rejected"], stats["n_failed"],
+              B, tspan * 1e9, reltol, vntol, newton_mode, t_dc, dcs["newton_iters"], wall, it, stats["steps_accepted"], stats["steps_rejected"], stats["n_failed"],
               wall / max(stats["launches"], 1) * 1e6, wall / max(it, 1) * 1e6, per_ns[0], vdd[0],
               (", %.3f ns at %.2f V" % (per_ns[-1], vdd[-1])) if B > 1 else ""), flush=True)
 
@@ -62,9 +62,10 @@ def main():
     ap.add_argument("--reltol", type=float, default=1e-3)
     ap.add_argument("--vntol", type=float, default=1e-6, help="absolute tolerance of voltages and (scaled) charges; currents 1e-3 of it. "
                     "The reference's run uses abstol = 1e-4, reltol = 1e-2 (runme.jl:66)")
+    ap.add_argument("--newton-mode", type=int, default=1, help="1 = IDA's convergence test (per-op path: a refactorisation every round), 0 = update norm < 1e-3")
     a = ap.parse_args()
     for B in [int(b) for b in a.batch.split(",")]:
-        run(B, a.tspan, a.reltol, a.vntol)
+        run(B, a.tspan, a.reltol, a.vntol, a.newton_mode)
 
 
 if __name__ == "__main__":
