@@ -248,7 +248,7 @@ def main(argv=None):
     ap.add_argument("--fused", type=int, default=int(os.environ.get("CADNIP_FUSED", "2")),
                     help="0 = one kernel per op (the kernels behind the callback ABI), non-zero = fused Newton kernel (default)")
     ap.add_argument("--newton-mode", type=int, default=-1, help="1 = the nonlinear iteration as the reference's IDA runs it (Jacobian reuse, rate test: "
-                    "csrc/tran_ctrl.hpp; fused kernel and CPU port), 0 = full Newton with a fixed update tolerance; default: 1 on the fused path, 0 per-op")
+                    "csrc/tran_ctrl.hpp; fused kernel and CPU port), 0 = full Newton with a fixed update tolerance; default: 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-pmc", action="store_true", help="skip the rocprofv3 child passes (roofline falls back to the committed profile)")
     ap.add_argument("--no-extras", action="store_true", help="skip stamp_kernel / single-instance / callback legs")
@@ -256,7 +256,7 @@ def main(argv=None):
     ap.add_argument("--calib-copy", type=int, default=0, help="also run the fp64 calibration copy of this many MiB (HBM counter passes)")
     args = ap.parse_args(argv)
     if args.newton_mode < 0:
-        args.newton_mode = 1 if int(args.fused) else 0
+        args.newton_mode = 1          # (per-op path: the convergence test only -- it refactors every round)
     if args.probe:
         return probe_main(args)
 
@@ -574,7 +574,8 @@ def cpu_baseline(args, circ, sim, pts, save_t):
         u0c, ok, dit = port.dc(abstol=1e-9)
         port.set_spec(mode="tran")
         _, _, rst, _ = port.tran(u0c if ok else u0_all[idx[k]], bm.DFF_TSPAN[0], bm.DFF_TSPAN[1], atol, RELTOL, breaks=breaks,
-                                 save_t=save_t, obs=obs, err_mask=pst.differential_mask(), use_pcnr=False, newton_mode=args.newton_mode)
+                                 save_t=save_t, obs=obs, err_mask=pst.differential_mask(), use_pcnr=False,
+                                 newton_mode=args.newton_mode if int(args.fused) or not args.newton_mode else 2)   # (port mode 2 = the per-op GPU path's mode 1)
         return rst["newton_iters"] + dit
 
     n1 = max(8, len(sample) // 8)                   # single-thread leg on a slice, multi-thread leg on the whole sample
