@@ -290,7 +290,7 @@ class VAModule:
         a, b, guards = self.shorts[i][:3]
         np_ = len(self.ports)
         if b < 0:
-            return True
+            return a >= np_                 # an internal net to ground is merged into ground; a terminal to ground carries a current
         return len(guards) == 1 and guards[0][1] is True and ((a >= np_) != (b >= np_))
 
     def aliases(self, par, given=None):
@@ -1055,8 +1055,7 @@ def _analyse(m: VAModule):
                 a, b = node(s[1]), node(s[2])
                 if a < 0 or a == b:
                     raise VAError("%s: V(%s,%s) <+ 0 must join two distinct nets of the module" % (m.name, s[1], s[2]))
-                if b < 0 and a < len(m.ports):
-                    raise VAError("%s: V(%s) <+ 0 would ground a terminal" % (m.name, s[1]))
+                # (V(terminal) <+ 0 ties a terminal to ground: not an alias -- it owns a branch current like any other executed short)
                 for c, _ in guards:
                     if not is_static(c):
                         raise VAError("%s: V(%s,%s) <+ 0 under a condition that is not decided by the parameters" % (m.name, s[1], s[2]))

@@ -306,7 +306,7 @@ def short_aliases_a_terminal(mod, stmt):
     a, b, guards = next(x[:3] for x in mod.shorts if x[3] is stmt)
     np_ = len(mod.ports)
     if b < 0:
-        return True
+        return a >= np_
     return len(guards) == 1 and guards[0][1] is True and ((a >= np_) != (b >= np_))
 
 

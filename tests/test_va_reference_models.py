@@ -32,10 +32,10 @@ EXPECTED = {
     "resistor.va": (2, 2, 0, 0, 0), "capacitor.va": (2, 2, 2, 0, 0), "diode.va": (3, 3, 2, 2, 1),
     "jfet1.va": (5, 5, 3, 4, 2), "jfet2.va": (8, 8, 6, 4, 5), "mes1.va": (5, 5, 3, 4, 2),
     "mos1.va": (6, 6, 4, 8, 2), "mos2.va": (6, 6, 4, 8, 2), "mos3.va": (6, 6, 4, 8, 2), "mos6.va": (6, 6, 4, 8, 2), "mos9.va": (6, 6, 4, 8, 2),
-    "bsim3v3.va": (7, 7, 5, 8, 3), "bsim4v8.va": (13, 23, 9, 18, 9),
+    "bsim3v3.va": (7, 7, 5, 8, 3), "bsim4v8.va": (13, 23, 9, 18, 9), "bjt.va": (11, 11, 9, 6, 9),
 }
-# refused, with the reason: these need a branch-current unknown (a potential contribution, or a terminal tied to ground)
-REFUSED = {"inductor.va": "potential contributions", "vdmos.va": "potential contributions", "bjt.va": "ground a terminal"}
+# refused, with the reason: general potential contributions V(a,b) <+ expr (a branch-current probe / a thermal branch)
+REFUSED = {"inductor.va": "potential contributions", "vdmos.va": "potential contributions"}
 
 
 @pytest.mark.parametrize("fn", sorted(EXPECTED))
@@ -150,6 +150,34 @@ def test_reference_resistor_and_capacitor_text_stamp_the_closed_forms():
         assert np.allclose(A, want * np.array([[1.0, -1.0], [-1.0, 1.0]]), rtol=1e-12, atol=0.0), (fn, A)
 
 
+def test_reference_bjt_text_is_a_gummel_poon_transistor():
+    """bjt.va (11 nodes; V(sub) <+ 0 ties the substrate terminal to ground through a branch current, two internal-internal shorts): the
+    oracle's interpretation in a common-emitter stage -- Vbe = 0.7 V, bf = 100, is at its default 1e-16 A -- gives the textbook numbers
+    Ic = Is exp(Vbe / Vt), Ib = Ic / bf."""
+    import math
+    from oracle import devices_ref as D
+    mod = F.parse_file(os.path.join(VA_DIR, "bjt.va"))
+    assert mod.ports == ["c", "b", "e", "sub"] and len(mod.vshorts) == 4
+    card = dict(bf=100.0)
+    par = host_eval.defaults(mod, card)
+
+    def b(params, spec, t, x=ZERO_VECTOR, ctx=None):
+        ctx = ctx or MNAContext()
+        c, bb, vcc = ctx.get_node("c"), ctx.get_node("b"), ctx.get_node("vcc")
+        D.stamp_vsource(ctx, vcc, 0, 5.0, name="vcc")
+        D.stamp_vsource(ctx, bb, 0, 0.7, name="vb")
+        D.stamp_resistor(ctx, vcc, c, 1e3)
+        va_ref.stamp_va(ctx, mod, [c, bb, 0, 0], x, par, spec, "q1", given=set(card))
+        return ctx
+    sol = M.solve_dc(b, {}, M.MNASpec(mode="dcop", temp=27.0))
+    assert sol.converged
+    x = dict(zip(sol.sys.node_names + sol.sys.current_names, sol.x))
+    ic, ib = -x["I_vcc"], -x["I_vb"]
+    vt = 1.380649e-23 * 300.15 / 1.602176634e-19
+    assert ic == pytest.approx(1e-16 * math.exp(0.7 / vt), rel=1e-3) and ib == pytest.approx(ic / 100.0, rel=1e-3)
+    assert x["c"] == pytest.approx(5.0 - 1e3 * ic, rel=1e-9) and x["q1_I_V_c_int_cx_int"] == pytest.approx(-ic, rel=1e-9)
+
+
 def _device_compile(header_text, tmp_path, opt="-O1"):
     """hipcc --cuda-device-only on a translation unit that instantiates every generated stamp function through stamp_va, against
     the product's devices.hpp / va_runtime.hpp (symlinked next to the generated header, which they include by name)."""
@@ -181,7 +209,7 @@ def test_reference_models_generate_hip_that_compiles_for_gfx950(tmp_path):
     tests/test_gpu_parity.py, tests/test_gpu_va.py; va_feat.va covers the constructs only the reference's files use -- and
     the reference's mos1.va itself is pinned above through the interpreter both generators' outputs are compared with.)"""
     from cadnip_jl_amd.va import hipgen
-    mods = [F.parse_file(os.path.join(VA_DIR, f)) for f in ("resistor.va", "capacitor.va", "diode.va", "mos1.va")]
+    mods = [F.parse_file(os.path.join(VA_DIR, f)) for f in ("resistor.va", "capacitor.va", "diode.va", "mos1.va", "bjt.va")]
     text = hipgen.generate_header(mods)
     assert "stamp_va_sp_mos1" in text and "vaf_sp_mos1_DEVqmeyer" in text and "g_tox" in text
     _device_compile(text, tmp_path)
