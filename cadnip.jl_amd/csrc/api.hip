@@ -163,6 +163,7 @@ int cadnip_create(const CadnipStructure* s, int32_t n_instances, int32_t device,
         ok = b.n_nodes == sh.n_nodes && b.n_g == sh.n_g && b.n_c == sh.n_c && b.n_b == sh.n_b && b.n_par == sh.n_par;
       }
       if (!ok) { cadnip_destroy(h); return CADNIP_BADARG; }
+      b.va_model = id;
       if (id >= CADNIP_VA_NBUILTIN) { static const int tl_lanes[] = {CADNIP_VA_EXT_TL_LANES 0}, n_cache[] = {CADNIP_VA_EXT_NCACHE 0}; h->va_ext = true; b.va_tl = tl_lanes[id - CADNIP_VA_NBUILTIN]; b.n_cache = n_cache[id - CADNIP_VA_NBUILTIN]; }   // a large external model (PSP103): per-op kernels only (fused2_fits)
     }
     b.h_nodes.assign(sb.nodes, sb.nodes + (size_t)b.n_nodes * b.count);

@@ -6,11 +6,12 @@ cd "$(dirname "$0")"
 VA_LIST=$(python3 -c "import sys; sys.path.insert(0, '../..'); import importlib; print(' '.join(importlib.import_module('cadnip_jl_amd.va').MODEL_FILES))")
 (cd ../.. && python3 -m cadnip_jl_amd.va.hipgen $(for f in $VA_LIST; do echo cadnip.jl_amd/va/models/$f; done)) > va_generated.hpp.tmp
 cmp -s va_generated.hpp.tmp va_generated.hpp || mv va_generated.hpp.tmp va_generated.hpp; rm -f va_generated.hpp.tmp
-# the external models (PSP103: source inside the reference checkout or $CADNIP_VA_PATH, never copied): their generated header is
-# committed and only regenerated when every source is found
+# the external models (the reference's own model files: sources inside the reference checkout or $CADNIP_VA_PATH, never copied): the
+# generated table (va_generated_ext.hpp) and translation units (va_ext/<module>.hip) are committed and only regenerated when every
+# source is found
 EXT_LIST=$(python3 -c "import sys; sys.path.insert(0, '../..'); import importlib; va = importlib.import_module('cadnip_jl_amd.va'); ps = [va.external_source(fn, sd) for _, fn, sd in va.EXTERNAL]; print(' '.join(ps) if all(ps) else '')")
 if [ -n "$EXT_LIST" ]; then
-  (cd ../.. && python3 -m cadnip_jl_amd.va.hipgen --ext $EXT_LIST) > va_generated_ext.hpp.tmp
+  (cd ../.. && python3 -m cadnip_jl_amd.va.hipgen --ext cadnip.jl_amd/csrc/va_ext $EXT_LIST) > va_generated_ext.hpp.tmp
   cmp -s va_generated_ext.hpp.tmp va_generated_ext.hpp || mv va_generated_ext.hpp.tmp va_generated_ext.hpp; rm -f va_generated_ext.hpp.tmp
 fi
 # `build.sh --trace` builds the diagnostic library (cycle timeline of one wave, devices.hpp CADNIP_TRACE_POINT)

@@ -68,6 +68,7 @@ struct DeviceBlock {
   int* d_nodes = nullptr;
   std::vector<int> h_nodes;  // host copy (the fused kernel keeps an int16 copy in LDS)
   double* d_cache = nullptr; int n_cache = 0;   // generated external model: [B][n_cache][count] results of its setup pass (bias-independent statements)
+  int va_model = -1;         // CADNIP_DEV_VA: the block's model id (ipar row 0)
   int va_tl = 0;             // generated external model: lanes per device when evaluated with one derivative direction per lane (16 / 32; stamp_csr.hip)
   bool mos1_plain = false;   // sp_mos1 block: every instance has gd = gs = OxideCap = 0 (set by cadnip_set_params)
   int* d_ipar = nullptr;

@@ -14,8 +14,14 @@ MODEL_FILES = ("va_resistor.va", "va_capacitor.va", "va_diode.va", "va_sqmos.va"
 # their generated stamp functions (csrc/va_generated_ext.hpp, model ids after the built-in ones); the host side -- structure
 # discovery, parameter defaults -- needs the source itself and looks for it in $CADNIP_VA_PATH (os.pathsep-separated directories)
 # and then in the reference checkout.  (module name, file name, directories below the reference root)
-EXTERNAL = (("PSP103VA", "psp103.va", ("models/PSPModels.jl/va",)),
-            ("sp_bsim4v8", "bsim4v8.va", ("models/VADistillerModels.jl/va",)))
+_VAD, _PSP, _CMC = ("models/VADistillerModels.jl/va",), ("models/PSPModels.jl/va",), ("models/CMCModels.jl/va",)
+EXTERNAL = (("PSP103VA", "psp103.va", _PSP), ("sp_bsim4v8", "bsim4v8.va", _VAD),
+            # the rest of the reference's model packages (test/mna/vadistiller_integration.jl Tier 6 exercises each VADistiller model)
+            ("sp_resistor", "resistor.va", _VAD), ("sp_capacitor", "capacitor.va", _VAD), ("sp_diode", "diode.va", _VAD),
+            ("sp_bjt", "bjt.va", _VAD), ("sp_jfet1", "jfet1.va", _VAD), ("sp_jfet2", "jfet2.va", _VAD), ("sp_mes1", "mes1.va", _VAD),
+            ("sp_mos1", "mos1.va", _VAD), ("sp_mos2", "mos2.va", _VAD), ("sp_mos3", "mos3.va", _VAD), ("sp_mos6", "mos6.va", _VAD),
+            ("sp_mos9", "mos9.va", _VAD), ("sp_bsim3v3", "bsim3v3.va", _VAD), ("JUNCAP200", "juncap200.va", _PSP),
+            ("bsimcmg", "bsimcmg.va", _CMC))
 REFERENCE_ROOT = "/root/reference"
 
 _cache = {}

@@ -53,7 +53,7 @@ _TOKEN = re.compile(r"""
     (?P<ws>\s+|//[^\n]*|/\*.*?\*/|\(\*(?!\s*\)).*?\*\))
   | (?P<num>(?:\d+\.?\d*|\.\d+)(?:[eE][+-]?\d+)?[TGMKkmunpfa]?(?![A-Za-z_0-9]))
   | (?P<id>\$?[A-Za-z_][A-Za-z_0-9$]*)
-  | (?P<str>"[^"]*")
+  | (?P<str>"(?:[^"\\]|\\.)*")
   | (?P<op><\+|==|!=|<=|>=|&&|\|\||\*\*|<<|>>|[-+*/%()<>!?:;,=@\[\]{}&|^~#.])
 """, re.X | re.S)
 
@@ -81,6 +81,42 @@ class VAError(ValueError):
 STD_INCLUDES = ("constants.vams", "disciplines.vams", "discipline.h", "constants.h", "disciplines.h", "constants.va", "disciplines.va")
 
 
+def _string_end(line, i):
+    """Index of the quote that closes the string opening at line[i] (backslash escapes skipped); the last character if unterminated."""
+    j = i + 1
+    while j < len(line):
+        if line[j] == "\\":
+            j += 2
+            continue
+        if line[j] == '"':
+            return j
+        j += 1
+    return len(line) - 1
+
+
+def _strip_block_comments(text):
+    """Block comments out, line structure kept.  A comment opener inside a string or behind // opens nothing."""
+    res, i, n = [], 0, len(text)
+    while i < n:
+        ch = text[i]
+        if ch == '"':
+            j = i + 1
+            while j < n and text[j] != '"' and text[j] != "\n":
+                j += 2 if text[j] == "\\" else 1
+            res.append(text[i:j + 1]); i = j + 1
+        elif ch == "/" and text[i:i + 2] == "//":
+            j = text.find("\n", i)
+            j = n if j < 0 else j
+            res.append(text[i:j]); i = j
+        elif ch == "/" and text[i:i + 2] == "/*":
+            j = text.find("*/", i + 2)
+            j = n if j < 0 else j + 2
+            res.append("\n" * text.count("\n", i, j)); i = j
+        else:
+            res.append(ch); i += 1
+    return "".join(res)
+
+
 def preprocess(text, defines=None, include_dir=None, _macros=None, _depth=0):
     """The compiler directives compact models use: `include (dropped -- constants.vams / disciplines.vams content is
     predefined), `define with or without arguments, `undef, `ifdef / `ifndef / `else / `elsif / `endif, and macro
@@ -94,7 +130,7 @@ def preprocess(text, defines=None, include_dir=None, _macros=None, _depth=0):
     if _depth > 20:
         raise VAError("`include nesting too deep")
     text = re.sub(r"\\\r?\n", " ", text)
-    text = re.sub(r"/\*.*?\*/", lambda m: "\n" * m.group(0).count("\n"), text, flags=re.S)   # block comments (keep line numbers)
+    text = _strip_block_comments(text)
     out, stack = [], []          # stack of [taking, any branch taken so far]
 
     def expand(line, depth=0):
@@ -106,7 +142,7 @@ def preprocess(text, defines=None, include_dir=None, _macros=None, _depth=0):
         while i < len(line):
             ch = line[i]
             if ch == '"':                                    # strings are opaque
-                j = line.index('"', i + 1) if '"' in line[i + 1:] else len(line) - 1
+                j = _string_end(line, i)
                 res.append(line[i:j + 1]); i = j + 1
                 continue
             if ch == "/" and line[i:i + 2] == "//":
@@ -133,7 +169,7 @@ def preprocess(text, defines=None, include_dir=None, _macros=None, _depth=0):
                         raise VAError("unterminated argument list of `%s" % name)
                     c = line[j]
                     if c == '"':                                   # a string argument may hold commas and parentheses
-                        k = line.index('"', j + 1) if '"' in line[j + 1:] else len(line) - 1
+                        k = _string_end(line, j)
                         cur.append(line[j:k + 1]); j = k + 1
                         continue
                     if c in "([{":

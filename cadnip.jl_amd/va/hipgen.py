@@ -9,6 +9,7 @@ are the hand-written ``va_emit_branch`` in devices.hpp.
 
     python -m cadnip_jl_amd.va.hipgen  model1.va model2.va ...  > csrc/va_generated.hpp      (csrc/build.sh does this)
 """
+import os
 import sys
 
 from .frontend import VAError, parse_file, parse_module
@@ -185,7 +186,15 @@ class _Gen:
                 if not self.func and bool(m.var_is_dual.get(ex[1], False)) != dual:
                     raise VAError("%s: %s: output argument %s is %s, the call is %s" % (m.name, fname, ex[1],
                                   "a dual" if m.var_is_dual.get(ex[1]) else "a plain number", "on duals" if dual else "on plain numbers"))
-                parts.append(a[0])
+                if self.phase == "eval" and not self.func and ex[1] in m.hoist_vars:
+                    # the variable belongs to the setup pass (read here through the per-device cache, not assignable): the call writes
+                    # the same bias-independent value the setup pass already left there, into a scratch copy
+                    self.n_scratch = getattr(self, "n_scratch", 0) + 1
+                    nm = "t_out%d" % self.n_scratch
+                    self.pre.append("double %s = %s;" % (nm, a[0] if ex[1] in m.cache_vars else "0.0"))
+                    parts.append(nm)
+                else:
+                    parts.append(a[0])
         return "%s<%s>(%s)" % (self.fname(fname), ty, ", ".join(parts + ["sys"])), dual, None
 
     def stmts(self, body, ind):
@@ -454,7 +463,7 @@ def generate_header(modules):
     out = ["// GENERATED by cadnip.jl_amd/va/hipgen.py from the Verilog-A sources listed below -- do not edit.",
            "// Included by devices.hpp (device code) and api.hip (shape table).", "#pragma once", ""]
     out.append("#define CADNIP_VA_NBUILTIN %d" % len(modules))
-    out.append('#include "va_generated_ext.hpp"   // CADNIP_VA_NEXT, CADNIP_VA_EXT_DISPATCH_TL, CADNIP_VA_EXT_SHAPES (+ device code under CADNIP_VA_WITH_EXT)')
+    out.append('#include "va_generated_ext.hpp"   // CADNIP_VA_NEXT, CADNIP_VA_EXT_LIST, CADNIP_VA_EXT_SHAPES: the external models (device code: va_ext/<module>.hip)')
     out.append("#ifdef CADNIP_VA_DEVICE_CODE   // set by va_runtime.hpp (device translation units); api.hip takes the shape table only")
     out.append("namespace cadnip {")
     for m in modules:
@@ -469,24 +478,6 @@ def generate_header(modules):
     out.append("    default: break;")
     out.append("  }")
     out.append("}")
-    out.append("#ifdef CADNIP_VA_WITH_EXT   // only the per-op stamping kernel carries the large external models (stamp_csr.hip)")
-    out.append("// external models: the bias-independent statements, once per parameter set (one thread per device)")
-    out.append("template <class Ctx>")
-    out.append("__device__ inline void setup_va(const Ctx& d, double* cache, const int stride) {")
-    out.append("  switch (d.ipar[0 * d.count + d.dev]) {")
-    out.append("    CADNIP_VA_EXT_DISPATCH_SETUP")
-    out.append("    default: break;")
-    out.append("  }")
-    out.append("}")
-    out.append("// external models: lane `dir` of the device's 16-lane group computes the partial of direction `dir`")
-    out.append("template <class Ctx, class Out>")
-    out.append("__device__ inline void stamp_va_tl(const Ctx& d, const double* u, const Out& s, double* lw, const int dir) {")
-    out.append("  switch (d.ipar[0 * d.count + d.dev]) {")
-    out.append("    CADNIP_VA_EXT_DISPATCH_TL")
-    out.append("    default: break;")
-    out.append("  }")
-    out.append("}")
-    out.append("#endif")
     out.append("}  // namespace cadnip")
     out.append("#endif")
     out.append("")
@@ -501,39 +492,64 @@ def generate_header(modules):
 
 
 def generate_ext_header(modules):
-    """va_generated_ext.hpp: the stamp functions of the external models (the reference's PSP103: its source is third-party
-    text inside the reference and is not copied -- this generated header is what the repository keeps, regenerated by
-    csrc/build.sh whenever the source is present).  Device code only under CADNIP_VA_WITH_EXT: these functions are thousands of
-    statements long and belong to the per-op stamping kernel only; circuits that use them never run in the fused kernel."""
+    """va_generated_ext.hpp: the table of the external models (the reference's own model files: their sources are third-party text
+    inside the reference and are not copied -- what the repository keeps is generated: this table and one translation unit per model,
+    generate_ext_unit, regenerated by csrc/build.sh whenever the sources are present).  Model ids follow the built-in ones."""
     out = ["// GENERATED by cadnip.jl_amd/va/hipgen.py from %s -- do not edit." % (", ".join(m.name for m in modules) or "(no external model)"),
            "// Included by va_generated.hpp.", "#pragma once", ""]
     out.append("#define CADNIP_VA_NEXT %d" % len(modules))
+    out.append("#define CADNIP_VA_EXT_LIST(X) " + " ".join("X(%d, %s)" % (i, m.name) for i, m in enumerate(modules)))
     out.append("#define CADNIP_VA_EXT_SHAPES " + " ".join('{"%s", %d, %d, %d, %d, %d, %d},' % ((m.name,) + m.shape()) for m in modules))
     out.append("// evaluated with one derivative direction per lane, 16 or 32 lanes per device (va_runtime.hpp: tangent lanes)")
     out.append("#define CADNIP_VA_EXT_TL_LANES " + " ".join("%d," % tl_lanes(m) for m in modules))
-    out.append("#define CADNIP_VA_EXT_DISPATCH_TL " + " ".join("case CADNIP_VA_NBUILTIN + %d: stamp_va_%s_tl(d, u, s, lw, dir); break;" % (i, m.name) for i, m in enumerate(modules)))
     out.append("// doubles per device that the setup pass leaves for the per-call code (VAModule.cache_vars)")
     out.append("#define CADNIP_VA_EXT_NCACHE " + " ".join("%d," % len(m.cache_vars) for m in modules))
-    out.append("#define CADNIP_VA_EXT_DISPATCH_SETUP " + " ".join("case CADNIP_VA_NBUILTIN + %d: setup_va_%s(d, cache, stride); break;" % (i, m.name) for i, m in enumerate(modules)))
-    out.append("#if defined(CADNIP_VA_DEVICE_CODE) && defined(CADNIP_VA_WITH_EXT)")
-    out.append("namespace cadnip {")
-    for m in modules:
-        if m.functions:
-            out.append(generate_analog_functions(m))
-        out.append(generate_setup(m))
-        out.append("")
-        out.append(generate_function(m, tl=True, with_functions=False))
-        out.append("")
-    out.append("}  // namespace cadnip")
-    out.append("#endif")
     return "\n".join(out) + "\n"
 
 
+def generate_ext_unit(m):
+    """va_ext/<module>.hip: the device code of one external model -- its analog functions, its setup pass, its tangent-lane stamp
+    function -- with the model's own instantiation of the per-op stamping kernel and of the setup kernel (stamp_csr_kernel.hpp).  These
+    functions are thousands of statements long: a kernel per model keeps each one's register budget and compile time its own; circuits
+    that use them never run in the fused kernel."""
+    out = ["// GENERATED by cadnip.jl_amd/va/hipgen.py from the Verilog-A source of %s -- do not edit." % m.name,
+           '#include "../stamp_csr_kernel.hpp"', "", "namespace cadnip {"]
+    if m.functions:
+        out.append(generate_analog_functions(m))
+    out.append(generate_setup(m))
+    out.append("")
+    out.append(generate_function(m, tl=True, with_functions=False))
+    out.append("")
+    out.append("struct VaExt_%s {" % m.name)
+    out.append("  template <class Ctx, class Out> static __device__ __forceinline__ void stamp(const Ctx& d, const double* u, const Out& s, double* lw, const int dir) { stamp_va_%s_tl(d, u, s, lw, dir); }" % m.name)
+    out.append("  template <class Ctx> static __device__ __forceinline__ void setup(const Ctx& d, double* cache, const int stride) { setup_va_%s(d, cache, stride); }" % m.name)
+    out.append("};")
+    out.append("int va_ext_stamp_launch_%s(const CsrStampArgs& a, unsigned grid, size_t shmem, hipStream_t stream) { return launch_stamp_kernel<CADNIP_DEV_VA, VaExt_%s>(a, grid, shmem, stream); }" % (m.name, m.name))
+    out.append("int va_ext_setup_launch_%s(const VaSetupArgs& a, hipStream_t stream) { return launch_va_setup_kernel<VaExt_%s>(a, stream); }" % (m.name, m.name))
+    out.append("}  // namespace cadnip")
+    return "\n".join(out) + "\n"
+
+
+def _write_if_changed(path, text):
+    if not os.path.exists(path) or open(path).read() != text:
+        with open(path, "w") as f:
+            f.write(text)
+
+
 def main(argv):
-    """hipgen.py a.va b.va ...        -> va_generated.hpp on stdout
-       hipgen.py --ext x.va y.va ...  -> va_generated_ext.hpp on stdout"""
+    """hipgen.py a.va b.va ...                 -> va_generated.hpp on stdout
+       hipgen.py --ext DIR x.va y.va ...       -> va_generated_ext.hpp on stdout, DIR/<module>.hip per model (rewritten only when changed;
+                                                  units of models no longer listed are removed)"""
     if argv and argv[0] == "--ext":
-        sys.stdout.write(generate_ext_header([parse_file(fn) for fn in argv[1:]]))
+        d = argv[1]
+        mods = [parse_file(fn) for fn in argv[2:]]
+        os.makedirs(d, exist_ok=True)
+        for m in mods:
+            _write_if_changed(os.path.join(d, m.name + ".hip"), generate_ext_unit(m))
+        for fn in os.listdir(d):
+            if fn.endswith(".hip") and fn[:-4] not in [m.name for m in mods]:
+                os.remove(os.path.join(d, fn))
+        sys.stdout.write(generate_ext_header(mods))
         return
     mods = [parse_file(fn) for fn in argv]
     sys.stdout.write(generate_header(mods))

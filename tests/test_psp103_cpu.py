@@ -34,15 +34,16 @@ def test_ring_fixture_carries_the_reference_layout():
 
 
 @needs_source
-@pytest.mark.parametrize("name", ["nmos_defaults", "nmos_card", "ring", "bsim4_nmos", "bsim4_dff"])
+@pytest.mark.parametrize("name", ["nmos_defaults", "nmos_card", "ring", "bsim4_nmos", "bsim4_dff", "resistor", "capacitor", "diode", "diode_rs", "bjt",
+                                  "jfet1", "mes1", "jfet2", "mos1", "mos2", "mos3", "mos6", "mos9", "bsim3v3", "bsim4v8"])
 def test_committed_fixtures_are_current(name):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_psp103_fixtures as mk
     st, extra = mk.build(name)
-    st0, x0 = S.load_structure(os.path.join(GOLD, "%s%s.npz" % ("" if name.startswith("bsim4") else "psp103_", name)))
+    st0, x0 = S.load_structure(mk.fixture_path(name))
     assert st.signature() == st0.signature()
-    for k in ("U", "G", "C", "b"):
-        assert np.array_equal(extra[k], x0[k]), k
+    for k in ("U", "G", "C", "b") + (("dc_x", "dc_ok") if "dc_ok" in extra else ()):
+        assert np.array_equal(extra[k], x0[k], equal_nan=True), k
     for i in range(int(x0["n_packed"][0])):
         assert np.array_equal(extra["packed%d" % i], x0["packed%d" % i])
 
@@ -60,14 +61,26 @@ def test_oracle_passes_the_reference_psp103_dc_tests():
 
 
 @needs_source
-def test_generated_external_header_is_current():
-    """csrc/va_generated_ext.hpp (committed: the library must build where the model source is absent) is what the generator
-    writes from the source today."""
+def test_generated_external_sources_are_current():
+    """csrc/va_generated_ext.hpp and csrc/va_ext/<module>.hip (committed: the library must build where the model sources are absent) are
+    what the generator writes from the sources today."""
     from cadnip_jl_amd.va import hipgen, frontend
     mods = [frontend.parse_file(va.external_source(fn, sd)) for _, fn, sd in va.EXTERNAL]
-    want = hipgen.generate_ext_header(mods)
-    have = open(os.path.join(ROOT, "cadnip.jl_amd", "csrc", "va_generated_ext.hpp")).read()
-    assert have == want
+    csrc = os.path.join(ROOT, "cadnip.jl_amd", "csrc")
+    assert open(os.path.join(csrc, "va_generated_ext.hpp")).read() == hipgen.generate_ext_header(mods)
+    assert sorted(os.listdir(os.path.join(csrc, "va_ext"))) == sorted(m.name + ".hip" for m in mods)
+    for m in mods:
+        assert open(os.path.join(csrc, "va_ext", m.name + ".hip")).read() == hipgen.generate_ext_unit(m), m.name
+
+
+def test_tier6_fixtures_carry_the_reference_windows():
+    """test/mna/vadistiller_integration.jl Tier 6: the oracle's DC solution of every circuit lies in the window the reference asserts."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_psp103_fixtures as mk
+    for name, (_, probe, lo, hi) in mk.TIER6.items():
+        st, x = S.load_structure(mk.fixture_path(name))
+        assert lo < x["dc_x"][st.index_of(probe)] < hi, name
+        assert bool(x["dc_ok"][0]) == (name not in ("mos3", "mos9")), name
 
 
 def test_bsim4_dff_fixture_layout():

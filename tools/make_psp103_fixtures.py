@@ -63,11 +63,42 @@ Vgs g 0 DC 0.8
 """
 
 
+# test/mna/vadistiller_integration.jl:185-775 ("Tier 6: Full VADistiller Models (from file)"): one small DC circuit per model of
+# models/VADistillerModels.jl, with the bounds the reference asserts on the solution.  name -> (deck, probe net, lower, upper)
+def _stage(vdd, vg, rd, inst):
+    return "Vdd vdd 0 DC %s\nVg gate 0 DC %s\nRd vdd drain %s\n%s\n" % (vdd, vg, rd, inst)
+
+
+TIER6 = {
+    "resistor": ("* sp_resistor divider (:191-213)\nV1 vcc 0 DC 5\nX1 vcc mid sp_resistor resistance=1000\nX2 mid 0 sp_resistor resistance=1000\n", "mid", 2.5 - 1e-9, 2.5 + 1e-9),
+    "capacitor": ("* sp_capacitor DC (:215-238)\nV1 vcc 0 DC 5\nR1 vcc mid 1k\nX1 mid 0 sp_capacitor capacitance=1u\n", "mid", 5.0 - 1e-6, 5.0 + 1e-6),
+    "diode": ("* sp_diode (:268-283)\nV1 vcc 0 DC 1\nR1 vcc diode_a 1k\nX1 diode_a 0 sp_diode\n", "diode_a", 0.6, 0.7),
+    "diode_rs": ("* sp_diode with series resistance (:322-346)\nV1 vcc 0 DC 1\nR1 vcc diode_a 1k\nX1 diode_a 0 sp_diode rs=10\n", "diode_a", 0.6, 0.71),
+    "bjt": ("* sp_bjt (:375-398)\nV1 vcc 0 DC 5\nV2 vb 0 DC 0.7\nRb vb base 10k\nRc vcc collector 1k\nXq collector base 0 0 sp_bjt bf=100 is=1e-15\n", "collector", 0.0, 5.0),
+    "jfet1": ("* sp_jfet1 (:427-447)\n" + _stage(10, 0, "1k", "Xj drain gate 0 sp_jfet1 vt0=-2 beta=1m"), "drain", 0.0, 10.0),
+    "mes1": ("* sp_mes1 (:449-469)\n" + _stage(5, 0, 500, "Xj drain gate 0 sp_mes1 vt0=-1 beta=2.5m"), "drain", 0.0, 5.0),
+    "jfet2": ("* sp_jfet2 (:471-491)\n" + _stage(10, 0, "1k", "Xj drain gate 0 sp_jfet2 vto=-2 beta=1m"), "drain", 0.0, 10.0),
+    "mos1": ("* sp_mos1 (:498-518)\n" + _stage(5, 2, "1k", "Xm drain gate 0 0 sp_mos1 l=1u w=10u vto=0.7 kp=1e-4"), "drain", 0.0, 5.0),
+    "mos2": ("* sp_mos2 (:520-540)\n" + _stage(5, 2, "1k", "Xm drain gate 0 0 sp_mos2 l=1u w=10u vto=0.7 kp=1e-4"), "drain", 0.0, 5.0),
+    "mos3": ("* sp_mos3 (:542-562)\n" + _stage(5, 2, "1k", "Xm drain gate 0 0 sp_mos3 l=1u w=10u vto=0.7 kp=1e-4"), "drain", 0.0, 5.0),
+    "mos6": ("* sp_mos6 (:564-584)\n" + _stage(5, 2, "1k", "Xm drain gate 0 0 sp_mos6 l=1u w=10u vto=0.7 u0=600 tox=10n"), "drain", 0.0, 5.0),
+    "mos9": ("* sp_mos9 (:586-606)\n" + _stage(5, 2, "1k", "Xm drain gate 0 0 sp_mos9 l=1u w=10u vto=0.7 kp=1e-4"), "drain", 0.0, 5.0),
+    "bsim3v3": ("* sp_bsim3v3 (:716-742)\n" + _stage(1.8, 1.0, "1k", "Xm drain gate 0 0 sp_bsim3v3 l=100n w=1u"), "drain", 0.0, 1.8),
+    "bsim4v8": ("* sp_bsim4v8 (:756-775)\n" + _stage(1.0, 0.5, "1k", "Xm drain gate 0 0 sp_bsim4v8 l=100n w=1u"), "drain", 0.9, 1.0),
+}
+
+
+def fixture_path(name):
+    return os.path.join(GOLD, "%s%s.npz" % ("" if name.startswith("bsim4_") else "vad_" if name in TIER6 else "psp103_", name))
+
+
 def cases():
     """name -> (deck text or Circuit, includes, mode)"""
     from cadnip_jl_amd import benchmarks as bm
-    return {"nmos_defaults": (NMOS_DEFAULTS, {}, "dcop"), "nmos_card": (NMOS_CARD, {}, "dcop"), "ring": ring_deck() + ("tran",),
-            "bsim4_nmos": (BSIM4_NMOS, {}, "dcop"), "bsim4_dff": (bm.dff_circuit_bsim4(vdd=1.8), {}, "tran")}
+    out = {"nmos_defaults": (NMOS_DEFAULTS, {}, "dcop"), "nmos_card": (NMOS_CARD, {}, "dcop"), "ring": ring_deck() + ("tran",),
+           "bsim4_nmos": (BSIM4_NMOS, {}, "dcop"), "bsim4_dff": (bm.dff_circuit_bsim4(vdd=1.8), {}, "tran")}
+    out.update({k: (v[0], {}, "dcop") for k, v in TIER6.items()})
+    return out
 
 
 def states(st, K, seed, vmax):
@@ -95,6 +126,9 @@ def build(name, K=5):
     assert (st.n, st.node_names, st.current_names, st.charge_names) == (cs.n, ctx.node_names, ctx.current_names, ctx.charge_names)
     assert np.array_equal(st.ref_colptr, cs.colptr) and np.array_equal(st.ref_rowval, cs.rowval)
     U = states(st, K, 20261004, 1.8 if name == "bsim4_dff" else 1.2)
+    if name in TIER6:                       # (volts of the circuit's own scale; limit unknowns near their probes)
+        U = states(st, K, 20261004, 2.0)
+        U[1:, st.n - st.n_limits:] = np.random.default_rng(7).random((K - 1, st.n_limits)) * 1.4 - 0.2
     T = np.array([0.0, 0.0, 1.5e-9, 3e-9, 7e-9][:K])
     Gs, Cs, bs = [], [], []
     for u, t in zip(U, T):
@@ -106,15 +140,18 @@ def build(name, K=5):
         extra["packed%d" % i] = p
     if mode == "dcop":
         sol = M.solve_dc(bld, {}, spec)
-        assert sol.converged
+        # (the reference's solve_dc returns whatever its fallback chain ends with; its Tier 6 tests assert bounds, not convergence: sp_mos3 (and sp_mos9, the same equations)
+        # on its default card takes sqrt(0 * dual) in saturation -- a NaN partial under ForwardDiff -- and ends unconverged there too)
+        assert sol.converged or name in ("mos3", "mos9"), name
         extra["dc_x"] = np.asarray(sol.x, dtype=float)
+        extra["dc_ok"] = np.array([1 if sol.converged else 0])
     return st, extra
 
 
 def main():
-    for name in cases():
+    for name in (sys.argv[1:] or cases()):
         st, extra = build(name)
-        path = os.path.join(GOLD, "%s%s.npz" % ("" if name.startswith("bsim4") else "psp103_", name))
+        path = fixture_path(name)
         S.save_structure(st, path, **extra)
         print("%-14s n = %d (nodes %d, currents %d, charges %d)  nnz %d  ->  %s (%.1f KB)" % (
             name, st.n, st.n_nodes, st.n_currents, st.n_charges, st.nnz, os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
