@@ -23,13 +23,16 @@ TIER6 = {"resistor": ("mid", 2.5 - 1e-9, 2.5 + 1e-9), "capacitor": ("mid", 5.0 -
          "mos6": ("drain", 0.0, 5.0), "mos9": ("drain", 0.0, 5.0), "bsim3v3": ("drain", 0.0, 1.8), "bsim4v8": ("drain", 0.9, 1.0)}
 
 
+OTHER = ("bsimcmg_nmos", "juncap200")     # models/CMCModels.jl (BSIM-CMG), JUNCAP200 of models/PSPModels.jl: pinned by the oracle's interpreter alone
+
+
 def _sim(name):
-    st, x = S.load_structure(os.path.join(GOLD, "vad_%s.npz" % name))
+    st, x = S.load_structure(os.path.join(GOLD, "%s_%s.npz" % ("va" if name in OTHER else "vad", name)))
     packed = [x["packed%d" % i] for i in range(int(x["n_packed"][0]))]
     return st, x, api.BatchSimulator.from_packed(st, packed, api.MNASpec(mode="dcop", temp=27.0), vscale=2.0)
 
 
-@pytest.mark.parametrize("name", sorted(TIER6))
+@pytest.mark.parametrize("name", sorted(TIER6) + list(OTHER))
 def test_stamps_match_the_oracle(name):
     st, x, sim = _sim(name)
     h = sim.h
@@ -86,3 +89,17 @@ def test_diode_series_resistance_keeps_its_internal_node():
     assert 0.6 < vi < 0.7 and 0.0 < va - vi < 0.01
     st0, _ = S.load_structure(os.path.join(GOLD, "vad_diode.npz"))
     assert st0.n_nodes == 2 and st0.n_limits == 1
+
+
+@pytest.mark.parametrize("name", OTHER)
+def test_other_model_packages_dc(name):
+    """BSIM-CMG (one fin, default card, Vgs = 0.6, Vds = 0.8) and a JUNCAP200 diode behind 100 Ohm: the GPU's DC solve equals the oracle's."""
+    st, x, sim = _sim(name)
+    u, conv, stats = sim.dc(abstol=1e-10, mode="dcop")
+    sim.close()
+    assert conv[0] and bool(x["dc_ok"][0]), stats
+    nn = st.n_nodes + st.n_currents
+    ref = x["dc_x"]
+    assert np.max(np.abs(u[0, :nn] - ref[:nn]) / np.maximum(np.abs(ref[:nn]), 1e-3)) < 1e-8
+    if name == "bsimcmg_nmos":
+        assert 1e-6 < abs(u[0, st.index_of("I_Vds")]) < 1e-4
