@@ -166,6 +166,30 @@ __device__ __forceinline__ void va_emit_short(const double* u, const Out& s, con
   }
 }
 
+// A potential contribution with a value.  Two-node form V(p,n) <+ X (vasim.jl:2340-2393, 3780-3812): KCL columns, the constraint row
+// G[I,p] = 1, G[I,n] = -1, G[I,k] = -dX/dV_k in every node column, b[I] = X - sum_k dX/dV_k V_k.  Per-op path only.
+__device__ __forceinline__ double va_probe_current(const double* u, int node, bool on) { return on && node >= 0 ? u[node] : 0.0; }
+template <int N, int W, class Out>
+__device__ __forceinline__ void va_emit_vcontrib(const Out& s, const double (&Vf)[N], int g0, int bk, bool on, const Dual<W>& X) {
+  static_assert(!Out::DIRECT, "potential contributions with a value exist on the per-op path only");
+  if (!on) return;
+  s.G(g0, 1.0); s.G(g0 + 1, -1.0); s.G(g0 + 2, 1.0); s.G(g0 + 3, -1.0);
+  double beq = X.v;
+#pragma unroll
+  for (int k = 0; k < N; ++k) { s.G(g0 + 4 + k, -X.p[k]); beq -= X.p[k] * Vf[k]; }
+  s.B(bk, beq);
+}
+// Named branch V(br) <+ X at the top level of the analog block (vasim.jl:3669-3746): no partials -- b[I] = the resistive value,
+// C[I,I] = -(the value under ddt()) when there is one.
+template <class Out>
+__device__ __forceinline__ void va_emit_vnamed(const Out& s, int g0, int bk, int ck, bool on, double val, double react) {
+  static_assert(!Out::DIRECT, "potential contributions with a value exist on the per-op path only");
+  if (!on) return;
+  s.G(g0, 1.0); s.G(g0 + 1, -1.0); s.G(g0 + 2, 1.0); s.G(g0 + 3, -1.0);
+  s.B(bk, val);
+  if (ck >= 0) s.C(ck, -react);
+}
+
 // One branch (p, n) of a generated module: I = resistive current (value + d/dV_k), Q = charge (value + d/dV_k), both
 // already scaled by the multiplicity factor.  Slot layout: VAModule.shape / .program (cadnip.jl_amd/va/frontend.py).
 // Both reactive forms are written; the circuit's pattern holds the one the host's voltage-dependence detection chose, the
@@ -248,6 +272,16 @@ template <int LANES> __device__ __forceinline__ double va_group_sum(double v) {
   v += dpp_row_f64<0x140>(v);   // row_mirror
   if (LANES == 32) v += __shfl_xor(v, 16);
   return v;
+}
+
+// two-node potential contribution on tangent lanes: wgt_node = -V_dir for a node direction, 0 otherwise (the constraint row takes the node
+// partials only, vasim.jl:3795-3810); every lane of the device's group takes part in the sum
+template <int N, int LANES, class Out>
+__device__ __forceinline__ void va_emit_vcontrib_tl(const Out& s, int g0, int bk, bool on, const Dual<1>& X, double wgt_node, int dir) {
+  const double beq = X.v + va_group_sum<LANES>(X.p[0] * wgt_node);
+  if (!on) return;
+  if (dir == 0) { s.G(g0, 1.0); s.G(g0 + 1, -1.0); s.G(g0 + 2, 1.0); s.G(g0 + 3, -1.0); s.B(bk, beq); }
+  if (dir < N) s.G(g0 + 4 + dir, -X.p[0]);
 }
 
 // wgt: this direction's weight in  X - sum_k dX/dV_k V_k + sum_j dX/dsite_j (V(probe_j) - w_j):  -V_dir for a node direction,

@@ -438,6 +438,22 @@ def va_instance(mod, dev, params):
     return hit
 
 
+def _shorts_connected(mod, shorts_on, nodes):
+    """``shorts_on`` of the instance's card, without the two-node potential contributions whose nets the CIRCUIT has already made one
+    unknown (both tied to ground, or to one net): the reference skips them (vasim.jl:2364, 3765 `if p_node != n_node`).  ``nodes``: the
+    instance's global unknowns, ports then internal nodes."""
+    out = list(shorts_on)
+    for j, si in enumerate(mod.vshorts):
+        if out[j] and mod.short_kind[si] != "named":
+            a, b = mod.shorts[si][0], mod.shorts[si][1]
+            if nodes[a] == (nodes[b] if b >= 0 else GND):
+                if mod.short_kind[si] == "top":
+                    raise ValueError("%s: V(%s,%s) <+ ... at the top level of the analog block joins two nets the circuit has already made one" % (
+                        mod.name, mod.nodes[a], mod.nodes[b] if b >= 0 else "0"))
+                out[j] = False
+    return out
+
+
 def detect_va_vdep(circuit: Circuit, params: Dict[str, float], seed: int = 0xDEADBEEF):
     """Per Verilog-A module in the circuit: which reactive branches use a charge unknown.  Emulates the reference's
     detection run (build_with_detection, solve.jl:1793-1822) pass by pass: five builder passes, the first at x = 0, pass
@@ -482,7 +498,6 @@ def detect_va_vdep(circuit: Circuit, params: Dict[str, float], seed: int = 0xDEA
         elif ty.startswith("VA:"):
             mod = va.get(ty[3:])[1]
             _, alias, shorts_on, _ = va_instance(mod, d, params)
-            n_cur += sum(shorts_on)
             ext = [A.node(nm) for nm in d.nodes]
             loc = list(ext) + [None] * mod.n_internal
             for k in range(len(mod.ports), mod.n_nodes):
@@ -492,6 +507,7 @@ def detect_va_vdep(circuit: Circuit, params: Dict[str, float], seed: int = 0xDEA
                 if k in alias:
                     loc[k] = loc[alias[k]] if alias[k] >= 0 else A.node("0")       # V(a) <+ 0: the internal node is ground
             internal[d.name] = loc[len(mod.ports):]
+            n_cur += sum(_shorts_connected(mod, shorts_on, loc))
             n_lim += len(mod.limit_branches)
     n_nodes = len(A.node_names)
     rng = np.random.default_rng(seed)
@@ -538,7 +554,7 @@ def detect_va_vdep(circuit: Circuit, params: Dict[str, float], seed: int = 0xDEA
             for l in range(len(mod.limit_branches)):
                 lim_sf += 1
                 vold.append(xat(len(seen_nodes) + cur_sf + q_sf + lim_sf - 1))
-            cur_sf += sum(shorts_on)            # V(a,b) <+ 0 with a branch current: allocated while the body runs (vasim.jl:2365)
+            cur_sf += sum(_shorts_connected(mod, shorts_on, idx))   # potential contributions with a branch current (vasim.jl:2365, 3253-3280)
             mf = float(np.asarray(resolve(d.params["m"], params)).flat[0])
             vals = va.host_eval.evaluate(mod, V, par, 27.0 + 273.15, mf, 1e-12, vold=vold, given=set(d.model))
             flags, pos = [], 0
@@ -655,9 +671,9 @@ def discover(circuit: Circuit, params: Dict[str, float]) -> Structure:
                 nodes.append(A.charge(nm) if (mod.reactive[b] and vd[b]) else GND)
             for (p, n) in mod.limit_branches:      # one limit unknown per $limit probe branch, init 0 (vasim.jl:3110-3138)
                 nodes.append(A.limit("%s_%s_lim_%s_%s" % (dev.name, mod.name, mod.nodes[p] if p >= 0 else "0", mod.nodes[n] if n >= 0 else "0"), 0.0))
-            for j, si in enumerate(mod.vshorts):   # the branch current of an executed V(a,b) <+ 0 (vasim.jl:2365: I_V_<p>_<n>)
-                a_, b_ = mod.shorts[si][0], mod.shorts[si][1]
-                nodes.append(A.current("%s_I_V_%s_%s" % (dev.name, mod.nodes[a_], mod.nodes[b_] if b_ >= 0 else "0")) if shorts_on[j] else GND)
+            shorts_on = _shorts_connected(mod, shorts_on, nodes)
+            for j, si in enumerate(mod.vshorts):   # the branch current of an executed potential contribution (vasim.jl:2365: I_V_<p>_<n>; 3262, 3274)
+                nodes.append(A.current(mod.short_current_name(j, dev.name)) if shorts_on[j] else GND)
             ipar = [mid, sum((1 << b) for b in range(len(mod.branches)) if mod.reactive[b] and vd[b]), sum((1 << j) for j in range(len(mod.vshorts)) if shorts_on[j])]
             prog = mod.program(vd, active, shorts_on)
         d_in_block = len(per_type[ty])

@@ -61,6 +61,8 @@ FUNCS = {"exp": 1, "ln": 1, "log": 1, "sqrt": 1, "pow": 2, "abs": 1, "min": 2, "
          "cosh": 1, "sin": 1, "cos": 1, "atan": 1, "tan": 1, "asin": 1, "acos": 1, "atan2": 2, "hypot": 2, "asinh": 1, "acosh": 1,
          "atanh": 1, "floor": 1, "ceil": 1, "int": 1}
 NOISE_FUNCS = ("white_noise", "flicker_noise", "noise_table")
+POTENTIAL_ACCESS = ("V", "Temp")        # access functions of the electrical and thermal disciplines (disciplines.vams): potential ...
+FLOW_ACCESS = ("I", "Pwr")              # ... and flow
 SILENT_TASKS = ("$warning", "$strobe", "$display", "$write", "$debug", "$info", "$discontinuity", "$bound_step", "$finish", "$monitor")
 FATAL_TASKS = ("$error", "$fatal")
 # constants.vams (Verilog-AMS LRM 2.4 annex D): the macros compact models take from the standard include
@@ -292,6 +294,9 @@ class VAModule:
     limit_branches: List[Tuple[int, int]] = field(default_factory=list)   # probe branches of the $limit sites, first-use order
     limit_sites: List[int] = field(default_factory=list)              # per $limit call site (evaluation order): its limit branch
     shorts: List[tuple] = field(default_factory=list)                 # V(a,b) <+ 0: (a, b, [(static condition, wanted truth)])
+    short_kind: List[str] = field(default_factory=list)               # per `shorts` entry: "named" (V(br) <+ ... at the top level of the analog block), "top"
+                                                                      # (two-node, top level), "cond" (inside parameter-decided conditionals)
+    short_reactive: List[bool] = field(default_factory=list)          # per `vshorts` entry: the value carries ddt() (named branches only)
     vshorts: List[int] = field(default_factory=list)                  # indices into `shorts` of the statements that are NOT a node alias: a short
                                                                       # that executes owns a branch-current unknown (see short_is_alias)
     branch_guarded: List[bool] = field(default_factory=list)          # per branch: every contribution sits under parameter-decided conditions only
@@ -325,6 +330,9 @@ class VAModule:
         (internal net to ground) keeps this build's alias-to-ground treatment."""
         a, b, guards = self.shorts[i][:3]
         np_ = len(self.ports)
+        st = self.shorts[i][3]
+        if st[3] != ("num", 0.0) or st[4] is not None:
+            return False                    # a value, or a named branch: a branch with its own current (vasim.jl:3253-3280)
         if b < 0:
             return a >= np_                 # an internal net to ground is merged into ground; a terminal to ground carries a current
         return len(guards) == 1 and guards[0][1] is True and ((a >= np_) != (b >= np_))
@@ -357,8 +365,31 @@ class VAModule:
             n_par += len(self.params)       # + one $param_given flag per parameter
         n_par += len(self.string_tests)     # + one flag per (string parameter == literal) test
         NV = len(self.vshorts)
-        # short currents: local unknown N + B + L + j;  G slots g_short(j) + {0: (p,I), 1: (n,I), 2: (I,p), 3: (I,n), 4 + k: (I,k)};  b slot 3B + j
-        return (N + B + L + NV, 2 * N * B + (N + 1) * B + 3 * L + (4 + N) * NV, 2 * B + 2 * N * B, 3 * B + NV, n_par, 3)
+        # short currents: local unknown N + B + L + j;  G slots g_short(j) + {0: (p,I), 1: (n,I), 2: (I,p), 3: (I,n), 4 + k: (I,k)};  b slot 3B + j;
+        # C slot c_short(j) = (I,I) for the named branches whose value carries ddt()
+        return (N + B + L + NV, 2 * N * B + (N + 1) * B + 3 * L + (4 + N) * NV, 2 * B + 2 * N * B + sum(self.short_reactive), 3 * B + NV, n_par, 3)
+
+    def c_short(self, j):
+        N, B = self.n_nodes, len(self.branches)
+        return 2 * B + 2 * N * B + sum(self.short_reactive[:j])
+
+    def probe_short(self, e):
+        """``I(br)`` / ``I(a,b)`` in an expression: the index into `vshorts` of the potential contribution whose current it reads, or
+        None (a branch that carries noise only: zero on the DC / transient path)"""
+        for j, si in enumerate(self.vshorts):
+            st = self.shorts[si][3]
+            if (e[3] is not None and st[4] == e[3]) or (e[3] is None and st[4] is None and (st[1], st[2]) == (e[1], e[2])):
+                return j
+        return None
+
+    def short_current_name(self, j, instance):
+        """name of the branch-current unknown of `vshorts` entry j (alloc_current! base names: vasim.jl:3262, 3274, 2336)"""
+        a, b = self.shorts[self.vshorts[j]][0], self.shorts[self.vshorts[j]][1]
+        kind, st = self.short_kind[self.vshorts[j]], self.shorts[self.vshorts[j]][3]
+        pn = "%s_%s" % (self.nodes[a], self.nodes[b] if b >= 0 else "0")
+        if kind == "named":
+            return "%s_%s_I_%s" % (instance, self.name, st[4])
+        return "%s_%s_I_V_%s" % (instance, self.name, pn) if kind == "top" else "%s_I_V_%s" % (instance, pn)
 
     def g_short(self, j):
         N, B, L = self.n_nodes, len(self.branches), len(self.limit_branches)
@@ -376,11 +407,11 @@ class VAModule:
                 prog.append(("G", g0 + 1, ul, p))
             if n >= 0:
                 prog.append(("G", g0 + 2, ul, n))
-        # executed V(a,b) <+ 0 statements with a branch current (vasim.jl:2363-2393: stamped where the statement stands, i.e.
-        # while the body runs, before the collected branches): KCL columns, the constraint row with its (zero) partials, b
-        for j, si in enumerate(self.vshorts):
-            if shorts_on is None or not shorts_on[j]:
-                continue
+        # executed potential contributions with a branch current.  Inside conditionals (vasim.jl:2363-2393) they are stamped where the
+        # statement stands, i.e. while the body runs, before the collected branches: KCL columns, the constraint row with its partials, b.
+        # At the top level of the analog block they follow the branches: named branches first (vasim.jl:3669-3746: no partials; C[I,I]
+        # when the value carries ddt()), then the two-node ones (vasim.jl:3750-3815)
+        def short_stamps(j, si):
             p, n = self.shorts[si][0], self.shorts[si][1]
             ui, g0 = N + B + len(self.limit_branches) + j, self.g_short(j)
             if p >= 0:
@@ -391,9 +422,15 @@ class VAModule:
                 prog.append(("G", g0 + 2, ui, p))
             if n >= 0:
                 prog.append(("G", g0 + 3, ui, n))
-            for k in range(N):
-                prog.append(("G", g0 + 4 + k, ui, k))
+            if self.short_kind[si] != "named":
+                for k in range(N):
+                    prog.append(("G", g0 + 4 + k, ui, k))
             prog.append(("b", 3 * B + j, ui, None))
+            if self.short_reactive[j]:
+                prog.append(("C", self.c_short(j), ui, ui))
+        for j, si in enumerate(self.vshorts):
+            if self.short_kind[si] == "cond" and shorts_on is not None and shorts_on[j]:
+                short_stamps(j, si)
         for b, (p, n) in enumerate(self.branches):
             if active is not None and not active[b]:
                 continue          # every contribution of the branch sits in a conditional this instance does not take (inline stamps, vasim.jl:2397-2470)
@@ -423,6 +460,10 @@ class VAModule:
                 prog.append(("b", 3 * b, p, None))
             if n >= 0:
                 prog.append(("b", 3 * b + 1, n, None))
+        for kind in ("named", "top"):
+            for j, si in enumerate(self.vshorts):
+                if self.short_kind[si] == kind and shorts_on is not None and shorts_on[j]:
+                    short_stamps(j, si)
         return prog
 
 
@@ -563,20 +604,21 @@ class _Parser:
                     raise VAError("unterminated %s(" % v)
                 depth += (t[1] == "(") - (t[1] == ")")
             return ("noise", v)
-        if v == "V" and self.peek()[1] == "(":
+        if v in POTENTIAL_ACCESS and self.peek()[1] == "(":
             self.next()
             a, b = self.probe_nets()
             return ("V", a, b)
-        if v == "I" and self.peek()[1] == "(":
+        if v in FLOW_ACCESS and self.peek()[1] == "(":
             self.next()
             if self.peek()[1] in self.named and self.peek(1)[1] == ")":
-                # the current of a NAMED branch: such branches (parallel helper branches of correlated-noise models) carry no
-                # potential contribution here, and the reference reads their current as 0.0 on the DC / transient path
-                # (vasim.jl:3641-3650)
-                self.next(); self.next()
-                return ("num", 0.0)
+                # the current of a NAMED branch: the branch-current unknown when the branch carries a potential contribution
+                # V(br) <+ ... (vasim.jl:3632-3640), else -- parallel helper branches of correlated-noise models -- 0.0 on the DC /
+                # transient path (vasim.jl:3641-3650): decided in _analyse
+                br = self.next()[1]; self.next()
+                a, b = self.named[br]
+                return ("Iprobe", a, b, br)
             a, b = self.probe_nets()
-            return ("Iprobe", a, b)      # allowed for branches that carry noise only (their current is zero on this path): _analyse
+            return ("Iprobe", a, b, None)      # the current of a two-node potential contribution, or of a branch that carries noise only (zero): _analyse
         if v == "ddt":
             self.expect("(")
             e = self.expr()
@@ -706,20 +748,20 @@ class _Parser:
             if ev == "final_step":
                 return ("block", [])
             raise VAError("event controls other than @(initial_step) / @(final_step) are not supported")
-        if self.peek()[1] in ("I", "V") and self.peek(1)[1] == "(":
+        if (self.peek()[1] in FLOW_ACCESS or self.peek()[1] in POTENTIAL_ACCESS) and self.peek(1)[1] == "(":
             acc = self.next()[1]
             self.next()
+            br = self.peek()[1] if (self.peek()[1] in self.named and self.peek(1)[1] == ")") else None
             a, b = self.probe_nets()
             if self.peek()[1] == "<+":
                 self.next()
                 e = self.expr()
                 self.expect(";")
-                if acc == "V":
-                    # the one potential contribution compact models use: V(a,b) <+ 0 collapses an internal node onto its
-                    # neighbour when a series resistance is zero (vasim.jl:2313-2395, 3533-3564)
-                    if e != ("num", 0.0):
-                        raise VAError("potential contributions other than V(a,b) <+ 0 (node collapse) are not supported")
-                    return ("short", a, b)
+                if acc in POTENTIAL_ACCESS:
+                    # potential contribution.  V(a,b) <+ 0 collapses an internal node onto its neighbour when a series resistance is
+                    # zero (vasim.jl:2313-2395, 3533-3564); with a value -- or on a named branch -- it is a branch with its own
+                    # current unknown (vasim.jl:3253-3280, 3669-3815)
+                    return ("short", a, b, e, br)
                 return ("contrib", a, b, e)
             raise VAError("expected <+ after %s(%s...)" % (acc, a))
         kind, name = self.peek()
@@ -902,7 +944,7 @@ def _subexprs(s):
     k = s[0]
     if k == "assign":
         return [s[2]]
-    if k == "contrib":
+    if k in ("contrib", "short"):
         return [s[3]]
     if k == "if":
         return [s[1]]
@@ -928,7 +970,13 @@ def _analyse(m: VAModule):
         return idx[nm]
 
     names = set(m.params) | set(m.locals_)
-    probes = []          # branches whose current is read: must carry noise only
+    probes = []          # branches whose current is read: a potential contribution's own current, else they must carry noise only
+    # potential contributions that own a branch current whatever their value: on a named branch, or with a value other than 0
+    pot_named = {s[4] for s in _walk(m.body) if s[0] == "short" and s[4] is not None}
+    pot_pairs = {(node(s[1]), node(s[2])) for s in _walk(m.body) if s[0] == "short" and s[4] is None}
+
+    def probe_is_unknown(e):
+        return e[3] in pot_named if e[3] is not None else (node(e[1]), node(e[2])) in pot_pairs
 
     def check(e, names=names, in_func=False):
         k = e[0]
@@ -939,7 +987,7 @@ def _analyse(m: VAModule):
             check(e[1], names, in_func)
             return
         if k == "Iprobe":
-            probes.append((node(e[1]), node(e[2])))
+            probes.append((node(e[1]), node(e[2]), e[3]))
             return
         if k == "given":
             if e[1] not in m.params and e[1] not in m.aliasparams:
@@ -1016,8 +1064,10 @@ def _analyse(m: VAModule):
         k = e[0]
         if k in ("V", "ddt", "limit", "analysis", "ddx"):
             return True
-        if k in ("given", "num", "str", "noise", "Iprobe"):
+        if k in ("given", "num", "str", "noise"):
             return False
+        if k == "Iprobe":
+            return probe_is_unknown(e)          # a branch-current unknown is part of the solution
         if k == "var":
             return dyn.get(e[1], False)
         if k == "sys":
@@ -1085,28 +1135,39 @@ def _analyse(m: VAModule):
             return e[1] != "$simparam" or not (e[2] and e[2][0] == ("str", "initjct"))
         return all(is_static(a) for sub in e[1:] for a in (sub if isinstance(sub, list) else [sub]) if isinstance(a, tuple) and a and isinstance(a[0], str) and a[0] != "str")
 
-    def short_walk(stmts, guards):
+    def short_walk(stmts, guards, top):
         for s in stmts:
             if s[0] == "short":
                 a, b = node(s[1]), node(s[2])
                 if a < 0 or a == b:
-                    raise VAError("%s: V(%s,%s) <+ 0 must join two distinct nets of the module" % (m.name, s[1], s[2]))
+                    raise VAError("%s: V(%s,%s) <+ ... must join two distinct nets of the module" % (m.name, s[1], s[2]))
                 # (V(terminal) <+ 0 ties a terminal to ground: not an alias -- it owns a branch current like any other executed short)
                 for c, _ in guards:
                     if not is_static(c):
-                        raise VAError("%s: V(%s,%s) <+ 0 under a condition that is not decided by the parameters" % (m.name, s[1], s[2]))
+                        raise VAError("%s: V(%s,%s) <+ ... under a condition that is not decided by the parameters" % (m.name, s[1], s[2]))
+                if s[4] is not None and not top:
+                    raise VAError("%s: V(%s) <+ ... on a named branch inside a conditional is not supported" % (m.name, s[4]))
                 m.shorts.append((a, b, list(guards), s))
+                m.short_kind.append("named" if s[4] is not None else "top" if top else "cond")
             elif s[0] == "block":
-                short_walk(s[1], guards)
+                short_walk(s[1], guards, top)
             elif s[0] == "if":
-                short_walk([s[2]], guards + [(s[1], True)])
-                short_walk([s[3]], guards + [(s[1], False)])
+                short_walk([s[2]], guards + [(s[1], True)], False)
+                short_walk([s[3]], guards + [(s[1], False)], False)
             elif s[0] in ("case", "for", "while"):
                 for inner in _walk([s]):
                     if inner[0] == "short":
-                        raise VAError("%s: V(%s,%s) <+ 0 inside a case / loop statement" % (m.name, inner[1], inner[2]))
-    short_walk(m.body, [])
-    m.vshorts = [i for i in range(len(m.shorts)) if not m.short_is_alias(i)]
+                        raise VAError("%s: V(%s,%s) <+ ... inside a case / loop statement" % (m.name, inner[1], inner[2]))
+    m.short_kind = []
+    short_walk(m.body, [], True)
+    # the statements that own a branch current, in the order the reference allocates the currents: named branches and two-node
+    # contributions at the top level of the analog block first (branch_current_alloc, vasim.jl:3253-3280), then the ones inside
+    # conditionals where they stand (vasim.jl:2366)
+    rank = {"named": 0, "top": 1, "cond": 2}
+    m.vshorts = sorted((i for i in range(len(m.shorts)) if not m.short_is_alias(i)), key=lambda i: (rank[m.short_kind[i]], i))
+    tops = [(m.shorts[i][3][4] or (m.shorts[i][0], m.shorts[i][1])) for i in m.vshorts if m.short_kind[i] != "cond"]
+    if len(set(tops)) != len(tops):
+        raise VAError("%s: several potential contributions to one branch at the top level of the analog block are not supported" % m.name)
 
 
     # ---- $limit call sites: numbered in source order; top level of the analog block only (vasim.jl:1278-1279)
@@ -1305,7 +1366,15 @@ def _analyse(m: VAModule):
                     dual[v] = True; changed = True
     taint_flow(m.body, {}, {})
     # current probes: only of branches that carry nothing but noise (correlated-noise helper branches): zero on this path
-    for br in probes:
+    for pa, pb, pbr in probes:
+        br = (pa, pb)
+        if (pbr in pot_named) if pbr is not None else (br in pot_pairs):
+            j = m.probe_short(("Iprobe", m.nodes[pa], m.nodes[pb] if pb >= 0 else None, pbr))
+            if j is None or m.short_kind[m.vshorts[j]] == "cond":
+                raise VAError("%s: I(%s) reads the current of a potential contribution inside a conditional: not supported" % (m.name, pbr or "%s,%s" % (m.nodes[pa], m.nodes[pb] if pb >= 0 else "gnd")))
+            continue
+        if pbr is not None:
+            continue                    # a named branch without a potential contribution: its current reads 0.0 (vasim.jl:3641-3650)
         if br in m.branches:
             raise VAError("%s: I(%s,%s) is read in an expression and the branch carries a contribution: branch-current "
                           "unknowns are not supported" % (m.name, m.nodes[br[0]] if br[0] >= 0 else "gnd", m.nodes[br[1]] if br[1] >= 0 else "gnd"))
@@ -1331,6 +1400,17 @@ def _analyse(m: VAModule):
     for s in _walk(m.body):
         if s[0] == "contrib" and not only_noise(s[3]) and is_react(s[3]):
             m.reactive[m.branches.index((node(s[1]), node(s[2])))] = True
+    m.short_reactive = []
+    for i in m.vshorts:
+        st = m.shorts[i][3]
+        r = is_react(st[3])
+        if r and m.short_kind[i] != "named":
+            raise VAError("%s: V(%s,%s) <+ ... with a ddt() term is supported on named branches only" % (m.name, st[1], st[2]))
+        m.short_reactive.append(r)
+    for i in range(len(m.shorts)):
+        if i not in m.vshorts and m.shorts[i][3][3] != ("num", 0.0):
+            raise VAError("%s: internal: a potential contribution with a value was classified as a node alias" % m.name)
+
     def has_given(e):
         if e[0] == "given":
             return True
@@ -1394,7 +1474,7 @@ def _hoist_analysis(m):
                 last_write[s[1]] = p
                 if loop:
                     barred.add(s[1])
-            elif k == "contrib":
+            elif k in ("contrib", "short"):
                 note_reads([s[3]], p)
             elif k == "block":
                 walk(s[1], loop)
@@ -1434,7 +1514,7 @@ def _hoist_analysis(m):
             if k == "assign":
                 if s[1] not in H:
                     reads(s[2], used)
-            elif k == "contrib":
+            elif k in ("contrib", "short"):
                 reads(s[3], used)
             elif k == "block":
                 stay(s[1])

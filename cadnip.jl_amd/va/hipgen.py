@@ -58,8 +58,13 @@ class _Gen:
             if any(a in ("tran", "transient") for a in e[1]):
                 tests.append("sys.mode == 1")
             return "((%s) ? 1.0 : 0.0)" % (" || ".join(tests) if tests else "false"), False, None
-        if k in ("noise", "Iprobe"):
+        if k == "noise":
             return "0.0", False, None
+        if k == "Iprobe":
+            j = m.probe_short(e)
+            if j is None:
+                return "0.0", False, None          # a branch that carries noise only: zero on the DC / transient path
+            return "va_probe_current(u, nd[N + B + NL + %d], ((smask >> %d) & 1) != 0)" % (j, j), False, None
         if k == "ddx":
             c, t, _ = self.g(e[1])
             a = m.node_index(e[2])
@@ -197,6 +202,15 @@ class _Gen:
                     parts.append(a[0])
         return "%s<%s>(%s)" % (self.fname(fname), ty, ", ".join(parts + ["sys"])), dual, None
 
+    def emit_vcontrib(self, j, value):
+        """the stamps of the two-node potential contribution `vshorts[j]` with the (dual) value ``value``"""
+        m = self.m
+        a, b = m.shorts[m.vshorts[j]][0], m.shorts[m.vshorts[j]][1]
+        on = "((smask >> %d) & 1) != 0" % j
+        if self.tl:
+            return "va_emit_vcontrib_tl<N, %d>(s, %d, %d, %s, %s, dir < N ? -Vf[dir < N ? dir : 0] : 0.0, dir)" % (tl_lanes(m), m.g_short(j), 3 * len(m.branches) + j, on, value)
+        return "va_emit_vcontrib<N>(s, Vf, %d, %d, %s, %s)" % (m.g_short(j), 3 * len(m.branches) + j, on, value)
+
     def stmts(self, body, ind):
         m, pad = self.m, "  " * ind
         for s in body:
@@ -273,10 +287,19 @@ class _Gen:
                 j = next((jj for jj, si in enumerate(m.vshorts) if m.shorts[si][3] is s), -1)
                 if j < 0:
                     self.lines.append("%s// V(%s,%s) <+ 0: the two nets are one unknown for this instance (collapsed at structure discovery)" % (pad, s[1], s[2]))
-                else:
+                elif m.short_kind[m.vshorts[j]] == "cond" and s[3] == ("num", 0.0):
                     a, b = m.shorts[m.vshorts[j]][0], m.shorts[m.vshorts[j]][1]
                     self.lines.append("%sva_emit_short<N>(u, s, Vf, nd, N + B + NL + %d, %d, %d, %d, %d, ((smask >> %d) & 1) != 0%s);   // V(%s,%s) <+ 0 with a branch current"
                                       % (pad, j, a, b, m.g_short(j), 3 * len(m.branches) + j, j, " && dir == 0" if self.tl else "", s[1], s[2]))
+                else:
+                    c, t, q = self.g(s[3])
+                    self.flush(pad)
+                    if m.short_kind[m.vshorts[j]] == "cond":       # stamped where it stands (vasim.jl:2340-2393)
+                        self.lines.append("%s%s;   // V(%s,%s) <+ ... with a branch current" % (pad, self.emit_vcontrib(j, self.T(c, t)), s[1], s[2]))
+                    else:                                          # top level of the analog block: stamped behind the branches
+                        self.lines.append("%ssv%d = %s;" % (pad, j, self.T(c, t)))
+                        if m.short_reactive[j]:
+                            self.lines.append("%ssv%d_q = %s;" % (pad, j, q if q else "0.0"))
             elif s[0] == "block":
                 self.stmts(s[1], ind)
             elif s[0] == "if":
@@ -400,6 +423,9 @@ def generate_function(m, tl=False, with_functions=True):
             L.append("  T v_%s_q = 0.0;" % v)
     for b in range(B):
         L.append("  T br%d_r = 0.0, br%d_q = 0.0;" % (b, b))
+    tops = [(j, si) for kind in ("named", "top") for j, si in enumerate(m.vshorts) if m.short_kind[si] == kind]
+    for j, si in tops:                                                 # potential contributions at the top level: value now, stamps behind the branches
+        L.append("  T sv%d = 0.0%s;" % (j, (", sv%d_q = 0.0" % j) if m.short_reactive[j] else ""))
     g.stmts([("assign", nm, ie) for nm, ie in m.local_init], 1)       # module-scope initialisers, in declaration order
     g.stmts(m.body, 1)
     if tl:
@@ -411,6 +437,12 @@ def generate_function(m, tl=False, with_functions=True):
             L.append("  if (dir == N + %d) wgt = ld[%d];" % (j, j))
         for b, ((p, n), r) in enumerate(zip(m.branches, m.reactive)):
             L.append("  va_emit_branch_tl<N, S, B, %s, %d>(s, %d, sys.mf * br%d_r, sys.mf * br%d_q, wgt, dir);" % ("true" if r else "false", lanes, b, b, b))
+        for j, si in tops:
+            if m.short_kind[si] == "named":
+                L.append("  va_emit_vnamed(s, %d, %d, %d, ((smask >> %d) & 1) != 0 && dir == 0, va_val(sv%d), %s);   // V(%s) <+ ..." % (
+                    m.g_short(j), 3 * B + j, m.c_short(j) if m.short_reactive[j] else -1, j, j, ("va_val(sv%d_q)" % j) if m.short_reactive[j] else "0.0", m.shorts[si][3][4]))
+            else:
+                L.append("  %s;" % g.emit_vcontrib(j, "sv%d" % j))
         L.append("}")
         k = next(i for i, l in enumerate(L) if l.startswith("template <class Ctx, class Out>"))
         return "\n".join(L[:k] + ["#define %s %s" % mc for mc in macros] + L[k:] + ["#undef %s" % mc[0] for mc in macros])
@@ -418,6 +450,12 @@ def generate_function(m, tl=False, with_functions=True):
     for b, ((p, n), r) in enumerate(zip(m.branches, m.reactive)):
         L.append("  va_emit_branch<N, S, B, %s>(d, u, s, Vf, ld, nd, %d, %d, %d, sys.mf * br%d_r, sys.mf * br%d_q, ((vdep >> %d) & 1) != 0);"
                  % ("true" if r else "false", b, p, n, b, b, b))
+    for j, si in tops:
+        if m.short_kind[si] == "named":
+            L.append("  va_emit_vnamed(s, %d, %d, %d, ((smask >> %d) & 1) != 0, va_val(sv%d), %s);   // V(%s) <+ ..." % (
+                m.g_short(j), 3 * B + j, m.c_short(j) if m.short_reactive[j] else -1, j, j, ("va_val(sv%d_q)" % j) if m.short_reactive[j] else "0.0", m.shorts[si][3][4]))
+        else:
+            L.append("  %s;" % g.emit_vcontrib(j, "sv%d" % j))
     for lb, (p, n) in enumerate(m.limit_branches):
         L.append("  if constexpr (Out::DIRECT) s.Rn(nd[N + B + %d], vold%d - (%s));   // limit row: u_l - V(probe)" % (
             lb, lb, " - ".join(["Vf[%d]" % p if p >= 0 else "0.0", "Vf[%d]" % n if n >= 0 else "0.0"])))

@@ -268,8 +268,12 @@ def instance_structure(m, par, given=None, temp_k=300.15, mfactor=1.0, gmin=1e-1
     except (ValueError, ZeroDivisionError, OverflowError):
         pass                    # a zero-bias probe may leave the model's domain after the collapse statements (setup section) ran
     alias = {k: root(k) for k in out}
-    for j, si in enumerate(m.vshorts):           # both nets already one unknown: nothing to stamp (vasim.jl:2364 `if p != n`)
-        a, b = m.shorts[si][0], m.shorts[si][1]
+    for j, si in enumerate(m.vshorts):
+        if m.short_kind[si] != "cond":
+            shorts_on[j] = True                  # top level of the analog block: executes for every instance
+        if m.short_kind[si] == "named":
+            continue                             # (a named branch is stamped unconditionally, vasim.jl:3700-3712)
+        a, b = m.shorts[si][0], m.shorts[si][1]   # both nets already one unknown: nothing to stamp (vasim.jl:2364, 3765 `if p != n`)
         if shorts_on[j] and alias.get(a, a) == alias.get(b, b):
             shorts_on[j] = False
     active = [touched[b] or not m.branch_guarded[b] for b in range(len(m.branches))]

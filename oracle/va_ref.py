@@ -111,11 +111,13 @@ class VAFatal(RuntimeError):
     pass
 
 
-def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False, given=None, spec=None, on_short=None, touched=None):
+def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False, given=None, spec=None, on_short=None, touched=None, probe=None):
     """Branch contributions of ``mod`` on dual node voltages ``Vd``: one Dual / CDual / float per branch.
     ``limit_site(j, vnew_dual, fn)`` implements a $limit call site (stamp_va); ``given``: the parameters the instance sets
-    explicitly ($param_given); ``on_short(a, b, stmt)``: called for every executed V(a,b) <+ 0; ``touched``: a list that
-    receives True at the index of every branch a current contribution executes for."""
+    explicitly ($param_given); ``on_short(a, b, stmt, value)``: called for every executed potential contribution V(a,b) <+ value;
+    ``touched``: a list that receives True at the index of every branch a current contribution executes for; ``probe(e)``: the value
+    of a current probe I(br) / I(a,b) -- a plain number, the branch-current unknown of a potential contribution (vasim.jl:3632-3640,
+    3652-3667) -- default 0.0 (branches that carry noise only, vasim.jl:3641-3650)."""
     given = set(par) if given is None else set(given)
     for al, target in mod.aliasparams.items():
         if al in given:
@@ -177,8 +179,10 @@ def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False
             # vasim.jl:1220-1250: dc / static -> :dcop, tran / transient -> :tran, ac -> :ac, nodeset -> false
             return float(any((a in ("dc", "static") and mode == "dcop") or (a in ("tran", "transient") and mode == "tran")
                              or (a == "ac" and mode == "ac") for a in e[1]))
-        if k in ("noise", "Iprobe"):
+        if k == "noise":
             return 0.0                                          # noise sources contribute no current on this path
+        if k == "Iprobe":
+            return float(probe(e)) if probe is not None else 0.0
         if k == "ddx":
             x = _res(ev(e[1]))
             a = mod.node_index(e[2])
@@ -291,7 +295,7 @@ def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False
                 raise VAFatal("%s: %s %s" % (mod.name, s[1], s[2]))
             elif k == "short":
                 if on_short is not None:
-                    on_short(mod.node_index(s[1]), mod.node_index(s[2]), s)
+                    on_short(mod.node_index(s[1]), mod.node_index(s[2]), s, ev(s[3]))
 
     for name, ie in mod.local_init:                             # module-scope initialisers, in declaration order
         env[name] = ev(ie)
@@ -305,6 +309,8 @@ def short_aliases_a_terminal(mod, stmt):
     (vasim.jl:2311-2395).  (The one-net form V(a) <+ 0 stays this build's alias to ground.)"""
     a, b, guards = next(x[:3] for x in mod.shorts if x[3] is stmt)
     np_ = len(mod.ports)
+    if stmt[3] != ("num", 0.0) or stmt[4] is not None:
+        return False              # a value, or a named branch: always a branch with its own current (vasim.jl:3229-3246)
     if b < 0:
         return a >= np_
     return len(guards) == 1 and guards[0][1] is True and ((a >= np_) != (b >= np_))
@@ -322,7 +328,7 @@ def collapsed_nodes(mod, par, given, spec, mfactor=1.0, gmin=1e-12):
             i = out[i]
         return i
 
-    def on_short(a, b, stmt):
+    def on_short(a, b, stmt, value=0.0):
         if not short_aliases_a_terminal(mod, stmt):
             return
         a, b = root(a), root(b)
@@ -384,26 +390,55 @@ def stamp_va(ctx, mod, ext_nodes, x, par, spec, instance, mfactor=1.0, gmin=None
         pl, nl = mod.limit_branches[mod.limit_sites[j]]
         return (Vf[pl] if pl >= 0 else 0.0) - (Vf[nl] if nl >= 0 else 0.0) - limw[j]
 
-    def on_short(a, b, stmt):
-        """An executed V(a,b) <+ 0 that is not a terminal alias: stamped where it stands, with its own branch current
-        (vasim.jl:2363-2393): KCL columns, the constraint row and its (zero) partials in every node column, b = 0."""
-        if short_aliases_a_terminal(mod, stmt):
-            return
+    # Potential contributions at the top level of the analog block own their branch currents from the start of the call: named
+    # branches first, then two-node ones (branch_current_alloc, vasim.jl:3253-3280); their stamps follow the branches (below).
+    def where(stmt):
+        return next(i for i, x in enumerate(mod.shorts) if x[3] is stmt)
+    top_cur, top_val = {}, {}
+    for kind in ("named", "top"):
+        for i in mod.vshorts:
+            if mod.short_kind[i] == kind:
+                a, b, st = mod.shorts[i][0], mod.shorts[i][1], mod.shorts[i][3]
+                pn = "%s_%s" % (mod.nodes[a], mod.nodes[b] if b >= 0 else "0")
+                top_cur[i] = ctx.alloc_current("%s_%s_I_%s" % (instance, mod.name, st[4]) if kind == "named" else "%s_%s_I_V_%s" % (instance, mod.name, pn))
+
+    def probe(e):
+        j = mod.probe_short(e)
+        return 0.0 if j is None else x_at(x, ctx.resolve_index(top_cur[mod.vshorts[j]]))
+
+    def twonode_stamps(iv, a, b, value):
+        """vasim.jl:2363-2393 / 3765-3812: KCL columns, the constraint row with -dX/dV_k in every node column, b = X - sum dX/dV_k V_k"""
         p_node, n_node = (node[a] if a >= 0 else 0), (node[b] if b >= 0 else 0)
-        if p_node == n_node:
-            return
-        iv = ctx.alloc_current("%s_I_V_%s_%s" % (instance, mod.nodes[a], mod.nodes[b] if b >= 0 else "0"))
+        v_val, dv = val(_res(value)), partials(_res(value), W)
         ctx.stamp_G(p_node, iv, 1.0)
         ctx.stamp_G(n_node, iv, -1.0)
         ctx.stamp_G(iv, p_node, 1.0)
         ctx.stamp_G(iv, n_node, -1.0)
         for k in range(N):
-            ctx.stamp_G(iv, node[k], -0.0)
-        ctx.stamp_b(iv, 0.0)
+            ctx.stamp_G(iv, node[k], -dv[k])
+        b_v = v_val
+        for k in range(N):
+            b_v -= dv[k] * Vf[k]
+        ctx.stamp_b(iv, b_v)
+
+    def on_short(a, b, stmt, value=0.0):
+        """An executed potential contribution that is not a terminal alias.  Inside a conditional it is stamped where it stands, with
+        its own branch current (vasim.jl:2363-2393); at the top level its value is kept for the stamps behind the branches."""
+        if short_aliases_a_terminal(mod, stmt):
+            return
+        i = where(stmt)
+        if mod.short_kind[i] != "cond":
+            top_val[i] = value
+            return
+        p_node, n_node = (node[a] if a >= 0 else 0), (node[b] if b >= 0 else 0)
+        if p_node == n_node:
+            return
+        iv = ctx.alloc_current("%s_I_V_%s_%s" % (instance, mod.nodes[a], mod.nodes[b] if b >= 0 else "0"))
+        twonode_stamps(iv, a, b, value)
 
     temp_k = float(getattr(spec, "temp", 27.0)) + 273.15
     touched = [False] * len(mod.branches)
-    Ibr = evaluate(mod, Vd, par, temp_k, mfactor, spec.gmin if gmin is None else gmin, limit_site, ctx.initjct, given, spec, on_short, touched)
+    Ibr = evaluate(mod, Vd, par, temp_k, mfactor, spec.gmin if gmin is None else gmin, limit_site, ctx.initjct, given, spec, on_short, touched, probe)
     for b, (pl, nl) in enumerate(mod.branches):
         if mod.branch_guarded[b] and not touched[b]:
             continue          # contributions inside conditionals are stamped inline, when they execute (vasim.jl:2397-2470): none did
@@ -460,3 +495,24 @@ def stamp_va(ctx, mod, ext_nodes, x, par, spec, instance, mfactor=1.0, gmin=None
             ctx.stamp_b(p_node, -Ieq)
         if n_node != 0:
             ctx.stamp_b(n_node, Ieq)
+    # named branches V(br) <+ X (vasim.jl:3669-3746): no partials -- b[I] = the resistive value, C[I,I] = -(the value under ddt())
+    for i in mod.vshorts:
+        if mod.short_kind[i] == "named":
+            a, b, iv = mod.shorts[i][0], mod.shorts[i][1], top_cur[i]
+            p_node, n_node = (node[a] if a >= 0 else 0), (node[b] if b >= 0 else 0)
+            X = top_val.get(i, 0.0)
+            ctx.stamp_G(p_node, iv, 1.0)
+            ctx.stamp_G(n_node, iv, -1.0)
+            ctx.stamp_G(iv, p_node, 1.0)
+            ctx.stamp_G(iv, n_node, -1.0)
+            if isinstance(X, CDual):
+                ctx.stamp_b(iv, val(X.r))
+                ctx.stamp_C(iv, iv, -val(X.q))
+            else:
+                ctx.stamp_b(iv, val(X))
+    # two-node potential contributions at the top level (vasim.jl:3750-3815)
+    for i in mod.vshorts:
+        if mod.short_kind[i] == "top":
+            a, b = mod.shorts[i][0], mod.shorts[i][1]
+            if (node[a] if a >= 0 else 0) != (node[b] if b >= 0 else 0):
+                twonode_stamps(top_cur[i], a, b, top_val.get(i, 0.0))

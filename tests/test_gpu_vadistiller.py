@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 RTOL = 1e-11
 # case -> (probe net, lower, upper): the bounds of the reference's test (vadistiller_integration.jl, line ranges in the fixture tool)
-TIER6 = {"resistor": ("mid", 2.5 - 1e-9, 2.5 + 1e-9), "capacitor": ("mid", 5.0 - 1e-6, 5.0 + 1e-6), "diode": ("diode_a", 0.6, 0.7),
+TIER6 = {"inductor": ("mid", -0.01, 0.01), "vdmos": ("drain", 0.0, 10.0), "resistor": ("mid", 2.5 - 1e-9, 2.5 + 1e-9), "capacitor": ("mid", 5.0 - 1e-6, 5.0 + 1e-6), "diode": ("diode_a", 0.6, 0.7),
          "diode_rs": ("diode_a", 0.6, 0.71), "bjt": ("collector", 0.0, 5.0), "jfet1": ("drain", 0.0, 10.0), "mes1": ("drain", 0.0, 5.0),
          "jfet2": ("drain", 0.0, 10.0), "mos1": ("drain", 0.0, 5.0), "mos2": ("drain", 0.0, 5.0), "mos3": ("drain", 0.0, 5.0),
          "mos6": ("drain", 0.0, 5.0), "mos9": ("drain", 0.0, 5.0), "bsim3v3": ("drain", 0.0, 1.8), "bsim4v8": ("drain", 0.9, 1.0)}

@@ -658,7 +658,9 @@ def test_verilog_a_front_end_and_generator():
         cc.VA("x", "va_diode", ("a", "0"), rs=rs)
     assert cj.discover(c1, {}).node_names == ["a"] and cj.discover(c2, {}).node_names == ["a", "x_va_diode_ai"]
     # refused, never approximated
-    for bad in ("module x(a); electrical a; analog V(a) <+ 1.0; endmodule",                       # potential contribution other than <+ 0
+    ok = va.parse_module("module x(a); electrical a; analog V(a) <+ 1.0; endmodule")             # a potential contribution with a value: its own branch current
+    assert ok.vshorts == [0] and ok.short_kind == ["top"] and ok.shape()[0] == 1 + 0 + 0 + 1
+    for bad in ("module x(a); electrical a; analog V(a) <+ ddt(V(a)); endmodule",                 # ddt() in a two-node potential contribution
                 "module x(a, b); electrical a, b; analog if (V(a) > 0) V(a, b) <+ 0; endmodule",  # collapse under a voltage condition
                 'module x(a); electrical a; real v; analog begin v = $limit(V(a), "pnjlim", 1, 2); I(a) <+ v; end endmodule',   # string form
                 "module x(a); electrical a; real v; analog begin v = $limit(V(a), nofn, 1.0); I(a) <+ v; end endmodule",

@@ -33,23 +33,49 @@ EXPECTED = {
     "jfet1.va": (5, 5, 3, 4, 2), "jfet2.va": (8, 8, 6, 4, 5), "mes1.va": (5, 5, 3, 4, 2),
     "mos1.va": (6, 6, 4, 8, 2), "mos2.va": (6, 6, 4, 8, 2), "mos3.va": (6, 6, 4, 8, 2), "mos6.va": (6, 6, 4, 8, 2), "mos9.va": (6, 6, 4, 8, 2),
     "bsim3v3.va": (7, 7, 5, 8, 3), "bsim4v8.va": (13, 23, 9, 18, 9), "bjt.va": (11, 11, 9, 6, 9),
+    "inductor.va": (2, 0, 0, 0, 1),        # V(br) <+ req*I(br)+veq on a named branch: no current branch at all, one branch-current unknown
+    "vdmos.va": (10, 12, 5, 8, 7),         # five terminals (two thermal), V(tbr) <+ ... on the named thermal branch
 }
-# refused, with the reason: general potential contributions V(a,b) <+ expr (a branch-current probe / a thermal branch)
-REFUSED = {"inductor.va": "potential contributions", "vdmos.va": "potential contributions"}
+# refused, with the reason
+REFUSED = {os.path.join(PSP_DIR, "psp103_nqs.va"): "idt", "/root/reference/test/NLVCR.va": "branch potential",
+           "/root/reference/test/mna/fixtures/table_model/tm_1d.va": "$table_model"}
 
 
 @pytest.mark.parametrize("fn", sorted(EXPECTED))
 def test_reference_model_parses(fn):
     m = F.parse_file(os.path.join(VA_DIR, fn))
     assert (m.n_nodes, len(m.branches), sum(m.reactive), m.n_sites, len(m.shorts)) == EXPECTED[fn]
-    assert len(m.ports) in (2, 3, 4) and m.name.startswith("sp_")
+    assert len(m.ports) in (2, 3, 4, 5) and m.name.startswith("sp_")
 
 
 @pytest.mark.parametrize("fn", sorted(REFUSED))
 def test_unsupported_models_are_refused_with_a_reason(fn):
     with pytest.raises(F.VAError) as ei:
-        F.parse_file(os.path.join(VA_DIR, fn))
+        F.parse_file(fn)
     assert REFUSED[fn] in str(ei.value)
+
+
+def test_potential_contributions_of_inductor_and_vdmos():
+    """inductor.va: `V(br) <+ req*I(br)+veq` with veq = ddt(L * I(br)) -- a named branch at the top level of the analog block: its current is
+    allocated up front, I(br) reads it as a plain number, the value carries ddt() (vasim.jl:3253-3266, 3632-3640, 3669-3746).  vdmos.va: the
+    thermal branch `V(tbr) <+ ...` likewise; its conditional V(t) <+ 0 / V(tc) <+ 0 tie terminals to ground through branch currents."""
+    m = F.parse_file(os.path.join(VA_DIR, "inductor.va"))
+    assert m.short_kind == ["named"] and m.short_reactive == [True] and m.vshorts == [0]
+    assert m.short_current_name(0, "l1") == "l1_sp_inductor_I_br"
+    assert m.shape()[:4] == (2 + 0 + 0 + 1, (4 + 2) * 1, 1, 1)      # unknowns, G slots, the one C slot (I,I), the one b slot
+    assert m.program((), [], [True]) == [("G", 0, 0, 2), ("G", 1, 1, 2), ("G", 2, 2, 0), ("G", 3, 2, 1), ("b", 0, 2, None), ("C", 0, 2, 2)]
+    v = F.parse_file(os.path.join(VA_DIR, "vdmos.va"))
+    assert [v.short_kind[i] for i in v.vshorts] == ["named", "cond", "cond"] and v.short_current_name(0, "m1") == "m1_sp_vdmos_I_tbr"
+    assert v.short_current_name(1, "m1") == "m1_I_V_t_0"
+
+
+def test_other_model_packages_parse():
+    """models/CMCModels.jl (BSIM-CMG 107: 905 parameters, 2 internal nodes with the series-resistance option compiled in) and the self-heating
+    PSP103 (a fifth, thermal terminal; Temp() / Pwr() access functions)."""
+    c = F.parse_file("/root/reference/models/CMCModels.jl/va/bsimcmg.va")
+    assert (c.name, c.ports, c.n_internal, len(c.params), len(c.branches), sum(c.reactive)) == ("bsimcmg", ["d", "g", "s", "e"], 2, 905, 15, 9)
+    t = F.parse_file(os.path.join(PSP_DIR, "psp103t.va"))
+    assert (t.name, t.ports, t.n_internal, len(t.branches)) == ("PSP103TVA", ["D", "G", "S", "B", "DT"], 8, 19)
 
 
 def test_psp103_and_juncap_parse_through_their_includes():

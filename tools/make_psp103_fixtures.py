@@ -72,6 +72,8 @@ def _stage(vdd, vg, rd, inst):
 TIER6 = {
     "resistor": ("* sp_resistor divider (:191-213)\nV1 vcc 0 DC 5\nX1 vcc mid sp_resistor resistance=1000\nX2 mid 0 sp_resistor resistance=1000\n", "mid", 2.5 - 1e-9, 2.5 + 1e-9),
     "capacitor": ("* sp_capacitor DC (:215-238)\nV1 vcc 0 DC 5\nR1 vcc mid 1k\nX1 mid 0 sp_capacitor capacitance=1u\n", "mid", 5.0 - 1e-6, 5.0 + 1e-6),
+    "inductor": ("* sp_inductor DC (:240-261)\nV1 vcc 0 DC 5\nR1 vcc mid 1k\nX1 mid 0 sp_inductor inductance=1m\n", "mid", -0.01, 0.01),
+    "vdmos": ("* sp_vdmos (:693-712)\nVdd vdd 0 DC 10\nVg gate 0 DC 5\nRd vdd drain 100\nXm drain gate 0 0 0 sp_vdmos vto=2 kp=0.5\n", "drain", 0.0, 10.0),
     "diode": ("* sp_diode (:268-283)\nV1 vcc 0 DC 1\nR1 vcc diode_a 1k\nX1 diode_a 0 sp_diode\n", "diode_a", 0.6, 0.7),
     "diode_rs": ("* sp_diode with series resistance (:322-346)\nV1 vcc 0 DC 1\nR1 vcc diode_a 1k\nX1 diode_a 0 sp_diode rs=10\n", "diode_a", 0.6, 0.71),
     "bjt": ("* sp_bjt (:375-398)\nV1 vcc 0 DC 5\nV2 vb 0 DC 0.7\nRb vb base 10k\nRc vcc collector 1k\nXq collector base 0 0 sp_bjt bf=100 is=1e-15\n", "collector", 0.0, 5.0),
