@@ -604,6 +604,156 @@ def ac(target, freqs=(), gmin=1e-12, device=0):
     return SweepResult(pts, sols) if sweep else sols[0]
 
 
+# ---- noise! (src/noise.jl) ---------------------------------------------------------------------------------------------------------------
+K_BOLTZMANN, Q_ELEMENTARY = 1.380649e-23, 1.602176634e-19
+
+
+class NoiseSol:
+    """noise!'s result (src/noise.jl:31-40): output-referred noise PSD over a grid in hertz, per-source contributions (device names in lower
+    case), and -- when an input source was named -- the input -> output gain and the input-referred PSD.  ``ns["onoise"]``, ``ns["inoise"]``,
+    ``ns[source]`` as in noise.jl:239-253."""
+
+    def __init__(self, freqs, output, onoise, contributions, temp, input, gain, inoise):
+        self.freqs, self.output, self.onoise, self.contributions = freqs, output, onoise, contributions
+        self.temp, self.input, self.gain, self.inoise = temp, input, gain, inoise
+
+    def __getitem__(self, name):
+        if name == "onoise":
+            return self.onoise
+        if name == "inoise":
+            if self.input is None:
+                raise KeyError("NoiseSol: no input-referred noise -- call noise(circuit, output, freqs, input=...)")
+            return self.inoise
+        if name in self.contributions:
+            return self.contributions[name]
+        raise KeyError("NoiseSol: unknown key %r (have onoise, inoise and the sources %s)" % (name, sorted(self.contributions)))
+
+
+def total_noise(ns, referred="output"):
+    """band-integrated RMS noise sqrt(int S df) by the trapezoidal rule (noise.jl:258-276)"""
+    if referred not in ("output", "input"):
+        raise ValueError("total_noise: referred must be 'output' or 'input', got %r" % (referred,))
+    psd = ns["onoise"] if referred == "output" else ns["inoise"]
+    fs = ns.freqs
+    if len(fs) < 2:
+        return float(np.sqrt(psd[0] if len(fs) == 1 else 0.0))
+    return float(np.sqrt(np.sum(0.5 * (psd[:-1] + psd[1:]) * np.diff(fs))))
+
+
+def noise_psd(src, temp_c, f):
+    """one-sided PSD of a registered source (context.jl:179-189): thermal 4kT a, shot 2q a, white a, flicker a / f^b"""
+    kind, a, b = src[2], src[3], src[4]
+    if kind == "thermal":
+        return 4.0 * K_BOLTZMANN * (float(temp_c) + 273.15) * a
+    if kind == "shot":
+        return 2.0 * Q_ELEMENTARY * a
+    if kind == "white":
+        return a
+    return a / float(f) ** b
+
+
+def noise_sources(st, circuit, params, u, temp_c=27.0, gmin=1e-12):
+    """The noise sources of ``circuit`` at the solution ``u`` (one instance, [n]): (p, n, kind, a, b, name) with global unknown indices
+    (-1 = ground).  What the reference's devices register while the builder runs at the DC point (context.jl:1017-1127): resistors their
+    thermal noise 4kT/R (devices.jl:498-503), diodes the shot noise of their junction current (devices.jl:1393-1418), instances of
+    Verilog-A modules one source per white_noise / flicker_noise call of the contributions they execute (vasim.jl:2856-2893; evaluated by
+    va/host_eval.py at the node voltages of ``u``: needs the model source)."""
+    from .circuit import resolve
+    from .opinfo import _index
+    from . import va
+    num = lambda v: float(np.asarray(resolve(v, params)).flat[0])
+    out = []
+    info = {d["name"]: d for d in st.opinfo}
+    for d in circuit.devices:
+        gl = [_index(st, t) for t in info[d.name]["nodes"]]
+        name = d.name.lower()
+        if d.type == "R":
+            out.append((gl[0], gl[1], "thermal", 1.0 / num(d.params["r"]), 0.0, name))
+        elif d.type in ("D", "DCAP"):
+            v = (u[gl[0]] if gl[0] >= 0 else 0.0) - (u[gl[1]] if gl[1] >= 0 else 0.0)
+            nVt = num(d.params["n"]) * num(d.params["Vt"])
+            xarg = v / nVt
+            i0 = num(d.params["Is"]) * ((np.exp(80.0) * (1.0 + (xarg - 80.0)) - 1.0) if xarg > 80.0 else (np.exp(xarg) - 1.0))
+            out.append((gl[0], gl[1], "shot", abs(i0), 0.0, name))
+        elif d.type.startswith("VA:"):
+            mod = va.get(d.type[3:])[1]
+            given = {k: num(v) for k, v in d.model.items()}
+            par = va.host_eval.defaults(mod, given)
+            V = [u[g] if g >= 0 else 0.0 for g in gl[:mod.n_nodes]]
+            vold = [(V[p] if p >= 0 else 0.0) - (V[n] if n >= 0 else 0.0) for p, n in mod.limit_branches]   # at the solution the limit unknowns sit on their probes
+
+            def on_noise(a, b, fn, pwr, expo, label, gl=gl, name=name):
+                nm = ("%s_%s" % (name, label.lower())) if label else name
+                out.append((gl[a] if a >= 0 else -1, gl[b] if b >= 0 else -1, "white" if fn == "white_noise" else "flicker", pwr, expo, nm))
+            va.host_eval.evaluate(mod, V, par, temp_c + 273.15, num(d.params.get("m", 1.0)), gmin, vold=vold, given=set(d.model), mode="dcop", on_noise=on_noise)
+        elif d.type in ("MOS1", "SMOS"):
+            raise NotImplementedError("noise: %s (%s) registers no noise sources in this build; instantiate the Verilog-A module instead" % (d.name, d.type))
+    return out
+
+
+def noise_solve(st, G, C, sources, output, freqs, input=None, temp_c=27.0):
+    """noise.jl:150-188 on dense G (gmin already on the voltage-node diagonals) and C: one adjoint solve per frequency,
+    S_out(f) = sum_k |x_adj[p_k] - x_adj[n_k]|^2 S_k(f); the same adjoint gives the gain from the input source's branch row."""
+    freqs = np.asarray(freqs, dtype=float)
+    if freqs.size == 0:
+        raise ValueError("noise(circuit, output, freqs=...) needs a non-empty grid in hertz (e.g. acdec(20, 1, 1e6))")
+    names = list(st.node_names) + list(st.current_names)
+    if output in ("gnd", "0"):
+        raise KeyError("noise: the output cannot be ground")
+    if output not in names:
+        raise KeyError("noise: unknown output %s (nodes %s, currents %s)" % (output, st.node_names, st.current_names))
+    out_idx = names.index(output)
+    in_idx = None
+    if input is not None:
+        cand = [nm for nm in ("I_" + input, "I_" + input.lower()) if nm in st.current_names]
+        if not cand:
+            raise KeyError("noise: input source %s is not an independent voltage source (no current variable I_%s)" % (input, input))
+        in_idx = st.n_nodes + st.current_names.index(cand[0])
+    e_out = np.zeros(st.n, dtype=complex)
+    e_out[out_idx] = 1.0
+    onoise = np.zeros(len(freqs))
+    contributions = {s[5]: np.zeros(len(freqs)) for s in sources}
+    gain = np.zeros(len(freqs), dtype=complex) if input is not None else np.zeros(0, dtype=complex)
+    inoise = np.zeros(len(freqs)) if input is not None else np.zeros(0)
+    for fi, f in enumerate(freqs):
+        x_adj = np.linalg.solve((1j * 2.0 * np.pi * f * C + G).T, e_out)
+        for s in sources:
+            Hk = (x_adj[s[0]] if s[0] >= 0 else 0.0) - (x_adj[s[1]] if s[1] >= 0 else 0.0)
+            c = abs(Hk) ** 2 * noise_psd(s, temp_c, f)
+            onoise[fi] += c
+            contributions[s[5]][fi] += c
+        if input is not None:
+            H = x_adj[in_idx]
+            gain[fi] = H
+            inoise[fi] = np.inf if H == 0 else onoise[fi] / abs(H) ** 2
+    return NoiseSol(freqs, output, onoise, contributions, temp_c, input, gain, inoise)
+
+
+def noise(target, output, freqs, input=None, gmin=1e-12, device=0):
+    """noise!(circuit, output; freqs, input, gmin) -- src/noise.jl:118-190.  As for ``ac``: the DC operating point and the restamp at it run on the
+    GPU; the sources are collected on the host at that point (noise_sources) and the adjoint sweep is the reference's own dense solve."""
+    import scipy.sparse as sp
+    if len(freqs) == 0:
+        raise ValueError("noise(circuit, output, freqs=...) needs a non-empty grid in hertz (e.g. acdec(20, 1, 1e6))")
+    mc = MNACircuit(target.circuit, target.params, MNASpec(temp=target.spec.temp, mode="dcop", gmin=target.spec.gmin))
+    sim = BatchSimulator(mc, None, device)
+    try:
+        st = sim.st
+        u, conv, _ = sim.dc()
+        if not np.all(conv):
+            raise RuntimeError("noise: the DC operating point did not converge")
+        sim.h.rebuild(u, 0.0)
+        G, C, _, _ = sim.h.get_GCb()
+        dense = lambda nz: sp.csc_matrix((nz, st.ref_rowval, st.ref_colptr), shape=(st.n, st.n)).toarray()
+        Gd, Cd = dense(G[0]), dense(C[0])
+        Gd[np.arange(st.n_nodes), np.arange(st.n_nodes)] += gmin
+        p0 = {kk: float(v[0]) for kk, v in sim.params.items()}
+        srcs = noise_sources(st, mc.circuit, p0, u[0], mc.spec.temp, mc.spec.gmin)
+        return noise_solve(st, Gd, Cd, srcs, output, freqs, input, mc.spec.temp)
+    finally:
+        sim.close()
+
+
 def tran(target, tspan, abstol=1e-10, reltol=1e-8, saveat=None, device=0, **kw):
     """tran!(circuit, tspan) / tran!(cs::CircuitSweep, tspan) -- sweeps.jl:588-665, 692-707."""
     tspan = (float(tspan[0]), float(tspan[1]))

@@ -596,14 +596,24 @@ class _Parser:
                 self.accept(",")
             return ("analysis", kinds)
         if v in NOISE_FUNCS and self.peek()[1] == "(":
+            # white_noise(pwr[, name]) / flicker_noise(pwr, exp[, name]): 0.0 on the DC / transient path; the arguments are kept for the
+            # noise analysis (vasim.jl:2856-2893: the call registers a source between the enclosing contribution's nodes)
             self.next()
-            depth = 1
-            while depth:                                     # the arguments play no role on the DC / transient path
-                t = self.next()
-                if t[0] == "eof":
-                    raise VAError("unterminated %s(" % v)
-                depth += (t[1] == "(") - (t[1] == ")")
-            return ("noise", v)
+            args, label = [], ""
+            while not self.accept(")"):
+                if self.peek()[0] == "str":
+                    label = self.next()[1].strip('"')
+                elif v == "noise_table":
+                    depth = 0
+                    while depth or self.peek()[1] not in (",", ")"):      # (tables play no role here)
+                        t = self.next()
+                        if t[0] == "eof":
+                            raise VAError("unterminated %s(" % v)
+                        depth += (t[1] in "([{") - (t[1] in ")]}")
+                else:
+                    args.append(self.expr())
+                self.accept(",")
+            return ("noise", v, args, label)
         if v in POTENTIAL_ACCESS and self.peek()[1] == "(":
             self.next()
             a, b = self.probe_nets()
@@ -1449,7 +1459,7 @@ def _hoist_analysis(m):
     first_read, last_write, barred = {}, {}, set()
 
     def reads(e, acc):
-        if not isinstance(e, tuple) or not e:
+        if not isinstance(e, tuple) or not e or e[0] == "noise":      # (the device code never evaluates a noise power)
             return
         if e[0] == "var":
             acc.add(e[1])

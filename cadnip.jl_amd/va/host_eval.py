@@ -46,12 +46,13 @@ def _q(x):
 
 
 def evaluate(m, V, par, temp_k=300.15, mfactor=1.0, gmin=1e-12, vold=None, initjct=0, given=None, mode="tran", simparams=None,
-             on_short=None, on_contrib=None):
+             on_short=None, on_contrib=None, on_noise=None):
     """Branch values of module ``m`` at node voltages ``V`` (list over m.nodes): ``[(I_b, q_b)]`` per branch, before the
     multiplicity factor.  ``par``: parameter name -> number (all of them; see ``defaults``); ``vold``: the value of the
     limit unknown of every $limit probe branch (zeros when omitted); ``given``: the parameters the instance sets explicitly
     ($param_given; default: all of ``par``); ``on_short(a, b, stmt)``: called for every V(a,b) <+ 0 that executes; ``on_contrib(branch)``: for every
-    executed current contribution."""
+    executed current contribution; ``on_noise(a, b, fn, pwr, expo, label)``: for every white_noise / flicker_noise call inside the contribution to
+    (a, b) -- the source it registers between those nodes, power already scaled by the multiplicity factor (vasim.jl:2856-2893)."""
     given = set(par) if given is None else {g for g in given}
     for al, target in m.aliasparams.items():
         if al in given:
@@ -61,6 +62,7 @@ def evaluate(m, V, par, temp_k=300.15, mfactor=1.0, gmin=1e-12, vold=None, initj
         sp.update(simparams)
     env = {v: 0.0 for v in m.locals_}
     acc = [_Pair(0.0, 0.0) for _ in m.branches]
+    bound = [None]       # (p, n) of the contribution being evaluated: where a noise call in its right-hand side injects
     vold = list(vold) if vold is not None else [0.0] * len(m.limit_branches)
     scopes = []             # analog-function frames: the innermost shadows everything
 
@@ -101,8 +103,14 @@ def evaluate(m, V, par, temp_k=300.15, mfactor=1.0, gmin=1e-12, vold=None, initj
         if k == "analysis":
             return float(any((a in ("dc", "static") and mode == "dcop") or (a in ("tran", "transient") and mode == "tran")
                              or (a == "ac" and mode == "ac") for a in e[1]))
-        if k in ("noise", "Iprobe", "ddx"):
-            return 0.0           # noise: no current on this path; ddx: a derivative read-out, not a value the stamps use
+        if k == "noise":
+            if on_noise is not None and bound[0] is not None and e[1] in ("white_noise", "flicker_noise"):
+                pwr = _r(ev(e[2][0])) if e[2] else 0.0
+                expo = _r(ev(e[2][1])) if (e[1] == "flicker_noise" and len(e[2]) >= 2) else 1.0
+                on_noise(bound[0][0], bound[0][1], e[1], mfactor * pwr, expo, e[3])
+            return 0.0           # no current on this path
+        if k in ("Iprobe", "ddx"):
+            return 0.0           # ddx: a derivative read-out, not a value the stamps use
         if k == "ucall":
             return call(e[1], e[2])
         if k == "limit":
@@ -177,10 +185,14 @@ def evaluate(m, V, par, temp_k=300.15, mfactor=1.0, gmin=1e-12, vold=None, initj
             elif k == "contrib":
                 if on_contrib is not None and s[3][0] != "noise":
                     on_contrib(m.branches.index((m.node_index(s[1]), m.node_index(s[2]))))
+                bound[0] = (m.node_index(s[1]), m.node_index(s[2]))
                 if s[3][0] == "noise":
+                    ev(s[3])
+                    bound[0] = None
                     continue
                 b = m.branches.index((m.node_index(s[1]), m.node_index(s[2])))
                 x = ev(s[3])
+                bound[0] = None
                 acc[b] = _Pair(acc[b].r + _r(x), acc[b].q + _q(x))
             elif k == "block":
                 run(s[1])

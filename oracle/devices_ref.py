@@ -138,8 +138,10 @@ def get_source_value(dc, tran, t, mode):  # devices.jl:352-360
 
 
 # -- linear devices ---------------------------------------------------------------
-def stamp_resistor(ctx, p, n, r):  # devices.jl:498-510
+def stamp_resistor(ctx, p, n, r, name="R"):  # devices.jl:498-510
     stamp_conductance(ctx, p, n, 1.0 / r)
+    if hasattr(ctx, "register_thermal_noise"):           # Johnson-Nyquist 4kT G (a no-op on the direct-stamp context)
+        ctx.register_thermal_noise(p, n, 1.0 / r, name)
 
 
 def stamp_capacitor(ctx, p, n, c):  # devices.jl:531-534
@@ -304,6 +306,8 @@ def stamp_diode(ctx, p, n, x, Is=1e-14, Vt=0.026, nf=1.0, limit_=True, name="D")
         w = limit(ctx, name + "_vdlim", p, n, V0, x, lambda vn, vo: pnjlim(vn, vo, nVt, vcrit)[0], init=vcrit)
         I0, Gd = diode_iv(Is, nVt, w)
         stamp_limited_companion(ctx, p, n, w, I0, Gd)
+        if hasattr(ctx, "register_shot_noise"):          # devices.jl:1393-1397 (KF = 0: no flicker term)
+            ctx.register_shot_noise(p, n, I0, name)
     else:
         e = _exp(V0 / nVt)
         I0 = Is * (e - 1.0)
@@ -312,6 +316,8 @@ def stamp_diode(ctx, p, n, x, Is=1e-14, Vt=0.026, nf=1.0, limit_=True, name="D")
         stamp_conductance(ctx, p, n, Gd)
         ctx.stamp_b(p, -Ieq)
         ctx.stamp_b(n, Ieq)
+        if hasattr(ctx, "register_shot_noise"):          # devices.jl:1418
+            ctx.register_shot_noise(p, n, I0, name)
 
 
 def diode_junction_cap(V, Cj0, Vj, m):  # devices.jl:1505-1516

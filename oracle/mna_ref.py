@@ -116,6 +116,23 @@ class MNAContext:
         self.limit_w = []
         self.breakpoints = []
         self.initjct = False
+        self.noise = []          # deferred noise-source channel (context.jl:281-292): (p, n, kind, a, b, name)
+
+    # -- noise-source channel (context.jl:1017-1127): a small-signal noise current between p and n with PSD described by (kind, a, b)
+    def stamp_noise(self, p, n, kind, a, b, name):
+        self.noise.append((p, n, kind, float(a), float(b), str(name).lower()))
+
+    def register_thermal_noise(self, p, n, G, name):      # S = 4 k T G
+        self.stamp_noise(p, n, "thermal", G, 0.0, name)
+
+    def register_shot_noise(self, p, n, I, name):         # S = 2 q |I|
+        self.stamp_noise(p, n, "shot", abs(I), 0.0, name)
+
+    def register_white_noise(self, p, n, pwr, name):      # Verilog-A white_noise(pwr): S = pwr
+        self.stamp_noise(p, n, "white", pwr, 0.0, name)
+
+    def register_flicker_noise(self, p, n, pwr, expo, name):   # Verilog-A flicker_noise(pwr, exp): S = pwr / f^exp
+        self.stamp_noise(p, n, "flicker", pwr, expo, name)
 
     # -- allocation -------------------------------------------------------------
     def get_node(self, name):  # context.jl:467-490
@@ -804,6 +821,74 @@ def dc(builder, params=None, spec=None, u0=None):
     spec = spec if spec is not None else MNASpec()
     spec = MNASpec(temp=spec.temp, mode="dcop")  # with_mode keeps only temp+mode (solve.jl:1976-1989)
     return solve_dc(builder, params or {}, spec, u0=u0)
+
+
+# ---- noise analysis (src/noise.jl:118-190, context.jl:173-189) ------------------------------------------------------------------
+K_BOLTZMANN, Q_ELEMENTARY = 1.380649e-23, 1.602176634e-19
+
+
+def noise_psd(src, temp_c, f):  # context.jl:179-189
+    _, _, kind, a, b, _ = src
+    if kind == "thermal":
+        return 4 * K_BOLTZMANN * (float(temp_c) + 273.15) * a
+    if kind == "shot":
+        return 2 * Q_ELEMENTARY * a
+    if kind == "white":
+        return a
+    return a / float(f) ** b
+
+
+def noise(builder, params, spec, output, freqs, input=None, gmin=1e-12):
+    """noise!(circuit, output; freqs, input, gmin) -- noise.jl:118-190: DC point, rebuild at it (the sources register themselves), one adjoint
+    solve (jw C + G)^T x = e_out per frequency, S_out = sum_k |x_p - x_n|^2 S_k.  Returns (onoise, contributions by source name, gain, inoise)."""
+    freqs = [float(f) for f in freqs]
+    if not freqs:
+        raise ValueError("noise!(circuit, output; freqs=...) needs a non-empty Hz grid")
+    spec = MNASpec(temp=spec.temp, mode="dcop")
+    sol = solve_dc(builder, params, spec)
+    ctx = MNAContext()
+    builder(params, spec, 0.0, x=ZERO_VECTOR, ctx=ctx)
+    ctx.reset_for_restamping()
+    ctx.noise = []
+    builder(params, spec, 0.0, x=sol.x, ctx=ctx)
+    sysm = assemble(ctx)
+    n = ctx.system_size()
+    G = np.array(sysm.G.toarray() if hasattr(sysm.G, "toarray") else sysm.G, dtype=float)
+    C = np.array(sysm.C.toarray() if hasattr(sysm.C, "toarray") else sysm.C, dtype=float)
+    for i in range(ctx.n_nodes):
+        G[i, i] += gmin                                      # assemble_G(ctx; gshunt=gmin)
+    names = list(ctx.node_names) + list(ctx.current_names)
+    if output in ("gnd", "0") or output not in names:
+        raise KeyError("noise!: unknown output %s" % output)
+    out_idx = names.index(output)
+    in_idx = None
+    if input is not None:
+        cands = [nm for nm in ("I_" + input, "I_" + input.lower()) if nm in ctx.current_names]
+        if not cands:
+            raise KeyError("noise!: input source %s is not an independent voltage source" % input)
+        in_idx = ctx.n_nodes + ctx.current_names.index(cands[0])
+    e_out = np.zeros(n, dtype=complex)
+    e_out[out_idx] = 1.0
+    onoise = np.zeros(len(freqs))
+    contributions = {}
+    for src in ctx.noise:
+        contributions.setdefault(src[5], np.zeros(len(freqs)))
+    gain = np.zeros(len(freqs), dtype=complex) if input is not None else None
+    inoise = np.zeros(len(freqs)) if input is not None else None
+    for fi, f in enumerate(freqs):
+        w = 2 * np.pi * f
+        x_adj = np.linalg.solve((1j * w * C + G).T, e_out)
+        for src in ctx.noise:
+            pp, qq = ctx.resolve_index(src[0]), ctx.resolve_index(src[1])
+            Hk = (0.0 if pp == 0 else x_adj[pp - 1]) - (0.0 if qq == 0 else x_adj[qq - 1])
+            c = abs(Hk) ** 2 * noise_psd(src, spec.temp, f)
+            onoise[fi] += c
+            contributions[src[5]][fi] += c
+        if input is not None:
+            H = x_adj[in_idx]
+            gain[fi] = H
+            inoise[fi] = np.inf if H == 0 else onoise[fi] / abs(H) ** 2
+    return onoise, contributions, gain, inoise
 
 
 # ---- AC small-signal response at a DC point (src/ac.jl:113-170, 185-215) -----------------------------------------------------

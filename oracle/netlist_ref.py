@@ -77,7 +77,7 @@ def make_builder(devices):
             g = lambda k, default=None: _num(dev.get(k, default), params)
             name = dev.get("name", ty)
             if ty == "R":
-                D.stamp_resistor(ctx, nodes[0], nodes[1], g("r"))
+                D.stamp_resistor(ctx, nodes[0], nodes[1], g("r"), name)
             elif ty == "C":
                 D.stamp_capacitor(ctx, nodes[0], nodes[1], g("c"))
             elif ty == "L":

@@ -111,12 +111,14 @@ class VAFatal(RuntimeError):
     pass
 
 
-def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False, given=None, spec=None, on_short=None, touched=None, probe=None):
+def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False, given=None, spec=None, on_short=None, touched=None, probe=None, on_noise=None):
     """Branch contributions of ``mod`` on dual node voltages ``Vd``: one Dual / CDual / float per branch.
     ``limit_site(j, vnew_dual, fn)`` implements a $limit call site (stamp_va); ``given``: the parameters the instance sets
     explicitly ($param_given); ``on_short(a, b, stmt, value)``: called for every executed potential contribution V(a,b) <+ value;
     ``touched``: a list that receives True at the index of every branch a current contribution executes for; ``probe(e)``: the value
-    of a current probe I(br) / I(a,b) -- a plain number, the branch-current unknown of a potential contribution (vasim.jl:3632-3640,
+    ``on_noise(a, b, fn, pwr, expo, label)``: a white_noise / flicker_noise call inside the contribution to (a, b) (vasim.jl:2856-2893:
+    the call registers a source between the enclosing contribution's nodes, scaled by $mfactor; its value is 0.0); of a current probe:
+    a plain number, the branch-current unknown of a potential contribution (vasim.jl:3632-3640,
     3652-3667) -- default 0.0 (branches that carry noise only, vasim.jl:3641-3650)."""
     given = set(par) if given is None else set(given)
     for al, target in mod.aliasparams.items():
@@ -125,6 +127,7 @@ def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False
     env = {v: 0.0 for v in mod.locals_}
     acc = [0.0 for _ in mod.branches]
     scopes = []          # analog-function frames: the innermost shadows everything
+    bound = [None]       # (p, n) of the contribution being evaluated
     mode = getattr(spec, "mode", "tran") if spec is not None else "tran"
 
     def lookup(name):
@@ -180,6 +183,10 @@ def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False
             return float(any((a in ("dc", "static") and mode == "dcop") or (a in ("tran", "transient") and mode == "tran")
                              or (a == "ac" and mode == "ac") for a in e[1]))
         if k == "noise":
+            if on_noise is not None and bound[0] is not None and e[1] in ("white_noise", "flicker_noise"):
+                pwr = val(_res(ev(e[2][0]))) if e[2] else 0.0
+                expo = val(_res(ev(e[2][1]))) if (e[1] == "flicker_noise" and len(e[2]) >= 2) else 1.0
+                on_noise(bound[0][0], bound[0][1], e[1], mfactor * pwr, expo, e[3])
             return 0.0                                          # noise sources contribute no current on this path
         if k == "Iprobe":
             return float(probe(e)) if probe is not None else 0.0
@@ -253,12 +260,16 @@ def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False
             if k == "assign":
                 store(s[1], ev(s[2]))
             elif k == "contrib":
+                bound[0] = (mod.node_index(s[1]), mod.node_index(s[2]))     # the branch a noise call in this right-hand side injects into
                 if s[3][0] == "noise":
+                    ev(s[3])
+                    bound[0] = None
                     continue
                 b = mod.branches.index((mod.node_index(s[1]), mod.node_index(s[2])))
                 if touched is not None:
                     touched[b] = True
                 acc[b] = acc[b] + ev(s[3])
+                bound[0] = None
             elif k == "block":
                 run(s[1])
             elif k == "if":
@@ -438,7 +449,16 @@ def stamp_va(ctx, mod, ext_nodes, x, par, spec, instance, mfactor=1.0, gmin=None
 
     temp_k = float(getattr(spec, "temp", 27.0)) + 273.15
     touched = [False] * len(mod.branches)
-    Ibr = evaluate(mod, Vd, par, temp_k, mfactor, spec.gmin if gmin is None else gmin, limit_site, ctx.initjct, given, spec, on_short, touched, probe)
+    def on_noise(a, b, fn, pwr, expo, label):             # noise_source_name(instance, label), context.jl:1123-1127
+        p_node, n_node = (node[a] if a >= 0 else 0), (node[b] if b >= 0 else 0)
+        name = ("%s_%s" % (instance, label)) if (instance and label) else (instance or label or "va")
+        if fn == "white_noise":
+            ctx.register_white_noise(p_node, n_node, pwr, name)
+        else:
+            ctx.register_flicker_noise(p_node, n_node, pwr, expo, name)
+
+    Ibr = evaluate(mod, Vd, par, temp_k, mfactor, spec.gmin if gmin is None else gmin, limit_site, ctx.initjct, given, spec, on_short, touched, probe,
+                   on_noise if hasattr(ctx, "register_white_noise") else None)
     for b, (pl, nl) in enumerate(mod.branches):
         if mod.branch_guarded[b] and not touched[b]:
             continue          # contributions inside conditionals are stamped inline, when they execute (vasim.jl:2397-2470): none did

@@ -98,8 +98,17 @@ OTHER = {
 }
 
 
+# test/noise.jl:161-189: a forward-biased sp_diode loaded by a resistor (shot noise against the resistor's thermal noise) and an sp_bjt in the
+# active region (three parasitic-resistance thermal sources, collector and base shot noise, base flicker noise).  name -> (deck, output, freqs)
+NOISE = {
+    "noise_diode": ("* diode_shot (test/noise.jl:14-19)\nV1 in 0 DC 5\nR1 in out 10k\nXd1 out 0 sp_diode is=1e-14 rs=0\n", "out", [1e2, 1e4]),
+    "noise_bjt": ("* bjt_noise (test/noise.jl:21-27)\nVcc vcc 0 DC 5\nVb b 0 DC 0.7\nRc vcc c 4.7k\nXq1 c b 0 0 sp_bjt bf=100 is=1e-15 rb=100 re=1 rc=10 kf=1e-12 af=1\n", "c", [1e1, 1e2]),
+}
+NOISE_KINDS = ("thermal", "shot", "white", "flicker")
+
+
 def fixture_path(name):
-    return os.path.join(GOLD, "%s%s.npz" % ("" if name.startswith("bsim4_") else "vad_" if name in TIER6 else "va_" if name in OTHER else "psp103_", name))
+    return os.path.join(GOLD, "%s%s.npz" % ("" if name.startswith("bsim4_") else "vad_" if name in TIER6 else "va_" if name in OTHER or name in NOISE else "psp103_", name))
 
 
 def cases():
@@ -109,6 +118,7 @@ def cases():
            "bsim4_nmos": (BSIM4_NMOS, {}, "dcop"), "bsim4_dff": (bm.dff_circuit_bsim4(vdd=1.8), {}, "tran")}
     out.update({k: (v[0], {}, "dcop") for k, v in TIER6.items()})
     out.update({k: (v, {}, "dcop") for k, v in OTHER.items()})
+    out.update({k: (v[0], {}, "dcop") for k, v in NOISE.items()})
     return out
 
 
@@ -137,7 +147,7 @@ def build(name, K=5):
     assert (st.n, st.node_names, st.current_names, st.charge_names) == (cs.n, ctx.node_names, ctx.current_names, ctx.charge_names)
     assert np.array_equal(st.ref_colptr, cs.colptr) and np.array_equal(st.ref_rowval, cs.rowval)
     U = states(st, K, 20261004, 1.8 if name == "bsim4_dff" else 1.2)
-    if name in TIER6 or name in OTHER:      # (volts of the circuit's own scale; limit unknowns near their probes)
+    if name in TIER6 or name in OTHER or name in NOISE:      # (volts of the circuit's own scale; limit unknowns near their probes)
         U = states(st, K, 20261004, 2.0)
         U[1:, st.n - st.n_limits:] = np.random.default_rng(7).random((K - 1, st.n_limits)) * 1.4 - 0.2
     T = np.array([0.0, 0.0, 1.5e-9, 3e-9, 7e-9][:K])
@@ -156,6 +166,22 @@ def build(name, K=5):
         assert sol.converged or name in ("mos3", "mos9"), name
         extra["dc_x"] = np.asarray(sol.x, dtype=float)
         extra["dc_ok"] = np.array([1 if sol.converged else 0])
+    if name in NOISE:
+        # the oracle's noise! at its own DC point: the registered sources (system indices, 0 = ground) and the output PSD
+        _, output, freqs = NOISE[name]
+        onoise, contributions, _, _ = M.noise(bld, {}, spec, output, freqs)
+        nctx = M.MNAContext()
+        bld({}, spec, 0.0, x=M.ZERO_VECTOR, ctx=nctx)
+        nctx.reset_for_restamping()
+        nctx.noise = []
+        bld({}, spec, 0.0, x=sol.x, ctx=nctx)
+        extra["noise_freqs"], extra["noise_onoise"] = np.array(freqs, dtype=float), onoise
+        extra["noise_p"] = np.array([nctx.resolve_index(q[0]) for q in nctx.noise])
+        extra["noise_n"] = np.array([nctx.resolve_index(q[1]) for q in nctx.noise])
+        extra["noise_kind"] = np.array([NOISE_KINDS.index(q[2]) for q in nctx.noise])
+        extra["noise_a"], extra["noise_b"] = np.array([q[3] for q in nctx.noise]), np.array([q[4] for q in nctx.noise])
+        extra["noise_names"] = np.frombuffer(",".join(q[5] for q in nctx.noise).encode(), dtype=np.uint8)
+        extra["noise_output"] = np.frombuffer(output.encode(), dtype=np.uint8)
     return st, extra
 
 
