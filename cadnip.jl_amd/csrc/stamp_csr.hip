@@ -261,7 +261,8 @@ static int launch_stamp_csr_t(CadnipHandle* h, DeviceBlock& b) {
   const size_t tile_words = (size_t)nslots * b.sp_cs + b.sp_scratch;
   while (ipw > 1 && (size_t)ipw * tile_words * 8 > 64 * 1024) --ipw;
   const int u_lds = (size_t)ipw * h->n * 8 <= 16 * 1024 ? 1 : 0;
-  const size_t shmem = ((size_t)ipw * tile_words + 3 * (size_t)ipw + (u_lds ? (size_t)ipw * h->n : 0)) * 8;   // tiles (staged slots + tree scratch), per-instance scalars, u
+  static const size_t lds_pad = getenv("CADNIP_SC_PAD") ? (size_t)atol(getenv("CADNIP_SC_PAD")) : 0;        // experiments: occupancy as a function of the LDS request
+  const size_t shmem = ((size_t)ipw * tile_words + 3 * (size_t)ipw + (u_lds ? (size_t)ipw * h->n : 0)) * 8 + lds_pad;   // tiles (staged slots + tree scratch), per-instance scalars, u
   CsrStampArgs a{b.d_nodes, b.d_ipar, b.d_par, h->d_wave, h->d_u, h->d_t, h->d_active, h->d_cold, h->d_G, h->d_C, h->d_b, h->d_limit_w, h->d_nonfinite,
                  h->d_diag_flag, h->d_gshunt, h->d_srcfact, b.d_sp_tptr, b.d_sp_info, b.d_sp_rec,
                  h->B, b.count, h->n, h->nnz, b.n_par, b.n_g, b.n_c, b.n_b, b.sp_cs, b.sp_chunks, ipw, lpd, h->spec.mode, h->initjct,

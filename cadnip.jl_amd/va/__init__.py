@@ -21,7 +21,8 @@ EXTERNAL = (("PSP103VA", "psp103.va", _PSP), ("sp_bsim4v8", "bsim4v8.va", _VAD),
             ("sp_bjt", "bjt.va", _VAD), ("sp_jfet1", "jfet1.va", _VAD), ("sp_jfet2", "jfet2.va", _VAD), ("sp_mes1", "mes1.va", _VAD),
             ("sp_mos1", "mos1.va", _VAD), ("sp_mos2", "mos2.va", _VAD), ("sp_mos3", "mos3.va", _VAD), ("sp_mos6", "mos6.va", _VAD),
             ("sp_mos9", "mos9.va", _VAD), ("sp_bsim3v3", "bsim3v3.va", _VAD), ("JUNCAP200", "juncap200.va", _PSP),
-            ("bsimcmg", "bsimcmg.va", _CMC), ("sp_inductor", "inductor.va", _VAD), ("sp_vdmos", "vdmos.va", _VAD))
+            ("bsimcmg", "bsimcmg.va", _CMC), ("sp_inductor", "inductor.va", _VAD), ("sp_vdmos", "vdmos.va", _VAD),
+            ("NLVCR", "NLVCR.va", ("test",)))       # test/ddx.jl: ddx() with respect to a branch potential
 REFERENCE_ROOT = "/root/reference"
 
 _cache = {}

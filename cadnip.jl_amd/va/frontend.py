@@ -644,10 +644,8 @@ class _Parser:
                 raise VAError("ddx: the second argument must be a potential probe V(net)")
             self.expect("(")
             a, b = self.probe_nets()
-            if b is not None:
-                raise VAError("ddx: derivative with respect to a branch potential V(a,b) is not supported")
             self.expect(")")
-            return ("ddx", e, a)
+            return ("ddx", e, a, b)         # b: the partial with respect to a branch potential V(a,b) is (d/dV_a - d/dV_b) / 2 (vasim.jl:1168-1180)
         if v == "$limit":
             self.expect("(")
             if self.next()[1] != "V":
@@ -993,7 +991,7 @@ def _analyse(m: VAModule):
         if k in ("str", "noise", "analysis", "num"):
             return
         if k == "ddx":
-            node(e[2])
+            node(e[2]); node(e[3])
             check(e[1], names, in_func)
             return
         if k == "Iprobe":

@@ -68,7 +68,10 @@ class _Gen:
         if k == "ddx":
             c, t, _ = self.g(e[1])
             a = m.node_index(e[2])
-            return ("va_ddx%s(%s, %d)" % (("_tl<%d>" % tl_lanes(m)) if self.tl else "", c, a)) if (t and a >= 0) else "0.0", False, None
+            one = lambda k: ("va_ddx%s(%s, %d)" % (("_tl<%d>" % tl_lanes(m)) if self.tl else "", c, k)) if (t and k >= 0) else "0.0"
+            if e[3] is not None:           # with respect to a branch potential V(a,b): (d/dV_a - d/dV_b) / 2 (vasim.jl:1168-1180)
+                return "((%s - %s) / 2.0)" % (one(a), one(m.node_index(e[3]))), False, None
+            return one(a), False, None
         if k == "var":
             if self.func:
                 return "f_" + e[1], True, None

@@ -193,7 +193,12 @@ def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False
         if k == "ddx":
             x = _res(ev(e[1]))
             a = mod.node_index(e[2])
-            return float(x.p[a]) if isinstance(x, Dual) and a >= 0 else 0.0
+            d1 = float(x.p[a]) if isinstance(x, Dual) and a >= 0 else 0.0
+            if e[3] is None:
+                return d1
+            b = mod.node_index(e[3])                 # d/dV(a,b) = (d/dV_a - d/dV_b) / 2   (vasim.jl:1168-1180)
+            d2 = float(x.p[b]) if isinstance(x, Dual) and b >= 0 else 0.0
+            return (d1 - d2) / 2
         if k == "ucall":
             return call(e[1], e[2])
         if k == "limit":

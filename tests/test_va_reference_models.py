@@ -37,8 +37,7 @@ EXPECTED = {
     "vdmos.va": (10, 12, 5, 8, 7),         # five terminals (two thermal), V(tbr) <+ ... on the named thermal branch
 }
 # refused, with the reason
-REFUSED = {os.path.join(PSP_DIR, "psp103_nqs.va"): "idt", "/root/reference/test/NLVCR.va": "branch potential",
-           "/root/reference/test/mna/fixtures/table_model/tm_1d.va": "$table_model"}
+REFUSED = {os.path.join(PSP_DIR, "psp103_nqs.va"): "idt", "/root/reference/test/mna/fixtures/table_model/tm_1d.va": "$table_model"}
 
 
 @pytest.mark.parametrize("fn", sorted(EXPECTED))

@@ -94,6 +94,7 @@ TIER6 = {
 # models/PSPModels.jl.  No test of the reference that runs holds numbers for them (test/bsimcmg is legacy): the oracle's interpreter is the pin.
 OTHER = {
     "bsimcmg_nmos": "* bsimcmg NMOS, default card\n.model nfin bsimcmg\nM1 d g 0 0 nfin\nVds d 0 DC 0.8\nVgs g 0 DC 0.6\n",
+    "nlvcr": "* test/ddx.jl:38-73: NLVCR(R=2) between vcc (5 V), vg (3 V) and ground: I = 2 R V(d,s) V(g,s) = 60 A\nV1 vcc 0 DC 5\nV2 vg 0 DC 3\nX1 vcc vg 0 NLVCR R=2\n",
     "juncap200": "* JUNCAP200 diode behind 100 Ohm\nV1 a 0 DC 0.5\nR1 a k 100\nX1 k 0 juncap200\n",
 }
 
