@@ -79,6 +79,8 @@ struct DeviceBlock {
   struct Target { int chunk; unsigned word; std::vector<unsigned short> offs; };
   std::vector<Target> sp_targets;            // build-time only
   int *d_sp_tptr = nullptr, *d_sp_info = nullptr; uint4* d_sp_rec = nullptr;
+  int sp_rows = 0;                           // staged rows of a tile: the slots some target reads (+ one trash row for the rest); see build_stamp_plan
+  unsigned short* d_sp_rowoff = nullptr;     // [n_g + n_c + n_b] word offset of every slot's row inside a tile
 };
 
 struct ProfEntry { const char* name; double ms = 0; int64_t calls = 0; };

@@ -86,6 +86,43 @@ int build_stamp_plan(CadnipHandle* h, const CadnipStructure* s) {
   const int* slots[3] = {s->g_slots, s->c_slots, s->b_slots};
   const int n_tgt[3] = {nnz, nnz, n};
   const int totals[3] = {h->ns_g, h->ns_c, h->ns_b};
+  // Rows of a tile.  A tile stages [row][device]; only the slots that some target reads need a row of their own (a stamp into a
+  // ground row / column has no target, nor has the unused form -- charge state or linear -- of a reactive branch): they are packed,
+  // every other slot writes into one shared trash row, and a slot whose value is structurally zero is read from the tile's zero
+  // word.  Fewer rows = less LDS per wave = more waves per CU: this kernel's duration follows its occupancy.
+  const unsigned short ROW_ZERO = 0xFFFEu, ROW_NONE = 0xFFFFu;
+  std::vector<std::vector<unsigned short>> rowmap(h->blocks.size());
+  for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
+    const DeviceBlock& b = h->blocks[bi];
+    rowmap[bi].assign((size_t)(b.n_g + b.n_c + b.n_b), ROW_NONE);
+  }
+  for (int arr = 0; arr < 3; ++arr) {
+    const std::vector<Owner> own = owners(arr, totals[arr]);
+    for (int e = 0; e < n_tgt[arr]; ++e)
+      for (int p = ptrs[arr][e]; p < ptrs[arr][e + 1]; ++p) {
+        const Owner& o = own[(size_t)slots[arr][p]];
+        if (o.blk < 0) return CADNIP_BADARG;
+        const DeviceBlock& b = h->blocks[o.blk];
+        rowmap[o.blk][(size_t)(o.k + (arr == 0 ? 0 : arr == 1 ? b.n_g : b.n_g + b.n_c))] = 0;      // live
+      }
+  }
+  for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
+    DeviceBlock& b = h->blocks[bi];
+    if (b.count == 0) continue;
+    if (b.type == CADNIP_DEV_MOS1)                      // devices.hpp: the charge rows' d/dV_d and d/dV_s entries (gq[1], gq[3]) and their linear
+      for (int r = 0; r < 4; ++r)                       // form (dq[0], dq[2]) are zeros whatever the parameters
+        for (int k : {48 + 7 * r + 1, 48 + 7 * r + 3, b.n_g + 4 + 6 * r, b.n_g + 4 + 6 * r + 2})
+          if (rowmap[bi][(size_t)k] != ROW_NONE) rowmap[bi][(size_t)k] = ROW_ZERO;
+    int rows = 0;
+    for (auto& r : rowmap[bi]) if (r == 0) r = (unsigned short)rows++;
+    b.sp_rows = rows + 1;                               // + the trash row
+    if ((size_t)b.sp_rows * b.sp_cs > 65000) return CADNIP_BADARG;   // 16-bit staging offsets
+    std::vector<unsigned short> ro(rowmap[bi].size());
+    for (size_t k = 0; k < ro.size(); ++k) ro[k] = (unsigned short)((rowmap[bi][k] >= ROW_ZERO ? rows : rowmap[bi][k]) * b.sp_cs);
+    int rc = upload_vec(&b.d_sp_rowoff, ro);
+    if (rc) return rc;
+  }
+  const unsigned OFF_ZERO = 0xFFFFu;                    // operand that reads the tile's zero word (patched below, like an unused operand slot)
   std::vector<unsigned> prep, prep_orphan;   // atomically accumulated words nobody stores first | unstamped node diagonals
   std::vector<char> is_diag((size_t)nnz, 0);
   for (int i = 0; i < s->n_nodes; ++i) if (s->diag_nz[i] >= 0 && s->diag_nz[i] < nnz) is_diag[s->diag_nz[i]] = 1;
@@ -100,7 +137,8 @@ int build_stamp_plan(CadnipHandle* h, const CadnipStructure* s) {
         if (o.blk < 0) return CADNIP_BADARG;                            // a gather list names a slot no block owns
         const DeviceBlock& b = h->blocks[o.blk];
         const int kk = o.k + (arr == 0 ? 0 : arr == 1 ? b.n_g : b.n_g + b.n_c);
-        cl.push_back(Contrib{o.blk, o.dev / b.sp_cs, (unsigned short)(kk * b.sp_cs + o.dev % b.sp_cs)});
+        const unsigned short row = rowmap[o.blk][(size_t)kk];
+        cl.push_back(Contrib{o.blk, o.dev / b.sp_cs, row == ROW_ZERO ? (unsigned short)OFF_ZERO : (unsigned short)(row * b.sp_cs + o.dev % b.sp_cs)});
       }
       if (cl.empty()) {
         // a G entry nobody stamps stays zero for ever -- unless it is a node diagonal, which carries gshunt
@@ -136,7 +174,7 @@ int build_stamp_plan(CadnipHandle* h, const CadnipStructure* s) {
     // A target with more contributions becomes a 5-ary tree: level-0 records sum consecutive runs of five staged words into
     // scratch words of the tile, the next level combines five of those, ... until one record is left, which carries the
     // target's real destination.  Records are grouped per chunk and level.
-    const int nslots = b.n_g + b.n_c + b.n_b, stage_words = nslots * b.sp_cs;
+    const int stage_words = b.sp_rows * b.sp_cs;
     struct Rec { int chunk, level, cls; uint4 r; };
     auto cls_of = [](unsigned word) { const unsigned md = word >> 30, arr = (word >> 28) & 3u; return md == TGT_PARTIAL ? 3 : md == TGT_STORE ? (int)arr : 4; };
     std::vector<Rec> recs;
@@ -252,31 +290,43 @@ int launch_va_setup(CadnipHandle* h, DeviceBlock& b) {
 }
 
 template <int TYPE>
-static int launch_stamp_csr_t(CadnipHandle* h, DeviceBlock& b) {
+static int launch_stamp_csr_pass(CadnipHandle* h, DeviceBlock& b, bool dump_only) {
   const int nslots = b.n_g + b.n_c + b.n_b;
   const bool pair = TYPE == CADNIP_DEV_MOS1 && b.mos1_plain;
   const int lpd = pair ? 2 : (TYPE == CADNIP_DEV_VA && b.va_tl) ? b.va_tl : 1;
+  const int rows = dump_only ? nslots : b.sp_rows;      // the read-out pass stages every slot in a row of its own
   int ipw = 1;
   if (b.sp_chunks == 1) ipw = std::min(8, std::max(1, 64 / (b.count * lpd)));   // (a wave reduces its instances one after the other: few per wave)
-  const size_t tile_words = (size_t)nslots * b.sp_cs + b.sp_scratch;
+  const size_t tile_words = (size_t)rows * b.sp_cs + b.sp_scratch;
   while (ipw > 1 && (size_t)ipw * tile_words * 8 > 64 * 1024) --ipw;
   const int u_lds = (size_t)ipw * h->n * 8 <= 16 * 1024 ? 1 : 0;
   static const size_t lds_pad = getenv("CADNIP_SC_PAD") ? (size_t)atol(getenv("CADNIP_SC_PAD")) : 0;        // experiments: occupancy as a function of the LDS request
-  const size_t shmem = ((size_t)ipw * tile_words + 3 * (size_t)ipw + (u_lds ? (size_t)ipw * h->n : 0)) * 8 + lds_pad;   // tiles (staged slots + tree scratch), per-instance scalars, u
+  // tiles (staged rows + tree scratch), per-instance scalars, u, the slots' row offsets
+  const size_t shmem = ((size_t)ipw * tile_words + 3 * (size_t)ipw + (u_lds ? (size_t)ipw * h->n : 0)) * 8 + (((size_t)nslots * 2 + 7) & ~(size_t)7) + lds_pad;
   CsrStampArgs a{b.d_nodes, b.d_ipar, b.d_par, h->d_wave, h->d_u, h->d_t, h->d_active, h->d_cold, h->d_G, h->d_C, h->d_b, h->d_limit_w, h->d_nonfinite,
                  h->d_diag_flag, h->d_gshunt, h->d_srcfact, b.d_sp_tptr, b.d_sp_info, b.d_sp_rec,
                  h->B, b.count, h->n, h->nnz, b.n_par, b.n_g, b.n_c, b.n_b, b.sp_cs, b.sp_chunks, ipw, lpd, h->spec.mode, h->initjct,
                  (TYPE == CADNIP_DEV_MOS1 || TYPE == CADNIP_DEV_VA) ? 1 : 0, b.sp_levels, b.sp_scratch, u_lds,
-                 b.d_cache, b.n_cache, h->d_dump, h->ns, b.g_base, h->ns_g + b.c_base, h->ns_g + h->ns_c + b.b_base};
+                 b.d_cache, b.n_cache, dump_only ? h->d_dump : nullptr, h->ns, b.g_base, h->ns_g + b.c_base, h->ns_g + h->ns_c + b.b_base,
+                 dump_only ? nullptr : b.d_sp_rowoff, rows, dump_only ? 1 : 0};
   const unsigned grid = (unsigned)b.sp_chunks * (unsigned)((h->B + ipw - 1) / ipw);
-  if (getenv("CADNIP_SC_DEBUG")) fprintf(stderr, "[cadnip stamp] type %d count %d cs %d chunks %d ipw %d lpd %d nslots %d scratch %d tile_words %zu shmem %zu grid %u steps %d levels %d\n",
-                                         TYPE, b.count, b.sp_cs, b.sp_chunks, ipw, lpd, nslots, b.sp_scratch, tile_words, shmem, grid, 0, b.sp_levels);
+  if (getenv("CADNIP_SC_DEBUG")) fprintf(stderr, "[cadnip stamp] type %d count %d cs %d chunks %d ipw %d lpd %d slots %d rows %d scratch %d tile_words %zu shmem %zu grid %u levels %d%s\n",
+                                         TYPE, b.count, b.sp_cs, b.sp_chunks, ipw, lpd, nslots, rows, b.sp_scratch, tile_words, shmem, grid, b.sp_levels, dump_only ? " (read-out pass)" : "");
   if (TYPE == CADNIP_DEV_VA && b.va_tl) {           // external model: its own kernel (va_ext/<module>.hip)
     const int ext = b.va_model - CADNIP_VA_NBUILTIN;
     if (ext < 0 || ext >= CADNIP_VA_NEXT) return CADNIP_BADARG;
     return VA_EXT_STAMP[ext](a, grid, shmem, h->stream);
   }
   return launch_stamp_kernel<TYPE>(a, grid, shmem, h->stream);
+}
+
+// The stamping pass of one block; with the operating-point read-out armed (cadnip_get_contributions), a second pass that stages every
+// slot -- also those no target reads: the current into a grounded terminal is one of them -- and writes them out instead of reducing.
+template <int TYPE>
+static int launch_stamp_csr_t(CadnipHandle* h, DeviceBlock& b) {
+  int rc = launch_stamp_csr_pass<TYPE>(h, b, false);
+  if (!rc && h->d_dump) rc = launch_stamp_csr_pass<TYPE>(h, b, true);
+  return rc;
 }
 
 // one stamping kernel alone (bench.py times it back to back for the stamp-kernel roofline line)

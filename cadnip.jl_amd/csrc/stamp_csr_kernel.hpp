@@ -18,12 +18,14 @@ struct LdsOut {
   static constexpr bool DIRECT = false;
   __device__ __forceinline__ void Rn(int, double) const {}
   __device__ __forceinline__ double du(int) const { return 0.0; }
-  double *g, *c, *b;     // tile + 0, + n_g * cs, + (n_g + n_c) * cs
-  int cs, ldev;          // devices per tile row, this lane's device within the tile
-  bool on;               // false: no device behind this lane (or an inactive instance)
-  __device__ __forceinline__ void G(int k, double v) const { if (on) g[k * cs + ldev] = v; }
-  __device__ __forceinline__ void C(int k, double v) const { if (on) c[k * cs + ldev] = v; }
-  __device__ __forceinline__ void B(int k, double v) const { if (on) b[k * cs + ldev] = v; }
+  double* tile;                          // this lane's instance tile
+  const unsigned short *rg, *rc, *rb;    // LDS: word offset of the row of G / C / b slot k inside a tile (build_stamp_plan: the rows some target reads are
+                                         // packed; every other slot -- ground rows / columns, the unused form of a reactive branch -- shares one trash row)
+  int ldev;                              // this lane's device within the tile
+  bool on;                               // false: no device behind this lane (or an inactive instance)
+  __device__ __forceinline__ void G(int k, double v) const { if (on) tile[rg[k] + ldev] = v; }
+  __device__ __forceinline__ void C(int k, double v) const { if (on) tile[rc[k] + ldev] = v; }
+  __device__ __forceinline__ void B(int k, double v) const { if (on) tile[rb[k] + ldev] = v; }
   template <int N> __device__ __forceinline__ void Gv(int k0, const double (&v)[N]) const {
 #pragma unroll
     for (int i = 0; i < N; ++i) G(k0 + i, v[i]);
@@ -53,6 +55,8 @@ struct CsrStampArgs {
   const double* cache; int n_cache;                 // generated external models: setup-pass results [B][n_cache][count] (k_va_setup)
   double* dump; int ns, dump_g, dump_c, dump_b;   // operating-point read-out only (cadnip_get_contributions): the staged per-device
                                                     // contributions written out as [B][ns], slot (k, dev) of array A at A_base + k * count + dev
+  const unsigned short* rowoff; int n_rows;        // row offsets of the slots (null: identity, n_rows = all slots), rows of a tile
+  int dump_only;                                    // operating-point read-out pass: stage with the identity layout, write `dump`, skip the reduction
 
 };
 
@@ -85,7 +89,7 @@ __global__ void __launch_bounds__(64) k_stamp_csr(CsrStampArgs a) {
   // per step for that reason alone -- and keeps a shift register of PIPE steps' records: the first PIPE are requested
   // here, before the stamp phase, a new one enters with every step.  step_lane: lane s holds the descriptor of step s
   // (class | first-step-of-a-level flag << 8), read with v_readlane.
-  const int s0 = a.step_ptr[chunk], n_steps = a.step_ptr[chunk + 1] - s0;
+  const int s0 = a.step_ptr[chunk], n_steps = a.dump_only ? 0 : a.step_ptr[chunk + 1] - s0;
   const int step_lane = a.step_info[s0 + (lane < n_steps ? lane : 0)];   // steps beyond 64 read their descriptor from memory
   const uint4* recs = a.tgt_rec + (size_t)s0 * STEP_W + lane;
   uint4 pipe[PIPE][2];                                                    // stage p holds the records of step q + p
@@ -94,7 +98,7 @@ __global__ void __launch_bounds__(64) k_stamp_csr(CsrStampArgs a) {
     const int st = p < n_steps ? p : 0;
     pipe[p][0] = recs[(size_t)st * STEP_W]; pipe[p][1] = recs[(size_t)st * STEP_W + 64];
   }
-  const int nslots = a.n_g + a.n_c + a.n_b, tile_words = nslots * a.cs + a.n_scratch;   // staged slots | scratch of the reduction tree
+  const int nslots = a.n_g + a.n_c + a.n_b, tile_words = a.n_rows * a.cs + a.n_scratch;   // staged rows | scratch of the reduction tree
   // lane -> (instance of the tile, device of the chunk, side of a lane pair)
   const int dl = lane / a.lpd, side = lane - dl * a.lpd;
   const int ii = a.n_chunks == 1 ? dl / a.count : 0;
@@ -123,6 +127,9 @@ __global__ void __launch_bounds__(64) k_stamp_csr(CsrStampArgs a) {
     inst_par[3 * lane + 2] = in ? a.srcFact[i2] : 1.0;
   }
   double* u_tile = inst_par + 3 * a.ipw;                           // [ipw][n] when u_lds
+  unsigned short* rowoff = (unsigned short*)(u_tile + (a.u_lds ? (size_t)a.ipw * a.n : 0));   // [nslots]
+  for (int i = lane; i < nslots; i += 64) rowoff[i] = a.rowoff ? a.rowoff[i] : (unsigned short)(i * a.cs);
+  if (!a.u_lds) CADNIP_WAVE_SYNC();
   if (a.u_lds) {
     for (int r = 0; r < a.ipw; ++r) {
       const int i2 = grp * a.ipw + r < a.B ? grp * a.ipw + r : a.B - 1;
@@ -135,7 +142,7 @@ __global__ void __launch_bounds__(64) k_stamp_csr(CsrStampArgs a) {
   {
     DevCtx d{a.nodes, a.ipar, a.par + (size_t)inst_c * a.n_par * a.count, a.wave, a.count, dev < a.count ? dev : a.count - 1, a.t[inst_c], a.mode, (a.initjct && a.cold[inst_c]) ? 1 : 0,
              a.cache ? a.cache + (size_t)inst_c * a.n_cache * a.count : nullptr};
-    LdsOut s{tile, tile + (size_t)a.n_g * a.cs, tile + (size_t)(a.n_g + a.n_c) * a.cs, a.cs, ldev, valid};
+    LdsOut s{tile, rowoff, rowoff + a.n_g, rowoff + a.n_g + a.n_c, ldev, valid};
     const double* u = a.u_lds ? u_tile + (size_t)(ii < a.ipw ? ii : 0) * a.n : a.u + (size_t)inst_c * a.n;
     double* lw = valid ? a.limit_w + (size_t)inst_c * a.n : nullptr;
     if (TYPE == CADNIP_DEV_RESISTOR) stamp_resistor(d, u, s, lw);
@@ -162,8 +169,9 @@ __global__ void __launch_bounds__(64) k_stamp_csr(CsrStampArgs a) {
     }
   }
   CADNIP_WAVE_SYNC();
-  if (a.dump && valid && side == 0) {
+  if (a.dump_only && a.dump && valid && side == 0) {
     double* D = a.dump + (size_t)inst * a.ns;
+    // (dump_only pass: identity layout, every slot has its own row)
     for (int k = 0; k < a.n_g; ++k) D[a.dump_g + k * a.count + dev] = tile[k * a.cs + ldev];
     for (int k = 0; k < a.n_c; ++k) D[a.dump_c + k * a.count + dev] = tile[(a.n_g + k) * a.cs + ldev];
     for (int k = 0; k < a.n_b; ++k) D[a.dump_b + k * a.count + dev] = tile[(a.n_g + a.n_c + k) * a.cs + ldev];
