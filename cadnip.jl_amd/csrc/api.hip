@@ -205,7 +205,8 @@ void cadnip_destroy(CadnipHandle* h) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->d_f2tab) (void)hipFree(h->d_f2tab);
   for (auto& b : h->blocks) {
-    void* bp[] = {b.d_nodes, b.d_ipar, b.d_par, b.d_sp_tptr, b.d_sp_info, b.d_sp_rec, b.d_cache, b.d_sp_rowoff};
+    void* bp[] = {b.d_nodes, b.d_ipar, b.d_par, b.d_sp_tptr, b.d_sp_info, b.d_sp_rec, b.d_cache, b.d_sp_rowoff,
+                  b.sp_gen.tptr, b.sp_gen.info, b.sp_gen.rec, b.sp_gen.rowoff, b.sp_plain.tptr, b.sp_plain.info, b.sp_plain.rec, b.sp_plain.rowoff};
     for (void* p : bp) if (p) (void)hipFree(p);
   }
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);

@@ -54,7 +54,7 @@ template <class T> static int upload_vec(T** p, const std::vector<T>& v) {
   return CADNIP_OK;
 }
 
-int build_stamp_plan(CadnipHandle* h, const CadnipStructure* s) {
+static int build_plan_variant(CadnipHandle* h, const CadnipStructure* s, bool plain) {
   const int n = h->n, nnz = h->nnz;
   // slot -> (block, k, dev) per array; blocks own disjoint slot ranges
   struct Owner { int blk, k, dev; };
@@ -113,6 +113,12 @@ int build_stamp_plan(CadnipHandle* h, const CadnipStructure* s) {
       for (int r = 0; r < 4; ++r)                       // form (dq[0], dq[2]) are zeros whatever the parameters
         for (int k : {48 + 7 * r + 1, 48 + 7 * r + 3, b.n_g + 4 + 6 * r, b.n_g + 4 + 6 * r + 2})
           if (rowmap[bi][(size_t)k] != ROW_NONE) rowmap[bi][(size_t)k] = ROW_ZERO;
+    if (b.type == CADNIP_DEV_MOS1 && plain) {           // the lane-pair path (stamp_mos1_pair; gd = gs = OxideCap = 0): the KCL rows of the external
+      auto zero = [&](int k) { if (rowmap[bi][(size_t)k] != ROW_NONE) rowmap[bi][(size_t)k] = ROW_ZERO; };   // d, g, s terminals carry nothing ...
+      for (int k = 12; k < 12 + 18; ++k) zero(k);
+      for (int br = 3; br < 6; ++br) { zero(12 + 6 * br); zero(12 + 6 * br + 2); }      // ... and no row has an entry in the d / s columns
+      for (int k = 0; k < 3; ++k) zero(b.n_g + b.n_c + k);                               // b of rows d, g, s
+    }
     int rows = 0;
     for (auto& r : rowmap[bi]) if (r == 0) r = (unsigned short)rows++;
     b.sp_rows = rows + 1;                               // + the trash row
@@ -264,6 +270,25 @@ int build_stamp_plan(CadnipHandle* h, const CadnipStructure* s) {
   return CADNIP_OK;
 }
 
+int build_stamp_plan(CadnipHandle* h, const CadnipStructure* s) {
+  auto take = [](DeviceBlock& b) {
+    DeviceBlock::PlanSet p;
+    p.n_targets = b.sp_n_targets; p.levels = b.sp_levels; p.scratch = b.sp_scratch; p.rows = b.sp_rows;
+    p.tptr = b.d_sp_tptr; p.info = b.d_sp_info; p.rec = b.d_sp_rec; p.rowoff = b.d_sp_rowoff;
+    b.d_sp_tptr = nullptr; b.d_sp_info = nullptr; b.d_sp_rec = nullptr; b.d_sp_rowoff = nullptr;
+    return p;
+  };
+  bool any_mos1 = false;
+  for (auto& b : h->blocks) any_mos1 = any_mos1 || (b.type == CADNIP_DEV_MOS1 && b.count > 0);
+  int rc = build_plan_variant(h, s, false);
+  if (rc || !any_mos1) return rc;
+  for (auto& b : h->blocks) if (b.type == CADNIP_DEV_MOS1 && b.count > 0) b.sp_gen = take(b);
+  rc = build_plan_variant(h, s, true);
+  if (rc) return rc;
+  for (auto& b : h->blocks) if (b.type == CADNIP_DEV_MOS1 && b.count > 0) b.sp_plain = take(b);
+  return CADNIP_OK;
+}
+
 // The external generated models: one translation unit each (va_ext/<module>.hip, written by va/hipgen.py) with the model's own
 // instantiation of k_stamp_csr and of its setup kernel; reached through these tables (model id - CADNIP_VA_NBUILTIN).
 #define X(i, nm) int va_ext_stamp_launch_##nm(const CsrStampArgs&, unsigned, size_t, hipStream_t); int va_ext_setup_launch_##nm(const VaSetupArgs&, hipStream_t);
@@ -294,24 +319,27 @@ static int launch_stamp_csr_pass(CadnipHandle* h, DeviceBlock& b, bool dump_only
   const int nslots = b.n_g + b.n_c + b.n_b;
   const bool pair = TYPE == CADNIP_DEV_MOS1 && b.mos1_plain;
   const int lpd = pair ? 2 : (TYPE == CADNIP_DEV_VA && b.va_tl) ? b.va_tl : 1;
-  const int rows = dump_only ? nslots : b.sp_rows;      // the read-out pass stages every slot in a row of its own
+  DeviceBlock::PlanSet P;                              // the plan in force
+  if (TYPE == CADNIP_DEV_MOS1) P = b.mos1_plain ? b.sp_plain : b.sp_gen;
+  else { P.levels = b.sp_levels; P.scratch = b.sp_scratch; P.rows = b.sp_rows; P.tptr = b.d_sp_tptr; P.info = b.d_sp_info; P.rec = b.d_sp_rec; P.rowoff = b.d_sp_rowoff; }
+  const int rows = dump_only ? nslots : P.rows;        // the read-out pass stages every slot in a row of its own
   int ipw = 1;
   if (b.sp_chunks == 1) ipw = std::min(8, std::max(1, 64 / (b.count * lpd)));   // (a wave reduces its instances one after the other: few per wave)
-  const size_t tile_words = (size_t)rows * b.sp_cs + b.sp_scratch;
+  const size_t tile_words = (size_t)rows * b.sp_cs + P.scratch;
   while (ipw > 1 && (size_t)ipw * tile_words * 8 > 64 * 1024) --ipw;
   const int u_lds = (size_t)ipw * h->n * 8 <= 16 * 1024 ? 1 : 0;
   static const size_t lds_pad = getenv("CADNIP_SC_PAD") ? (size_t)atol(getenv("CADNIP_SC_PAD")) : 0;        // experiments: occupancy as a function of the LDS request
   // tiles (staged rows + tree scratch), per-instance scalars, u, the slots' row offsets
   const size_t shmem = ((size_t)ipw * tile_words + 3 * (size_t)ipw + (u_lds ? (size_t)ipw * h->n : 0)) * 8 + (((size_t)nslots * 2 + 7) & ~(size_t)7) + lds_pad;
   CsrStampArgs a{b.d_nodes, b.d_ipar, b.d_par, h->d_wave, h->d_u, h->d_t, h->d_active, h->d_cold, h->d_G, h->d_C, h->d_b, h->d_limit_w, h->d_nonfinite,
-                 h->d_diag_flag, h->d_gshunt, h->d_srcfact, b.d_sp_tptr, b.d_sp_info, b.d_sp_rec,
+                 h->d_diag_flag, h->d_gshunt, h->d_srcfact, P.tptr, P.info, P.rec,
                  h->B, b.count, h->n, h->nnz, b.n_par, b.n_g, b.n_c, b.n_b, b.sp_cs, b.sp_chunks, ipw, lpd, h->spec.mode, h->initjct,
-                 (TYPE == CADNIP_DEV_MOS1 || TYPE == CADNIP_DEV_VA) ? 1 : 0, b.sp_levels, b.sp_scratch, u_lds,
+                 (TYPE == CADNIP_DEV_MOS1 || TYPE == CADNIP_DEV_VA) ? 1 : 0, P.levels, P.scratch, u_lds,
                  b.d_cache, b.n_cache, dump_only ? h->d_dump : nullptr, h->ns, b.g_base, h->ns_g + b.c_base, h->ns_g + h->ns_c + b.b_base,
-                 dump_only ? nullptr : b.d_sp_rowoff, rows, dump_only ? 1 : 0};
+                 dump_only ? nullptr : P.rowoff, rows, dump_only ? 1 : 0};
   const unsigned grid = (unsigned)b.sp_chunks * (unsigned)((h->B + ipw - 1) / ipw);
   if (getenv("CADNIP_SC_DEBUG")) fprintf(stderr, "[cadnip stamp] type %d count %d cs %d chunks %d ipw %d lpd %d slots %d rows %d scratch %d tile_words %zu shmem %zu grid %u levels %d%s\n",
-                                         TYPE, b.count, b.sp_cs, b.sp_chunks, ipw, lpd, nslots, rows, b.sp_scratch, tile_words, shmem, grid, b.sp_levels, dump_only ? " (read-out pass)" : "");
+                                         TYPE, b.count, b.sp_cs, b.sp_chunks, ipw, lpd, nslots, rows, P.scratch, tile_words, shmem, grid, P.levels, dump_only ? " (read-out pass)" : "");
   if (TYPE == CADNIP_DEV_VA && b.va_tl) {           // external model: its own kernel (va_ext/<module>.hip)
     const int ext = b.va_model - CADNIP_VA_NBUILTIN;
     if (ext < 0 || ext >= CADNIP_VA_NEXT) return CADNIP_BADARG;
