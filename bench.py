@@ -193,6 +193,8 @@ def probe_main(args):
     atol = st.state_abstol(**ABSTOL)
     breaks = expand_breakpoints(st.breakpoints, bm.DFF_TSPAN)
     u0, conv, dcs = sim.dc(abstol=1e-9, mode="tranop", fused=bool(args.fused))
+    if not np.all(conv):                       # counters of a workload that did not run as benchmarked are worth nothing
+        raise RuntimeError("probe: DC initialisation failed for %d of %d instances (%s)" % (int((~np.asarray(conv, dtype=bool)).sum()), len(conv), dcs))
     sim.h.set_spec(mode="tran")
     _, _, stats = sim.h.tran_run(bm.DFF_TSPAN[0], bm.DFF_TSPAN[1], atol, RELTOL, breaks=breaks, save_t=np.linspace(*bm.DFF_TSPAN, 71),
                                  obs=[st.index_of("Q")], fused=int(args.fused), newton_mode=args.newton_mode)
@@ -318,7 +320,7 @@ def run(args, rank, world, local_rank, dist, dev, sync, reduce_max, reduce_sum, 
         def one_step(gather=True, newton_mode=None):
             u0, conv, dcs = sim.dc(abstol=1e-9, mode="tranop", fused=bool(args.fused))
             if not np.all(conv):
-                raise RuntimeError("DC initialisation failed on rank %d" % rank)
+                raise RuntimeError("DC initialisation failed on rank %d: %d of %d instances unconverged (%s)" % (rank, int((~np.asarray(conv, dtype=bool)).sum()), len(conv), dcs))
             sim.h.set_spec(mode="tran")
             out, per, stats = sim.h.tran_run(bm.DFF_TSPAN[0], bm.DFF_TSPAN[1], atol, RELTOL, breaks=breaks, save_t=save_t, obs=obs,
                                              fused=int(args.fused), newton_mode=args.newton_mode if newton_mode is None else newton_mode)

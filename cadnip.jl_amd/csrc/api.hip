@@ -68,10 +68,16 @@ int cadnip_create(const CadnipStructure* s, int32_t n_instances, int32_t device,
   h->n = s->n; h->n_nodes = s->n_nodes; h->n_currents = s->n_currents; h->n_charges = s->n_charges; h->n_limits = s->n_limits;
   h->nnz = s->nnz;
   h->ns_g = s->ns_g; h->ns_c = s->ns_c; h->ns_b = s->ns_b; h->ns = s->ns_g + s->ns_c + s->ns_b;
+  // Host-pointer transfers of this ABI are BLOCKING copies -- uploads at API entry, where the handle's stream is idle; downloads after a stream
+  // synchronisation -- not asynchronous copies on the stream: an asynchronous copy from pageable host memory is not reliably ordered with
+  // the kernels of a non-blocking stream (observed under `rocprofv3 --pmc`: cadnip_dc_run's start state landed after the first stamping
+  // kernels had run, the residual of the stale state was not finite and every instance failed; driver.hip: k_publish_int has the same story
+  // for the other direction).
   CREATE_HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CREATE_HIP_TRY(hipEventCreate(&h->ev0));
   CREATE_HIP_TRY(hipEventCreate(&h->ev1));
-  CREATE_HIP_TRY(hipHostMalloc((void**)&h->h_pinned, 64 * sizeof(int), hipHostMallocDefault));
+  CREATE_HIP_TRY(hipHostMalloc((void**)&h->h_pinned, 64 * sizeof(int), hipHostMallocMapped));
+  CREATE_HIP_TRY(hipHostGetDevicePointer((void**)&h->d_pinned, h->h_pinned, 0));
   h->h_rowptr.assign(s->rowptr, s->rowptr + s->n + 1);
   h->h_colidx.assign(s->colidx, s->colidx + s->nnz);
   h->h_to_ref.assign(s->to_ref_nz, s->to_ref_nz + s->nnz);
@@ -222,7 +228,7 @@ void cadnip_destroy(CadnipHandle* h) {
 int cadnip_set_params(CadnipHandle* h, int32_t block, const double* par_host) {
   if (!h || block < 0 || block >= (int)h->blocks.size() || !par_host) return CADNIP_BADARG;
   auto& b = h->blocks[block];
-  HIP_TRY(hipMemcpyAsync(b.d_par, par_host, (size_t)h->B * b.n_par * b.count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpy(b.d_par, par_host, (size_t)h->B * b.n_par * b.count * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (b.type == CADNIP_DEV_MOS1) {
     // the fused kernel's two-lanes-per-MOSFET stamp (devices.hpp: stamp_mos1_pair) applies when no instance has series
@@ -255,8 +261,8 @@ int cadnip_set_initjct(CadnipHandle* h, int32_t on) { if (!h) return CADNIP_BADA
 
 static int upload_state(CadnipHandle* h, const double* u_host, const double* t_host) {
   size_t B = h->B, n = h->n;
-  if (u_host) HIP_TRY(hipMemcpyAsync(h->d_u, u_host, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  if (t_host) HIP_TRY(hipMemcpyAsync(h->d_t, t_host, B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (u_host) HIP_TRY(hipMemcpy(h->d_u, u_host, B * n * sizeof(double), hipMemcpyHostToDevice));
+  if (t_host) HIP_TRY(hipMemcpy(h->d_t, t_host, B * sizeof(double), hipMemcpyHostToDevice));
   return CADNIP_OK;
 }
 
@@ -264,7 +270,7 @@ static int upload_state(CadnipHandle* h, const double* u_host, const double* t_h
 // d_nonfinite; the Julia shim maps the status to DomainError, which _dc_solve_with_fallbacks catches, solve.jl:887-897)
 static int check_nonfinite(CadnipHandle* h) {
   std::vector<int> nf((size_t)h->B);
-  HIP_TRY(hipMemcpyAsync(nf.data(), h->d_nonfinite, nf.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(nf.data(), h->d_nonfinite, nf.size() * sizeof(int), hipMemcpyDeviceToHost));
   HIP_TRY(hipStreamSynchronize(h->stream));
   for (int f : nf) if (f) return CADNIP_NONFINITE;
   return CADNIP_OK;
@@ -273,7 +279,7 @@ static int check_nonfinite(CadnipHandle* h) {
 int cadnip_rebuild(CadnipHandle* h, const double* u_host, const double* t_host) {
   if (!h) return CADNIP_BADARG;
   TRY(upload_state(h, u_host, t_host));
-  HIP_TRY(hipMemsetAsync(h->d_nonfinite, 0, (size_t)h->B * sizeof(int), h->stream));
+  TRY_RC(dev_zero_async(h, h->d_nonfinite, (size_t)h->B * sizeof(int)));
   TRY(launch_rebuild(h));
   return check_nonfinite(h);
 }
@@ -282,9 +288,9 @@ int cadnip_residual(CadnipHandle* h, const double* du_host, const double* u_host
   if (!h || !du_host || !resid_host) return CADNIP_BADARG;
   size_t B = h->B, n = h->n;
   TRY(upload_state(h, u_host, nullptr));
-  HIP_TRY(hipMemcpyAsync(h->d_du, du_host, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpy(h->d_du, du_host, B * n * sizeof(double), hipMemcpyHostToDevice));
   TRY(launch_residual(h, h->d_du));
-  HIP_TRY(hipMemcpyAsync(resid_host, h->d_resid, B * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(resid_host, h->d_resid, B * n * sizeof(double), hipMemcpyDeviceToHost));
   HIP_TRY(hipStreamSynchronize(h->stream));
   for (size_t k = 0; k < B * n; ++k) if (!(resid_host[k] == resid_host[k]) || resid_host[k] - resid_host[k] != 0.0) return CADNIP_NONFINITE;
   return CADNIP_OK;
@@ -293,7 +299,7 @@ int cadnip_residual(CadnipHandle* h, const double* du_host, const double* u_host
 static int readback_ref_order(CadnipHandle* h, const double* d_src, double* host_out) {
   size_t B = h->B, nnz = h->nnz;
   std::vector<double> tmp(B * nnz);
-  HIP_TRY(hipMemcpyAsync(tmp.data(), d_src, B * nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(tmp.data(), d_src, B * nnz * sizeof(double), hipMemcpyDeviceToHost));
   HIP_TRY(hipStreamSynchronize(h->stream));
   for (size_t i = 0; i < B; ++i)
     for (size_t k = 0; k < nnz; ++k) host_out[i * nnz + h->h_to_ref[k]] = tmp[i * nnz + k];
@@ -302,7 +308,7 @@ static int readback_ref_order(CadnipHandle* h, const double* d_src, double* host
 
 int cadnip_jacobian(CadnipHandle* h, const double* gamma_host, double* J_ref_nz_host) {
   if (!h || !gamma_host) return CADNIP_BADARG;
-  HIP_TRY(hipMemcpyAsync(h->d_gamma, gamma_host, (size_t)h->B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpy(h->d_gamma, gamma_host, (size_t)h->B * sizeof(double), hipMemcpyHostToDevice));
   TRY(launch_jacobian(h));
   if (J_ref_nz_host) TRY(readback_ref_order(h, h->d_J, J_ref_nz_host));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -314,10 +320,10 @@ int cadnip_ode_rhs(CadnipHandle* h, const double* u_host, const double* t_host, 
   if (!h || !du_host) return CADNIP_BADARG;
   size_t B = h->B, n = h->n;
   if (u_host) { TRY(upload_state(h, u_host, t_host)); TRY(launch_rebuild(h)); }
-  HIP_TRY(hipMemsetAsync(h->d_du, 0, B * n * sizeof(double), h->stream));
+  TRY_RC(dev_zero_async(h, h->d_du, B * n * sizeof(double)));
   TRY(launch_residual(h, h->d_du));                       // G u - b
   TRY(launch_negate(h, h->d_resid, (long)(B * n)));
-  HIP_TRY(hipMemcpyAsync(du_host, h->d_resid, B * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(du_host, h->d_resid, B * n * sizeof(double), hipMemcpyDeviceToHost));
   HIP_TRY(hipStreamSynchronize(h->stream));
   for (size_t k = 0; k < B * n; ++k) if (du_host[k] - du_host[k] != 0.0) return CADNIP_NONFINITE;
   return CADNIP_OK;
@@ -325,9 +331,9 @@ int cadnip_ode_rhs(CadnipHandle* h, const double* u_host, const double* t_host, 
 
 int cadnip_ode_jacobian(CadnipHandle* h, const double* u_host, const double* t_host, double* J_ref_nz_host) {
   if (!h || !J_ref_nz_host) return CADNIP_BADARG;
-  HIP_TRY(hipMemsetAsync(h->d_nonfinite, 0, (size_t)h->B * sizeof(int), h->stream));
+  TRY_RC(dev_zero_async(h, h->d_nonfinite, (size_t)h->B * sizeof(int)));
   if (u_host) { TRY(upload_state(h, u_host, t_host)); TRY(launch_rebuild(h)); }
-  HIP_TRY(hipMemsetAsync(h->d_gamma, 0, (size_t)h->B * sizeof(double), h->stream));
+  TRY_RC(dev_zero_async(h, h->d_gamma, (size_t)h->B * sizeof(double)));
   TRY(launch_jacobian(h));                                // G + 0*C
   TRY(launch_negate(h, h->d_J, (long)((size_t)h->B * h->nnz)));
   TRY(readback_ref_order(h, h->d_J, J_ref_nz_host));
@@ -339,10 +345,10 @@ int cadnip_get_GCb(CadnipHandle* h, double* G_ref_nz, double* C_ref_nz, double* 
   size_t B = h->B, n = h->n;
   if (G_ref_nz) TRY(readback_ref_order(h, h->d_G, G_ref_nz));
   if (C_ref_nz) TRY(readback_ref_order(h, h->d_C, C_ref_nz));
-  if (b) HIP_TRY(hipMemcpyAsync(b, h->d_b, B * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (b) HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(b, h->d_b, B * n * sizeof(double), hipMemcpyDeviceToHost));
   if (limit_w) {
     std::vector<double> tmp(B * n);
-    HIP_TRY(hipMemcpyAsync(tmp.data(), h->d_limit_w, B * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(tmp.data(), h->d_limit_w, B * n * sizeof(double), hipMemcpyDeviceToHost));
     HIP_TRY(hipStreamSynchronize(h->stream));
     size_t L = h->n_limits, l0 = n - L;
     for (size_t i = 0; i < B; ++i) for (size_t k = 0; k < L; ++k) limit_w[i * L + k] = tmp[i * n + l0 + k];
@@ -359,9 +365,9 @@ int cadnip_get_contributions(CadnipHandle* h, double* slots_host) {
   const size_t cnt = (size_t)h->B * h->ns;
   HIP_TRY(hipMalloc((void**)&h->d_dump, std::max<size_t>(cnt, 1) * sizeof(double)));
   int rc = CADNIP_OK;
-  if (hipMemsetAsync(h->d_dump, 0, cnt * sizeof(double), h->stream) != hipSuccess) rc = CADNIP_HIPERROR;
+  if (dev_zero_async(h, h->d_dump, cnt * sizeof(double)) != CADNIP_OK) rc = CADNIP_HIPERROR;
   if (!rc) rc = launch_rebuild(h);
-  if (!rc && hipMemcpyAsync(slots_host, h->d_dump, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = CADNIP_HIPERROR;
+  if (!rc && (hipStreamSynchronize(h->stream) != hipSuccess || hipMemcpy(slots_host, h->d_dump, cnt * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)) rc = CADNIP_HIPERROR;
   if (hipStreamSynchronize(h->stream) != hipSuccess) rc = CADNIP_HIPERROR;
   (void)hipFree(h->d_dump);
   h->d_dump = nullptr;
@@ -371,7 +377,7 @@ int cadnip_get_contributions(CadnipHandle* h, double* slots_host) {
 int cadnip_analyze(CadnipHandle* h, int32_t sample_instance) {
   if (!h || sample_instance < 0 || sample_instance >= h->B) return CADNIP_BADARG;
   std::vector<double> vals(h->nnz);
-  HIP_TRY(hipMemcpyAsync(vals.data(), h->d_J + (size_t)sample_instance * h->nnz, (size_t)h->nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(vals.data(), h->d_J + (size_t)sample_instance * h->nnz, (size_t)h->nnz * sizeof(double), hipMemcpyDeviceToHost));
   HIP_TRY(hipStreamSynchronize(h->stream));
   std::string err;
   int rc = lu_analyze(h->n, h->h_rowptr, h->h_colidx, vals, 1e-3, false, h->lu, err, h->leaves.q_begin >= 0 ? &h->leaves : nullptr);
@@ -458,10 +464,10 @@ void cadnip_host_lu_free(CadnipHostLU* lu) { delete lu; }
 
 int cadnip_factor(CadnipHandle* h) {
   if (!h) return CADNIP_BADARG;
-  HIP_TRY(hipMemsetAsync(h->d_flags, 0, (size_t)h->B * sizeof(int), h->stream));
+  TRY_RC(dev_zero_async(h, h->d_flags, (size_t)h->B * sizeof(int)));
   TRY(launch_factor(h, false));
   std::vector<int> fl(h->B);
-  HIP_TRY(hipMemcpyAsync(fl.data(), h->d_flags, (size_t)h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(fl.data(), h->d_flags, (size_t)h->B * sizeof(int), hipMemcpyDeviceToHost));
   HIP_TRY(hipStreamSynchronize(h->stream));
   for (int f : fl) if (f & 1) return CADNIP_SINGULAR;
   return CADNIP_OK;
@@ -470,9 +476,9 @@ int cadnip_factor(CadnipHandle* h) {
 int cadnip_solve(CadnipHandle* h, const double* rhs_host, double* x_host) {
   if (!h || !rhs_host || !x_host) return CADNIP_BADARG;
   size_t B = h->B, n = h->n;
-  HIP_TRY(hipMemcpyAsync(h->d_resid, rhs_host, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpy(h->d_resid, rhs_host, B * n * sizeof(double), hipMemcpyHostToDevice));
   TRY(launch_solve(h, h->d_resid, h->d_delta));
-  HIP_TRY(hipMemcpyAsync(x_host, h->d_delta, B * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(x_host, h->d_delta, B * n * sizeof(double), hipMemcpyDeviceToHost));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return CADNIP_OK;
 }
@@ -500,19 +506,19 @@ void* cadnip_stream(CadnipHandle* h) { return h ? (void*)h->stream : nullptr; }
 
 int cadnip_set_u(CadnipHandle* h, const double* u_host) {
   if (!h || !u_host) return CADNIP_BADARG;
-  HIP_TRY(hipMemcpyAsync(h->d_u, u_host, (size_t)h->B * h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpy(h->d_u, u_host, (size_t)h->B * h->n * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return CADNIP_OK;
 }
 int cadnip_get_u(CadnipHandle* h, double* u_host) {
   if (!h || !u_host) return CADNIP_BADARG;
-  HIP_TRY(hipMemcpyAsync(u_host, h->d_u, (size_t)h->B * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(u_host, h->d_u, (size_t)h->B * h->n * sizeof(double), hipMemcpyDeviceToHost));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return CADNIP_OK;
 }
 int cadnip_get_flags(CadnipHandle* h, int32_t* flags_host) {
   if (!h || !flags_host) return CADNIP_BADARG;
-  HIP_TRY(hipMemcpyAsync(flags_host, h->d_flags, (size_t)h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(flags_host, h->d_flags, (size_t)h->B * sizeof(int), hipMemcpyDeviceToHost));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return CADNIP_OK;
 }
@@ -559,8 +565,8 @@ int upload_homotopy(CadnipHandle* h, const double* gshunt, const double* srcfact
   if (srcfact) sf.assign(srcfact, srcfact + B);
   bool any = false;
   for (size_t i = 0; i < B; ++i) if (g[i] != 0.0 || sf[i] < 1.0) any = true;
-  HIP_TRY(hipMemcpyAsync(h->d_gshunt, g.data(), B * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->d_srcfact, sf.data(), B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpy(h->d_gshunt, g.data(), B * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_srcfact, sf.data(), B * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipStreamSynchronize(h->stream));   // the host vectors go out of scope
   h->homotopy = any;
   return CADNIP_OK;

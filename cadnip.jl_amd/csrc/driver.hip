@@ -127,6 +127,15 @@ __global__ void k_count_running(const int* status, int B, int* nactive) {
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(nactive, __popcll(m));
 }
 
+// The running-instance count reaches the host through a store of this kernel into mapped pinned memory, not through an asynchronous
+// device-to-host copy: under `rocprofv3 --pmc` (which serialises and re-queues the application's kernels) a copy queued behind the counting
+// kernel was observed to run BEFORE it -- the host read 0, the Newton loop of cadnip_dc_run stopped at round 0 and every instance counted
+// as failed.  Kernels of one stream stay ordered among themselves, and a finished kernel's stores to host memory are visible after the
+// stream / event synchronisation.
+__global__ void k_publish_int(const int* src, int* dst_host) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { *dst_host = *src; __threadfence_system(); }
+}
+
 // ------------------------------------------------------------------------------------------
 // DC: PCNR Newton state machine (solve.jl:599-698) / plain Newton (solve.jl:542-578)
 // ------------------------------------------------------------------------------------------
@@ -213,11 +222,11 @@ __global__ void __launch_bounds__(64) k_dc_update(DCArgs a) {
 
 int count_running(CadnipHandle* h, int* out) {
   Driver* d = h->drv;
-  HIP_TRY(hipMemsetAsync(d->nactive, 0, sizeof(int), h->stream));
+  TRY_RC(dev_zero_async(h, d->nactive, sizeof(int)));
   hipLaunchKernelGGL(k_count_running, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, d->status, h->B, d->nactive);
-  HIP_TRY(hipMemcpyAsync(h->h_pinned, d->nactive, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  hipLaunchKernelGGL(k_publish_int, dim3(1), dim3(64), 0, h->stream, (const int*)d->nactive, h->d_pinned);
   HIP_TRY(hipStreamSynchronize(h->stream));
-  *out = h->h_pinned[0];
+  *out = ((volatile int*)h->h_pinned)[0];
   return CADNIP_OK;
 }
 
@@ -227,9 +236,9 @@ int dc_newton(CadnipHandle* h, double abstol, int maxiters, int use_pcnr, int co
   DCArgs a{h->d_u, h->d_resid, h->d_delta, h->d_limit_w, h->d_limit_init, h->d_active, h->d_flags, d->status, d->dcstate, d->action, h->d_cold, d->cnt,
            h->B, h->n, h->n_limits, (use_pcnr && h->n_limits > 0) ? 1 : 0, maxiters, abstol};
   hipLaunchKernelGGL(k_dc_init, dim3(h->B), dim3(64), 0, h->stream, a, cold_start, d_part);
-  HIP_TRY(hipMemsetAsync(h->d_gamma, 0, (size_t)h->B * sizeof(double), h->stream));
-  HIP_TRY(hipMemsetAsync(h->d_du, 0, (size_t)h->B * h->n * sizeof(double), h->stream));
-  HIP_TRY(hipMemsetAsync(h->d_t, 0, (size_t)h->B * sizeof(double), h->stream));
+  TRY_RC(dev_zero_async(h, h->d_gamma, (size_t)h->B * sizeof(double)));
+  TRY_RC(dev_zero_async(h, h->d_du, (size_t)h->B * h->n * sizeof(double)));
+  TRY_RC(dev_zero_async(h, h->d_t, (size_t)h->B * sizeof(double)));
   int saved_initjct = h->initjct;
   h->initjct = (cold_start && a.use_pcnr) ? 1 : 0;   // armed for the first stamping only (solve.jl:624,632)
   int rc = CADNIP_OK;
@@ -336,11 +345,11 @@ int cadnip_dc_run(CadnipHandle* h, const CadnipDCOpts* o, double* u_host, int32_
   d->dc_log.clear();
   // the symbolic phase needs one numeric Jacobian: stamp once at the start point
   if (!h->analyzed) {
-    HIP_TRY(hipMemcpyAsync(h->d_u, u_host, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpy(h->d_u, u_host, B * n * sizeof(double), hipMemcpyHostToDevice));
     std::vector<int> ones(B, 1);
-    HIP_TRY(hipMemcpyAsync(h->d_active, ones.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_gamma, 0, B * sizeof(double), h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_t, 0, B * sizeof(double), h->stream));
+    HIP_TRY(hipMemcpy(h->d_active, ones.data(), B * sizeof(int), hipMemcpyHostToDevice));
+    TRY_RC(dev_zero_async(h, h->d_gamma, B * sizeof(double)));
+    TRY_RC(dev_zero_async(h, h->d_t, B * sizeof(double)));
     // pattern-complete sample: G + 1e9*C makes every structural entry of the unified pattern visible
     std::vector<double> g(B, 1e9);
     int ij = h->initjct;
@@ -348,7 +357,7 @@ int cadnip_dc_run(CadnipHandle* h, const CadnipDCOpts* o, double* u_host, int32_
     int rc = launch_rebuild(h);
     h->initjct = ij;
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(h->d_gamma, g.data(), B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpy(h->d_gamma, g.data(), B * sizeof(double), hipMemcpyHostToDevice));
     TRY(launch_jacobian(h));
     HIP_TRY(hipStreamSynchronize(h->stream));
     TRY(cadnip_analyze(h, 0));
@@ -370,8 +379,9 @@ int cadnip_dc_run(CadnipHandle* h, const CadnipDCOpts* o, double* u_host, int32_
   bool direct = false;
   // one Newton run of the instances in `part`, each from U[i] with its own (gsh[i], sfc[i]); results in status / R / cnt
   auto run = [&](int use_pcnr, int cold_start, int fused, int stage, const std::vector<double>& rung) -> int {
-    HIP_TRY(hipMemcpyAsync(h->d_u, U.empty() ? u_host : U.data(), B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(d->part, part.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    // (blocking copies: the stream is idle here, and the start state must be in place before the first kernel is queued -- see k_publish_int)
+    HIP_TRY(hipMemcpy(h->d_u, U.empty() ? u_host : U.data(), B * n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d->part, part.data(), B * sizeof(int), hipMemcpyHostToDevice));
     TRY(upload_homotopy(h, gsh.data(), sfc.data()));
     TRY(dc_newton(h, o->abstol, o->maxiters, use_pcnr, cold_start, nullptr, fused, d->part));
     HIP_TRY(hipMemcpy(status.data(), d->status, B * sizeof(int), hipMemcpyDeviceToHost));
@@ -529,16 +539,16 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
   TRY(drealloc(&d->save_t, &d->save_cap, (size_t)o->n_save));
   TRY(drealloc(&d->obs, &d->obs_cap, (size_t)n_obs));
   TRY(drealloc(&d->out, &d->out_cap, B * (size_t)o->n_save * n_obs));
-  if (o->n_break) HIP_TRY(hipMemcpyAsync(d->breaks, o->breaks, o->n_break * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  if (o->n_save) HIP_TRY(hipMemcpyAsync(d->save_t, o->save_t, o->n_save * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (o->n_break) HIP_TRY(hipMemcpy(d->breaks, o->breaks, o->n_break * sizeof(double), hipMemcpyHostToDevice));
+  if (o->n_save) HIP_TRY(hipMemcpy(d->save_t, o->save_t, o->n_save * sizeof(double), hipMemcpyHostToDevice));
   std::vector<int> obs(n_obs);
   for (int i = 0; i < n_obs; ++i) obs[i] = o->n_obs > 0 ? o->obs[i] : i;
-  HIP_TRY(hipMemcpyAsync(d->obs, obs.data(), n_obs * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(d->atol, o->abstol, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpy(d->obs, obs.data(), n_obs * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d->atol, o->abstol, n * sizeof(double), hipMemcpyHostToDevice));
   std::vector<double> emask(n, 1.0);
   int n_err = (int)n;
   if (o->err_mask) { n_err = 0; for (size_t i = 0; i < n; ++i) { emask[i] = o->err_mask[i] != 0.0 ? 1.0 : 0.0; n_err += emask[i] != 0.0; } }
-  HIP_TRY(hipMemcpyAsync(d->emask, emask.data(), n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpy(d->emask, emask.data(), n * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipStreamSynchronize(h->stream));
   const double span = o->t1 - o->t0;
   double hmax = o->hmax > 0 ? o->hmax : span / 50.0;
@@ -577,13 +587,13 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
     while (launches < max_it) {
       rc = launch_fused2_rounds(h, a, check_every); if (rc) break;
       launches += check_every;
-      if (hipMemsetAsync(d->nactive + slot, 0, sizeof(int), h->stream) != hipSuccess) { rc = CADNIP_HIPERROR; break; }
+      if (dev_zero_async(h, d->nactive + slot, sizeof(int)) != CADNIP_OK) { rc = CADNIP_HIPERROR; break; }
       hipLaunchKernelGGL(k_count_running, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, d->status, h->B, d->nactive + slot);
-      if (hipMemcpyAsync(h->h_pinned + slot, d->nactive + slot, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-          hipEventRecord(ev[slot], h->stream) != hipSuccess) { rc = CADNIP_HIPERROR; break; }
+      hipLaunchKernelGGL(k_publish_int, dim3(1), dim3(64), 0, h->stream, (const int*)(d->nactive + slot), h->d_pinned + slot);
+      if (hipEventRecord(ev[slot], h->stream) != hipSuccess) { rc = CADNIP_HIPERROR; break; }
       if (have_prev) {
         if (hipEventSynchronize(ev[1 - slot]) != hipSuccess) { rc = CADNIP_HIPERROR; break; }
-        running = h->h_pinned[1 - slot];
+        running = ((volatile int*)h->h_pinned)[1 - slot];
         if (running == 0) break;
       }
       have_prev = true;

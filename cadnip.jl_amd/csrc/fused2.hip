@@ -258,7 +258,7 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
   if (shmem > lds_cap) return CADNIP_BADARG;
   // resident workgroups only: the instances beyond them are handed out by the in-kernel queue as waves become free
   if (!h->d_f2queue) HIP_TRY(hipMalloc((void**)&h->d_f2queue, sizeof(int)));
-  HIP_TRY(hipMemsetAsync(h->d_f2queue, 0, sizeof(int), h->stream));
+  TRY_RC(dev_zero_async(h, h->d_f2queue, sizeof(int)));
   f.queue = h->d_f2queue;
   const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(lds_cap / shmem, (size_t)(32 / wpb)));
   int grid = std::min((h->B + wpb - 1) / wpb, h->n_cu * wg_per_cu);

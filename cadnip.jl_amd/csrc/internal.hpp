@@ -163,6 +163,7 @@ struct CadnipHandle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // pinned scratch
   int* h_pinned = nullptr;
+  int* d_pinned = nullptr;   // the same words as the device sees them: small results are PUBLISHED there by a kernel (driver.hip: k_publish_int), not copied
 };
 
 namespace cadnip {
@@ -181,6 +182,8 @@ int launch_factor_solve(CadnipHandle* h, bool fuse_jacobian, const double* d_rhs
 int upload_lu(CadnipHandle* h);
 int upload_homotopy(CadnipHandle* h, const double* gshunt /* [B] or null = spec */, const double* srcfact /* [B] or null = spec */);
 int launch_calib_copy(CadnipHandle* h, long n, int reps);
+#define TRY_RC(x) do { int _rc_ = (x); if (_rc_) return _rc_; } while (0)
+int dev_zero_async(CadnipHandle* h, void* p, size_t bytes);       // kernels.hip: zero-fill as a kernel on the handle's stream (ordered with the other kernels)
 int launch_negate(CadnipHandle* h, double* d_x, long n);
 struct TranArgs;                                                          // tran_ctrl.hpp
 int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds); // fused2.hip

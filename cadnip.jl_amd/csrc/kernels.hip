@@ -227,6 +227,22 @@ int launch_negate(CadnipHandle* h, double* d_x, long n) {
   return CADNIP_OK;
 }
 
+// Zero-fill of device words on the handle's stream, as a kernel of our own.  (A stream memset is implemented by the runtime with blit
+// kernels of its own; under `rocprofv3 --pmc`, which serialises and re-queues the application's kernels, such a fill was observed to land
+// AFTER the kernels queued behind it -- cadnip_dc_run then met the gamma = 1e9 left by the pivot analysis and every instance failed.  Kernels
+// of one stream stay ordered among themselves.)
+__global__ void __launch_bounds__(256) k_zero_words(unsigned* p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+int dev_zero_async(CadnipHandle* h, void* p, size_t bytes) {
+  if (!p || bytes == 0) return CADNIP_OK;
+  if (bytes & 3) return CADNIP_BADARG;
+  const size_t n = bytes / 4;
+  const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_zero_words, dim3(grid), dim3(256), 0, h->stream, (unsigned*)p, n);
+  return CADNIP_OK;
+}
+
 int launch_calib_copy(CadnipHandle* h, long n, int reps) {
   double *a = nullptr, *b = nullptr;
   HIP_TRY(hipMalloc((void**)&a, n * sizeof(double)));
