@@ -78,6 +78,9 @@ int cadnip_create(const CadnipStructure* s, int32_t n_instances, int32_t device,
   CREATE_HIP_TRY(hipEventCreate(&h->ev1));
   CREATE_HIP_TRY(hipHostMalloc((void**)&h->h_pinned, 64 * sizeof(int), hipHostMallocMapped));
   CREATE_HIP_TRY(hipHostGetDevicePointer((void**)&h->d_pinned, h->h_pinned, 0));
+  h->stage_bytes = (size_t)2 << 20;
+  CREATE_HIP_TRY(hipHostMalloc((void**)&h->h_stage, h->stage_bytes, hipHostMallocMapped));
+  CREATE_HIP_TRY(hipHostGetDevicePointer((void**)&h->d_stage, h->h_stage, 0));
   h->h_rowptr.assign(s->rowptr, s->rowptr + s->n + 1);
   h->h_colidx.assign(s->colidx, s->colidx + s->nnz);
   h->h_to_ref.assign(s->to_ref_nz, s->to_ref_nz + s->nnz);
@@ -216,6 +219,7 @@ void cadnip_destroy(CadnipHandle* h) {
     for (void* p : bp) if (p) (void)hipFree(p);
   }
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+  if (h->h_stage) (void)hipHostFree(h->h_stage);
   if (h->d_f2queue) (void)hipFree(h->d_f2queue);
   if (h->d_f2_lufac) (void)hipFree(h->d_f2_lufac);
   if (h->d_f2blk) (void)hipFree(h->d_f2blk);
@@ -259,10 +263,47 @@ int cadnip_set_spec(CadnipHandle* h, const CadnipSpec* spec) {
 
 int cadnip_set_initjct(CadnipHandle* h, int32_t on) { if (!h) return CADNIP_BADARG; h->initjct = on ? 1 : 0; return CADNIP_OK; }
 
+// ---- host-pointer transfers of the callback entry points.  Small ones are staged through mapped pinned memory and moved by a copy KERNEL
+// on the stream (kernels of a stream stay ordered among themselves; asynchronous copies were not ordered with them under a counter pass -- see
+// cadnip_create); what does not fit the staging area is a blocking copy (uploads: the stream holds at most earlier staged uploads, to other buffers; downloads:
+// after a stream synchronisation).  An entry point calls stage_begin first and stage_finish last (which synchronises and hands out the downloads).
+static void stage_begin(CadnipHandle* h) { h->stage_off = 0; h->stage_pending.clear(); }
+static char* stage_take(CadnipHandle* h, size_t bytes) {
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (!h->h_stage || h->stage_off + need > h->stage_bytes) return nullptr;
+  char* p = h->h_stage + h->stage_off;
+  h->stage_off += need;
+  return p;
+}
+static int stage_up(CadnipHandle* h, void* dst_dev, const void* src_host, size_t bytes) {
+  if (char* s = stage_take(h, bytes)) {
+    memcpy(s, src_host, bytes);
+    return dev_copy_async(h, dst_dev, h->d_stage + (s - h->h_stage), bytes, false);
+  }
+  HIP_TRY(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+  return CADNIP_OK;
+}
+static int stage_down(CadnipHandle* h, void* dst_host, const void* src_dev, size_t bytes) {
+  if (char* s = stage_take(h, bytes)) {
+    h->stage_pending.push_back({dst_host, s, bytes});
+    return dev_copy_async(h, h->d_stage + (s - h->h_stage), src_dev, bytes, true);
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+  return CADNIP_OK;
+}
+static int stage_finish(CadnipHandle* h) {
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (auto& p : h->stage_pending) memcpy(p.dst, p.src, p.bytes);
+  h->stage_pending.clear();
+  h->stage_off = 0;                 // nothing of the staging area is in flight any more
+  return CADNIP_OK;
+}
+
 static int upload_state(CadnipHandle* h, const double* u_host, const double* t_host) {
   size_t B = h->B, n = h->n;
-  if (u_host) HIP_TRY(hipMemcpy(h->d_u, u_host, B * n * sizeof(double), hipMemcpyHostToDevice));
-  if (t_host) HIP_TRY(hipMemcpy(h->d_t, t_host, B * sizeof(double), hipMemcpyHostToDevice));
+  if (u_host) TRY(stage_up(h, h->d_u, u_host, B * n * sizeof(double)));
+  if (t_host) TRY(stage_up(h, h->d_t, t_host, B * sizeof(double)));
   return CADNIP_OK;
 }
 
@@ -270,14 +311,15 @@ static int upload_state(CadnipHandle* h, const double* u_host, const double* t_h
 // d_nonfinite; the Julia shim maps the status to DomainError, which _dc_solve_with_fallbacks catches, solve.jl:887-897)
 static int check_nonfinite(CadnipHandle* h) {
   std::vector<int> nf((size_t)h->B);
-  HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(nf.data(), h->d_nonfinite, nf.size() * sizeof(int), hipMemcpyDeviceToHost));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  TRY(stage_down(h, nf.data(), h->d_nonfinite, nf.size() * sizeof(int)));
+  TRY(stage_finish(h));
   for (int f : nf) if (f) return CADNIP_NONFINITE;
   return CADNIP_OK;
 }
 
 int cadnip_rebuild(CadnipHandle* h, const double* u_host, const double* t_host) {
   if (!h) return CADNIP_BADARG;
+  stage_begin(h);
   TRY(upload_state(h, u_host, t_host));
   TRY_RC(dev_zero_async(h, h->d_nonfinite, (size_t)h->B * sizeof(int)));
   TRY(launch_rebuild(h));
@@ -287,11 +329,12 @@ int cadnip_rebuild(CadnipHandle* h, const double* u_host, const double* t_host) 
 int cadnip_residual(CadnipHandle* h, const double* du_host, const double* u_host, double* resid_host) {
   if (!h || !du_host || !resid_host) return CADNIP_BADARG;
   size_t B = h->B, n = h->n;
+  stage_begin(h);
   TRY(upload_state(h, u_host, nullptr));
-  HIP_TRY(hipMemcpy(h->d_du, du_host, B * n * sizeof(double), hipMemcpyHostToDevice));
+  TRY(stage_up(h, h->d_du, du_host, B * n * sizeof(double)));
   TRY(launch_residual(h, h->d_du));
-  HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(resid_host, h->d_resid, B * n * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  TRY(stage_down(h, resid_host, h->d_resid, B * n * sizeof(double)));
+  TRY(stage_finish(h));
   for (size_t k = 0; k < B * n; ++k) if (!(resid_host[k] == resid_host[k]) || resid_host[k] - resid_host[k] != 0.0) return CADNIP_NONFINITE;
   return CADNIP_OK;
 }
@@ -299,8 +342,8 @@ int cadnip_residual(CadnipHandle* h, const double* du_host, const double* u_host
 static int readback_ref_order(CadnipHandle* h, const double* d_src, double* host_out) {
   size_t B = h->B, nnz = h->nnz;
   std::vector<double> tmp(B * nnz);
-  HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(tmp.data(), d_src, B * nnz * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  TRY(stage_down(h, tmp.data(), d_src, B * nnz * sizeof(double)));
+  TRY(stage_finish(h));
   for (size_t i = 0; i < B; ++i)
     for (size_t k = 0; k < nnz; ++k) host_out[i * nnz + h->h_to_ref[k]] = tmp[i * nnz + k];
   return CADNIP_OK;
@@ -308,7 +351,8 @@ static int readback_ref_order(CadnipHandle* h, const double* d_src, double* host
 
 int cadnip_jacobian(CadnipHandle* h, const double* gamma_host, double* J_ref_nz_host) {
   if (!h || !gamma_host) return CADNIP_BADARG;
-  HIP_TRY(hipMemcpy(h->d_gamma, gamma_host, (size_t)h->B * sizeof(double), hipMemcpyHostToDevice));
+  stage_begin(h);
+  TRY(stage_up(h, h->d_gamma, gamma_host, (size_t)h->B * sizeof(double)));
   TRY(launch_jacobian(h));
   if (J_ref_nz_host) TRY(readback_ref_order(h, h->d_J, J_ref_nz_host));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -345,7 +389,7 @@ int cadnip_get_GCb(CadnipHandle* h, double* G_ref_nz, double* C_ref_nz, double* 
   size_t B = h->B, n = h->n;
   if (G_ref_nz) TRY(readback_ref_order(h, h->d_G, G_ref_nz));
   if (C_ref_nz) TRY(readback_ref_order(h, h->d_C, C_ref_nz));
-  if (b) HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(b, h->d_b, B * n * sizeof(double), hipMemcpyDeviceToHost));
+  if (b) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(b, h->d_b, B * n * sizeof(double), hipMemcpyDeviceToHost)); }
   if (limit_w) {
     std::vector<double> tmp(B * n);
     HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(tmp.data(), h->d_limit_w, B * n * sizeof(double), hipMemcpyDeviceToHost));
@@ -467,8 +511,9 @@ int cadnip_factor(CadnipHandle* h) {
   TRY_RC(dev_zero_async(h, h->d_flags, (size_t)h->B * sizeof(int)));
   TRY(launch_factor(h, false));
   std::vector<int> fl(h->B);
-  HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(fl.data(), h->d_flags, (size_t)h->B * sizeof(int), hipMemcpyDeviceToHost));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  stage_begin(h);
+  TRY(stage_down(h, fl.data(), h->d_flags, (size_t)h->B * sizeof(int)));
+  TRY(stage_finish(h));
   for (int f : fl) if (f & 1) return CADNIP_SINGULAR;
   return CADNIP_OK;
 }
@@ -476,11 +521,11 @@ int cadnip_factor(CadnipHandle* h) {
 int cadnip_solve(CadnipHandle* h, const double* rhs_host, double* x_host) {
   if (!h || !rhs_host || !x_host) return CADNIP_BADARG;
   size_t B = h->B, n = h->n;
-  HIP_TRY(hipMemcpy(h->d_resid, rhs_host, B * n * sizeof(double), hipMemcpyHostToDevice));
+  stage_begin(h);
+  TRY(stage_up(h, h->d_resid, rhs_host, B * n * sizeof(double)));
   TRY(launch_solve(h, h->d_resid, h->d_delta));
-  HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(x_host, h->d_delta, B * n * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return CADNIP_OK;
+  TRY(stage_down(h, x_host, h->d_delta, B * n * sizeof(double)));
+  return stage_finish(h);
 }
 
 int cadnip_lu_stats(CadnipHandle* h, int32_t* nnz_lu, int32_t* n_terms, int32_t* n_levels, int32_t* n_fwd, int32_t* n_bwd) {

@@ -163,7 +163,12 @@ struct CadnipHandle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // pinned scratch
   int* h_pinned = nullptr;
-  int* d_pinned = nullptr;   // the same words as the device sees them: small results are PUBLISHED there by a kernel (driver.hip: k_publish_int), not copied
+  int* d_pinned = nullptr;
+  // mapped pinned staging area of the host-pointer entry points (api.hip: stage_up / stage_down / stage_finish): small transfers are moved
+  // by a copy KERNEL on the stream that reads / writes the staging area across the bus; large ones are blocking copies
+  char* h_stage = nullptr; char* d_stage = nullptr; size_t stage_bytes = 0, stage_off = 0;   // (d_stage: the same memory as the device sees it)
+  struct PendingDown { void* dst; const void* src; size_t bytes; };
+  std::vector<PendingDown> stage_pending;   // the same words as the device sees them: small results are PUBLISHED there by a kernel (driver.hip: k_publish_int), not copied
 };
 
 namespace cadnip {
@@ -183,7 +188,8 @@ int upload_lu(CadnipHandle* h);
 int upload_homotopy(CadnipHandle* h, const double* gshunt /* [B] or null = spec */, const double* srcfact /* [B] or null = spec */);
 int launch_calib_copy(CadnipHandle* h, long n, int reps);
 #define TRY_RC(x) do { int _rc_ = (x); if (_rc_) return _rc_; } while (0)
-int dev_zero_async(CadnipHandle* h, void* p, size_t bytes);       // kernels.hip: zero-fill as a kernel on the handle's stream (ordered with the other kernels)
+int dev_zero_async(CadnipHandle* h, void* p, size_t bytes);
+int dev_copy_async(CadnipHandle* h, void* dst, const void* src, size_t bytes, bool to_host);   // kernels.hip: word copy as a kernel on the handle's stream       // kernels.hip: zero-fill as a kernel on the handle's stream (ordered with the other kernels)
 int launch_negate(CadnipHandle* h, double* d_x, long n);
 struct TranArgs;                                                          // tran_ctrl.hpp
 int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds); // fused2.hip

@@ -243,6 +243,20 @@ int dev_zero_async(CadnipHandle* h, void* p, size_t bytes) {
   return CADNIP_OK;
 }
 
+// Word copy as a kernel: how small host-pointer transfers travel between the mapped pinned staging area and device memory (api.hip).
+__global__ void __launch_bounds__(256) k_copy_words(unsigned* dst, const unsigned* src, size_t n, int to_host) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+  if (to_host) __threadfence_system();
+}
+int dev_copy_async(CadnipHandle* h, void* dst, const void* src, size_t bytes, bool to_host) {
+  if (bytes == 0) return CADNIP_OK;
+  if (bytes & 3) return CADNIP_BADARG;
+  const size_t n = bytes / 4;
+  const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 1024);
+  hipLaunchKernelGGL(k_copy_words, dim3(grid), dim3(256), 0, h->stream, (unsigned*)dst, (const unsigned*)src, n, to_host ? 1 : 0);
+  return CADNIP_OK;
+}
+
 int launch_calib_copy(CadnipHandle* h, long n, int reps) {
   double *a = nullptr, *b = nullptr;
   HIP_TRY(hipMalloc((void**)&a, n * sizeof(double)));
