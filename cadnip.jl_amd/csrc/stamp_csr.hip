@@ -96,6 +96,7 @@ static int build_plan_variant(CadnipHandle* h, const CadnipStructure* s, bool pl
     const DeviceBlock& b = h->blocks[bi];
     rowmap[bi].assign((size_t)(b.n_g + b.n_c + b.n_b), ROW_NONE);
   }
+  auto packs = [](const DeviceBlock& b) { return b.type == CADNIP_DEV_MOS1 || b.type == CADNIP_DEV_VA; };   // (stamp_csr_kernel.hpp: REMAP)
   for (int arr = 0; arr < 3; ++arr) {
     const std::vector<Owner> own = owners(arr, totals[arr]);
     for (int e = 0; e < n_tgt[arr]; ++e)
@@ -118,6 +119,12 @@ static int build_plan_variant(CadnipHandle* h, const CadnipStructure* s, bool pl
       for (int k = 12; k < 12 + 18; ++k) zero(k);
       for (int br = 3; br < 6; ++br) { zero(12 + 6 * br); zero(12 + 6 * br + 2); }      // ... and no row has an entry in the d / s columns
       for (int k = 0; k < 3; ++k) zero(b.n_g + b.n_c + k);                               // b of rows d, g, s
+    }
+    if (!packs(b)) {                                    // one row per slot, no table
+      for (size_t k = 0; k < rowmap[bi].size(); ++k) rowmap[bi][k] = (unsigned short)k;
+      b.sp_rows = (int)rowmap[bi].size();
+      if (b.d_sp_rowoff) { (void)hipFree(b.d_sp_rowoff); b.d_sp_rowoff = nullptr; }
+      continue;
     }
     int rows = 0;
     for (auto& r : rowmap[bi]) if (r == 0) r = (unsigned short)rows++;

@@ -14,7 +14,11 @@ enum { TGT_STORE = 0, TGT_RMW = 1, TGT_ATOMIC = 2, TGT_PARTIAL = 3 };   // bits 
                                                                        // (TGT_PARTIAL: index = LDS scratch word of the tile, relative to the tile)
 
 // LDS staging writer: slot (k, dev) of this lane's instance tile; same interface as SlotOut (devices.hpp)
-struct LdsOut {
+// REMAP: the block's plan packs its rows (sp_mos1 and the generated models: many slots, many of them without a target); the small device types
+// keep one row per slot, addressed arithmetically -- a table look-up per staged value and one more memory round trip at the start of a wave that
+// lives for ten microseconds cost their kernels 30 - 60 %
+template <bool REMAP>
+struct LdsOutT {
   static constexpr bool DIRECT = false;
   __device__ __forceinline__ void Rn(int, double) const {}
   __device__ __forceinline__ double du(int) const { return 0.0; }
@@ -23,9 +27,10 @@ struct LdsOut {
                                          // packed; every other slot -- ground rows / columns, the unused form of a reactive branch -- shares one trash row)
   int ldev;                              // this lane's device within the tile
   bool on;                               // false: no device behind this lane (or an inactive instance)
-  __device__ __forceinline__ void G(int k, double v) const { if (on) tile[rg[k] + ldev] = v; }
-  __device__ __forceinline__ void C(int k, double v) const { if (on) tile[rc[k] + ldev] = v; }
-  __device__ __forceinline__ void B(int k, double v) const { if (on) tile[rb[k] + ldev] = v; }
+  int cs, og, oc, ob;                    // !REMAP: devices per row, first row of the G / C / b slots
+  __device__ __forceinline__ void G(int k, double v) const { if (on) tile[(REMAP ? (int)rg[k] : (og + k) * cs) + ldev] = v; }
+  __device__ __forceinline__ void C(int k, double v) const { if (on) tile[(REMAP ? (int)rc[k] : (oc + k) * cs) + ldev] = v; }
+  __device__ __forceinline__ void B(int k, double v) const { if (on) tile[(REMAP ? (int)rb[k] : (ob + k) * cs) + ldev] = v; }
   template <int N> __device__ __forceinline__ void Gv(int k0, const double (&v)[N]) const {
 #pragma unroll
     for (int i = 0; i < N; ++i) G(k0 + i, v[i]);
@@ -127,9 +132,12 @@ __global__ void __launch_bounds__(64) k_stamp_csr(CsrStampArgs a) {
     inst_par[3 * lane + 2] = in ? a.srcFact[i2] : 1.0;
   }
   double* u_tile = inst_par + 3 * a.ipw;                           // [ipw][n] when u_lds
+  constexpr bool REMAP = TYPE == CADNIP_DEV_MOS1 || TYPE == CADNIP_DEV_VA;
   unsigned short* rowoff = (unsigned short*)(u_tile + (a.u_lds ? (size_t)a.ipw * a.n : 0));   // [nslots]
-  for (int i = lane; i < nslots; i += 64) rowoff[i] = a.rowoff ? a.rowoff[i] : (unsigned short)(i * a.cs);
-  if (!a.u_lds) CADNIP_WAVE_SYNC();
+  if (REMAP) {
+    for (int i = lane; i < nslots; i += 64) rowoff[i] = a.rowoff ? a.rowoff[i] : (unsigned short)(i * a.cs);
+    if (!a.u_lds) CADNIP_WAVE_SYNC();
+  }
   if (a.u_lds) {
     for (int r = 0; r < a.ipw; ++r) {
       const int i2 = grp * a.ipw + r < a.B ? grp * a.ipw + r : a.B - 1;
@@ -142,7 +150,7 @@ __global__ void __launch_bounds__(64) k_stamp_csr(CsrStampArgs a) {
   {
     DevCtx d{a.nodes, a.ipar, a.par + (size_t)inst_c * a.n_par * a.count, a.wave, a.count, dev < a.count ? dev : a.count - 1, a.t[inst_c], a.mode, (a.initjct && a.cold[inst_c]) ? 1 : 0,
              a.cache ? a.cache + (size_t)inst_c * a.n_cache * a.count : nullptr};
-    LdsOut s{tile, rowoff, rowoff + a.n_g, rowoff + a.n_g + a.n_c, ldev, valid};
+    LdsOutT<REMAP> s{tile, rowoff, rowoff + a.n_g, rowoff + a.n_g + a.n_c, ldev, valid, a.cs, 0, a.n_g, a.n_g + a.n_c};
     const double* u = a.u_lds ? u_tile + (size_t)(ii < a.ipw ? ii : 0) * a.n : a.u + (size_t)inst_c * a.n;
     double* lw = valid ? a.limit_w + (size_t)inst_c * a.n : nullptr;
     if (TYPE == CADNIP_DEV_RESISTOR) stamp_resistor(d, u, s, lw);
