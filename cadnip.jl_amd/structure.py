@@ -834,6 +834,11 @@ def pack_params(st: Structure, circuit: Circuit, params: Dict[str, np.ndarray], 
                 np_ = len(mod.params)
                 for k, (sp, lit) in enumerate(mod.string_tests):               # string parameter == literal: decided here
                     arr[:, np_ + 3 + (np_ if mod.uses_given else 0) + k, j] = 1.0 if str(par[sp]) == lit else 0.0
+                for k, call in enumerate(mod.table_calls):                     # $table_model of parameters: evaluated here, per instance
+                    base = np_ + 3 + (np_ if mod.uses_given else 0) + len(mod.string_tests) + k
+                    for i in range(B):
+                        pi = {nm: (float(np.asarray(v).flat[i if np.size(v) > 1 else 0]) if not isinstance(v, str) else v) for nm, v in par.items()}
+                        arr[i, base, j] = va.host_eval.table_value(mod, call, [va.host_eval.static_eval(a, pi) for a in call[2][:-2]])
                 arr[:, np_, j] = np.asarray(temp_c, dtype=float) + 273.15     # $temperature
                 arr[:, np_ + 1, j] = g("m")                                     # $mfactor
                 arr[:, np_ + 2, j] = gmin                                       # $simparam("gmin")

@@ -22,7 +22,8 @@ EXTERNAL = (("PSP103VA", "psp103.va", _PSP), ("sp_bsim4v8", "bsim4v8.va", _VAD),
             ("sp_mos1", "mos1.va", _VAD), ("sp_mos2", "mos2.va", _VAD), ("sp_mos3", "mos3.va", _VAD), ("sp_mos6", "mos6.va", _VAD),
             ("sp_mos9", "mos9.va", _VAD), ("sp_bsim3v3", "bsim3v3.va", _VAD), ("JUNCAP200", "juncap200.va", _PSP),
             ("bsimcmg", "bsimcmg.va", _CMC), ("sp_inductor", "inductor.va", _VAD), ("sp_vdmos", "vdmos.va", _VAD),
-            ("NLVCR", "NLVCR.va", ("test",)))       # test/ddx.jl: ddx() with respect to a branch potential
+            ("NLVCR", "NLVCR.va", ("test",)),       # test/ddx.jl: ddx() with respect to a branch potential
+            ("TMRoundTrip", "tm_1d.va", ("test/mna/fixtures/table_model",)), ("TM2D", "tm_2d.va", ("test/mna/fixtures/table_model",)))   # test/mna/table_model.jl
 REFERENCE_ROOT = "/root/reference"
 
 _cache = {}

@@ -306,6 +306,8 @@ class VAModule:
     func_dirs: Dict[str, list] = field(default_factory=dict)          # analog function -> direction of every argument ("in" | "out" | "inout")
     uses_given: bool = False                                          # the module asks $param_given(...): instances carry one flag per parameter
     string_tests: List[tuple] = field(default_factory=list)           # (string parameter, literal) pairs the module compares: one host-evaluated flag each
+    table_calls: List[tuple] = field(default_factory=list)            # distinct $table_model calls (inputs decided by the parameters): one host-evaluated value each
+    include_dir: Optional[str] = None                                 # where `include files and $table_model tables are looked for
     hoist_vars: set = field(default_factory=set)                      # bias-independent locals computed once per parameter set (_hoist_analysis)
     cache_vars: List[str] = field(default_factory=list)               # ... those the per-call code reads: the per-device cache layout
     source: str = ""
@@ -364,6 +366,7 @@ class VAModule:
         if self.uses_given:
             n_par += len(self.params)       # + one $param_given flag per parameter
         n_par += len(self.string_tests)     # + one flag per (string parameter == literal) test
+        n_par += len(self.table_calls)      # + one value per distinct $table_model call
         NV = len(self.vshorts)
         # short currents: local unknown N + B + L + j;  G slots g_short(j) + {0: (p,I), 1: (n,I), 2: (I,p), 3: (I,n), 4 + k: (I,k)};  b slot 3B + j;
         # C slot c_short(j) = (I,I) for the named branches whose value carries ddt()
@@ -668,7 +671,7 @@ class _Parser:
                     t = self.peek()
                     args.append(("str", self.next()[1].strip('"')) if t[0] == "str" else self.expr())
                     self.accept(",")
-            if v not in ("$vt", "$temperature", "$mfactor", "$simparam", "$abstime", "$realtime"):
+            if v not in ("$vt", "$temperature", "$mfactor", "$simparam", "$abstime", "$realtime", "$table_model"):
                 raise VAError("system function %s is not supported" % v)
             return ("sys", v, args)
         if self.peek()[1] == "(":
@@ -1433,11 +1436,34 @@ def _analyse(m: VAModule):
             for a in (sub if isinstance(sub, list) else [sub]):
                 if isinstance(a, tuple) and a and isinstance(a[0], str) and a[0] != "str":
                     string_tests(a)
+    def table_calls(e):
+        if e[0] == "sys" and e[1] == "$table_model":
+            if len(e[2]) < 3 or e[2][-1][0] != "str" or e[2][-2][0] != "str":
+                raise VAError("%s: $table_model(inputs..., \"file\", \"control\")" % m.name)
+            for a in e[2][:-2]:
+                if not _params_only(a):
+                    raise VAError("%s: $table_model of a quantity that is not decided by the parameters alone is not supported" % m.name)
+            if e not in m.table_calls:
+                m.table_calls.append(e)
+        for sub in e[1:]:
+            for a in (sub if isinstance(sub, list) else [sub]):
+                if isinstance(a, tuple) and a and isinstance(a[0], str) and a[0] != "str":
+                    table_calls(a)
+
+    def _params_only(e):
+        if e[0] == "num":
+            return True
+        if e[0] == "var":
+            return e[1] in m.params
+        if e[0] in ("un", "bin", "cond", "call"):
+            return all(_params_only(a) for sub in e[1:] for a in (sub if isinstance(sub, list) else [sub]) if isinstance(a, tuple))
+        return False
     bodies = [m.body] + [f[2] for f in m.functions.values()]
     for body in bodies:
         for st in _walk(body):
             for e in ([st] if st[0] == "callstmt" else _subexprs(st)):
                 string_tests(e)
+                table_calls(e)
     m.uses_given = any(has_given(e) for body in bodies for st in _walk(body) for e in ([st] if st[0] == "callstmt" else _subexprs(st))) \
         or any(has_given(ie) for _, ie in m.local_init)
     m.is_dual, m.is_react, m.node_index = is_dual, is_react, node
@@ -1558,4 +1584,5 @@ def parse_module(text, include_dir=None, defines=None) -> VAModule:
     if p.peek()[0] != "eof":
         raise VAError("text after endmodule (one module per source)")
     m.source = text
+    m.include_dir = include_dir
     return _analyse(m)

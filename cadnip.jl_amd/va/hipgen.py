@@ -125,6 +125,9 @@ class _Gen:
             args = [self.g(a) for a in e[2]]
             return "va_%s(%s)" % (e[1], ", ".join(a[0] for a in args)), any(a[1] for a in args) and e[1] not in ("floor", "ceil", "int"), None
         if k == "sys":
+            if e[1] == "$table_model":          # decided by the parameters: evaluated on the host, one more entry of the parameter block
+                NPm = len(m.params)
+                return "par_of(d, %d)" % (NPm + 3 + (NPm if m.uses_given else 0) + len(m.string_tests) + m.table_calls.index(e)), False, None
             if e[1] == "$temperature":
                 return "sys.temp", False, None
             if e[1] == "$mfactor":

@@ -134,6 +134,8 @@ def evaluate(m, V, par, temp_k=300.15, mfactor=1.0, gmin=1e-12, vold=None, initj
         if k == "call":
             return _F[e[1]](*[_r(ev(a)) for a in e[2]])
         if k == "sys":
+            if e[1] == "$table_model":
+                return table_value(m, e, [_r(ev(a)) for a in e[2][:-2]])
             if e[1] == "$temperature":
                 return temp_k
             if e[1] == "$vt":
@@ -295,6 +297,15 @@ def instance_structure(m, par, given=None, temp_k=300.15, mfactor=1.0, gmin=1e-1
 def collapsed_nodes(m, par, given=None, temp_k=300.15, mfactor=1.0, gmin=1e-12):
     """internal node -> the node it is merged into (-1 = ground) for this instance (see instance_structure)."""
     return instance_structure(m, par, given, temp_k, mfactor, gmin)[0]
+
+
+def table_value(m, e, xs):
+    """value of the $table_model call ``e`` of module ``m`` at the inputs ``xs`` (the table file is looked for next to the module's source)"""
+    import os
+    from . import table_model
+    fn = e[2][-2][1]
+    path = fn if os.path.isabs(fn) or m.include_dir is None else os.path.join(m.include_dir, fn)
+    return table_model.lookup(path, e[2][-1][1], xs)
 
 
 def static_eval(e, par, temp_k=300.15, mfactor=1.0, gmin=1e-12):

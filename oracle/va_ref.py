@@ -12,6 +12,7 @@ The syntax tree comes from the product's parser (cadnip.jl_amd/va/frontend.py); 
 (oracle/dual.py) and the stamping are the oracle's own.  Pure-Python: meant for small cases.
 """
 import math
+import os
 
 import numpy as np
 
@@ -109,6 +110,48 @@ SPEC_SIMPARAMS = ("temp", "gmin", "gshunt", "srcFact", "tnom", "abstol", "reltol
 
 class VAFatal(RuntimeError):
     pass
+
+
+def table_model_value(path, ctrl, xs):
+    """$table_model (src/vasim.jl:762-845 for the file and control string, src/mna/table_model.jl:49-58 for the interpolant: Interpolations.jl's
+    gridded linear interpolation with Line / Flat / Throw extrapolation) at plain-number inputs."""
+    interp, col = ctrl.split(";")
+    dims = [d.strip() for d in interp.split(",")]
+    assert len(dims) == len(xs) and all(d[:1] == "1" for d in dims), ctrl
+    ex = {(d[1:] or "L") for d in dims}
+    assert len(ex) == 1, ctrl
+    ex = ex.pop()
+    rows = [[float(t) for t in ln.split("#", 1)[0].split()] for ln in open(path) if ln.split("#", 1)[0].strip()]
+    D = len(xs)
+    axes = [sorted({r[k] for r in rows}) for k in range(D)]
+    grid = {tuple(axes[k].index(r[k]) for k in range(D)): r[D + int(col) - 1] for r in rows}
+    xc = [min(max(x, ax[0]), ax[-1]) for x, ax in zip(xs, axes)]
+    if ex == "E" and xc != list(xs):
+        raise ValueError("$table_model: outside the table")
+    cell = []
+    for x, ax in zip(xc, axes):
+        i = max(k for k in range(len(ax) - 1) if ax[k] <= x)
+        cell.append(i)
+
+    def at(pt):
+        fr = [(p - axes[d][cell[d]]) / (axes[d][cell[d] + 1] - axes[d][cell[d]]) for d, p in enumerate(pt)]
+        v = 0.0
+        for c in range(1 << D):
+            w, idx = 1.0, []
+            for d in range(D):
+                hi = (c >> d) & 1
+                w *= fr[d] if hi else 1.0 - fr[d]
+                idx.append(cell[d] + hi)
+            v += w * grid[tuple(idx)]
+        return v
+    v = at(xc)
+    if ex == "L":
+        for d in range(D):
+            if xs[d] != xc[d]:
+                lo, hi = list(xc), list(xc)
+                lo[d], hi[d] = axes[d][cell[d]], axes[d][cell[d] + 1]
+                v += (at(hi) - at(lo)) / (hi[d] - lo[d]) * (xs[d] - xc[d])
+    return v
 
 
 def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False, given=None, spec=None, on_short=None, touched=None, probe=None, on_noise=None):
@@ -224,6 +267,10 @@ def evaluate(mod, Vd, par, temp_k, mfactor, gmin, limit_site=None, initjct=False
         if k == "call":
             return FUNCS[e[1]](*[ev(a) for a in e[2]])
         if k == "sys":
+            if e[1] == "$table_model":
+                fn = e[2][-2][1]
+                path = fn if (os.path.isabs(fn) or getattr(mod, "include_dir", None) is None) else os.path.join(mod.include_dir, fn)
+                return table_model_value(path, e[2][-1][1], [val(_res(ev(a))) for a in e[2][:-2]])
             if e[1] == "$temperature":
                 return temp_k
             if e[1] == "$vt":

@@ -23,8 +23,8 @@ TIER6 = {"inductor": ("mid", -0.01, 0.01), "vdmos": ("drain", 0.0, 10.0), "resis
          "mos6": ("drain", 0.0, 5.0), "mos9": ("drain", 0.0, 5.0), "bsim3v3": ("drain", 0.0, 1.8), "bsim4v8": ("drain", 0.9, 1.0)}
 
 
-OTHER = ("bsimcmg_nmos", "juncap200", "nlvcr")   # models/CMCModels.jl (BSIM-CMG), JUNCAP200 of models/PSPModels.jl: pinned by the oracle's interpreter alone;
-                                                 # test/NLVCR.va: ddx() with respect to a branch potential (test/ddx.jl)
+OTHER = ("bsimcmg_nmos", "juncap200", "nlvcr", "tm_1d", "tm_1d_interior", "tm_2d")   # models/CMCModels.jl (BSIM-CMG), JUNCAP200 of models/PSPModels.jl: pinned by the oracle's interpreter alone;
+                                                 # test/NLVCR.va: ddx() with respect to a branch potential (test/ddx.jl); tm_*: test/mna/fixtures/table_model
 
 
 def _sim(name):
@@ -104,6 +104,9 @@ def test_other_model_packages_dc(name):
     assert np.max(np.abs(u[0, :nn] - ref[:nn]) / np.maximum(np.abs(ref[:nn]), 1e-3)) < 1e-8
     if name == "bsimcmg_nmos":
         assert 1e-6 < abs(u[0, st.index_of("I_Vds")]) < 1e-4
+    if name.startswith("tm_"):    # test/mna/table_model.jl:83-96: $table_model of the parameters, evaluated when they are packed
+        want = {"tm_1d": 0.02, "tm_1d_interior": 0.015, "tm_2d": 2 * 1.55 + 3 * 25.0 + 5}[name]
+        assert abs(u[0, st.index_of("I_V1")] + want) < 1e-8
     if name == "nlvcr":          # test/ddx.jl:66-73: I(d,s) = V(d,s) ddx(R V(g,s)^2, V(g,s)) = 2 R V(d,s) V(g,s) = 60 A out of V1
         assert abs(u[0, st.index_of("vcc")] - 5.0) < 1e-10 and abs(u[0, st.index_of("vg")] - 3.0) < 1e-10
         assert abs(u[0, st.index_of("I_V1")] + 60.0) < 1e-6

@@ -35,7 +35,7 @@ def test_ring_fixture_carries_the_reference_layout():
 
 @needs_source
 @pytest.mark.parametrize("name", ["nmos_defaults", "nmos_card", "ring", "bsim4_nmos", "bsim4_dff", "resistor", "capacitor", "diode", "diode_rs", "bjt",
-                                  "jfet1", "mes1", "jfet2", "mos1", "mos2", "mos3", "mos6", "mos9", "bsim3v3", "bsim4v8", "bsimcmg_nmos", "juncap200", "inductor", "vdmos", "nlvcr", "noise_diode", "noise_bjt"])
+                                  "jfet1", "mes1", "jfet2", "mos1", "mos2", "mos3", "mos6", "mos9", "bsim3v3", "bsim4v8", "bsimcmg_nmos", "juncap200", "inductor", "vdmos", "nlvcr", "noise_diode", "noise_bjt", "tm_1d", "tm_1d_interior", "tm_2d"])
 def test_committed_fixtures_are_current(name):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_psp103_fixtures as mk

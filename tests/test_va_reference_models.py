@@ -37,7 +37,26 @@ EXPECTED = {
     "vdmos.va": (10, 12, 5, 8, 7),         # five terminals (two thermal), V(tbr) <+ ... on the named thermal branch
 }
 # refused, with the reason
-REFUSED = {os.path.join(PSP_DIR, "psp103_nqs.va"): "idt", "/root/reference/test/mna/fixtures/table_model/tm_1d.va": "$table_model"}
+REFUSED = {os.path.join(PSP_DIR, "psp103_nqs.va"): "idt"}
+
+
+def test_table_model_interpolator_numerics():
+    """test/mna/table_model.jl:43-69: the 1-D and 2-D interpolators on the reference's fixture tables -- sample, interior, linear extrapolation
+    below and above the range -- in the product's host evaluator and in the oracle's restatement."""
+    from cadnip_jl_amd.va import table_model as T
+    d = "/root/reference/test/mna/fixtures/table_model/"
+    for f in (T.lookup, va_ref.table_model_value):
+        assert f(d + "tm_1d.tbl", "1L;1", [1.55]) == pytest.approx(0.02) and f(d + "tm_1d.tbl", "1L;1", [1.545]) == pytest.approx(0.015)
+        assert abs(f(d + "tm_1d.tbl", "1L;1", [1.53])) < 1e-12 and f(d + "tm_1d.tbl", "1L;1", [1.57]) == pytest.approx(0.04)
+        for a, b in ((1.55, 25.0), (1.545, 22.5), (1.53, 15.0), (1.57, 35.0)):
+            assert f(d + "tm_2d.tbl", "1L,1L;1", [a, b]) == pytest.approx(2 * a + 3 * b + 5)
+        assert f(d + "tm_1d.tbl", "1C;1", [1.57]) == pytest.approx(0.03)
+        with pytest.raises(ValueError):
+            f(d + "tm_1d.tbl", "1E;1", [1.57])
+    m = F.parse_file(d + "tm_1d.va")
+    assert len(m.table_calls) == 1 and m.shape()[4] == len(m.params) + 3 + 1
+    with pytest.raises(F.VAError):          # a look-up of a bias-dependent quantity has no host-side value
+        F.parse_module('module x(a); electrical a; analog I(a) <+ $table_model(V(a), "t.tbl", "1L;1"); endmodule')
 
 
 @pytest.mark.parametrize("fn", sorted(EXPECTED))

@@ -95,6 +95,10 @@ TIER6 = {
 OTHER = {
     "bsimcmg_nmos": "* bsimcmg NMOS, default card\n.model nfin bsimcmg\nM1 d g 0 0 nfin\nVds d 0 DC 0.8\nVgs g 0 DC 0.6\n",
     "nlvcr": "* test/ddx.jl:38-73: NLVCR(R=2) between vcc (5 V), vg (3 V) and ground: I = 2 R V(d,s) V(g,s) = 60 A\nV1 vcc 0 DC 5\nV2 vg 0 DC 3\nX1 vcc vg 0 NLVCR R=2\n",
+    # test/mna/table_model.jl:83-96 (fixtures tm_1d.scs / tm_2d.scs): V1 = 1 V across the table-model device, I_V1 = -g(wl[, T])
+    "tm_1d": "* $table_model 1-D, wl = 1.55 (a sample): I_V1 = -0.02\nV1 p 0 DC 1\nX1 p 0 TMRoundTrip wl=1.55\n",
+    "tm_1d_interior": "* $table_model 1-D, wl = 1.545 (between samples): I_V1 = -0.015\nV1 p 0 DC 1\nX1 p 0 TMRoundTrip wl=1.545\n",
+    "tm_2d": "* $table_model 2-D, wl = 1.55, T = 25: I_V1 = -(2 wl + 3 T + 5)\nV1 p 0 DC 1\nX1 p 0 TM2D wl=1.55 T=25\n",
     "juncap200": "* JUNCAP200 diode behind 100 Ohm\nV1 a 0 DC 0.5\nR1 a k 100\nX1 k 0 juncap200\n",
 }
 
