@@ -169,7 +169,7 @@ def live_counters(B, fused, newton_mode):
         fc = 1024.0 * 1024.0 / (cal_f["FETCH_SIZE"] / cal_f["calls"])
         wc_ = 1024.0 * 1024.0 / (cal_w["WRITE_SIZE"] / cal_w["calls"])
         out["calibration"] = {"fetch_correction": round(fc, 4), "write_correction": round(wc_, 4)}
-        for key, needles in (("fused", ("k_fused2<", ", false, ")), ("stamp", ("k_stamp_csr<12>",))):
+        for key, needles in (("fused", ("k_fused2<", ", false, ")), ("stamp", ("k_stamp_csr<12,",))):
             a, b = _find(hbm["FETCH_SIZE"], *needles), _find(hbm["WRITE_SIZE"], *needles)
             if a and b and a["calls"] and b["calls"]:
                 byt = (a["FETCH_SIZE"] / a["calls"] * fc + b["WRITE_SIZE"] / b["calls"] * wc_) * 1024.0
