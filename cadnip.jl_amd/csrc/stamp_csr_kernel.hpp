@@ -79,8 +79,11 @@ static __device__ unsigned long long g_sc_sum[8], g_sc_cnt;
 // EXT: void for the built-in device types; for a generated external model (va_ext/<module>.hip) a struct with
 //   template <class Ctx, class Out> static __device__ void stamp(const Ctx&, const double* u, const Out&, double* lw, int dir);
 // the kernel is then that model's own (its register budget is not the worst model's).
+#ifndef CADNIP_STAMP_KERNEL_ATTR
+#define CADNIP_STAMP_KERNEL_ATTR          // a generated unit may ask for a register budget of its own (e.g. amdgpu_waves_per_eu)
+#endif
 template <int TYPE, class EXT = void>
-__global__ void __launch_bounds__(64) k_stamp_csr(CsrStampArgs a) {
+__global__ void __launch_bounds__(64) CADNIP_STAMP_KERNEL_ATTR k_stamp_csr(CsrStampArgs a) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
 #ifdef CADNIP_TRACE
