@@ -47,7 +47,7 @@ CLOCK_HZ = 2.4e9          # same guide: max clock 2400 MHz
 SIMDS = 256 * 4           # 256 CUs x 4 SIMDs
 ABSTOL = dict(vntol=1e-6, iabstol=1e-9, chgtol=1e-6)
 RELTOL = 1e-4
-COMMITTED_PMC = "r02_fused_B4096_pmc_summary.json"   # fallback when no live counter pass is possible (profiles/)
+COMMITTED_PMC = "r02h_fused_B4096_pmc_summary.json"   # fallback when no live counter pass is possible (profiles/)
 SQ_COUNTERS = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
                "SQ_INSTS_SALU", "SQ_INSTS_LDS"]
 CALIB = "k_calib_copy_f64"
