@@ -686,8 +686,21 @@ def noise_sources(st, circuit, params, u, temp_c=27.0, gmin=1e-12):
                 nm = ("%s_%s" % (name, label.lower())) if label else name
                 out.append((gl[a] if a >= 0 else -1, gl[b] if b >= 0 else -1, "white" if fn == "white_noise" else "flicker", pwr, expo, nm))
             va.host_eval.evaluate(mod, V, par, temp_c + 273.15, num(d.params.get("m", 1.0)), gmin, vold=vold, given=set(d.model), mode="dcop", on_noise=on_noise)
-        elif d.type in ("MOS1", "SMOS"):
-            raise NotImplementedError("noise: %s (%s) registers no noise sources in this build; instantiate the Verilog-A module instead" % (d.name, d.type))
+        elif d.type == "MOS1":
+            # the hand-written sp_mos1 device: its sources are those of the model text it transcribes (models/VADistillerModels.jl/va/mos1.va:
+            # rd / rs thermal, channel thermal, flicker), evaluated by the host evaluator on that text at the solution
+            mod = va.get("sp_mos1")[1]
+            given = {k: num(v) for k, v in d.model.items()}
+            par = va.host_eval.defaults(mod, given)
+            V = [u[g] if g >= 0 else 0.0 for g in gl[:mod.n_nodes]]           # d, g, s, b, d_int, s_int: the module's node order
+            vold = [(V[p] if p >= 0 else 0.0) - (V[n] if n >= 0 else 0.0) for p, n in mod.limit_branches]
+
+            def on_noise(a, b, fn, pwr, expo, label, gl=gl, name=name):
+                nm = ("%s_%s" % (name, label.lower())) if label else name
+                out.append((gl[a] if a >= 0 else -1, gl[b] if b >= 0 else -1, "white" if fn == "white_noise" else "flicker", pwr, expo, nm))
+            va.host_eval.evaluate(mod, V, par, temp_c + 273.15, num(d.params.get("m", 1.0)), gmin, vold=vold, given=set(d.model), mode="dcop", on_noise=on_noise)
+        elif d.type == "SMOS":
+            raise NotImplementedError("noise: %s (SimpleMOSFET) registers no noise sources (nor does the reference's, devices.jl:1667-1749)" % d.name)
     return out
 
 

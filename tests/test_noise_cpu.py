@@ -131,3 +131,19 @@ def test_bjt_mechanisms_and_flicker():
     for k in c:
         assert np.allclose(ns[k], c[k], rtol=1e-6, atol=1e-40), k     # (the oracle evaluates at pnjlim(V, limit unknown), the product at V: they agree to the DC tolerance times exp sensitivity)
     assert np.allclose(ns["onoise"], on, rtol=1e-6)
+
+
+@needs_source
+def test_hand_written_mos1_devices_take_their_sources_from_the_model_text():
+    """An inverter stage on level-1 cards: the deck's `.model nmos` MOSFET is the hand-written sp_mos1 device of this build; its noise sources
+    are those of the reference's mos1.va evaluated at the solution -- the same the oracle registers when the deck instantiates the module."""
+    card = "level=1 vto=0.7 kp=100u lambda=0.01 rd=50"
+    hand = "* cs stage\n.model nch nmos %s\nVdd vdd 0 DC 3\nVin in 0 DC 1.2\nRd vdd out 10k\nM1 out in 0 0 nch W=20u L=1u\n" % card
+    gen = "* cs stage\nVdd vdd 0 DC 3\nVin in 0 DC 1.2\nRd vdd out 10k\nXm1 out in 0 0 sp_mos1 type=1 %s w=20u l=1u\n" % card.replace("level=1 ", "")
+    on, c, _, _ = oracle_noise(gen, "out", [1e2, 1e5])
+    ns = product_noise_at_the_oracle_point(hand, "out", [1e2, 1e5])
+    assert np.allclose(ns["onoise"], on, rtol=1e-6)
+    assert sorted(k.replace("xm1", "m1") for k in c) == sorted(ns.contributions)
+    for k in c:
+        assert np.allclose(ns[k.replace("xm1", "m1")], c[k], rtol=1e-6, atol=1e-60), k
+    assert any(np.any(v > 0) for k, v in ns.contributions.items() if k.startswith("m1_"))      # the channel's thermal noise at least
