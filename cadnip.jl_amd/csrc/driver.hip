@@ -98,14 +98,16 @@ __global__ void __launch_bounds__(64) k_tran_init(TranArgs a) {
   store_state(a, inst, tid, s);
 }
 
-__global__ void __launch_bounds__(64) k_tran_update(TranArgs a) {
+// NT threads per instance: one wave for the circuits of a sweep (n of a few hundred), a workgroup of four for a large one
+template <int NT>
+__global__ void __launch_bounds__(NT) k_tran_update(TranArgs a) {
   const int inst = blockIdx.x, tid = threadIdx.x;
   StepState s = load_state(a, inst);
   if (s.status != 0) return;
   const int bad = a.flags[inst] & 1;
-  CADNIP_WAVE_SYNC();
+  grp_sync<GlobalVecsT<NT>>();
   if (tid == 0) a.flags[inst] = 0;
-  GlobalVecs v(a, inst);
+  GlobalVecsT<NT> v(a, inst);
   if (a.newton_mode) {
     // per-op path: every round restamps and refactors (the factors live in LDS for the length of one k_lu_f2 launch), so the Jacobian is
     // always current -- a failed iteration halves the step at once, nothing is scaled.  The rate constant follows the same events as in
@@ -609,7 +611,9 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
       rc = launch_rebuild(h); if (rc) break;
       rc = launch_residual(h, h->d_du); if (rc) break;
       rc = launch_factor_solve(h, true, h->d_resid, h->d_delta); if (rc) break;
-      { ProfScope ps(h, "tran_update"); hipLaunchKernelGGL(k_tran_update, dim3(h->B), dim3(64), 0, h->stream, a); }
+      { ProfScope ps(h, "tran_update");
+        if (h->n >= 4096) hipLaunchKernelGGL(k_tran_update<256>, dim3(h->B), dim3(256), 0, h->stream, a);
+        else hipLaunchKernelGGL(k_tran_update<64>, dim3(h->B), dim3(64), 0, h->stream, a); }
       ++launches;
     }
     if (rc) break;

@@ -214,6 +214,7 @@ struct FusedVecs {
   // per-lane elements kept in registers (covers n <= 256): the history u0 / u1 / u2 and the predictor for the whole
   // residence of the instance, the error weights from `prefetch` to the update.  Elements beyond stay in HBM.
   static constexpr int KPF = 4;
+  static constexpr int NT = 64;          // one wave per instance (tran_ctrl.hpp: grp_sum / grp_sync)
   double *us, *betas; const double* W; const u16* qinv;
   size_t vo;                   // this instance's offset into the per-unknown vectors; their bases come from the kernarg segment
   const double* lw;

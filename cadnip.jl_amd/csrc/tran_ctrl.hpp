@@ -133,12 +133,38 @@ template <class A> __device__ inline void store_state(const A& a, int inst, int 
   c[0] += s.c_newton; c[1] += s.c_accept; c[2] += s.c_reject; c[3] += s.c_fail;
 }
 
+// Group helpers of the controller: a sweep instance is handled by V::NT threads -- one wave (the fused kernel, small systems on the per-op
+// path) or a workgroup of several (large systems on the per-op path: one wave walking 76 k unknowns of the c6288 multiplier took 0.8 ms).
+template <class V> __device__ __forceinline__ void grp_sync() {
+  if constexpr (V::NT == 64) CADNIP_WAVE_SYNC(); else __syncthreads();
+}
+template <class V> __device__ __forceinline__ double grp_sum(double v) {
+  if constexpr (V::NT == 64) return wave_sum(v);
+  else {
+    __shared__ double red[V::NT / 64];
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < V::NT / 64; ++k) t += red[k];
+    return t;
+  }
+}
+template <class V> __device__ __forceinline__ int grp_any(int v) {
+  if constexpr (V::NT == 64) return wave_any(v);
+  else return __syncthreads_or(v);
+}
+
 // every per-unknown vector in HBM (per-op path)
-struct GlobalVecs {
+template <int NT_>
+struct GlobalVecsT {
   static constexpr int KPF = 0;
+  static constexpr int NT = NT_;
   double *__restrict__ u, *__restrict__ du, *__restrict__ up, *__restrict__ beta, *__restrict__ u0, *__restrict__ u1, *__restrict__ u2;
   const double *__restrict__ delta, *__restrict__ lw;
-  __device__ GlobalVecs(const TranArgs& a, int inst) {
+  __device__ GlobalVecsT(const TranArgs& a, int inst) {
     const size_t o = (size_t)inst * a.n;
     u = a.u + o; du = a.du + o; up = a.up + o; beta = a.beta + o; u0 = a.u0 + o; u1 = a.u1 + o; u2 = a.u2 + o; delta = a.delta + o; lw = a.limit_w + o;
   }
@@ -165,6 +191,7 @@ struct GlobalVecs {
   __device__ __forceinline__ double mem_u0(int i) const { return u0[i]; }   // any unknown's u0 / u1 (valid after history_to_memory)
   __device__ __forceinline__ double mem_u1(int i) const { return u1[i]; }
 };
+typedef GlobalVecsT<64> GlobalVecs;
 
 // f(i, k) for the elements i = tid, tid + 64, ... < n of one lane; k = the ordinal for the first V::KPF of them (a
 // compile-time constant after unrolling, so that V's per-lane register arrays are indexed statically), -1 beyond
@@ -172,15 +199,15 @@ template <class V, class F>
 __device__ __forceinline__ void each_elem(int n, int tid, F&& f) {
   if constexpr (V::KPF > 0) {
 #pragma unroll
-    for (int k = 0; k < V::KPF; ++k) { const int i = tid + 64 * k; if (i < n) f(i, k); }
+    for (int k = 0; k < V::KPF; ++k) { const int i = tid + V::NT * k; if (i < n) f(i, k); }
   }
   // several elements in flight per lane: with every vector in HBM (per-op path, large n) an element is a chain of memory
   // latencies, and one wave walks n / 64 of them
   if constexpr (V::KPF == 0) {
 #pragma unroll 4
-    for (int i = tid; i < n; i += 64) f(i, -1);
+    for (int i = tid; i < n; i += V::NT) f(i, -1);
   } else {
-    for (int i = tid + 64 * V::KPF; i < n; i += 64) f(i, -1);
+    for (int i = tid + V::NT * V::KPF; i < n; i += V::NT) f(i, -1);
   }
 }
 
@@ -246,10 +273,10 @@ __device__ inline void save_outputs(const TranArgs& a, V& v, StepState& s, int i
       double La = (x - 0.0) * (x - xc) / ((xa - 0.0) * (xa - xc));
       double Lb = (x - xa) * (x - xc) / ((0.0 - xa) * (0.0 - xc));
       double Lc = (x - xa) * (x - 0.0) / ((xc - xa) * (xc - 0.0));
-      for (int j = tid; j < a.n_obs; j += 64) { int i = a.obs[j]; o[j] = La * v.get_u(i) + Lb * v.mem_u0(i) + Lc * v.mem_u1(i); }
+      for (int j = tid; j < a.n_obs; j += V::NT) { int i = a.obs[j]; o[j] = La * v.get_u(i) + Lb * v.mem_u0(i) + Lc * v.mem_u1(i); }
     } else {
       double sc = (ts - told) / hh;
-      for (int j = tid; j < a.n_obs; j += 64) { int i = a.obs[j]; double x0 = v.mem_u0(i); o[j] = x0 + sc * (v.get_u(i) - x0); }
+      for (int j = tid; j < a.n_obs; j += V::NT) { int i = a.obs[j]; double x0 = v.mem_u0(i); o[j] = x0 + sc * (v.get_u(i) - x0); }
     }
     ++si;
     s.t_save = next_save(a, si);
@@ -276,8 +303,8 @@ __device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, i
     s2 += (e * w2) * (e * w2);
     v.set_u(i, un);
   });
-  s1 = wave_sum(s1); s2 = wave_sum(s2);
-  bad = wave_any(bad);
+  s1 = grp_sum<V>(s1); s2 = grp_sum<V>(s2);
+  bad = grp_any<V>(bad);
   const double dnorm = sqrt(s1 / n);
   CADNIP_TRACE_POINT(30);
   s.c_newton += 1;
@@ -306,7 +333,7 @@ __device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, i
       accept = errn <= 1.0;
     }
     if (accept) {
-      CADNIP_WAVE_SYNC();
+      grp_sync<V>();
       save_outputs(a, v, s, inst, tid);
       each_elem<V>(n, tid, [&](int i, int k) { double v1 = v.h1(i, k), v0 = v.h0(i, k); v.set_h2(i, k, v1); v.set_h1(i, k, v0); v.set_h0(i, k, v.get_u(i)); });
       const double tn = s.tn;
@@ -333,7 +360,7 @@ __device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, i
       CADNIP_TRACE_POINT(31);
       if (tn >= a.t1) { s.status = 1; return; }
       if (hnext < a.hmin) hnext = a.hmin;
-      CADNIP_WAVE_SYNC();
+      grp_sync<V>();
       prepare_step(a, v, s, tid, tn, hnext, nh_new, s.hprev, s.hpp);
       CADNIP_TRACE_POINT(32);
     } else {
@@ -342,28 +369,28 @@ __device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, i
       double hn = h * fac;
       s.c_reject += 1;
       if (hn < a.hmin) { s.status = -1; return; }
-      CADNIP_WAVE_SYNC();
+      grp_sync<V>();
       prepare_step(a, v, s, tid, s.t, hn, s.nhist, hprev, hpp);
     }
   } else {
     if (a.newton_mode && (bad || diverge || s.k + 1 >= a.max_newton) && !(s.mflags & MN_JCUR)) {
       // the iteration failed on a stale Jacobian: same step again, refactored first (IDA: IDA_NLS recoverable with callSetup)
       s.mflags |= MN_NEED;
-      CADNIP_WAVE_SYNC();
+      grp_sync<V>();
       prepare_step(a, v, s, tid, s.t, h, s.nhist, hprev, hpp);
     } else if (bad || diverge || s.k + 1 >= a.max_newton) {
       double hn = 0.25 * h;
       s.c_fail += 1;
       if (hn < a.hmin) { s.status = -2; return; }
-      CADNIP_WAVE_SYNC();
+      grp_sync<V>();
       prepare_step(a, v, s, tid, s.t, hn, s.nhist, hprev, hpp);
     } else {
-      CADNIP_WAVE_SYNC();
+      grp_sync<V>();
       if (a.use_pcnr && a.n_limits > 0)
-        for (int i = n - a.n_limits + tid; i < n; i += 64) v.set_u(i, v.get_lw(i));
-      CADNIP_WAVE_SYNC();
+        for (int i = n - a.n_limits + tid; i < n; i += V::NT) v.set_u(i, v.get_lw(i));
+      grp_sync<V>();
       const double a0 = s.a0;
-      for (int i = tid; i < n; i += 64) v.set_du(i, a0 * v.get_u(i) + v.get_beta(i));
+      for (int i = tid; i < n; i += V::NT) v.set_du(i, a0 * v.get_u(i) + v.get_beta(i));
       s.k += 1;
     }
   }
