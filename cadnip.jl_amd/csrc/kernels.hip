@@ -296,7 +296,8 @@ int launch_residual(CadnipHandle* h, const double* d_du) {
   ResArgs a{h->d_G, h->d_C, h->d_b, h->d_u, d_du, h->d_rowptr, h->d_colidx, h->d_active, h->d_resid, h->B, h->n, h->nnz};
   long total = (long)h->B * h->n;
   const size_t lds = ((size_t)2 * h->nnz + 2 * h->n) * sizeof(double);
-  if (lds <= 40 * 1024 && h->n_long_rows == 0 && !getenv("CADNIP_RESIDUAL_ROWS")) {
+  if (lds <= 96 * 1024 && h->n_long_rows == 0 && !getenv("CADNIP_RESIDUAL_ROWS")) {
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_residual_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_residual_lds, dim3((unsigned)h->B), dim3(256), lds, h->stream, a);
     HIP_TRY(hipGetLastError());
     return CADNIP_OK;
