@@ -213,6 +213,7 @@ void cadnip_destroy(CadnipHandle* h) {
                   h->d_cperm, h->d_fwd_rows, h->d_fwd_lev_ptr, h->d_bwd_rows, h->d_bwd_lev_ptr};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->d_f2tab) (void)hipFree(h->d_f2tab);
+  for (int k = 0; k < 2; ++k) if (h->d_team_desc[k]) (void)hipFree(h->d_team_desc[k]);
   for (auto& b : h->blocks) {
     void* bp[] = {b.d_nodes, b.d_ipar, b.d_par, b.d_sp_tptr, b.d_sp_info, b.d_sp_rec, b.d_cache, b.d_sp_rowoff,
                   b.sp_gen.tptr, b.sp_gen.info, b.sp_gen.rec, b.sp_gen.rowoff, b.sp_plain.tptr, b.sp_plain.info, b.sp_plain.rec, b.sp_plain.rowoff};

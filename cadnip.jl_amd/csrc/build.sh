@@ -16,7 +16,8 @@ if [ -n "$EXT_LIST" ]; then
 fi
 # `build.sh --trace` builds the diagnostic library (cycle timeline of one wave, devices.hpp CADNIP_TRACE_POINT)
 if [ "${1:-}" = "--trace" ]; then
-  make -j"$(nproc)" OUT=../libcadnip_hip_trace.so OBJ=_obj_trace EXTRA=-DCADNIP_TRACE
+  # --trace [1|2]: 1 = phase boundaries only, 2 (default) = every point (devices.hpp)
+  make -j"$(nproc)" OUT=../libcadnip_hip_trace.so OBJ=_obj_trace${2:-2} EXTRA=-DCADNIP_TRACE=${2:-2}
   echo "built $(realpath ../libcadnip_hip_trace.so)"
 else
   make -j"$(nproc)"

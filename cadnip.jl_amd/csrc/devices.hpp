@@ -21,16 +21,24 @@ namespace cadnip {
 // Each point adds the cycles since the previous point to its own bucket; read back with cadnip_debug_trace.
 #ifdef CADNIP_TRACE
 static __device__ unsigned long long g_trace_sum[64], g_trace_cnt[64];
+static __device__ int g_trace_wave;   // the traced wave of workgroup 0 (team kernel: one role per wave)
 __shared__ unsigned long long g_trace_last;
+// -DCADNIP_TRACE=1: the phase boundaries of a Newton round only (a point costs ~250 cycles: the fine points inside the device functions and
+// the update shift what they measure); -DCADNIP_TRACE=2: every point.
+#define CADNIP_TRACE_FINE(id) (((id) >= 8 && (id) <= 15) || (id) >= 20 || (id) == 0 || (id) == 2)
 #define CADNIP_TRACE_POINT(id)                                                                          \
   do {                                                                                                  \
-    if (blockIdx.x == 0 && threadIdx.x < 64) {                                                          \
+    if ((CADNIP_TRACE + 0 >= 2 || !CADNIP_TRACE_FINE(id)) && blockIdx.x == 0 && (int)(threadIdx.x >> 6) == g_trace_wave) { \
       unsigned long long _t = clock64();                                                                \
-      if (threadIdx.x == 0) {                                                                           \
+      if ((threadIdx.x & 63) == 0) {                                                                    \
         atomicAdd(&g_trace_sum[id], _t - g_trace_last); atomicAdd(&g_trace_cnt[id], 1ull); g_trace_last = _t; \
       }                                                                                                 \
     }                                                                                                   \
   } while (0)
+#elif defined(CADNIP_MARKS)
+// analysis build (tools/kernel_regs.sh ... -DCADNIP_MARKS): the trace points become comments in the assembly, so that the instructions of a
+// phase can be counted statically (tools/phase_instr.py)
+#define CADNIP_TRACE_POINT(id) asm volatile("; @@MARK " #id)
 #else
 #define CADNIP_TRACE_POINT(id) do {} while (0)
 #endif
@@ -907,6 +915,123 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
     }
   }
   CADNIP_TRACE_POINT(27);
+}
+
+// ---- sp_mos1 for a TEAM of waves (fused_team_kernel.hpp: several waves per sweep instance) --------------------------
+// A single transient is a latency problem: one wave evaluates a MOSFET as one serial instruction stream of ~1 400
+// instructions, whatever the number of devices.  The load section of mos1.va has three independent parts behind the
+// limiting code -- the bulk-junction currents (mos1.va:983-998), the channel current (:1000-1040) and the depletion
+// charges (:1049-1109) -- and every matrix / residual entry is a SUM of contributions of those parts (I(b) = type (cbs +
+// cbd), I(d_int) = -(type cbd - cdreq), I(s_int) = -(cdreq + type cbs); q_b = type (qbs + qbd), q_dint = -type qbd,
+// q_sint = -type qbs).  So the parts run on different waves (`roles`, wave-uniform), each wave on lane pairs -- lane 2j + s
+// serves junction s (0 = source side, 1 = drain side) of device j, or one of the channel's two rows -- and adds its share into
+// the work array with LDS atomics.  Limiting is evaluated by every role (same inputs, same result).  No cross-lane traffic.
+// Plain cards only (gd = gs = OxideCap = 0), direct residuals only: the caller checks.
+#define M1_ROLE_J 1    // junction currents: rows b, d_int | s_int
+#define M1_ROLE_Q 2    // depletion charges: reactive rows b, d_int | s_int (charge-state or linear form)
+#define M1_ROLE_CH 4   // channel current: rows d_int | s_int; the limit rows (g_lim block, limit residuals, limit_w)
+template <class Ctx, class Out>
+__device__ inline void stamp_mos1_team(const Ctx& d, const double* u, const Out& s, double* limit_w_base, int side, bool valid, int roles, int vdep) {
+  static_assert(Out::DIRECT, "team stamping emits direct residuals");
+  const double CS = CADNIP_CHARGE_SCALE;
+  const bool D = side != 0;
+  int ng = node_of(d, 1), nb = node_of(d, 3), ndi = node_of(d, 4), nsi = node_of(d, 5);
+  int l0 = node_of(d, 6), l1 = node_of(d, 7), l2 = node_of(d, 8), l3 = node_of(d, 9);
+  double Vg = volt(u, ng), Vb = volt(u, nb), Vdi = volt(u, ndi), Vsi = volt(u, nsi);
+  double type = par_of(d, M1_TYPE), vt = par_of(d, M1_VT), tPhi = par_of(d, M1_TPHI), tVbi = par_of(d, M1_TVBI);
+  double gamma = par_of(d, M1_GAMMA);
+  const double mf = par_of(d, M1_MFACTOR);
+  CADNIP_TRACE_POINT(20);               // (vdep, bit r: reactive branch r uses a charge unknown -- a property of the circuit, fetched by the caller)
+  double w_gs, w_ds, w_bs, w_bd;
+  m1_limit(d, u, type, vt, tPhi, tVbi, gamma, Vg, Vb, Vdi, Vsi, l0, l1, l2, l3, w_gs, w_ds, w_bs, w_bd);
+  CADNIP_TRACE_POINT(21);
+  D3 a = D3::seed(type * w_gs, 0), b = D3::seed(type * w_ds, 1), c = D3::seed(type * w_bs, 2);
+  D3 dvbd = c - b, dvgd = a - b;
+  const D3 vj = m1_sel(D, dvbd, c);                                  // this lane's junction voltage (J, Q roles)
+  const double dW_gs = (Vg - Vsi) - w_gs, dW_ds = (Vdi - Vsi) - w_ds, dW_bs = (Vb - Vsi) - w_bs;   // lim_rhs deltas
+  // one current contribution I (a dual over vgs, vds, vbs): its Jacobian entries d/dV_g, d/dV_b, d/dV_dint, d/dV_sint and
+  // its residual share I + lim_rhs anchoring terms (vasim.jl:2957-2966)
+  auto row = [&](const D3& I, double (&g)[6], double& res) {
+    const double fa = type * I.p[0], fb = type * I.p[1], fc = type * I.p[2];
+    g[0] = 0.0; g[1] = mf * fa; g[2] = 0.0; g[3] = mf * fc; g[4] = mf * fb; g[5] = mf * -(fa + fb + fc);
+    res = mf * I.v + (mf * type * I.p[0]) * dW_gs + (mf * type * I.p[1]) * dW_ds + (mf * type * I.p[2]) * dW_bs;
+  };
+  if (roles & M1_ROLE_CH) {
+    if (limit_w_base && valid && !D) { limit_w_base[l0] = w_gs; limit_w_base[l1] = w_ds; limit_w_base[l2] = w_bs; limit_w_base[l3] = w_bd; }
+    {   // g_lim rows (vasim.jl:3134-3136) and the limit rows' residuals r_l = u_l - (V_p - V_n): two limit variables per lane
+      const double gl[6] = {1.0, -1.0, 1.0, 1.0, -1.0, 1.0};
+      s.Gv(6 * side, gl);
+      s.Rn(D ? l2 : l0, u[D ? l2 : l0] - ((D ? Vb : Vg) - Vsi));
+      s.Rn(D ? l3 : l1, u[D ? l3 : l1] - (D ? Vb - Vdi : Vdi - Vsi));
+    }
+    CADNIP_TRACE_POINT(22);
+    const double lambda = par_of(d, M1_LAMBDA), Beta = par_of(d, M1_BETA);
+    int mode;
+    D3 dvon, vdsat, cdrain;
+    m1_channel(a, b, c, dvbd, dvgd, tPhi, tVbi, type, gamma, lambda, Beta, mode, dvon, vdsat, cdrain);
+    CADNIP_TRACE_POINT(24);
+    const D3 cdreq = (mode >= 0 ? type : -type) * cdrain;
+    const D3 I = m1_sel(D, cdreq, -1.0 * cdreq);              // row d_int carries +cdreq, row s_int -cdreq (mos1.va:1168-1169)
+    double g[6], res;
+    row(I, g, res);
+    s.Gv(12 + 6 * (D ? 4 : 5), g);
+    s.Rn(D ? ndi : nsi, res);
+    CADNIP_TRACE_POINT(26);
+  }
+  if (roles & M1_ROLE_J) {
+    const double gmin_m = par_of(d, M1_GMIN) / mf, isat = par_of(d, D ? M1_DSATCUR : M1_SSATCUR);
+    const D3 cj = m1_junction(vj, vt, gmin_m, isat);
+    CADNIP_TRACE_POINT(23);
+    const D3 Ib = type * cj;                                  // into row b; the junction's own terminal row takes the negative
+    double g[6], res;
+    row(Ib, g, res);
+    s.Gv(12 + 6 * 3, g);
+    s.Rn(nb, res);
+    const double gn[6] = {0.0, -g[1], 0.0, -g[3], -g[4], -g[5]};
+    s.Gv(12 + 6 * (D ? 4 : 5), gn);
+    s.Rn(D ? ndi : nsi, -res);
+    CADNIP_TRACE_POINT(26);
+  }
+  if (roles & M1_ROLE_Q) {
+    const double q_cb = par_of(d, D ? M1_CBD : M1_CBS), q_cbsw = par_of(d, D ? M1_CBDSW : M1_CBSSW), q_pot = par_of(d, M1_TBULKPOT), q_dep = par_of(d, M1_TDEPCAP);
+    const double q_mj = par_of(d, M1_MJ), q_mjsw = par_of(d, M1_MJSW), q_f2 = par_of(d, D ? M1_F2D : M1_F2S), q_f3 = par_of(d, D ? M1_F3D : M1_F3S), q_f4 = par_of(d, D ? M1_F4D : M1_F4S);
+    const D3 qj = m1_qdep(vj, q_cb, q_cbsw, q_pot, q_dep, q_mj, q_mjsw, q_f2, q_f3, q_f4);
+    CADNIP_TRACE_POINT(25);
+    {   // charge-state columns C[p, q_r] = 1 / CS (vasim.jl:3433-3472): two per lane
+      const double cs2[2] = {1.0 / CS, 1.0 / CS};
+      s.Cv(2 * side, cs2);
+    }
+    // this junction's charge enters reactive branch 1 (node b) with +type, and its own terminal's branch (2: d_int, 3: s_int)
+    // with -type.  Each branch has one owner lane for what is stamped once: the charge unknown's unit diagonal, its own
+    // value in the residual and the du_q / CS term of the node row.  Branch 0 (gate) carries no charge on a plain card.
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int r = it == 0 ? 1 : (D ? 2 : 3);
+      const bool owner = it == 0 ? !D : true;
+      const D3 q = it == 0 ? type * qj : -1.0 * (type * qj);
+      const double fa = mf * type * q.p[0], fb = mf * type * q.p[1], fc = mf * type * q.p[2];
+      const double dq[6] = {0.0, fa, 0.0, fc, fb, -(fa + fb + fc)};
+      const int np = r == 1 ? nb : r == 2 ? ndi : nsi;
+      if ((vdep >> r) & 1) {
+        const double gq[7] = {owner ? 1.0 : 0.0, 0.0, -CS * dq[1], 0.0, -CS * dq[3], -CS * dq[4], -CS * dq[5]};
+        s.Gv(48 + 7 * r, gq);
+        const int nq = node_of(d, 10 + r);
+        s.Rn(nq, (owner ? u[nq] : 0.0) - CS * (mf * q.v + fa * dW_gs + fb * dW_ds + fc * dW_bs));
+        s.Rn(np, owner ? s.du(nq) * (1.0 / CS) : 0.0);
+      } else {
+        s.Cv(4 + 6 * r, dq);
+        s.Rn(np, dq[1] * s.du(ng) + dq[3] * s.du(nb) + dq[4] * s.du(ndi) + dq[5] * s.du(nsi));
+      }
+    }
+    if (!D && (vdep & 1)) {   // a gate charge unknown exists in the pattern (never on a plain card's own detection, kept for safety): q_g = 0
+      const double g1[1] = {1.0};
+      s.Gv(48, g1);
+      const int nq = node_of(d, 10);
+      s.Rn(nq, u[nq]);
+      s.Rn(ng, s.du(nq) * (1.0 / CS));
+    }
+    CADNIP_TRACE_POINT(27);
+  }
 }
 
 }  // namespace cadnip

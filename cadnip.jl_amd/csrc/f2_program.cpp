@@ -77,7 +77,9 @@ static bool f2_emit_passes(std::vector<F2Ent>& ents, F2Program& G, int& n_passes
 //          updates of the core block by the leaf pivots, forward substitution as the recurrence of an extra column (for core
 //          rows: their leaf part);
 //   post : back substitution of the leaf rows, in place (the core rows of x are written by the dense solve).
-bool f2_build_program(const LUProgram& P, int n, int nc, F2Program& G) {
+// max_terms > 0 (team program): an entry with more multiply-add terms than that is split into a chain of partial entries on consecutive
+// levels (all but the last only subtract their share; the last one also divides), so that one lane never carries more than one term.
+static void f2_build_entries(const LUProgram& P, int n, int nc, int max_terms, F2Program& G, std::vector<F2Ent>& pre, std::vector<F2Ent>& post, std::vector<F2Ent>& fwd) {
   G = F2Program();
   G.nc = nc;
   const int cs0 = n - nc;
@@ -98,7 +100,20 @@ bool f2_build_program(const LUProgram& P, int n, int nc, F2Program& G) {
   };
   auto unit = [&](int k) { return !P.unit.empty() && P.unit[k] != 0; };   // pivot k is the stamped constant 1 (symbolic.cpp: leaf phase)
   std::vector<int> lev(P.nnz_lu, -1);        // level at which a sparse entry is final (-1: as assembled)
-  std::vector<F2Ent> pre, post;
+  pre.clear(); post.clear(); fwd.clear();
+  // append entry x (its level set); returns the level at which its value is final
+  auto push = [&](std::vector<F2Ent>& list, F2Ent&& x) -> int {
+    const size_t nt = x.a.size();
+    if (max_terms <= 0 || nt <= (size_t)max_terms) { const int l = x.lvl; list.push_back(std::move(x)); return l; }
+    const size_t chunks = (nt + max_terms - 1) / max_terms;
+    int l = x.lvl;
+    for (size_t c = 0; c < chunks; ++c, ++l) {
+      F2Ent y; y.pos = x.pos; y.lvl = l; y.dg = c + 1 == chunks ? x.dg : -1;
+      for (size_t t = c * max_terms; t < std::min(nt, (c + 1) * (size_t)max_terms); ++t) { y.a.push_back(x.a[t]); y.b.push_back(x.b[t]); }
+      list.push_back(std::move(y));
+    }
+    return l - 1;
+  };
   for (int i = 0; i < n; ++i)
     for (int p = P.lu_rowptr[i]; p < P.lu_rowptr[i + 1]; ++p) {
       const int j = P.lu_col[p];
@@ -115,8 +130,7 @@ bool f2_build_program(const LUProgram& P, int n, int nc, F2Program& G) {
       if (j < i && !unit(j)) { x.dg = G.posW[P.lu_diag[j]]; x.lvl = std::max(x.lvl, lev[P.lu_diag[j]]); }   // L entry / pivot (a constant-1 pivot divides nothing)
       if (x.a.empty() && x.dg < 0) continue;
       x.lvl += 1;
-      lev[p] = x.lvl;
-      pre.push_back(std::move(x));
+      lev[p] = push(pre, std::move(x));
     }
   for (int i = cs0; i < n; ++i)
     for (int j = cs0; j < n; ++j) {
@@ -131,7 +145,7 @@ bool f2_build_program(const LUProgram& P, int n, int nc, F2Program& G) {
       }
       if (x.a.empty()) continue;
       x.lvl += 1;
-      pre.push_back(std::move(x));
+      push(pre, std::move(x));
     }
   std::vector<int> ylev(n, -1);
   for (int i = 0; i < n; ++i) {
@@ -144,8 +158,7 @@ bool f2_build_program(const LUProgram& P, int n, int nc, F2Program& G) {
     }
     if (x.a.empty()) continue;
     x.lvl += 1;
-    ylev[i] = x.lvl;
-    pre.push_back(std::move(x));
+    ylev[i] = push(pre, std::move(x));
   }
   std::vector<int> xlev(n, -1);
   for (int i = cs0 - 1; i >= 0; --i) {
@@ -157,12 +170,10 @@ bool f2_build_program(const LUProgram& P, int n, int nc, F2Program& G) {
     }
     if (x.a.empty() && x.dg < 0) continue;     // x_i = y_i: nothing to do (xlev stays -1: final as forward substitution left it)
     x.lvl += 1;
-    xlev[i] = x.lvl;
-    post.push_back(std::move(x));
+    xlev[i] = push(post, std::move(x));
   }
   // forward substitution on KEPT factors (Newton mode 1, a round that does not refactor): the y recurrences alone; every L entry is
   // final, so a row's level is one more than the deepest y it reads
-  std::vector<F2Ent> fwd;
   {
     std::vector<int> fl(n, -1);
     for (int i = 0; i < n; ++i) {
@@ -175,10 +186,14 @@ bool f2_build_program(const LUProgram& P, int n, int nc, F2Program& G) {
       }
       if (x.a.empty()) continue;
       x.lvl += 1;
-      fl[i] = x.lvl;
-      fwd.push_back(std::move(x));
+      fl[i] = push(fwd, std::move(x));
     }
   }
+}
+
+bool f2_build_program(const LUProgram& P, int n, int nc, F2Program& G) {
+  std::vector<F2Ent> pre, post, fwd;
+  f2_build_entries(P, n, nc, 0, G, pre, post, fwd);
   if (!f2_emit_passes(pre, G, G.n_pre) || !f2_emit_passes(post, G, G.n_post) || !f2_emit_passes(fwd, G, G.n_fwd)) return false;
   G.terms.push_back(0);   // a lane without terms still prefetches term[t0]
   if (G.terms.size() >= 65535) return false;
@@ -187,5 +202,57 @@ bool f2_build_program(const LUProgram& P, int n, int nc, F2Program& G) {
   return true;
 }
 
+// ---- the same program for a TEAM of nw waves per instance (fused_team_kernel.hpp) ----------------------------------------------------
+// One wave alone pays for instructions, not for data (~8 cycles per instruction, ~25 per taken branch: tools/ubench/lat.hip), so a step of
+// the team's linear solve is straight-line code: every lane gets ONE 8-byte descriptor per step -- four 15-bit word offsets into the work
+// array: the entry, its pivot, and the two factors of its single multiply-add term; the leader flag and the lane-group width sit in the
+// top bits of the four 16-bit fields -- staged in LDS (160 KB = 20 480 doubles: 15 bits address all of it); no term lists, no loops, no
+// per-pass variants.  Lanes without work point at the constant words behind the work array: W[zero] = 0.0 (factors, entry) and
+// W[zero + 1] = 1.0 (pivot of an entry that is not divided).  A step is nw * 64 lanes of ONE dependency level (a level with more lanes
+// takes several steps); every step ends with a workgroup barrier.
+bool f2_build_team(const LUProgram& P, int n, int nc, int nw, F2Team& T) {
+  F2Program G;
+  std::vector<F2Ent> lists[3];
+  f2_build_entries(P, n, nc, 16, G, lists[0], lists[1], lists[2]);
+  T = F2Team();
+  T.nw = nw; T.nc = G.nc; T.lu_words = G.lu_words; T.dn0 = G.dn0; T.posW = G.posW;
+  const unsigned zero_w = (unsigned)(G.lu_words + n + 64 /* F2_TRASH */), one_w = zero_w + 1u;
+  if (one_w >= (1u << 15)) return false;
+  const size_t lanes_per_step = 64 * (size_t)nw;
+  auto p2c = [](size_t x) { size_t r = 1; while (r < x) r *= 2; return r; };
+  auto pack = [](unsigned pos, unsigned leader, unsigned piv, unsigned a, unsigned b, unsigned lg) -> unsigned long long {
+    return (unsigned long long)(pos | leader << 15) | (unsigned long long)(piv | (lg & 1u) << 15) << 16 |
+           (unsigned long long)(a | ((lg >> 1) & 1u) << 15) << 32 | (unsigned long long)(b | ((lg >> 2) & 1u) << 15) << 48;
+  };
+  const unsigned long long idle = pack(zero_w, 0, one_w, zero_w, zero_w, 0);
+  for (int li = 0; li < 3; ++li) {
+    auto& ents = lists[li];
+    std::stable_sort(ents.begin(), ents.end(), [](const F2Ent& p, const F2Ent& q) { return p.lvl < q.lvl; });
+    for (size_t i = 0; i < ents.size();) {
+      size_t j = i;
+      while (j < ents.size() && ents[j].lvl == ents[i].lvl) ++j;
+      std::vector<size_t> ord;
+      for (size_t e = i; e < j; ++e) ord.push_back(e);
+      auto width = [&](size_t e) { return std::min<size_t>(16, p2c(std::max<size_t>(ents[e].a.size(), 1))); };
+      std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return width(x) > width(y); });   // widest first: groups stay aligned
+      size_t used = lanes_per_step;          // lanes filled in the current step (full: the level opens a new one)
+      for (size_t e : ord) {
+        const F2Ent& x = ents[e];
+        const size_t L = width(e);
+        if (used + L > lanes_per_step) { T.desc.resize(T.desc.size() + lanes_per_step, idle); used = 0; ++T.n_steps[li]; }
+        unsigned lg = 0;
+        while (((size_t)1 << lg) < L) ++lg;
+        for (size_t sub = 0; sub < L; ++sub)
+          T.desc[T.desc.size() - lanes_per_step + used + sub] =
+              pack((unsigned)x.pos, sub == 0 ? 1u : 0u, x.dg < 0 ? one_w : (unsigned)x.dg, sub < x.a.size() ? (unsigned)x.a[sub] : zero_w,
+                   sub < x.a.size() ? (unsigned)x.b[sub] : zero_w, lg);
+        used += L;
+      }
+      i = j;
+    }
+  }
+  T.desc.resize(T.desc.size() + lanes_per_step, idle);   // the kernel reads one step beyond a list's end
+  return true;
+}
 
 }  // namespace cadnip

@@ -26,7 +26,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <vector>
-#include "fused2_kernel.hpp"
+#include "fused_team_kernel.hpp"
 
 namespace cadnip {
 
@@ -127,7 +127,19 @@ static bool f2_prepare(CadnipHandle* h, F2Tables& T, const std::vector<int>& g_p
     for (auto& b : h->blocks) { h->f2_nodes_off.push_back((int)all.size()); all.insert(all.end(), b.h_nodes.begin(), b.h_nodes.end()); }
     T.add16(all);
   }
-  if (T.data.size() & 1) T.data.push_back(0);
+  while (T.data.size() & 3) T.data.push_back(0);   // the work arrays behind the tables stay 16-byte aligned
+  h->f2_lds_len = (int)T.data.size();              // what the kernels copy to LDS ends here
+  // ---- team kernel (fused_team_kernel.hpp): the same program as straight-line steps for teams of 2 and 4 waves (f2_build_team); the
+  // kernel stages the descriptors in LDS
+  for (int k = 0; k < 2; ++k) {
+    F2Team TM;
+    if (h->d_team_desc[k]) { (void)hipFree(h->d_team_desc[k]); h->d_team_desc[k] = nullptr; }
+    if (!f2_build_team(P, n, G.nc, k == 0 ? 2 : 4, TM) || TM.lu_words != G.lu_words) continue;      // (no team kernel for this circuit then)
+    if (hipMalloc((void**)&h->d_team_desc[k], TM.desc.size() * sizeof(unsigned long long)) != hipSuccess) { h->d_team_desc[k] = nullptr; continue; }
+    if (hipMemcpy(h->d_team_desc[k], TM.desc.data(), TM.desc.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(h->d_team_desc[k]); h->d_team_desc[k] = nullptr; continue; }
+    for (int li = 0; li < 3; ++li) h->team_steps[k][li] = TM.n_steps[li];
+    h->team_desc_len[k] = (int)TM.desc.size();
+  }
   return true;
 }
 
@@ -148,13 +160,12 @@ static int fused2_tables(CadnipHandle* h) {
   if (!b_slots.empty()) HIP_TRY(hipMemcpy(b_slots.data(), h->d_b_slots, b_slots.size() * 4, hipMemcpyDeviceToHost));
   F2Tables T;
   if (!f2_prepare(h, T, g_ptr, g_slots, c_ptr, c_slots, b_ptr, b_slots)) return CADNIP_BADARG;
-  while (T.data.size() & 3) T.data.push_back(0);           // the per-wave work arrays behind the tables stay 16-byte aligned
   if (h->d_f2tab) (void)hipFree(h->d_f2tab);
   h->d_f2tab = nullptr;
   HIP_TRY(hipMalloc((void**)&h->d_f2tab, T.data.size() * sizeof(unsigned)));
   HIP_TRY(hipMemcpy(h->d_f2tab, T.data.data(), T.data.size() * sizeof(unsigned), hipMemcpyHostToDevice));
   for (int i = 0; i < S_NSEC; ++i) h->f2off[i] = T.off[i];
-  h->f2len = (int)T.data.size();
+  h->f2len = h->f2_lds_len;                        // words the kernels stage in LDS (the team's step lists behind them stay in global memory)
   h->fused2_dirty = false;
   h->f2_blk_dirty = true;
   return CADNIP_OK;
@@ -187,7 +198,7 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
     for (size_t bi = 0; bi < h->blocks.size() && nb < F2_MAX_BLOCKS; ++bi) {
       auto& b = h->blocks[bi];
       if (b.count == 0) continue;
-      hb[nb++] = F2Block{b.d_ipar, b.d_par, b.type, b.count, b.n_par, b.g_base, b.c_base, b.b_base, h->f2_nodes_off[bi], b.mos1_plain ? 1 : 0};
+      hb[nb++] = F2Block{b.d_ipar, b.d_par, b.type, b.count, b.n_par, b.g_base, b.c_base, b.b_base, h->f2_nodes_off[bi], b.mos1_plain ? 1 : 0, -1};
     }
     // the heaviest device type first
     for (int i = 0; i < nb; ++i)
@@ -207,6 +218,10 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
       if (heavy) h->f2_lean = false;
     }
     h->f2_n_blk = nb;
+    // team kernel (fused_team_kernel.hpp): the parameter rows of the lane-paired sp_mos1 blocks are staged in LDS
+    h->f2_par_words = 0;
+    for (int i = 0; i < nb; ++i)
+      if (hb[i].type == CADNIP_DEV_MOS1 && hb[i].mos1_plain) { hb[i].lds_par = h->f2_par_words; h->f2_par_words += hb[i].n_par * hb[i].count; }
     // every device type emits its residual directly (devices.hpp, Rn); CADNIP_F2_NODIRECT=1 selects the assembled form
     // r = J u + C beta - b instead (diagnostic: the two must agree)
     h->f2_direct = !getenv("CADNIP_F2_NODIRECT");
@@ -223,7 +238,7 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
   f.tab_len = h->f2len;
   f.n = h->n; f.nnz = h->nnz; f.nnz_lu = h->f2_lu_words;
   f.n_pre = h->f2_n_pre; f.n_post = h->f2_n_post; f.nc = h->f2_nc; f.dn0 = h->f2_dn0; f.n_fwd = h->f2_n_fwd;
-  f.lufac = nullptr;
+  f.lufac = nullptr; f.team_desc = nullptr; f.team_desc_len = 0; f.par_words = 0; f.ts_pre = f.ts_post = f.ts_fwd = 0;
   if (!dc && t.newton_mode) {
     // IDA-style Jacobian reuse exists in the lean direct-residual variant (fused2_kernel.hpp); the kept factors of instances that
     // are not resident live in HBM
@@ -248,6 +263,26 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
     HIP_TRY(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, h->device));
     h->n_cu = cu > 0 ? cu : 256;
   }
+  if (!h->d_f2queue) HIP_TRY(hipMalloc((void**)&h->d_f2queue, sizeof(int)));
+  // Few instances: a team of waves per instance (fused_team_kernel.hpp) -- the latency of ONE transient is what counts when the batch
+  // cannot fill the chip.  Transient, direct residuals, lean device set.  CADNIP_F2_TEAM = 0 | 2 | 4 forces the choice (diagnostic, tests).
+  if (!dc && h->f2_direct && h->f2_lean) {
+    int nw = h->B <= h->n_cu ? 4 : 0;
+    if (const char* e = getenv("CADNIP_F2_TEAM")) nw = atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 0;
+    const size_t shmem_t = (tab_dbl + per + 2 + (size_t)h->f2_par_words + (nw ? (size_t)h->team_desc_len[nw / 4] : 0)) * 8;     // (+ the two constant words behind the trash words)
+    if (nw && h->d_team_desc[nw / 4] && shmem_t <= lds_cap) {
+      f.team_desc = h->d_team_desc[nw / 4]; f.team_desc_len = h->team_desc_len[nw / 4]; f.par_words = h->f2_par_words;
+      f.ts_pre = h->team_steps[nw / 4][0]; f.ts_post = h->team_steps[nw / 4][1]; f.ts_fwd = h->team_steps[nw / 4][2];
+      TRY_RC(dev_zero_async(h, h->d_f2queue, sizeof(int)));
+      f.queue = h->d_f2queue;
+      const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(lds_cap / shmem_t, (size_t)(16 / nw)));
+      const int grid = std::min(h->B, h->n_cu * wg_per_cu);
+      if (getenv("CADNIP_F2_DEBUG")) fprintf(stderr, "[cadnip f2] team of %d waves: B %d n_cu %d grid %d shmem %zu rounds %d nc %d steps %d+%d / %d\n", nw, h->B, h->n_cu, grid, shmem_t, rounds, h->f2_nc, f.ts_pre, f.ts_post, f.ts_fwd);
+      TRY_RC(fteam_launch(nw, grid, shmem_t, h->stream, f));
+      HIP_TRY(hipGetLastError());
+      return CADNIP_OK;
+    }
+  }
   // waves (= instances) per workgroup: 8 (two waves per SIMD) when they fit into LDS; fewer when the whole batch is then
   // still resident in one generation with a workgroup on every CU -- a wave runs about 20 % faster with half as many
   // neighbours on its CU (1024 instances: 4 per workgroup on 256 CUs, 57.7 M iterations/s, against 48.1 M as 8 x 128)
@@ -257,7 +292,6 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
   size_t shmem = (tab_dbl + wpb * per) * 8;
   if (shmem > lds_cap) return CADNIP_BADARG;
   // resident workgroups only: the instances beyond them are handed out by the in-kernel queue as waves become free
-  if (!h->d_f2queue) HIP_TRY(hipMalloc((void**)&h->d_f2queue, sizeof(int)));
   TRY_RC(dev_zero_async(h, h->d_f2queue, sizeof(int)));
   f.queue = h->d_f2queue;
   const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(lds_cap / shmem, (size_t)(32 / wpb)));

@@ -23,6 +23,7 @@ enum { S_GPOS = 0, S_CDESC, S_BROW, S_NZ, S_ENT, S_TERM, S_LEV, S_QINV, S_NODES,
 struct F2Block {
   const int* ipar; const double* par;
   int type, count, n_par, g_base, c_base, b_base, nodes_off, mos1_plain;
+  int lds_par;               // team kernel (fused_team_kernel.hpp): word offset of the block's parameter rows in the LDS parameter area, -1 = not staged
 };
 
 // The device blocks are read through a pointer: an array inside the by-value argument struct, indexed by the block
@@ -33,7 +34,7 @@ __device__ __forceinline__ F2Block load_block(const F2Block* blk, int i) {
   F2BlockPtr q = (F2BlockPtr)blk + i;
   F2Block b;
   b.ipar = q->ipar; b.par = q->par; b.type = q->type; b.count = q->count; b.n_par = q->n_par; b.g_base = q->g_base; b.c_base = q->c_base;
-  b.b_base = q->b_base; b.nodes_off = q->nodes_off; b.mos1_plain = q->mos1_plain;
+  b.b_base = q->b_base; b.nodes_off = q->nodes_off; b.mos1_plain = q->mos1_plain; b.lds_par = q->lds_par;
   return b;
 }
 
@@ -49,6 +50,9 @@ struct F2Args {
   int n_pre, n_post, nc, dn0;       // passes before / after the dense core solve, core size, first word of the core block
   int n_fwd;                        // Newton mode 1: passes of the forward substitution alone (kept factors), behind the pre / post passes
   double* lufac;                    // [B][nnz_lu] kept factors of the instances that are not resident (between launches / while queued)
+  const unsigned long long* team_desc; int team_desc_len;   // team kernel (fused_team_kernel.hpp): step descriptors of the linear solve (f2_program.cpp: f2_build_team)
+  int ts_pre, ts_post, ts_fwd;      // ... steps of the pre-core, post-core and forward-only lists
+  int par_words;                    // team kernel: doubles of the LDS-staged sp_mos1 parameter rows (F2Block::lds_par)
   // DC mode (k_fused2<WPB, true>): PCNR / plain Newton on G u = b (driver.hip: k_dc_check, k_dc_update)
   double dc_abstol; int dc_maxiters, dc_pcnr, dc_mode, dc_initjct; int* dcstate;
   const int* cold;           // [B] DC mode: 1 = the instance starts cold (initjct applies to it), driver.hip: k_dc_init
@@ -278,8 +282,8 @@ struct FusedVecs {
 // The core of the linear system: the Schur complement of the last NC pivots (accumulated in W by the entry program), one
 // row per lane, eliminated and solved in registers.  Pivot rows are broadcast with v_readlane; no LDS traffic and no fences
 // inside.  Static pivot order like the rest of the factorisation; a zero / non-finite pivot raises `bad`.
-// MODE 0: eliminate and solve; `keep` writes the factors back (multipliers below the diagonal, U on and above it) for later
-// MODE 1 calls, which only carry the right-hand side through them (Newton mode 1: a round on kept factors).
+// MODE 0: eliminate and solve; `keep` writes the factors back (multipliers below the diagonal, U above it, the reciprocal pivots on it) for
+// later MODE 1 calls, which only carry the right-hand side through them (Newton mode 1: a round on kept factors).
 template <int NC, int MODE>
 __device__ __forceinline__ void dense_core_solve(double* W, int dn0, int yc0, int lane, int& bad, bool keep) {
   const int row = lane < NC ? lane : 0;
@@ -291,7 +295,7 @@ __device__ __forceinline__ void dense_core_solve(double* W, int dn0, int yc0, in
   for (int k = 0; k < NC; ++k) {
     const double pkk = readlane_f64(A[k], k);
     if (MODE == 0 && (pkk == 0.0 || !isfinite(pkk))) bad = 1;
-    rp[k] = fast_div(1.0, pkk);
+    rp[k] = MODE == 0 ? fast_div(1.0, pkk) : pkk;          // kept factors carry 1 / pivot on the diagonal
     const double m = lane > k ? (MODE == 0 ? A[k] * rp[k] : A[k]) : 0.0;       // rows up to k keep their (final) U rows
     if (MODE == 0) {
 #pragma unroll
@@ -309,7 +313,7 @@ __device__ __forceinline__ void dense_core_solve(double* W, int dn0, int yc0, in
     W[yc0 + lane] = bc;
     if (MODE == 0 && keep) {
 #pragma unroll
-      for (int j = 0; j < NC; ++j) S[j] = A[j];
+      for (int j = 0; j < NC; ++j) S[j] = j == lane ? rp[j] : A[j];
     }
   }
 }
@@ -462,7 +466,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
       refresh = (st.mflags & MN_NEED) || !(st.mflags & MN_VALID) ||
                 (st.k == 0 && (st.a0 < 0.6 * st.a0f || st.a0 * 0.6 > st.a0f || (st.mflags >> MN_SINCE_SHIFT) >= 20));
       if (refresh) { st.a0f = st.a0; st.ss = 20.0; st.mflags = MN_VALID | MN_JCUR; st.dsc = 1.0; }
-      else st.dsc = st.a0 == st.a0f ? 1.0 : 2.0 / (1.0 + st.a0 / st.a0f);
+      else st.dsc = st.a0 == st.a0f ? 1.0 : fast_div(2.0, 1.0 + fast_div(st.a0, st.a0f));
     }
     if (refresh) {
       for (int i = lane; i < (nW >> 1); i += 64) ((double2*)W)[i] = make_double2(0.0, 0.0);   // nW is even (f2_program.cpp), W 16-byte aligned

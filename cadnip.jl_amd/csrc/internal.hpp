@@ -62,6 +62,15 @@ struct F2Ent { int pos, dg, lvl; std::vector<int> a, b; };
 
 bool f2_build_program(const LUProgram& P, int n, int nc, F2Program& G);
 
+// the same program laid out for a team of nw waves per instance (f2_program.cpp: f2_build_team; fused_team_kernel.hpp)
+struct F2Team {
+  int nw = 0, nc = 0, lu_words = 0, dn0 = 0;
+  int n_steps[3] = {0, 0, 0};              // steps of the pre-core, post-core and forward-only (kept factors) lists
+  std::vector<int> posW;                   // as F2Program::posW (same layout for the same nc)
+  std::vector<unsigned long long> desc;    // [step][nw * 64 lanes] packed word offsets into W (f2_program.cpp: f2_build_team)
+};
+bool f2_build_team(const LUProgram& P, int n, int nc, int nw, F2Team& T);
+
 struct DeviceBlock {
   int type, count, n_nodes, n_ipar, n_par;
   int g_base, c_base, b_base, n_g, n_c, n_b;
@@ -146,6 +155,11 @@ struct CadnipHandle {
   void* d_f2blk = nullptr;    // fused kernel: device-block descriptors
   bool f2_blk_dirty = true;
   int f2_n_blk = 0, f2_rc_blk = -1;
+  unsigned long long* d_team_desc[2] = {nullptr, nullptr};   // team kernel: step descriptors for teams of 2 / 4 waves (f2_build_team), built with the tables
+  int team_steps[2][3] = {{0, 0, 0}, {0, 0, 0}};
+  int team_desc_len[2] = {0, 0};   // 64-bit words each
+  int f2_lds_len = 0;         // 32-bit words of the table that the fused kernels copy to LDS (f2len; the team kernel's step lists lie behind)
+  int f2_par_words = 0;       // team kernel: doubles of the LDS-staged sp_mos1 parameter rows of one instance
   bool f2_direct = false;     // devices emit their residuals directly: no J*u pass (off: CADNIP_F2_NODIRECT=1)
   std::vector<unsigned char> leaf_unit_ok;   // per unknown: its diagonal is one constant G stamp, no C stamp (leaf-first pivot order, symbolic.cpp)
   cadnip::LULeaves leaves;    // charge / limit ranges of the unknown layout [V | I | q | lim]

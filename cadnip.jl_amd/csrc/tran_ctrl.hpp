@@ -24,8 +24,9 @@ namespace cadnip {
 // ---- cross-lane sums on DPP (no LDS round trips) -----------------------------------------------------
 template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  // (bound_ctrl: every lane of these permutations has a source lane, so the "old" operand is dead -- saying so saves its zero-fill)
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 // sum over aligned groups of `width` consecutive lanes (width = 1, 2, 4, 8 or 16; uniform), result in every
@@ -46,14 +47,37 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 __device__ __forceinline__ int wave_any(int v) { return __any(v); }
 
-// a / b for finite, non-zero, normal-range b (pivots, positive error weights): v_rcp_f64 + two Newton steps +
-// one residual correction, about 1 ulp; none of IEEE division's range scaling.
+// a / b for finite, non-zero, normal-range b (pivots, positive error weights, step sizes): v_rcp_f64 + two Newton steps +
+// one residual correction; none of IEEE division's range scaling.  For normal-range operands and quotients it IS the correctly rounded
+// quotient -- bit for bit the result of `a / b` over 1.3e9 random pairs with exponents up to +-500 apart (tools/ubench/divcheck.hip) --
+// so the CPU port's plain divisions stay its exact counterpart.  One wave alone pays ~45 cycles for it, 117 for the compiler's IEEE
+// sequence (tools/ubench/lat.hip), and the controller's scalars are a chain of such divisions.
 __device__ __forceinline__ double fast_div(double a, double b) {
   double r = __builtin_amdgcn_rcp(b);
   r = fma(fma(-b, r, 1.0), r, r);
   r = fma(fma(-b, r, 1.0), r, r);
   const double q = a * r;
   return fma(fma(-b, q, a), r, q);
+}
+
+// x^(-1/(ord+1)) for the step-size rule, ord = 1 or 2, x > 0 finite.  `pow` costs one wave ~870 cycles (tools/ubench/lat.hip) once per
+// accepted step.  Order 1: 1 / sqrt(x), both IEEE-exact.  Order 2: x = m 8^q with m in [0.5, 4), y ~ m^(-1/3) by four Newton steps
+// y <- y (4 - m y^3) / 3 from a linear start (relative error 1e-13: a step-size heuristic does not need the last bits, it needs the same
+// bits on both sides) -- written with single-rounding operations only (products, fma, exact frexp / ldexp), so that oracle/cpu_port.cpp's
+// copy (step_root) returns the same double.
+__device__ __forceinline__ double step_root(double x, int ord) {
+  if (ord == 1) return fast_div(1.0, sqrt(x));
+  int e;
+  double m = frexp(x, &e);                 // x = m 2^e, m in [0.5, 1)
+  const int q = (e >= 0 ? e : e - 2) / 3;  // floor(e / 3)
+  m = ldexp(m, e - 3 * q);                 // [0.5, 4)
+  double y = fma(m, -0.17, 1.18);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const double y3 = (y * y) * y;
+    y = (y * fma(-m, y3, 4.0)) * (1.0 / 3.0);
+  }
+  return ldexp(y, -q);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -156,6 +180,23 @@ template <class V> __device__ __forceinline__ int grp_any(int v) {
   if constexpr (V::NT == 64) return wave_any(v);
   else return __syncthreads_or(v);
 }
+// the update's three reductions at once (two norms and the failure flag): for a group of several waves one LDS exchange and ONE barrier
+// instead of five.  Every wave adds the partial sums in the same order, so all of them take the same decisions.  The exchange words are
+// rewritten by the next call only: callers have a barrier between two updates (a Newton round has several).
+template <class V> __device__ __forceinline__ void grp_reduce3(double& s1, double& s2, int& bad) {
+  if constexpr (V::NT == 64) { s1 = wave_sum(s1); s2 = wave_sum(s2); bad = wave_any(bad); }
+  else {
+    __shared__ double red[V::NT / 64][3];
+    const double p1 = wave_sum(s1), p2 = wave_sum(s2);
+    const int pb = wave_any(bad);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = p1; red[threadIdx.x >> 6][1] = p2; red[threadIdx.x >> 6][2] = pb ? 1.0 : 0.0; }
+    __syncthreads();
+    double t1 = 0.0, t2 = 0.0, tb = 0.0;
+#pragma unroll
+    for (int k = 0; k < V::NT / 64; ++k) { t1 += red[k][0]; t2 += red[k][1]; tb += red[k][2]; }
+    s1 = t1; s2 = t2; bad = tb != 0.0;
+  }
+}
 
 // every per-unknown vector in HBM (per-op path)
 template <int NT_>
@@ -225,27 +266,27 @@ __device__ inline void prepare_step(const TranArgs& a, V& v, StepState& s, int t
   int ord;
   double a0;
   if (nhist <= 1) {
-    ord = 1; a0 = 1.0 / h;
-    each_elem<V>(n, tid, [&](int i, int k) { double p = v.h0(i, k); v.set_hp(i, k, p); v.set_u(i, p); double b = -p / h; v.set_beta(i, b); v.set_du(i, a0 * p + b); });
+    ord = 1; a0 = fast_div(1.0, h);
+    each_elem<V>(n, tid, [&](int i, int k) { double p = v.h0(i, k); v.set_hp(i, k, p); v.set_u(i, p); double b = fast_div(-p, h); v.set_beta(i, b); v.set_du(i, a0 * p + b); });
   } else if (nhist == 2 || a.max_order < 2) {
-    ord = 1; a0 = 1.0 / h;
-    double w = h / hprev;
+    ord = 1; a0 = fast_div(1.0, h);
+    double w = fast_div(h, hprev);
     each_elem<V>(n, tid, [&](int i, int k) {
       double x0 = v.h0(i, k);
       double p = x0 + w * (x0 - v.h1(i, k));
       v.set_hp(i, k, p); v.set_u(i, p);
-      double b = -x0 / h;
+      double b = fast_div(-x0, h);
       v.set_beta(i, b); v.set_du(i, a0 * p + b);
     });
   } else {
     ord = 2;
-    double w = h / hprev;
-    a0 = (1.0 + 2.0 * w) / ((1.0 + w) * h);
-    double a1 = -(1.0 + w) / h, a2 = (w * w) / ((1.0 + w) * h);
+    double w = fast_div(h, hprev);
+    a0 = fast_div(1.0 + 2.0 * w, (1.0 + w) * h);
+    double a1 = fast_div(-(1.0 + w), h), a2 = fast_div(w * w, (1.0 + w) * h);
     double x1 = -hprev, x2 = -(hprev + hpp), x = h;
-    double L0 = (x - x1) * (x - x2) / ((0.0 - x1) * (0.0 - x2));
-    double L1 = (x - 0.0) * (x - x2) / ((x1 - 0.0) * (x1 - x2));
-    double L2 = (x - 0.0) * (x - x1) / ((x2 - 0.0) * (x2 - x1));
+    double L0 = fast_div((x - x1) * (x - x2), (0.0 - x1) * (0.0 - x2));
+    double L1 = fast_div((x - 0.0) * (x - x2), (x1 - 0.0) * (x1 - x2));
+    double L2 = fast_div((x - 0.0) * (x - x1), (x2 - 0.0) * (x2 - x1));
     each_elem<V>(n, tid, [&](int i, int k) {
       double x0 = v.h0(i, k), xm1 = v.h1(i, k);
       double p = L0 * x0 + L1 * xm1 + L2 * v.h2(i, k);
@@ -270,12 +311,12 @@ __device__ inline void save_outputs(const TranArgs& a, V& v, StepState& s, int i
     double* o = a.out + ((size_t)inst * a.n_save + si) * a.n_obs;
     if (s.nhist >= 2) {   // quadratic through (tn,unew) (told,u0) (told-hprev,u1)
       double x = ts - told, xa = hh, xc = -s.hprev;
-      double La = (x - 0.0) * (x - xc) / ((xa - 0.0) * (xa - xc));
-      double Lb = (x - xa) * (x - xc) / ((0.0 - xa) * (0.0 - xc));
-      double Lc = (x - xa) * (x - 0.0) / ((xc - xa) * (xc - 0.0));
+      double La = fast_div((x - 0.0) * (x - xc), (xa - 0.0) * (xa - xc));
+      double Lb = fast_div((x - xa) * (x - xc), (0.0 - xa) * (0.0 - xc));
+      double Lc = fast_div((x - xa) * (x - 0.0), (xc - xa) * (xc - 0.0));
       for (int j = tid; j < a.n_obs; j += V::NT) { int i = a.obs[j]; o[j] = La * v.get_u(i) + Lb * v.mem_u0(i) + Lc * v.mem_u1(i); }
     } else {
-      double sc = (ts - told) / hh;
+      double sc = fast_div(ts - told, hh);
       for (int j = tid; j < a.n_obs; j += V::NT) { int i = a.obs[j]; double x0 = v.mem_u0(i); o[j] = x0 + sc * (v.get_u(i) - x0); }
     }
     ++si;
@@ -303,9 +344,8 @@ __device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, i
     s2 += (e * w2) * (e * w2);
     v.set_u(i, un);
   });
-  s1 = grp_sum<V>(s1); s2 = grp_sum<V>(s2);
-  bad = grp_any<V>(bad);
-  const double dnorm = sqrt(s1 / n);
+  grp_reduce3<V>(s1, s2, bad);
+  const double dnorm = sqrt(fast_div(s1, (double)n));
   CADNIP_TRACE_POINT(30);
   s.c_newton += 1;
   bool conv = !bad && dnorm < a.newton_tol, diverge = false;
@@ -314,8 +354,8 @@ __device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, i
     if (!bad) {
       if (s.k == 0) conv = dnorm <= 0.33e-4;
       else {
-        const double rate = s.dnp > 0.0 ? dnorm / s.dnp : 0.0;
-        if (rate > 0.9) diverge = true; else s.ss = rate / (1.0 - rate);
+        const double rate = s.dnp > 0.0 ? fast_div(dnorm, s.dnp) : 0.0;
+        if (rate > 0.9) diverge = true; else s.ss = fast_div(rate, 1.0 - rate);
       }
       if (!diverge && s.ss * dnorm <= 0.33) conv = true;
       s.dnp = dnorm;
@@ -327,9 +367,9 @@ __device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, i
     const bool tested = s.nhist >= 2 && a.n_err > 0;
     if (tested) {
       double errc;
-      if (s.ord == 1) errc = h / (h + hprev);
-      else { double w = h / hprev; errc = ((1.0 + w) * h / (1.0 + 2.0 * w)) / (h + hprev + hpp); }
-      errn = errc * sqrt(s2 / a.n_err);
+      if (s.ord == 1) errc = fast_div(h, h + hprev);
+      else { double w = fast_div(h, hprev); errc = fast_div(fast_div((1.0 + w) * h, 1.0 + 2.0 * w), h + hprev + hpp); }
+      errn = errc * sqrt(fast_div(s2, (double)a.n_err));
       accept = errn <= 1.0;
     }
     if (accept) {
@@ -341,7 +381,7 @@ __device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, i
       int nh_new = s.nhist + 1 > 3 ? 3 : s.nhist + 1;
       double hnext;
       if (tested) {
-        double fac = errn > 0.0 ? 0.9 * pow(errn, -1.0 / (s.ord + 1)) : 2.0;
+        double fac = errn > 0.0 ? 0.9 * step_root(errn, s.ord) : 2.0;
         fac = fmin(2.0, fmax(0.2, fac));
         hnext = h * fac;
       } else hnext = 2.0 * h;
@@ -364,7 +404,7 @@ __device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, i
       prepare_step(a, v, s, tid, tn, hnext, nh_new, s.hprev, s.hpp);
       CADNIP_TRACE_POINT(32);
     } else {
-      double fac = 0.9 * pow(errn, -1.0 / (s.ord + 1));
+      double fac = 0.9 * step_root(errn, s.ord);
       fac = fmin(0.9, fmax(0.1, fac));
       double hn = h * fac;
       s.c_reject += 1;

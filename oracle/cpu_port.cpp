@@ -23,6 +23,22 @@
 
 namespace {
 
+// x^(-1/(ord+1)) of the step-size rule: operation for operation the product's step_root (csrc/tran_ctrl.hpp) -- IEEE sqrt and division
+// for order 1; for order 2 exact frexp / ldexp, products and fused multiply-adds only, so that both sides get the same double.
+static double step_root(double x, int ord) {
+  if (ord == 1) return 1.0 / std::sqrt(x);
+  int e;
+  double m = std::frexp(x, &e);
+  const int q = (e >= 0 ? e : e - 2) / 3;
+  m = std::ldexp(m, e - 3 * q);
+  double y = std::fma(m, -0.17, 1.18);
+  for (int it = 0; it < 4; ++it) {
+    const double y3 = (y * y) * y;
+    y = (y * std::fma(-m, y3, 4.0)) * (1.0 / 3.0);
+  }
+  return std::ldexp(y, -q);
+}
+
 const double CS = 1e12;  // contrib.jl:39
 
 struct Block {
@@ -591,7 +607,7 @@ int port_tran(void* p, double* u_io, const TranOpts* o, double* out, TranStats* 
         u2 = u1; u1 = u0; u0 = u;
         bool landed = bp < o->n_break && tn == o->breaks[bp];
         int nh_new = std::min(nhist + 1, 3); double hnext;
-        if (nhist >= 2 && n_err > 0) { double fac = errn > 0.0 ? 0.9 * std::pow(errn, -1.0 / (ord + 1)) : 2.0; fac = std::min(2.0, std::max(0.2, fac)); hnext = h * fac; }
+        if (nhist >= 2 && n_err > 0) { double fac = errn > 0.0 ? 0.9 * step_root(errn, ord) : 2.0; fac = std::min(2.0, std::max(0.2, fac)); hnext = h * fac; }
         else hnext = 2.0 * h;
         double new_hprev = h, new_hpp = hprev;
         if (landed) { ++bp; nh_new = 1; double tstop = o->t1; if (bp < o->n_break && o->breaks[bp] < tstop) tstop = o->breaks[bp]; hnext = 0.1 * std::min(h, tstop - tn); }
@@ -602,7 +618,7 @@ int port_tran(void* p, double* u_io, const TranOpts* o, double* out, TranStats* 
         if (hnext < hmin) hnext = hmin;
         prepare_attempt(t, hnext, nhist, hprev, hpp);
       } else {
-        double fac = 0.9 * std::pow(errn, -1.0 / (ord + 1)); fac = std::min(0.9, std::max(0.1, fac));
+        double fac = 0.9 * step_root(errn, ord); fac = std::min(0.9, std::max(0.1, fac));
         double hn = h * fac; S.rejected += 1;
         if (hn < hmin) { status = -1; break; }
         prepare_attempt(t, hn, nhist, hprev, hpp);
