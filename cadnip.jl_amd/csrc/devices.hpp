@@ -478,7 +478,7 @@ template <int N> __device__ __forceinline__ Dual<N> dlog(const Dual<N>& a) {
 enum { M1_TYPE = 0, M1_VT, M1_TPHI, M1_TVBI, M1_TVTO, M1_GAMMA, M1_LAMBDA, M1_BETA, M1_OXCAP, M1_SSATCUR, M1_DSATCUR,
        M1_SVCRIT, M1_DVCRIT, M1_CBS, M1_CBSSW, M1_CBD, M1_CBDSW, M1_TBULKPOT, M1_TDEPCAP, M1_F2S, M1_F3S, M1_F4S,
        M1_F2D, M1_F3D, M1_F4D, M1_MJ, M1_MJSW, M1_CGSOV, M1_CGDOV, M1_CGBOV, M1_GD, M1_GS, M1_MFACTOR, M1_GMIN };
-static_assert(M1_OXCAP == 8 && M1_GD == 30 && M1_GS == 31, "keep CADNIP_MOS1_PAR_* (internal.hpp) in step");
+static_assert(M1_GMIN == 33 && M1_OXCAP == 8 && M1_GD == 30 && M1_GS == 31, "keep CADNIP_MOS1_PAR_* (internal.hpp) in step");
 
 __device__ inline double m1_fetlim(double vnew, double vold, double vto) {   // DEVfetlim mos1.va:542-605
   double vlimited = vnew;
@@ -582,13 +582,37 @@ template <class Ctx>
 __device__ inline void m1_limit(const Ctx& d, const double* u, double type, double vt, double tPhi, double tVbi, double gamma, double Vg, double Vb,
                                 double Vdi, double Vsi, int l0, int l1, int l2, int l3, double& w_gs, double& w_ds, double& w_bs, double& w_bd) {
   double o_vgs = type * u[l0], o_vds = type * u[l1], o_vbs = type * u[l2], o_vbd = type * u[l3];
+  double vbs = type * (Vb - Vsi), vgs = type * (Vg - Vsi), vds = type * (Vdi - Vsi);
+  double vbd = vbs - vds, vgd = vgs - vds, vgdo = o_vgs - o_vds;
+  // Quiet rounds.  The three limiters return their argument unchanged when the iterate has moved little since the last one: DEVfetlim
+  // whenever |vnew - vold| <= 0.5 whatever the threshold voltage (every clamp of mos1.va:542-605 needs a larger move -- the closest is the
+  // step across vto + 0.5 from below vto), DEVlimvds whenever |vnew - vold| <= 0.5 and vnew >= -0.5 (mos1.va:607-635; the second holds by itself
+  // since the old value has the sign the branch was chosen by), DEVpnjlim whenever |vnew - vold| <= 2 vt (its first branch is that very
+  // test, its second one needs a step below -1 V; mos1.va:503-540).  Most Newton rounds of a transient are like that for every device at
+  // once; then the limiting code -- a square root, a division and some forty branches per device -- reduces to the four subtractions that
+  // rebuild vds / vgd / vbd, with the same operations in the same order as the full code, so the results are the same doubles.  (0.4
+  // instead of 0.5: no rounding case to argue about.)
+  {
+    const bool fwd = o_vds >= 0;
+    const double q_vgs = fwd ? vgs : vgd + (vgs - vgd), q_vgd = fwd ? vgs - (vgs - vgd) : vgd, q_vds = vgs - vgd;
+    const bool c1 = fabs(fwd ? vgs - o_vgs : vgd - vgdo) <= 0.4, c2 = fabs(q_vds - o_vds) <= 0.4;
+    const bool c3 = q_vds >= 0 ? !(fabs(vbs - o_vbs) > (vt + vt)) : !(fabs(vbd - o_vbd) > (vt + vt));
+    if (__all(c1 && c2 && c3)) {
+      double r_vgs = q_vgs, r_vds = q_vds, r_vbs, r_vbd;
+      (void)q_vgd;
+      if (r_vds >= 0) { r_vbs = vbs; r_vbd = r_vbs - r_vds; }
+      else { r_vbd = vbd; r_vbs = r_vbd + r_vds; }
+      if (d.initjct) { r_vbs = -1; r_vgs = type * par_of(d, M1_TVTO); r_vds = 0; r_vbd = r_vbs - r_vds; }   // mos1.va:969-974
+      w_gs = type * r_vgs; w_ds = type * r_vds; w_bs = type * r_vbs; w_bd = type * r_vbd;
+      return;
+    }
+  }
   int omode = o_vds >= 0 ? 1 : -1;
   double osel = omode == 1 ? o_vbs : o_vbd, osarg;
   if (osel <= 0) osarg = sqrt(tPhi - osel);
   else { osarg = sqrt(tPhi); osarg = osarg - o_vbs / (osarg + osarg); osarg = fmax(0.0, osarg); }   // mos1.va:940 (sic: always vbs)
   double o_von = (tVbi * type) + gamma * osarg;
-  double vbs = type * (Vb - Vsi), vgs = type * (Vg - Vsi), vds = type * (Vdi - Vsi);
-  double vbd = vbs - vds, vgd = vgs - vds, vgdo = o_vgs - o_vds, von = type * o_von;
+  double von = type * o_von;
   if (o_vds >= 0) {
     vgs = m1_fetlim(vgs, o_vgs, von);
     vds = vgs - vgd;
@@ -927,6 +951,29 @@ __device__ inline void stamp_mos1_pair(const Ctx& d, const double* u, const Out&
 // serves junction s (0 = source side, 1 = drain side) of device j, or one of the channel's two rows -- and adds its share into
 // the work array with LDS atomics.  Limiting is evaluated by every role (same inputs, same result).  No cross-lane traffic.
 // Plain cards only (gd = gs = OxideCap = 0), direct residuals only: the caller checks.
+// Register-resident view of ONE device for one lane (team kernel, first pass over the first sp_mos1 block): the node indices are a property
+// of the circuit (read once per launch), the 34 derived parameters of the instance (read once per residence).  Side-dependent parameters --
+// the source-side lane needs the source junction's, the drain-side lane the drain junction's -- are resolved when they are loaded: the slot
+// of the source-side parameter holds this lane's value (par_side).  Indices are literals at every use, so the arrays are registers.
+#define M1_NPAR 34
+struct M1RegView {
+  double p[M1_NPAR];
+  int nd[14];
+  int initjct;
+};
+__device__ __forceinline__ int node_of(const M1RegView& d, int k) { return d.nd[k]; }
+__device__ __forceinline__ double par_of(const M1RegView& d, int k) { return d.p[k]; }
+__device__ __forceinline__ double par_side(const M1RegView& d, int ks, int, bool) { return d.p[ks]; }
+template <class Ctx> __device__ __forceinline__ double par_side(const Ctx& d, int ks, int kd, bool D) { return par_of(d, D ? kd : ks); }
+__device__ __forceinline__ int node_side(const M1RegView& d, int ks, int kd, bool D) { return D ? d.nd[kd] : d.nd[ks]; }
+template <class Ctx> __device__ __forceinline__ int node_side(const Ctx& d, int ks, int kd, bool D) { return node_of(d, D ? kd : ks); }
+// (one sweep instance: its parameter block `par` [M1_NPAR][count], device `dev`, this lane's junction side)
+__device__ __forceinline__ void m1_load_params(M1RegView& v, const double* par, int count, int dev, bool D) {
+#pragma unroll
+  for (int k = 0; k < M1_NPAR; ++k) v.p[k] = par[k * count + dev];
+  if (D) { v.p[M1_SSATCUR] = v.p[M1_DSATCUR]; v.p[M1_CBS] = v.p[M1_CBD]; v.p[M1_CBSSW] = v.p[M1_CBDSW]; v.p[M1_F2S] = v.p[M1_F2D]; v.p[M1_F3S] = v.p[M1_F3D]; v.p[M1_F4S] = v.p[M1_F4D]; }
+}
+
 #define M1_ROLE_J 1    // junction currents: rows b, d_int | s_int
 #define M1_ROLE_Q 2    // depletion charges: reactive rows b, d_int | s_int (charge-state or linear form)
 #define M1_ROLE_CH 4   // channel current: rows d_int | s_int; the limit rows (g_lim block, limit residuals, limit_w)
@@ -979,7 +1026,7 @@ __device__ inline void stamp_mos1_team(const Ctx& d, const double* u, const Out&
     CADNIP_TRACE_POINT(26);
   }
   if (roles & M1_ROLE_J) {
-    const double gmin_m = par_of(d, M1_GMIN) / mf, isat = par_of(d, D ? M1_DSATCUR : M1_SSATCUR);
+    const double gmin_m = par_of(d, M1_GMIN) / mf, isat = par_side(d, M1_SSATCUR, M1_DSATCUR, D);
     const D3 cj = m1_junction(vj, vt, gmin_m, isat);
     CADNIP_TRACE_POINT(23);
     const D3 Ib = type * cj;                                  // into row b; the junction's own terminal row takes the negative
@@ -993,8 +1040,8 @@ __device__ inline void stamp_mos1_team(const Ctx& d, const double* u, const Out&
     CADNIP_TRACE_POINT(26);
   }
   if (roles & M1_ROLE_Q) {
-    const double q_cb = par_of(d, D ? M1_CBD : M1_CBS), q_cbsw = par_of(d, D ? M1_CBDSW : M1_CBSSW), q_pot = par_of(d, M1_TBULKPOT), q_dep = par_of(d, M1_TDEPCAP);
-    const double q_mj = par_of(d, M1_MJ), q_mjsw = par_of(d, M1_MJSW), q_f2 = par_of(d, D ? M1_F2D : M1_F2S), q_f3 = par_of(d, D ? M1_F3D : M1_F3S), q_f4 = par_of(d, D ? M1_F4D : M1_F4S);
+    const double q_cb = par_side(d, M1_CBS, M1_CBD, D), q_cbsw = par_side(d, M1_CBSSW, M1_CBDSW, D), q_pot = par_of(d, M1_TBULKPOT), q_dep = par_of(d, M1_TDEPCAP);
+    const double q_mj = par_of(d, M1_MJ), q_mjsw = par_of(d, M1_MJSW), q_f2 = par_side(d, M1_F2S, M1_F2D, D), q_f3 = par_side(d, M1_F3S, M1_F3D, D), q_f4 = par_side(d, M1_F4S, M1_F4D, D);
     const D3 qj = m1_qdep(vj, q_cb, q_cbsw, q_pot, q_dep, q_mj, q_mjsw, q_f2, q_f3, q_f4);
     CADNIP_TRACE_POINT(25);
     {   // charge-state columns C[p, q_r] = 1 / CS (vasim.jl:3433-3472): two per lane
@@ -1015,7 +1062,7 @@ __device__ inline void stamp_mos1_team(const Ctx& d, const double* u, const Out&
       if ((vdep >> r) & 1) {
         const double gq[7] = {owner ? 1.0 : 0.0, 0.0, -CS * dq[1], 0.0, -CS * dq[3], -CS * dq[4], -CS * dq[5]};
         s.Gv(48 + 7 * r, gq);
-        const int nq = node_of(d, 10 + r);
+        const int nq = it == 0 ? node_of(d, 11) : node_side(d, 13, 12, D);      // the charge unknown of branch r
         s.Rn(nq, (owner ? u[nq] : 0.0) - CS * (mf * q.v + fa * dW_gs + fb * dW_ds + fc * dW_bs));
         s.Rn(np, owner ? s.du(nq) * (1.0 / CS) : 0.0);
       } else {

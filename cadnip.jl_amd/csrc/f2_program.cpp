@@ -102,17 +102,28 @@ static void f2_build_entries(const LUProgram& P, int n, int nc, int max_terms, F
   std::vector<int> lev(P.nnz_lu, -1);        // level at which a sparse entry is final (-1: as assembled)
   pre.clear(); post.clear(); fwd.clear();
   // append entry x (its level set); returns the level at which its value is final
+  // (x.tl[t]: the level at which both factors of term t are final, -1 = as assembled; x.dl: that of the pivot.)  A long entry is cut into
+  // chunks of max_terms terms in the order in which its terms become available: a chunk runs one level behind its latest term and behind
+  // the previous chunk (they update the same word), so only the terms that arrive last lengthen the critical path.
   auto push = [&](std::vector<F2Ent>& list, F2Ent&& x) -> int {
     const size_t nt = x.a.size();
     if (max_terms <= 0 || nt <= (size_t)max_terms) { const int l = x.lvl; list.push_back(std::move(x)); return l; }
-    const size_t chunks = (nt + max_terms - 1) / max_terms;
-    int l = x.lvl;
-    for (size_t c = 0; c < chunks; ++c, ++l) {
-      F2Ent y; y.pos = x.pos; y.lvl = l; y.dg = c + 1 == chunks ? x.dg : -1;
-      for (size_t t = c * max_terms; t < std::min(nt, (c + 1) * (size_t)max_terms); ++t) { y.a.push_back(x.a[t]); y.b.push_back(x.b[t]); }
+    std::vector<size_t> ord(nt);
+    for (size_t t = 0; t < nt; ++t) ord[t] = t;
+    std::stable_sort(ord.begin(), ord.end(), [&](size_t p, size_t q) { return x.tl[p] < x.tl[q]; });
+    int prev = -1, l = -1;
+    for (size_t c0 = 0; c0 < nt; c0 += max_terms) {
+      const size_t c1 = std::min(nt, c0 + (size_t)max_terms);
+      const bool last = c1 == nt;
+      F2Ent y; y.pos = x.pos; y.dg = last ? x.dg : -1;
+      int ready = prev;
+      for (size_t t = c0; t < c1; ++t) { y.a.push_back(x.a[ord[t]]); y.b.push_back(x.b[ord[t]]); ready = std::max(ready, x.tl[ord[t]]); }
+      if (last) ready = std::max(ready, x.dl);
+      l = ready + 1;
+      y.lvl = l; prev = l;
       list.push_back(std::move(y));
     }
-    return l - 1;
+    return l;
   };
   for (int i = 0; i < n; ++i)
     for (int p = P.lu_rowptr[i]; p < P.lu_rowptr[i + 1]; ++p) {
@@ -124,10 +135,10 @@ static void f2_build_entries(const LUProgram& P, int n, int nc, int max_terms, F
         if (k >= j) break;
         const int pu = find(k, j);
         if (pu < 0) continue;
-        x.a.push_back(G.posW[pl]); x.b.push_back(G.posW[pu]);
+        x.a.push_back(G.posW[pl]); x.b.push_back(G.posW[pu]); x.tl.push_back(std::max(lev[pl], lev[pu]));
         x.lvl = std::max(x.lvl, std::max(lev[pl], lev[pu]));
       }
-      if (j < i && !unit(j)) { x.dg = G.posW[P.lu_diag[j]]; x.lvl = std::max(x.lvl, lev[P.lu_diag[j]]); }   // L entry / pivot (a constant-1 pivot divides nothing)
+      if (j < i && !unit(j)) { x.dg = G.posW[P.lu_diag[j]]; x.dl = lev[P.lu_diag[j]]; x.lvl = std::max(x.lvl, lev[P.lu_diag[j]]); }   // L entry / pivot (a constant-1 pivot divides nothing)
       if (x.a.empty() && x.dg < 0) continue;
       x.lvl += 1;
       lev[p] = push(pre, std::move(x));
@@ -140,7 +151,7 @@ static void f2_build_entries(const LUProgram& P, int n, int nc, int max_terms, F
         if (k >= cs0) break;
         const int pu = find(k, j);
         if (pu < 0) continue;
-        x.a.push_back(G.posW[pl]); x.b.push_back(G.posW[pu]);
+        x.a.push_back(G.posW[pl]); x.b.push_back(G.posW[pu]); x.tl.push_back(std::max(lev[pl], lev[pu]));
         x.lvl = std::max(x.lvl, std::max(lev[pl], lev[pu]));
       }
       if (x.a.empty()) continue;
@@ -153,7 +164,7 @@ static void f2_build_entries(const LUProgram& P, int n, int nc, int max_terms, F
     for (int pl = P.lu_rowptr[i]; pl < P.lu_diag[i]; ++pl) {
       const int k = P.lu_col[pl];
       if (k >= cs0) break;
-      x.a.push_back(G.posW[pl]); x.b.push_back(y0 + k);
+      x.a.push_back(G.posW[pl]); x.b.push_back(y0 + k); x.tl.push_back(std::max(lev[pl], ylev[k]));
       x.lvl = std::max(x.lvl, std::max(lev[pl], ylev[k]));
     }
     if (x.a.empty()) continue;
@@ -165,7 +176,7 @@ static void f2_build_entries(const LUProgram& P, int n, int nc, int max_terms, F
     F2Ent x; x.pos = y0 + i; x.dg = unit(i) ? -1 : G.posW[P.lu_diag[i]]; x.lvl = -1;
     for (int pu = P.lu_diag[i] + 1; pu < P.lu_rowptr[i + 1]; ++pu) {
       const int j = P.lu_col[pu];
-      x.a.push_back(G.posW[pu]); x.b.push_back(y0 + j);
+      x.a.push_back(G.posW[pu]); x.b.push_back(y0 + j); x.tl.push_back(j < cs0 ? xlev[j] : -1);
       if (j < cs0) x.lvl = std::max(x.lvl, xlev[j]);
     }
     if (x.a.empty() && x.dg < 0) continue;     // x_i = y_i: nothing to do (xlev stays -1: final as forward substitution left it)
@@ -181,7 +192,7 @@ static void f2_build_entries(const LUProgram& P, int n, int nc, int max_terms, F
       for (int pl = P.lu_rowptr[i]; pl < P.lu_diag[i]; ++pl) {
         const int k = P.lu_col[pl];
         if (k >= cs0) break;
-        x.a.push_back(G.posW[pl]); x.b.push_back(y0 + k);
+        x.a.push_back(G.posW[pl]); x.b.push_back(y0 + k); x.tl.push_back(fl[k]);
         x.lvl = std::max(x.lvl, fl[k]);
       }
       if (x.a.empty()) continue;
@@ -252,6 +263,7 @@ bool f2_build_team(const LUProgram& P, int n, int nc, int nw, F2Team& T) {
     }
   }
   T.desc.resize(T.desc.size() + lanes_per_step, idle);   // the kernel reads one step beyond a list's end
+  if (T.desc.size() & 1) T.desc.push_back(idle);         // (what follows the descriptors in LDS stays 16-byte aligned)
   return true;
 }
 

@@ -219,9 +219,14 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
     }
     h->f2_n_blk = nb;
     // team kernel (fused_team_kernel.hpp): the parameter rows of the lane-paired sp_mos1 blocks are staged in LDS
+    // ... of what the register-resident first pass over the first block does not cover (more than 32 MOSFETs, several blocks)
     h->f2_par_words = 0;
-    for (int i = 0; i < nb; ++i)
-      if (hb[i].type == CADNIP_DEV_MOS1 && hb[i].mos1_plain) { hb[i].lds_par = h->f2_par_words; h->f2_par_words += hb[i].n_par * hb[i].count; }
+    { bool first = true;
+      for (int i = 0; i < nb; ++i)
+        if (hb[i].type == CADNIP_DEV_MOS1 && hb[i].mos1_plain) {
+          if (!first || hb[i].count > 32) { hb[i].lds_par = h->f2_par_words; h->f2_par_words += hb[i].n_par * hb[i].count; }
+          first = false;
+        } }
     // every device type emits its residual directly (devices.hpp, Rn); CADNIP_F2_NODIRECT=1 selects the assembled form
     // r = J u + C beta - b instead (diagnostic: the two must agree)
     h->f2_direct = !getenv("CADNIP_F2_NODIRECT");
@@ -269,7 +274,8 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
   if (!dc && h->f2_direct && h->f2_lean) {
     int nw = h->B <= h->n_cu ? 4 : 0;
     if (const char* e = getenv("CADNIP_F2_TEAM")) nw = atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 0;
-    const size_t shmem_t = (tab_dbl + per + 2 + (size_t)h->f2_par_words + (nw ? (size_t)h->team_desc_len[nw / 4] : 0)) * 8;     // (+ the two constant words behind the trash words)
+    const size_t shmem_t = (tab_dbl + per + 2 + 4 * (size_t)nw + (size_t)h->f2_par_words + (nw ? (size_t)h->team_desc_len[nw / 4] : 0) +
+                            (nw ? (size_t)(nw - 1) * ((size_t)h->f2_lu_words + h->n + F2_TRASH) : 0)) * 8;     // (+ the two constant words behind the trash words)
     if (nw && h->d_team_desc[nw / 4] && shmem_t <= lds_cap) {
       f.team_desc = h->d_team_desc[nw / 4]; f.team_desc_len = h->team_desc_len[nw / 4]; f.par_words = h->f2_par_words;
       f.ts_pre = h->team_steps[nw / 4][0]; f.ts_post = h->team_steps[nw / 4][1]; f.ts_fwd = h->team_steps[nw / 4][2];

@@ -218,6 +218,7 @@ struct FusedVecs {
   // per-lane elements kept in registers (covers n <= 256): the history u0 / u1 / u2 and the predictor for the whole
   // residence of the instance, the error weights from `prefetch` to the update.  Elements beyond stay in HBM.
   static constexpr int KPF = 4;
+  static constexpr bool OWN_REDUCE = false;
   static constexpr int NT = 64;          // one wave per instance (tran_ctrl.hpp: grp_sum / grp_sync)
   double *us, *betas; const double* W; const u16* qinv;
   size_t vo;                   // this instance's offset into the per-unknown vectors; their bases come from the kernarg segment
@@ -259,7 +260,8 @@ struct FusedVecs {
       pf_at[k] = a.atol[i]; pf_em[k] = a.emask[i];
     }
   }
-  __device__ __forceinline__ double get_delta(int i) const { return W[qinv[i]]; }
+  __device__ __forceinline__ double get_delta(int i, int) const { return W[qinv[i]]; }
+  __device__ __forceinline__ void step_consumed(int) const {}
   __device__ __forceinline__ double get_u(int i) const { return us[i]; }
   __device__ __forceinline__ void set_u(int i, double v) const { us[i] = v; }
   __device__ __forceinline__ double get_beta(int i) const { return betas[i]; }

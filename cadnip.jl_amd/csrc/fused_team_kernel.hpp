@@ -27,7 +27,10 @@ template <int NT_, int KPF_>
 struct TeamVecs {
   static constexpr int KPF = KPF_;
   static constexpr int NT = NT_;
+  static constexpr bool OWN_REDUCE = true;
   double *us, *betas; const double* W; const u16* qinv;
+  double* red;                 // [NT / 64][4] exchange words of the update's reductions
+  int qi[KPF];                 // W word of this thread's unknowns' Newton step (a property of the circuit)
   size_t vo;
   const double* lw;
   double r_u0[KPF], r_u1[KPF], r_u2[KPF], r_up[KPF], pf_at[KPF], pf_em[KPF];
@@ -64,10 +67,32 @@ struct TeamVecs {
 #pragma unroll
     for (int k = 0; k < KPF; ++k) {
       const int i = tid + NT * k < a.n ? tid + NT * k : 0;
-      pf_at[k] = a.atol[i]; pf_em[k] = a.emask[i];
+      pf_at[k] = a.atol[i]; pf_em[k] = a.emask[i]; qi[k] = qinv[i];
     }
   }
-  __device__ __forceinline__ double get_delta(int i) const { return W[qinv[i]]; }
+  __device__ __forceinline__ double get_delta(int i, int k) const { return W[k >= 0 ? qi[k] : (int)qinv[i]]; }
+  // Behind the barrier of the update's reductions the right-hand side and the trash words are dead: clear them here for the next round
+  // (both kinds of round need that; a refactoring round clears the matrix words on top, k_fteam: begin_round), so that the end of a round
+  // on kept factors is ONE barrier.
+  int z0, z1;                  // the words [z0, z1) = rhs | trash of the work array
+  __device__ __forceinline__ void step_consumed(int tid) const {
+    double* Wm = const_cast<double*>(W);
+    for (int i = z0 + tid; i < z1; i += NT) Wm[i] = 0.0;
+  }
+  // the update's two norms and its failure flag over the team: DPP sums per wave, one LDS exchange, ONE barrier; every thread adds the
+  // waves' words in the same order.  (Letting every lane add into its wave's word with an LDS atomic looked cheaper -- 20 instructions
+  // instead of 110 -- and was slower: 64 same-address fp64 atomics serialise, +1.1 k cycles per round.)
+  __device__ __forceinline__ void reduce3(double& s1, double& s2, int& bad) const {
+    const double p1 = wave_sum(s1), p2 = wave_sum(s2);
+    const int pb = wave_any(bad);
+    double* mine = red + 4 * (threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0) { mine[0] = p1; mine[1] = p2; mine[2] = pb ? 1.0 : 0.0; }
+    __syncthreads();
+    double t1 = 0.0, t2 = 0.0, tb = 0.0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k) { t1 += red[4 * k]; t2 += red[4 * k + 1]; tb += red[4 * k + 2]; }
+    s1 = t1; s2 = t2; bad = tb != 0.0;
+  }
   __device__ __forceinline__ double get_u(int i) const { return us[i]; }
   __device__ __forceinline__ void set_u(int i, double v) const { us[i] = v; }
   __device__ __forceinline__ double get_beta(int i) const { return betas[i]; }
@@ -106,12 +131,21 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
   const int nW = f.nnz_lu + n + F2_TRASH;                 // LU | rhs | trash
   double* W = sm + tab_dbl;
   if (tid == 0) { W[nW] = 0.0; W[nW + 1] = 1.0; }         // the linear solve's constant words, directly behind the trash words (f2_build_team); never cleared
-  double* us = W + nW + 2;
+  double* red = W + nW + 2;                               // [NW][4] exchange words of the update's reductions
+  double* us = red + 4 * NW;
   double* betas = us + n;
   double* parc = betas + n;                               // sp_mos1 parameter rows of the resident instance (F2Block::lds_par)
   const int par_words = f.par_words;
   u64* tdesc = (u64*)(parc + par_words);                  // step descriptors of the linear solve (f2_build_team)
   for (int i = tid; i < f.team_desc_len; i += NT) tdesc[i] = f.team_desc[i];
+  // Reproducible sums.  Four waves adding into one word with LDS atomics would do so in the order in which they happen to arrive, and a
+  // floating-point sum depends on that order: the last bits of a transient would change from run to run.  So only wave 0 accumulates into
+  // W itself; every other wave has a private copy of the work array (matrix words and right-hand side), and after the stamping barrier the
+  // copies are added to W in wave order (and cleared for the next round by the thread that reads them).  Within a wave the atomics of one
+  // instruction are applied in lane order and the instructions in program order (as in k_fused2), so every word's sum is a fixed sequence.
+  double* const WP = (double*)(tdesc + f.team_desc_len);  // [NW - 1][nW]
+  for (int i = tid; i < (NW - 1) * nW; i += NT) WP[i] = 0.0;
+  double* const Wacc = w == 0 ? W : WP + (size_t)(w - 1) * nW;
 
   const u16* gpos = (const u16*)(tab + f.off[S_GPOS]);
   const u64* cdesc = (const u64*)(tab + f.off[S_CDESC]);
@@ -170,16 +204,38 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
 #ifdef CADNIP_TRACE
   if (blockIdx.x == 0 && tid == 0) g_trace_last = clock64();
 #endif
-  // charge-form flags of this lane's device in the first pass over the first sp_mos1 block: a property of the circuit, read once per launch
-  int vdep0 = 0, m1_blk0 = -1;
-  if (roles) {
-    for (int bi = 0; bi < f.n_blk && m1_blk0 < 0; ++bi) {
-      const F2Block B = load_block(f.blk, bi);
-      if (B.type == CADNIP_DEV_MOS1 && B.mos1_plain) { m1_blk0 = bi; vdep0 = B.ipar[(lane0 >> 1) < B.count ? (lane0 >> 1) : B.count - 1]; }
-    }
+  // The first pass over the first sp_mos1 block (all of them when the circuit has at most 32 MOSFETs) runs on a register-resident view of
+  // this lane's device (devices.hpp: M1RegView): node indices and charge-form flags are properties of the circuit and read here, once per
+  // launch; its stamp tables' base pointers likewise.  What is left for the per-round block loop -- further passes, further blocks, blocks
+  // beyond the pinned ones on the last wave -- is usually nothing: `more` says so and the loop is skipped.
+  M1RegView rv;
+  int vdep0 = 0, m1_blk0 = -1, m1_count0 = 0, m1_npar0 = 0;
+  bool m1_valid0 = false, more = false;
+  const u16* m1_gpos = gpos; const u64* m1_cdesc = cdesc; const u16* m1_brow = brow;
+  const double* m1_par0 = nullptr;
+  for (int bi = 0; bi < f.n_blk; ++bi) {
+    const F2Block B = load_block(f.blk, bi);
+    if (B.type == CADNIP_DEV_MOS1 && B.mos1_plain) {
+      if (m1_blk0 < 0) {
+        m1_blk0 = bi; m1_count0 = B.count; m1_npar0 = B.n_par;
+        const int dv = lane0 >> 1;
+        m1_valid0 = dv < B.count;
+        const int dev = m1_valid0 ? dv : B.count - 1;
+        vdep0 = B.ipar[dev];
+        const short* nd = nodes + B.nodes_off;
+#pragma unroll
+        for (int k = 0; k < 14; ++k) rv.nd[k] = nd[k * B.count + dev];
+        rv.initjct = 0;
+        m1_gpos = gpos + B.g_base; m1_cdesc = cdesc + B.c_base; m1_brow = brow + B.b_base;
+        m1_par0 = B.par;
+        if (roles && B.count > 32) more = true;
+      } else if (roles) more = true;
+    } else if (others && !((bi == f.rc_blk && B.count <= 128) || (bi == f.src_blk && B.count <= 64))) more = true;
   }
+#pragma unroll
+  for (int k = 0; k < M1_NPAR; ++k) rv.p[k] = 0.0;
   TeamVecs<NT, KPF> vec;
-  vec.us = us; vec.betas = betas; vec.W = W; vec.qinv = qinv;
+  vec.us = us; vec.betas = betas; vec.W = W; vec.qinv = qinv; vec.red = red; vec.z0 = f.nnz_lu; vec.z1 = nW;
   vec.load_weights(a, tid);
   // The team works through instances one after the other: its first one by position, further ones from the grid's queue.
   int inst = blockIdx.x;
@@ -206,7 +262,8 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
       const double *ug = ka->t.u + vo, *betag = ka->t.beta + vo;
       for (int i = tid; i < n; i += NT) { us[i] = ug[i]; betas[i] = betag[i]; }
     }
-    for (int bi = 0; bi < f.n_blk; ++bi) {                  // parameter rows of the sp_mos1 blocks: one coalesced copy per residence
+    if (par_words > 0)
+    for (int bi = 0; bi < f.n_blk; ++bi) {                  // parameter rows of the sp_mos1 blocks beyond the register-resident pass: one coalesced copy per residence
       const F2Block B = load_block(f.blk, bi);
       if (B.lds_par < 0) continue;
       const int words = B.n_par * B.count;
@@ -218,6 +275,8 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
       const double* src = kargs()->lufac + (size_t)inst * f.nnz_lu;
       for (int i = tid; i < f.nnz_lu; i += NT) W[i] = src[i];
     }
+    if (roles && m1_blk0 >= 0)                               // this lane's device, this lane's junction side: into registers for the residence
+      m1_load_params(rv, m1_par0 + (size_t)inst * m1_npar0 * m1_count0, m1_count0, m1_valid0 ? (lane0 >> 1) : m1_count0 - 1, (lane0 & 1) != 0);
     double rc_val[2] = {0.0, 0.0};
     if (others && f.rc_blk >= 0) {
       const F2Block B = load_block(f.blk, f.rc_blk);
@@ -240,10 +299,10 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
         if (refresh) { st.a0f = st.a0; st.ss = 20.0; st.mflags = MN_VALID | MN_JCUR; st.dsc = 1.0; }
         else st.dsc = st.a0 == st.a0f ? 1.0 : fast_div(2.0, 1.0 + fast_div(st.a0, st.a0f));
       }
-      if (refresh) { for (int i = tid; i < (nW >> 1); i += NT) ((double2*)W)[i] = make_double2(0.0, 0.0); }
-      else { for (int i = f.nnz_lu + tid; i < nW; i += NT) W[i] = 0.0; }
+      if (refresh) { for (int i = tid; i < (f.nnz_lu >> 1); i += NT) ((double2*)W)[i] = make_double2(0.0, 0.0); if (tid == 0 && (f.nnz_lu & 1)) W[f.nnz_lu - 1] = 0.0; }
     };
-    __syncthreads();                                        // the kept factors are in place before a partial clearing ... (disjoint words, but u / beta / parameters must be visible too)
+    __syncthreads();                                        // the kept factors are in place before they are cleared (a refactoring round)
+    vec.step_consumed(tid);                                 // rhs | trash: cleared by the update from now on
     begin_round();
     __syncthreads();
     for (;;) {
@@ -274,10 +333,10 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
           for (int q = 0; q < 2; ++q) {
             if (q == 1 && rc_count <= 64) break;
             if (refresh) {
-              atomicAdd(&W[rc_gp[q][0] & 0xFFFFu], jv[q]); atomicAdd(&W[rc_gp[q][0] >> 16], -jv[q]);
-              atomicAdd(&W[rc_gp[q][1] & 0xFFFFu], -jv[q]); atomicAdd(&W[rc_gp[q][1] >> 16], jv[q]);
+              atomicAdd(&Wacc[rc_gp[q][0] & 0xFFFFu], jv[q]); atomicAdd(&Wacc[rc_gp[q][0] >> 16], -jv[q]);
+              atomicAdd(&Wacc[rc_gp[q][1] & 0xFFFFu], -jv[q]); atomicAdd(&Wacc[rc_gp[q][1] >> 16], jv[q]);
             }
-            atomicAdd(&W[rc_row[q] & 0xFFFFu], cur[q]); atomicAdd(&W[rc_row[q] >> 16], -cur[q]);
+            atomicAdd(&Wacc[rc_row[q] & 0xFFFFu], cur[q]); atomicAdd(&Wacc[rc_row[q] >> 16], -cur[q]);
           }
         }
         if (f.src_blk >= 0) {
@@ -291,33 +350,45 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
           if (src_type == CADNIP_DEV_VSOURCE) {
             const double ui = at(src_nd[1]), vd = at(src_nd[0] & 0xFFFFu) - at(src_nd[0] >> 16) - src_val;
             if (refresh) {
-              atomicAdd(&W[src_gp[0] & 0xFFFFu], 1.0); atomicAdd(&W[src_gp[0] >> 16], -1.0);
-              atomicAdd(&W[src_gp[1] & 0xFFFFu], 1.0); atomicAdd(&W[src_gp[1] >> 16], -1.0);
+              atomicAdd(&Wacc[src_gp[0] & 0xFFFFu], 1.0); atomicAdd(&Wacc[src_gp[0] >> 16], -1.0);
+              atomicAdd(&Wacc[src_gp[1] & 0xFFFFu], 1.0); atomicAdd(&Wacc[src_gp[1] >> 16], -1.0);
             }
-            atomicAdd(&W[src_row[0] & 0xFFFFu], ui); atomicAdd(&W[src_row[0] >> 16], -ui);
-            atomicAdd(&W[src_row[1]], vd);
+            atomicAdd(&Wacc[src_row[0] & 0xFFFFu], ui); atomicAdd(&Wacc[src_row[0] >> 16], -ui);
+            atomicAdd(&Wacc[src_row[1]], vd);
           } else {
-            atomicAdd(&W[src_row[0] & 0xFFFFu], -src_val); atomicAdd(&W[src_row[0] >> 16], src_val);
+            atomicAdd(&Wacc[src_row[0] & 0xFFFFu], -src_val); atomicAdd(&Wacc[src_row[0] >> 16], src_val);
           }
         }
         CADNIP_TRACE_POINT(13);
       }
+      if (roles && m1_blk0 >= 0) {
+        const int side = lane & 1;
+        rv.initjct = 0;
+        if (!refresh) {       // round on kept factors: residuals only
+          AccumOutT<true, true, false> s{Wacc, betas, a0, m1_gpos, m1_cdesc, m1_brow, m1_count0, m1_valid0 ? (lane >> 1) : m1_count0 - 1, m1_valid0 ? 0u : trash_w, us, rowof, trash_w};
+          stamp_mos1_team(rv, us, s, lw, side, m1_valid0, roles, vdep0);
+        } else {
+          AccumOutT<true, true> s{Wacc, betas, a0, m1_gpos, m1_cdesc, m1_brow, m1_count0, m1_valid0 ? (lane >> 1) : m1_count0 - 1, m1_valid0 ? 0u : trash_w, us, rowof, trash_w};
+          stamp_mos1_team(rv, us, s, lw, side, m1_valid0, roles, vdep0);
+        }
+      }
+      if (more)
       for (int bi = 0; bi < f.n_blk; ++bi) {
         const F2Block B = load_block(f.blk, bi);
         if (B.type == CADNIP_DEV_MOS1 && B.mos1_plain) {
           if (roles == 0) continue;
           const double* par = parc + B.lds_par;
           const int side = lane & 1;
-          for (int d0 = 0; d0 < B.count; d0 += 32) {
+          for (int d0 = bi == m1_blk0 ? 32 : 0; d0 < B.count; d0 += 32) {
             const int dv = d0 + (lane >> 1);
             const bool valid = dv < B.count;
             LdsCtx d{nodes + B.nodes_off, B.ipar, par, f.wave, B.count, valid ? dv : B.count - 1, tcur, 1, 0};
-            const int vdep = (bi == m1_blk0 && d0 == 0) ? vdep0 : B.ipar[d.dev];
+            const int vdep = B.ipar[d.dev];
             if (!refresh) {       // round on kept factors: residuals only
-              AccumOutT<true, true, false> s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, d.dev, valid ? 0u : trash_w, us, rowof, trash_w};
+              AccumOutT<true, true, false> s{Wacc, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, d.dev, valid ? 0u : trash_w, us, rowof, trash_w};
               stamp_mos1_team(d, us, s, lw, side, valid, roles, vdep);
             } else {
-              AccumOutT<true, true> s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, d.dev, valid ? 0u : trash_w, us, rowof, trash_w};
+              AccumOutT<true, true> s{Wacc, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, d.dev, valid ? 0u : trash_w, us, rowof, trash_w};
               stamp_mos1_team(d, us, s, lw, side, valid, roles, vdep);
             }
           }
@@ -332,15 +403,23 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
         for (int dev = dev0; dev < B.count; dev += 64) {
           LdsCtx d{nodes + B.nodes_off, B.ipar, par, f.wave, B.count, dev, tcur, 1, 0};
           if (!refresh) {
-            AccumOutT<false, true, false> s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev, 0u, us, rowof, trash_w};
+            AccumOutT<false, true, false> s{Wacc, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev, 0u, us, rowof, trash_w};
             dispatch_stamp2<true>(B.type, d, us, s, lw);
           } else {
-            AccumOutT<false, true> s{W, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev, 0u, us, rowof, trash_w};
+            AccumOutT<false, true> s{Wacc, betas, a0, gpos + B.g_base, cdesc + B.c_base, brow + B.b_base, B.count, dev, 0u, us, rowof, trash_w};
             dispatch_stamp2<true>(B.type, d, us, s, lw);
           }
         }
       }
       CADNIP_TRACE_POINT(8);
+      __syncthreads();
+      // the other waves' contributions, in wave order (a round on kept factors has stamped the right-hand side only)
+      for (int i = (refresh ? 0 : f.nnz_lu) + tid; i < f.nnz_lu + n; i += NT) {
+        double acc = W[i];
+#pragma unroll
+        for (int k = 0; k < NW - 1; ++k) { double* q = WP + (size_t)k * nW + i; acc += *q; *q = 0.0; }
+        W[i] = acc;
+      }
       __syncthreads();
       CADNIP_TRACE_POINT(1);
       // ---- refactor + forward + backward substitution: straight-line steps (f2_program.cpp: f2_build_team).  A step gives every thread of
@@ -366,7 +445,9 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
           { const double o = dpp_f64<0x140>(part); part += lg >= 4 ? o : 0.0; }
           if (piv == 0.0 || !isfinite(piv)) bad = 1;
           const double acc = fast_div(acc0 - part, piv);
-          if (lo & 0x8000u) *pp = acc;
+          // every lane divides and stores -- the lanes that are not their group's leader into their trash word: no branch, and the entry's
+          // old value is read with the other operands instead of behind the group sum
+          *((lo & 0x8000u) ? pp : W + trash_w) = acc;
           __syncthreads();
           D = Dn;
         }
@@ -398,8 +479,7 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
       CADNIP_TRACE_POINT(16);
       if (st.status != 0) { --budget; break; }
       if (--budget <= 0) break;
-      __syncthreads();                                      // every thread has read its part of the Newton step out of W
-      begin_round();
+      begin_round();                                        // (a refactoring round clears the matrix words: every thread is past the linear solve -- the update's barrier)
       __syncthreads();
     }
     __syncthreads();

@@ -58,7 +58,7 @@ struct F2Program {
   double cost = 0;                         // issue-slot estimate used to choose nc
 };
 
-struct F2Ent { int pos, dg, lvl; std::vector<int> a, b; };
+struct F2Ent { int pos, dg, lvl; std::vector<int> a, b; std::vector<int> tl; int dl = -1; };   // tl / dl: level at which term t's factors / the pivot are final
 
 bool f2_build_program(const LUProgram& P, int n, int nc, F2Program& G);
 

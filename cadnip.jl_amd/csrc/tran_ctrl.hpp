@@ -183,8 +183,9 @@ template <class V> __device__ __forceinline__ int grp_any(int v) {
 // the update's three reductions at once (two norms and the failure flag): for a group of several waves one LDS exchange and ONE barrier
 // instead of five.  Every wave adds the partial sums in the same order, so all of them take the same decisions.  The exchange words are
 // rewritten by the next call only: callers have a barrier between two updates (a Newton round has several).
-template <class V> __device__ __forceinline__ void grp_reduce3(double& s1, double& s2, int& bad) {
+template <class V> __device__ __forceinline__ void grp_reduce3(V& v, double& s1, double& s2, int& bad) {
   if constexpr (V::NT == 64) { s1 = wave_sum(s1); s2 = wave_sum(s2); bad = wave_any(bad); }
+  else if constexpr (V::OWN_REDUCE) v.reduce3(s1, s2, bad);
   else {
     __shared__ double red[V::NT / 64][3];
     const double p1 = wave_sum(s1), p2 = wave_sum(s2);
@@ -203,13 +204,15 @@ template <int NT_>
 struct GlobalVecsT {
   static constexpr int KPF = 0;
   static constexpr int NT = NT_;
+  static constexpr bool OWN_REDUCE = false;
   double *__restrict__ u, *__restrict__ du, *__restrict__ up, *__restrict__ beta, *__restrict__ u0, *__restrict__ u1, *__restrict__ u2;
   const double *__restrict__ delta, *__restrict__ lw;
   __device__ GlobalVecsT(const TranArgs& a, int inst) {
     const size_t o = (size_t)inst * a.n;
     u = a.u + o; du = a.du + o; up = a.up + o; beta = a.beta + o; u0 = a.u0 + o; u1 = a.u1 + o; u2 = a.u2 + o; delta = a.delta + o; lw = a.limit_w + o;
   }
-  __device__ __forceinline__ double get_delta(int i) const { return delta[i]; }
+  __device__ __forceinline__ double get_delta(int i, int) const { return delta[i]; }
+  __device__ __forceinline__ void step_consumed(int) const {}
   __device__ __forceinline__ double get_u(int i) const { return u[i]; }
   __device__ __forceinline__ void set_u(int i, double v) const { u[i] = v; }
   __device__ __forceinline__ double get_beta(int i) const { return beta[i]; }
@@ -334,7 +337,7 @@ __device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, i
   double s1 = 0.0, s2 = 0.0;
   each_elem<V>(n, tid, [&](int i, int k) {
     const double x0 = v.h0(i, k), at = v.atol_of(a, i, k), upv = v.hp(i, k), em = v.emask_of(a, i, k);
-    double d = v.get_delta(i) * s.dsc;
+    double d = v.get_delta(i, k) * s.dsc;
     double un = v.get_u(i) - d;
     if (!isfinite(d)) bad = 1;
     double w = fast_div(1.0, at + a.reltol * fabs(x0));
@@ -344,7 +347,8 @@ __device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, i
     s2 += (e * w2) * (e * w2);
     v.set_u(i, un);
   });
-  grp_reduce3<V>(s1, s2, bad);
+  grp_reduce3<V>(v, s1, s2, bad);
+  v.step_consumed(tid);          // every thread of the group has read its share of the Newton step (the fused kernels may clear its storage now)
   const double dnorm = sqrt(fast_div(s1, (double)n));
   CADNIP_TRACE_POINT(30);
   s.c_newton += 1;

@@ -26,9 +26,13 @@ def _port_run(circ, params, temp, u0, ts, obs, vscale, newton_mode=0):
     return out, stats
 
 
-@pytest.mark.parametrize("fused", [0, 1])
+# fused: 0 = one kernel per op; otherwise the fused Newton kernel with (fused - 1) waves per instance forced: 1 -> k_fused2 (one wave per
+# instance, the sweep kernel), 3 / 5 -> the team kernel with 2 / 4 waves per instance (k_fteam, what a batch this small gets by itself)
+@pytest.mark.parametrize("fused", [0, 1, 3, 5])
 @pytest.mark.parametrize("points", [[{}], [{"vdd": 4.5, "temp": -40.0}, {"vdd": 5.5, "temp": 125.0}, {"vdd": 4.5, "temp": 125.0}, {"vdd": 5.2, "temp": 60.0}]])
-def test_dff_transient_matches_port(points, fused):
+def test_dff_transient_matches_port(points, fused, monkeypatch):
+    if fused:
+        monkeypatch.setenv("CADNIP_F2_TEAM", str(fused - 1 if fused > 1 else 0))
     circ = bm.dff_circuit()
     mc = api.MNACircuit(circ, {"vdd": 5.0})
     sim = api.BatchSimulator(mc, points)
@@ -146,7 +150,7 @@ def test_fused_kernel_matches_per_op_path(name):
 
 
 @pytest.mark.parametrize("newton_mode", [0, 1])
-def test_full_size_corner_sweep_properties(newton_mode):
+def test_full_size_corner_sweep_properties(newton_mode, monkeypatch):
     """(both Newton modes of the fused kernel: full Newton, and IDA's Jacobian reuse with factors that travel with the instances)
     BASELINE.json config 4 at full size (32 Vdd x 32 temperature corners of the DFF transient, one resident batch)
     checked through size-independent properties: every instance finishes; the race-free logic pins hold at every corner;
@@ -170,9 +174,12 @@ def test_full_size_corner_sweep_properties(newton_mode):
     assert np.all(np.abs(out[:, 0, 0]) < 0.05) and np.all(np.abs(out[:, 1, 0]) < 0.05) and np.all(np.abs(out[:, 2, 0] - vdd) < 0.05)
     assert np.all(np.abs(out[:, 2, 1]) < 0.05)                       # Q_neg is the complement at 700 ns
     assert stats["newton_iters"] == int(per[:, 0].sum())
-    # batch independence: 5 scattered corners alone == the same corners inside the 1024-batch, bit for bit
+    # batch independence: 5 scattered corners alone == the same corners inside the 1024-batch, bit for bit -- in the same kernel (a batch
+    # this small would by itself run in the team kernel, whose sums have another order: next test)
     pick = [0, 31, 500, 777, 1023]
+    monkeypatch.setenv("CADNIP_F2_TEAM", "0")
     out_s, per_s, _ = run([pts[i] for i in pick])
+    monkeypatch.delenv("CADNIP_F2_TEAM")
     assert np.array_equal(out_s, out[pick]) and np.array_equal(per_s, per[pick])
     # permutation invariance
     perm = np.random.default_rng(3).permutation(len(pts))
@@ -182,7 +189,7 @@ def test_full_size_corner_sweep_properties(newton_mode):
 
 @pytest.mark.parametrize("newton_mode", [0, 1])
 @pytest.mark.parametrize("B", [70, 300, 700])
-def test_inverter_sweep_batch_sizes(B, newton_mode):
+def test_inverter_sweep_batch_sizes(B, newton_mode, monkeypatch):
     """Batch sizes that select the 1-, 2- and 4-instance-per-workgroup variants of the fused kernel (and, with the small
     LDS footprint of this circuit, several workgroups per CU): every instance equals its single-instance run bit for bit."""
     circ = bm.inverter_circuit()
@@ -198,12 +205,70 @@ def test_inverter_sweep_batch_sizes(B, newton_mode):
         assert stats["n_failed"] == 0
         return out, per
 
+    monkeypatch.setenv("CADNIP_F2_TEAM", "0")        # (one wave per instance at every batch size; the team kernel: test_team_kernel_*)
     out, per = run(pts)
     for i in (0, B // 2, B - 1):
         o1, p1 = run([pts[i]])
         assert np.array_equal(o1[0], out[i]) and np.array_equal(p1[0], per[i]), i
     vdd = np.array([p["vdd"] for p in pts])
     assert np.all(np.abs(out[:, 1, 0]) < 0.05) and np.all(np.abs(out[:, 3, 0]) < 0.05) and np.all(np.abs(out[:, 2, 0] - vdd) < 0.05)
+
+
+@pytest.mark.parametrize("newton_mode", [0, 1])
+def test_team_kernel_is_reproducible_and_batch_independent(newton_mode, monkeypatch):
+    """The team kernel (several waves per instance, what batches of at most one instance per CU get): the waves accumulate into private
+    copies of the work array that are added in wave order, so a transient is the same doubles from run to run, alone or inside a batch,
+    with more instances than workgroups (in-kernel queue) or not; against the one-wave-per-instance kernel -- another summation order --
+    it agrees to the integrator's tolerance with Newton counts within 1 %."""
+    circ = bm.dff_circuit()
+    pts = [p for k, p in enumerate(bm.corner_grid(32, 32)) if k % 53 == 0]          # 20 scattered corners
+    ts = np.array([150e-9, 250e-9, 700e-9])
+
+    def run(points, team):
+        monkeypatch.setenv("CADNIP_F2_TEAM", str(team))
+        sim = api.BatchSimulator(api.MNACircuit(circ, {"vdd": 5.0}), points)
+        st = sim.st
+        out, per, stats = sim.tran(bm.DFF_TSPAN, st.state_abstol(**ABSTOL), 1e-4, ts, obs=[st.index_of("Q"), st.index_of("Q_neg")], fused=1, newton_mode=newton_mode)
+        sim.close()
+        assert stats["n_failed"] == 0
+        return out, per
+
+    out4, per4 = run(pts, 4)
+    again, per_again = run(pts, 4)
+    assert np.array_equal(out4, again) and np.array_equal(per4, per_again)
+    for i in (0, 7, 19):
+        o1, p1 = run([pts[i]], 4)
+        assert np.array_equal(o1[0], out4[i]) and np.array_equal(p1[0], per4[i]), i
+    out2, per2 = run(pts, 2)
+    out1, per1 = run(pts, 0)
+    for o, pr in ((out2, per2), (out1, per1)):
+        assert np.max(np.abs(o - out4)) < 1e-3 and np.all(np.abs(pr[:, 0] - per4[:, 0]) <= 0.01 * per4[:, 0] + 3)
+
+
+def test_team_kernel_with_more_mosfets_than_one_pass(monkeypatch):
+    """Two flip-flops in one circuit: 60 MOSFETs = two passes of the team kernel's sp_mos1 waves (the first on the register-resident
+    device view, the second on parameter rows staged in LDS); same waveforms as the one-wave-per-instance kernel."""
+    import dataclasses
+    from cadnip_jl_amd.circuit import Circuit
+    c = bm.dff_circuit()
+    shared = {"0", "VDD", "VSS", "CLKN", "D", "VNW", "VPW"}
+    two = Circuit("two flip-flops on one clock")
+    two.devices = list(c.devices)
+    for d in c.devices:
+        if d.type == "V" and d.name != "VQ":
+            continue
+        two.devices.append(dataclasses.replace(d, name=d.name + "_b", nodes=tuple(nd if nd in shared else nd + "_b" for nd in d.nodes)))
+    res = {}
+    for team in (0, 4):
+        monkeypatch.setenv("CADNIP_F2_TEAM", str(team))
+        sim = api.BatchSimulator(api.MNACircuit(two, {"vdd": 5.0}), [{"vdd": 5.0}, {"vdd": 4.6, "temp": 90.0}])
+        st = sim.st
+        out, per, stats = sim.tran(bm.DFF_TSPAN, st.state_abstol(**ABSTOL), 1e-4, np.array([150e-9, 250e-9, 700e-9]), obs=[st.index_of("Q"), st.index_of("Q_b")], fused=1, newton_mode=1)
+        sim.close()
+        assert stats["n_failed"] == 0
+        res[team] = (out, per)
+    assert np.max(np.abs(res[0][0] - res[4][0])) < 1e-3
+    assert np.all(np.abs(res[4][0][:, 2, :] - np.array([[5.0], [4.6]])) < 0.05)      # both flops latch
 
 
 def test_circuit_too_large_for_the_fused_kernel_runs_per_op():
@@ -253,10 +318,12 @@ def test_dff_monte_carlo_variant_matches_port(newton_mode):
         assert np.max(np.abs(out[i] - ref) / np.maximum(np.abs(ref), 1.0)) <= REL_TOL, i
 
 
-def test_dff_transient_newton_mode_1_matches_port():
-    """Newton mode 1 -- Jacobian reuse and the rate-based convergence test as IDA runs them (tran_ctrl.hpp) -- in the fused kernel
+@pytest.mark.parametrize("team", [0, 2, 4])
+def test_dff_transient_newton_mode_1_matches_port(team, monkeypatch):
+    """(team: waves per instance of the fused kernel -- 0 = k_fused2, 2 / 4 = k_fteam)  Newton mode 1 -- Jacobian reuse and the rate-based convergence test as IDA runs them (tran_ctrl.hpp) -- in the fused kernel
     against the port's statement-for-statement mirror: the same policy must take the same path (counts within 1 %, as for full
     Newton in the fused kernel) and land on the same waveforms (1e-9); it needs fewer refactorisations than Newton rounds."""
+    monkeypatch.setenv("CADNIP_F2_TEAM", str(team))
     circ = bm.dff_circuit()
     points = [{}, {"vdd": 4.5, "temp": 125.0}, {"vdd": 5.5, "temp": -40.0}]
     sim = api.BatchSimulator(api.MNACircuit(circ, {"vdd": 5.0}), points)
