@@ -655,7 +655,8 @@ def noise_psd(src, temp_c, f):
 def noise_sources(st, circuit, params, u, temp_c=27.0, gmin=1e-12):
     """The noise sources of ``circuit`` at the solution ``u`` (one instance, [n]): (p, n, kind, a, b, name) with global unknown indices
     (-1 = ground).  What the reference's devices register while the builder runs at the DC point (context.jl:1017-1127): resistors their
-    thermal noise 4kT/R (devices.jl:498-503), diodes the shot noise of their junction current (devices.jl:1393-1418), instances of
+    thermal noise 4kT/R (devices.jl:498-503), diodes the shot noise of their junction current and, with KF > 0, its flicker noise
+    (devices.jl:1393-1443, 1582-1585), SimpleMOSFETs their channel thermal and flicker noise (devices.jl:1718-1732), instances of
     Verilog-A modules one source per white_noise / flicker_noise call of the contributions they execute (vasim.jl:2856-2893; evaluated by
     va/host_eval.py at the node voltages of ``u``: needs the model source)."""
     from .circuit import resolve
@@ -675,6 +676,9 @@ def noise_sources(st, circuit, params, u, temp_c=27.0, gmin=1e-12):
             xarg = v / nVt
             i0 = num(d.params["Is"]) * ((np.exp(80.0) * (1.0 + (xarg - 80.0)) - 1.0) if xarg > 80.0 else (np.exp(xarg) - 1.0))
             out.append((gl[0], gl[1], "shot", abs(i0), 0.0, name))
+            kf = num(d.params.get("KF", 0.0))
+            if kf > 0:                           # devices.jl:1435-1443: KF |I0|^AF / f^FFE, under the device's own name like its shot noise
+                out.append((gl[0], gl[1], "flicker", kf * abs(i0) ** num(d.params.get("AF", 1.0)), num(d.params.get("FFE", 1.0)), name))
         elif d.type.startswith("VA:"):
             mod = va.get(d.type[3:])[1]
             given = {k: num(v) for k, v in d.model.items()}
@@ -700,7 +704,22 @@ def noise_sources(st, circuit, params, u, temp_c=27.0, gmin=1e-12):
                 out.append((gl[a] if a >= 0 else -1, gl[b] if b >= 0 else -1, "white" if fn == "white_noise" else "flicker", pwr, expo, nm))
             va.host_eval.evaluate(mod, V, par, temp_c + 273.15, num(d.params.get("m", 1.0)), gmin, vold=vold, given=set(d.model), mode="dcop", on_noise=on_noise)
         elif d.type == "SMOS":
-            raise NotImplementedError("noise: %s (SimpleMOSFET) registers no noise sources (nor does the reference's, devices.jl:1667-1749)" % d.name)
+            # SimpleMOSFET (devices.jl:1667-1732): channel thermal noise 4kT (2/3) gm between drain and source where the device conducts,
+            # flicker noise KF |Ids|^AF / f^FFE when KF > 0 -- gm and Ids of the square law at the operating point
+            vat = lambda k: u[gl[k]] if gl[k] >= 0 else 0.0
+            vgs, vds = vat(1) - vat(2), vat(0) - vat(2)
+            vth, kk, lam = num(d.params["Vth"]), num(d.params["K"]), num(d.params["lambda"])
+            if vgs <= vth:
+                ids = gm = 0.0
+            elif vds <= vgs - vth:
+                ids, gm = kk * ((vgs - vth) * vds - vds ** 2 / 2), kk * vds
+            else:
+                ids, gm = kk / 2 * (vgs - vth) ** 2 * (1 + lam * vds), kk * (vgs - vth) * (1 + lam * vds)
+            if gm > 0:
+                out.append((gl[0], gl[2], "thermal", 2.0 / 3.0 * gm, 0.0, name))
+            kf = num(d.params.get("KF", 0.0))
+            if kf > 0 and ids != 0.0:
+                out.append((gl[0], gl[2], "flicker", kf * abs(ids) ** num(d.params.get("AF", 1.0)), num(d.params.get("FFE", 1.0)), name))
     return out
 
 

@@ -81,14 +81,16 @@ class Circuit:
         """BehavioralCurrentSource (devices.jl:1032-1058, stamp :1118-1131): scale * expr flows into p."""
         return self._add("BI", name, (p, n), {"expr": str(expr), "scale": scale})
 
-    def D(self, name, p, n, Is=1e-14, Vt=0.026, n_=1.0, limit=True):
-        return self._add("D", name, (p, n), {"Is": Is, "Vt": Vt, "n": n_, "limit": bool(limit)})
+    # KF / AF / FFE: flicker-noise coefficient and exponents of the reference's Diode, DiodeWithCap and SimpleMOSFET (devices.jl:1277-1279,
+    # 1462-1464, 1625-1627); read by noise analysis only (no stamp depends on them)
+    def D(self, name, p, n, Is=1e-14, Vt=0.026, n_=1.0, limit=True, KF=0.0, AF=1.0, FFE=1.0):
+        return self._add("D", name, (p, n), {"Is": Is, "Vt": Vt, "n": n_, "limit": bool(limit), "KF": KF, "AF": AF, "FFE": FFE})
 
-    def DCAP(self, name, p, n, Is=1e-14, Vt=0.026, n_=1.0, Cj0=1e-12, Vj=0.7, m=0.5):
-        return self._add("DCAP", name, (p, n), {"Is": Is, "Vt": Vt, "n": n_, "Cj0": Cj0, "Vj": Vj, "m": m})
+    def DCAP(self, name, p, n, Is=1e-14, Vt=0.026, n_=1.0, Cj0=1e-12, Vj=0.7, m=0.5, KF=0.0, AF=1.0, FFE=1.0):
+        return self._add("DCAP", name, (p, n), {"Is": Is, "Vt": Vt, "n": n_, "Cj0": Cj0, "Vj": Vj, "m": m, "KF": KF, "AF": AF, "FFE": FFE})
 
-    def SMOS(self, name, d, g, s, Vth=0.5, K=1e-3, lambda_=0.0, Cgd=1e-15, Cgs=1e-15):
-        return self._add("SMOS", name, (d, g, s), {"Vth": Vth, "K": K, "lambda": lambda_, "Cgd": Cgd, "Cgs": Cgs})
+    def SMOS(self, name, d, g, s, Vth=0.5, K=1e-3, lambda_=0.0, Cgd=1e-15, Cgs=1e-15, KF=0.0, AF=1.0, FFE=1.0):
+        return self._add("SMOS", name, (d, g, s), {"Vth": Vth, "K": K, "lambda": lambda_, "Cgd": Cgd, "Cgs": Cgs, "KF": KF, "AF": AF, "FFE": FFE})
 
     def MOS1(self, name, d, g, s, b, model, m=1.0, **instance):
         """sp_mos1 (models/VADistillerModels.jl/va/mos1.va).  ``model`` holds the model-card

@@ -564,7 +564,9 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
              o->max_newton > 0 ? o->max_newton : 10, o->max_order > 0 ? o->max_order : 2, o->use_pcnr,
              o->newton_mode ? 1 : 0, d->mn_a0f, d->mn_ss, d->mn_dnp, d->mn_flags};
   if (!h->analyzed) return CADNIP_NOTREADY;              // the symbolic LU phase (cadnip_analyze*) comes first
-  const bool use_fused = o->fused && !h->va_ext && fused2_fits(h);   // (external generated models exist in the per-op stamping kernel only)     // a circuit too large for the LDS-resident kernel runs on the per-op kernels
+  // the per-op kernels take over where the fused kernel cannot run: external generated models (they exist in the per-op stamping kernel only), a
+  // circuit too large for the LDS-resident kernel, Newton mode 1 on a circuit outside the lean device set
+  const bool use_fused = o->fused && !h->va_ext && fused2_fits(h) && (!o->newton_mode || fused2_mode1_ok(h));
   struct ModeGuard { CadnipHandle* h; int saved; ~ModeGuard() { h->spec.mode = saved; } } mode_guard{h, h->spec.mode};
   h->spec.mode = 1;   // :tran (restored on every exit path)
   hipLaunchKernelGGL(k_tran_init, dim3(h->B), dim3(64), 0, h->stream, a);

@@ -184,14 +184,10 @@ bool fused2_fits(CadnipHandle* h) {
   return ((size_t)h->f2len / 2 + per) * 8 <= 160 * 1024;
 }
 
-static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F2DcOpts* dc) {
-  if (!h->analyzed) return CADNIP_NOTREADY;
-  if (h->homotopy || h->spec.gshunt != 0.0 || h->spec.srcFact < 1.0) return CADNIP_BADARG;   // homotopies run on the per-op path
+// device-block descriptors of the fused kernels: rebuilt when the tables were, or when cadnip_set_params changed a block (sp_mos1 pairing);
+// also decides the kernel variant (f2_lean, f2_direct)
+static int fused2_blocks(CadnipHandle* h) {
   { int rc = fused2_tables(h); if (rc) return rc; }
-  ProfScope ps(h, dc ? "fused2_dc" : "fused2_newton");
-  const LUProgram& P = h->lu;
-  F2Args f;
-  // device-block descriptors: rebuilt when the tables were, or when cadnip_set_params changed a block (sp_mos1 pairing)
   if (h->f2_blk_dirty || !h->d_f2blk) {
     F2Block hb[F2_MAX_BLOCKS];
     int nb = 0;
@@ -235,6 +231,21 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
     HIP_TRY(hipMemcpy(h->d_f2blk, hb, sizeof(F2Block) * (size_t)nb, hipMemcpyHostToDevice));
     h->f2_blk_dirty = false;
   }
+  return CADNIP_OK;
+}
+
+// Newton mode 1 (Jacobian reuse) exists in the lean direct-residual variant of the fused kernels only; a circuit with other device types
+// (diodes, behavioural sources, sp_mos1 with series resistances, built-in Verilog-A modules ...) takes the per-op kernels, which support
+// the mode (driver.hip), instead of failing
+bool fused2_mode1_ok(CadnipHandle* h) { return fused2_blocks(h) == CADNIP_OK && h->f2_direct && h->f2_lean; }
+
+static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F2DcOpts* dc) {
+  if (!h->analyzed) return CADNIP_NOTREADY;
+  if (h->homotopy || h->spec.gshunt != 0.0 || h->spec.srcFact < 1.0) return CADNIP_BADARG;   // homotopies run on the per-op path
+  { int rc = fused2_blocks(h); if (rc) return rc; }
+  ProfScope ps(h, dc ? "fused2_dc" : "fused2_newton");
+  const LUProgram& P = h->lu;
+  F2Args f;
   f.n_blk = h->f2_n_blk; f.rc_blk = h->f2_rc_blk; f.src_blk = h->f2_src_blk;
   f.blk = (const F2Block*)h->d_f2blk;
   f.wave = h->d_wave;

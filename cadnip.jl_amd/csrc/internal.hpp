@@ -210,6 +210,7 @@ int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds); // fus
 int launch_va_setup(CadnipHandle* h, DeviceBlock& b);                        // stamp_csr.hip: the setup pass of a generated external model's block
 bool fused2_tables_ready(CadnipHandle* h);                                 // the packed tables exist (built on demand)
 bool fused2_fits(CadnipHandle* h);                                        // false: circuit too large for the LDS-resident kernel
+bool fused2_mode1_ok(CadnipHandle* h);                                    // Newton mode 1 can run in the fused kernel (lean device set, direct residuals)
 int launch_fused2_dc(CadnipHandle* h, const TranArgs& t, int rounds, double abstol, int maxiters, int use_pcnr, int mode, int initjct, int* d_dcstate);
 struct ProfScope {
   CadnipHandle* h; int idx;

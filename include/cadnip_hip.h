@@ -219,7 +219,11 @@ typedef struct {
   int32_t n_save;  const double* save_t; /* sorted output times (saveat) */
   int32_t n_obs;   const int32_t* obs;   /* unknown indices to record; n_obs = 0 -> all n */
   int64_t max_iterations;   /* safety bound on lock-step Newton launches */
-  int32_t fused;            /* non-zero = fused per-instance Newton kernel (csrc/fused2.hip), 0 = one kernel per op */
+  int32_t fused;            /* non-zero = fused per-instance Newton kernel, 0 = one kernel per op.  The fused kernel is chosen by batch size: one wave per
+                               instance for sweeps (csrc/fused2_kernel.hpp), a team of four waves per instance for batches of at most one instance per
+                               compute unit (csrc/fused_team_kernel.hpp: a single transient's latency).  A circuit the fused kernel cannot run -- too
+                               large for LDS, an external generated model, or newton_mode 1 with device types outside its lean set (diodes, behavioural
+                               sources, sp_mos1 with series resistances, built-in Verilog-A modules) -- runs on the per-op kernels instead */
   int32_t newton_mode;      /* 0 = full Newton, converged when the weighted update norm < newton_tol (every round restamps and refactors);
                                1 = the nonlinear iteration as IDA runs it (the reference's integrator, src/sweeps.jl:600): refactor on a setup
                                only (first round, a0 outside [0.6, 1/0.6] of its last setup value, 20 steps, failure on a stale Jacobian), kept factors in between, rate-based

@@ -298,7 +298,12 @@ def diode_iv(Is, nVt, v):  # _diode_iv  devices.jl:1333-1345
     return Is * (e - 1.0), Is / nVt * e
 
 
-def stamp_diode(ctx, p, n, x, Is=1e-14, Vt=0.026, nf=1.0, limit_=True, name="D"):  # devices.jl:1370-1428
+def _register_diode_flicker(ctx, p, n, I0, KF, AF, FFE, name):  # devices.jl:1435-1443: KF |I0|^AF / f^FFE, only with KF > 0
+    if KF > 0 and hasattr(ctx, "register_flicker_noise"):
+        ctx.register_flicker_noise(p, n, KF * abs(I0) ** AF, FFE, name)
+
+
+def stamp_diode(ctx, p, n, x, Is=1e-14, Vt=0.026, nf=1.0, limit_=True, name="D", KF=0.0, AF=1.0, FFE=1.0):  # devices.jl:1370-1428
     V0 = x_at(x, p) - x_at(x, n)
     nVt = nf * Vt
     if limit_:
@@ -306,8 +311,9 @@ def stamp_diode(ctx, p, n, x, Is=1e-14, Vt=0.026, nf=1.0, limit_=True, name="D")
         w = limit(ctx, name + "_vdlim", p, n, V0, x, lambda vn, vo: pnjlim(vn, vo, nVt, vcrit)[0], init=vcrit)
         I0, Gd = diode_iv(Is, nVt, w)
         stamp_limited_companion(ctx, p, n, w, I0, Gd)
-        if hasattr(ctx, "register_shot_noise"):          # devices.jl:1393-1397 (KF = 0: no flicker term)
+        if hasattr(ctx, "register_shot_noise"):          # devices.jl:1393-1397
             ctx.register_shot_noise(p, n, I0, name)
+        _register_diode_flicker(ctx, p, n, I0, KF, AF, FFE, name)
     else:
         e = _exp(V0 / nVt)
         I0 = Is * (e - 1.0)
@@ -316,8 +322,9 @@ def stamp_diode(ctx, p, n, x, Is=1e-14, Vt=0.026, nf=1.0, limit_=True, name="D")
         stamp_conductance(ctx, p, n, Gd)
         ctx.stamp_b(p, -Ieq)
         ctx.stamp_b(n, Ieq)
-        if hasattr(ctx, "register_shot_noise"):          # devices.jl:1418
+        if hasattr(ctx, "register_shot_noise"):          # devices.jl:1418-1419
             ctx.register_shot_noise(p, n, I0, name)
+        _register_diode_flicker(ctx, p, n, I0, KF, AF, FFE, name)
 
 
 def diode_junction_cap(V, Cj0, Vj, m):  # devices.jl:1505-1516
@@ -329,7 +336,7 @@ def diode_junction_cap(V, Cj0, Vj, m):  # devices.jl:1505-1516
     return C_at + dC * (V - Vmax)
 
 
-def stamp_diode_with_cap(ctx, p, n, x, Is=1e-14, Vt=0.026, nf=1.0, Cj0=1e-12, Vj=0.7, m=0.5):  # devices.jl:1558-1602
+def stamp_diode_with_cap(ctx, p, n, x, Is=1e-14, Vt=0.026, nf=1.0, Cj0=1e-12, Vj=0.7, m=0.5, name="D", KF=0.0, AF=1.0, FFE=1.0):  # devices.jl:1558-1602
     V0 = x_at(x, p) - x_at(x, n)
     nVt = nf * Vt
     e = _exp(V0 / nVt)
@@ -339,10 +346,13 @@ def stamp_diode_with_cap(ctx, p, n, x, Is=1e-14, Vt=0.026, nf=1.0, Cj0=1e-12, Vj
     stamp_conductance(ctx, p, n, G)
     ctx.stamp_b(p, -Ieq)
     ctx.stamp_b(n, Ieq)
+    if hasattr(ctx, "register_shot_noise"):              # devices.jl:1582-1585: shot and flicker noise at the junction bias
+        ctx.register_shot_noise(p, n, I0, name)
+    _register_diode_flicker(ctx, p, n, I0, KF, AF, FFE, name)
     stamp_capacitance(ctx, p, n, diode_junction_cap(V0, Cj0, Vj, m))
 
 
-def stamp_simple_mosfet(ctx, d, g, s, x, Vth=0.5, K=1e-3, lam=0.0, Cgd=1e-15, Cgs=1e-15):  # devices.jl:1667-1749
+def stamp_simple_mosfet(ctx, d, g, s, x, Vth=0.5, K=1e-3, lam=0.0, Cgd=1e-15, Cgs=1e-15, name="M", KF=0.0, AF=1.0, FFE=1.0):  # devices.jl:1667-1749
     Vd, Vg, Vs = x_at(x, d), x_at(x, g), x_at(x, s)
     Vgs = Vg - Vs
     Vds = Vd - Vs
@@ -365,5 +375,9 @@ def stamp_simple_mosfet(ctx, d, g, s, x, Vth=0.5, K=1e-3, lam=0.0, Cgd=1e-15, Cg
     ctx.stamp_G(s, s, gds + gm)
     ctx.stamp_b(d, -Ieq)
     ctx.stamp_b(s, Ieq)
+    if gm > 0 and hasattr(ctx, "register_channel_thermal_noise"):     # devices.jl:1718-1724: 4kT (2/3) gm between drain and source, not in cutoff
+        ctx.register_channel_thermal_noise(d, s, gm, name)
+    if KF > 0 and Ids != 0.0 and hasattr(ctx, "register_flicker_noise"):   # devices.jl:1725-1732: KF |Ids|^AF / f^FFE
+        ctx.register_flicker_noise(d, s, KF * abs(Ids) ** AF, FFE, name)
     stamp_capacitance(ctx, g, s, Cgs)
     stamp_capacitance(ctx, g, d, Cgd)

@@ -125,6 +125,9 @@ class MNAContext:
     def register_thermal_noise(self, p, n, G, name):      # S = 4 k T G
         self.stamp_noise(p, n, "thermal", G, 0.0, name)
 
+    def register_channel_thermal_noise(self, p, n, gm, name, gamma=2.0 / 3.0):   # context.jl:1076-1077: the THERMAL shape with the conductance gamma gm
+        self.stamp_noise(p, n, "thermal", gamma * gm, 0.0, name)
+
     def register_shot_noise(self, p, n, I, name):         # S = 2 q |I|
         self.stamp_noise(p, n, "shot", abs(I), 0.0, name)
 

@@ -107,13 +107,13 @@ def make_builder(devices):
                     D.stamp_behavioral_isource(ctx, nodes[0], nodes[1], fn, get_voltage)
             elif ty == "D":
                 D.stamp_diode(ctx, nodes[0], nodes[1], x, g("Is", 1e-14), g("Vt", 0.026), g("n", 1.0),
-                              bool(dev.get("limit", True)), name)
+                              bool(dev.get("limit", True)), name, g("KF", 0.0), g("AF", 1.0), g("FFE", 1.0))
             elif ty == "DCAP":
                 D.stamp_diode_with_cap(ctx, nodes[0], nodes[1], x, g("Is", 1e-14), g("Vt", 0.026), g("n", 1.0),
-                                       g("Cj0", 1e-12), g("Vj", 0.7), g("m", 0.5))
+                                       g("Cj0", 1e-12), g("Vj", 0.7), g("m", 0.5), name, g("KF", 0.0), g("AF", 1.0), g("FFE", 1.0))
             elif ty == "SMOS":
                 D.stamp_simple_mosfet(ctx, nodes[0], nodes[1], nodes[2], x, g("Vth", 0.5), g("K", 1e-3),
-                                      g("lambda", 0.0), g("Cgd", 1e-15), g("Cgs", 1e-15))
+                                      g("lambda", 0.0), g("Cgd", 1e-15), g("Cgs", 1e-15), name, g("KF", 0.0), g("AF", 1.0), g("FFE", 1.0))
             elif ty == "MOS1":
                 mp = {k: _num(v, params) for k, v in dev["model"].items()}
                 stamp_mos1(ctx, Mos1Model(**mp), nodes[0], nodes[1], nodes[2], nodes[3], x, spec, name,

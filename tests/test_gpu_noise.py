@@ -44,6 +44,34 @@ def test_builtin_diode_shot_noise():
     assert np.allclose(ns["d1"] + ns["r1"], ns["onoise"])
 
 
+def test_simple_mosfet_and_diode_flicker_noise_through_the_library():
+    """devices.jl:1718-1732 (SimpleMOSFET: channel thermal 4kT (2/3) gm, flicker KF |Ids|^AF / f^FFE) and :1435-1443 (diode flicker) at the
+    GPU's operating point: the common-source stage's closed form S_out = (4kT / Rd + 4kT (2/3) gm + KF Ids^AF / f^FFE) (Rd || 1 / gds)^2."""
+    from cadnip_jl_amd.circuit import Circuit
+    c = Circuit("SimpleMOSFET common-source stage")
+    c.V("vdd", "vdd", "0", dc=5.0)
+    c.V("vg", "in", "0", dc=1.0)
+    c.R("rd", "vdd", "out", 10e3)
+    c.SMOS("m1", "out", "in", "0", Vth=0.5, K=1e-3, lambda_=0.02, KF=1e-14, AF=1.2, FFE=0.9)
+    mc = api.MNACircuit(c, {})
+    freqs = np.array([1.0, 10.0, 1e3, 1e5])
+    ns = api.noise(mc, "out", freqs)
+    vds = api.dc(mc)["out"]
+    ids = 1e-3 / 2 * 0.5 ** 2 * (1 + 0.02 * vds)
+    gm, gds = 1e-3 * 0.5 * (1 + 0.02 * vds), 1e-3 / 2 * 0.5 ** 2 * 0.02
+    rout = 1.0 / (1.0 / 10e3 + gds)
+    assert np.allclose(ns["onoise"], (4 * KT / 10e3 + 4 * KT * (2.0 / 3.0) * gm + 1e-14 * ids ** 1.2 / freqs ** 0.9) * rout ** 2, rtol=1e-6)
+    assert np.allclose(ns["m1"] + ns["rd"], ns["onoise"])
+    d = Circuit("diode flicker")
+    d.V("v1", "in", "0", dc=5.0)
+    d.R("r1", "in", "out", 10e3)
+    d.D("d1", "out", "0", Is=1e-14, KF=1e-15, AF=1.5, FFE=1.1)
+    mc = api.MNACircuit(d, {})
+    nd = api.noise(mc, "out", freqs)
+    i0 = (5.0 - api.dc(mc)["out"]) / 10e3
+    assert np.allclose(nd["d1"] / nd["r1"], (2 * api.Q_ELEMENTARY * i0 + 1e-15 * i0 ** 1.5 / freqs ** 1.1) / (4 * KT / 10e3), rtol=1e-5)
+
+
 def _fixture_noise(name):
     st, x = S.load_structure(os.path.join(GOLD, "va_%s.npz" % name))
     packed = [x["packed%d" % i] for i in range(int(x["n_packed"][0]))]

@@ -149,6 +149,24 @@ def test_fused_kernel_matches_per_op_path(name):
     assert abs(int(got[0][1][0]) - int(got[1][1][0])) <= max(3, 0.02 * got[0][1][0]), (name, got[0][1], got[1][1])
 
 
+@pytest.mark.parametrize("name", ["nonlinear", "diode_limited", "behavioral", "meyer_inverter_rd"])
+def test_newton_mode_1_outside_the_lean_device_set_runs_per_op(name):
+    """Newton mode 1 (Jacobian reuse) exists in the fused kernels' lean variant only.  A circuit with diodes, behavioural sources or an
+    sp_mos1 with series resistances that asks for the fused path with that mode must not fail: the driver gives it the per-op kernels
+    (which take the mode's convergence test), i.e. exactly what fused = 0 runs."""
+    mk, params, tspan, saveat, names, abstol = FUSED_CASES[name]
+    circ = mk()
+    got = {}
+    for fused in (0, 1):
+        sim = api.BatchSimulator(api.MNACircuit(circ, params))
+        st = sim.st
+        out, per, stats = sim.tran(tspan, np.full(st.n, abstol), 1e-6, np.array(saveat), obs=[st.index_of(nm) for nm in names], fused=fused, newton_mode=1)
+        assert stats["n_failed"] == 0, (name, fused, stats)
+        got[fused] = (out, per)
+        sim.close()
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+
+
 @pytest.mark.parametrize("newton_mode", [0, 1])
 def test_full_size_corner_sweep_properties(newton_mode, monkeypatch):
     """(both Newton modes of the fused kernel: full Newton, and IDA's Jacobian reuse with factors that travel with the instances)

@@ -28,7 +28,7 @@ def oracle_noise(deck, output, freqs, input=None):
 
 def product_noise_at_the_oracle_point(deck, output, freqs, input=None, gmin=1e-12):
     """api.noise without the GPU: DC point, G and C from the oracle; sources, adjoint sweep and result object from the product"""
-    circ, _ = netlist.read_spice(deck)
+    circ = deck if not isinstance(deck, str) else netlist.read_spice(deck)[0]
     st = cj.discover(circ, {})
     bld = make_builder(circ.to_dicts({}))
     spec = M.MNASpec(mode="dcop", temp=27.0)
@@ -147,3 +147,65 @@ def test_hand_written_mos1_devices_take_their_sources_from_the_model_text():
     for k in c:
         assert np.allclose(ns[k.replace("xm1", "m1")], c[k], rtol=1e-6, atol=1e-60), k
     assert any(np.any(v > 0) for k, v in ns.contributions.items() if k.startswith("m1_"))      # the channel's thermal noise at least
+
+
+def _common_source(KF=0.0, AF=1.0, FFE=1.0):
+    from cadnip_jl_amd.circuit import Circuit
+    c = Circuit("SimpleMOSFET common-source stage")
+    c.V("vdd", "vdd", "0", dc=5.0)
+    c.V("vg", "in", "0", dc=1.0)
+    c.R("rd", "vdd", "out", 10e3)
+    c.SMOS("m1", "out", "in", "0", Vth=0.5, K=1e-3, lambda_=0.02, KF=KF, AF=AF, FFE=FFE)
+    return c
+
+
+def test_simple_mosfet_channel_thermal_and_flicker_noise():
+    """The reference's SimpleMOSFET registers 4kT (2/3) gm between drain and source where it conducts (devices.jl:1718-1724,
+    context.jl:1076-1077) and KF |Ids|^AF / f^FFE with KF > 0 (devices.jl:1725-1732).  Closed form of a common-source stage with a
+    resistive load: S_out = (4kT / Rd + 4kT (2/3) gm + KF Ids^AF / f^FFE) (Rd || 1/gds)^2, at the oracle's operating point; the
+    product's host logic gives the same numbers."""
+    freqs = np.array([1.0, 10.0, 1e3, 1e5])
+    for kf, af, ffe in ((0.0, 1.0, 1.0), (1e-14, 1.2, 0.9)):
+        circ = _common_source(kf, af, ffe)
+        bld = make_builder(circ.to_dicts({}))
+        sol = M.solve_dc(bld, {}, M.MNASpec(mode="dcop", temp=27.0))
+        vds = float(sol["out"])
+        ids = 1e-3 / 2 * 0.5 ** 2 * (1 + 0.02 * vds)
+        assert vds > 0.5 and abs((5.0 - vds) / 10e3 - ids) < 1e-12              # saturation, KCL at the drain
+        gm, gds = 1e-3 * 0.5 * (1 + 0.02 * vds), 1e-3 / 2 * 0.5 ** 2 * 0.02
+        rout = 1.0 / (1.0 / 10e3 + gds)
+        expected = (4 * KT / 10e3 + 4 * KT * (2.0 / 3.0) * gm + kf * ids ** af / freqs ** ffe) * rout ** 2
+        on, c, _, _ = M.noise(bld, {}, M.MNASpec(temp=27.0), "out", freqs)
+        assert np.allclose(on, expected, rtol=1e-6)
+        assert np.allclose(c["rd"], 4 * KT / 10e3 * rout ** 2, rtol=1e-6) and np.allclose(c["m1"], expected - c["rd"], rtol=1e-6)
+        ns = product_noise_at_the_oracle_point(circ, "out", freqs)
+        assert np.allclose(ns["onoise"], on, rtol=1e-12) and np.allclose(ns["m1"], c["m1"], rtol=1e-12)
+    cut = _common_source()
+    cut.devices[1].params["dc"] = 0.2                                           # cutoff: the channel injects nothing
+    on, c, _, _ = M.noise(make_builder(cut.to_dicts({})), {}, M.MNASpec(temp=27.0), "out", freqs)
+    assert "m1" not in c and np.allclose(on, 4 * KT * 10e3, rtol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["D", "DCAP"])
+def test_builtin_diode_flicker_noise(kind):
+    """Diode / DiodeWithCap with KF > 0: shot noise 2q|I0| plus KF |I0|^AF / f^FFE at the junction bias (devices.jl:1393-1443, 1582-1585);
+    both under the device's name.  A forward-biased diode behind 10 kOhm: S_out = (4kT / R + 2q I0 + KF I0^AF / f^FFE) (R || rd)^2."""
+    from cadnip_jl_amd.circuit import Circuit
+    c = Circuit("diode flicker")
+    c.V("v1", "in", "0", dc=5.0)
+    c.R("r1", "in", "out", 10e3)
+    if kind == "D":
+        c.D("d1", "out", "0", Is=1e-14, KF=1e-15, AF=1.5, FFE=1.1)
+    else:
+        c.DCAP("d1", "out", "0", Is=1e-14, Cj0=0.0, KF=1e-15, AF=1.5, FFE=1.1)
+    freqs = np.array([1.0, 100.0, 1e4])
+    bld = make_builder(c.to_dicts({}))
+    sol = M.solve_dc(bld, {}, M.MNASpec(mode="dcop", temp=27.0))
+    vd = float(sol["out"])
+    i0 = 1e-14 * (np.exp(vd / 0.026) - 1.0)
+    rout = 1.0 / (1.0 / 10e3 + 1e-14 / 0.026 * np.exp(vd / 0.026))
+    expected = (4 * KT / 10e3 + 2 * M.Q_ELEMENTARY * i0 + 1e-15 * i0 ** 1.5 / freqs ** 1.1) * rout ** 2
+    on, cc, _, _ = M.noise(bld, {}, M.MNASpec(temp=27.0), "out", freqs)
+    assert np.allclose(on, expected, rtol=1e-5) and on[0] > 1.5 * on[2]          # the flicker term is visible at 1 Hz
+    ns = product_noise_at_the_oracle_point(c, "out", freqs)
+    assert np.allclose(ns["onoise"], on, rtol=1e-10) and np.allclose(ns["d1"], cc["d1"], rtol=1e-10)
