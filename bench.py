@@ -562,7 +562,29 @@ def single_and_callback(circ, device, args):
                 h.solve(rhs)
             t1 = time.perf_counter()
         out["callback_us_per_iter"] = round(1e6 * (t1 - t0) / n_seq, 2)
-        out["callback_note"] = "B = 1: cadnip_rebuild -> residual -> jacobian -> factor -> solve through ctypes with host pointers (PCIe both ways every call)"
+        # the same iteration through cadnip_newton_step: one call, one synchronisation, the launch sequence replayed as a HIP graph
+        for rep in range(2):
+            t0 = time.perf_counter()
+            for k in range(n_seq):
+                h.newton_step(u0, du, gam, 1e-8, refresh=True)
+            t1 = time.perf_counter()
+        out["callback_one_call_us_per_iter"] = round(1e6 * (t1 - t0) / n_seq, 2)
+        for rep in range(2):
+            t0 = time.perf_counter()
+            for k in range(n_seq):
+                h.newton_step(u0, du, None, None, refresh=False)
+            t1 = time.perf_counter()
+        out["callback_one_call_kept_factors_us_per_iter"] = round(1e6 * (t1 - t0) / n_seq, 2)
+        for key, refresh in (("callback_one_call_fused_us_per_iter", True), ("callback_one_call_fused_kept_factors_us_per_iter", False)):
+            for rep in range(2):
+                t0 = time.perf_counter()
+                for k in range(n_seq):
+                    h.newton_step(u0, du, gam if refresh else None, 1e-8 if refresh else None, refresh=refresh, fused=True)
+                t1 = time.perf_counter()
+            out[key] = round(1e6 * (t1 - t0) / n_seq, 2)
+        out["callback_note"] = ("B = 1, through ctypes with host pointers: callback_us_per_iter = cadnip_rebuild -> residual -> jacobian -> factor -> solve (five calls, five "
+                                "synchronisations); callback_one_call_* = cadnip_newton_step (the same kernels, one call, HIP graph); callback_one_call_fused_* = "
+                                "cadnip_newton_step_fused (one kernel: the team kernel's STEP mode)")
     finally:
         sim.close()
     return out

@@ -214,6 +214,7 @@ void cadnip_destroy(CadnipHandle* h) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->d_f2tab) (void)hipFree(h->d_f2tab);
   for (int k = 0; k < 2; ++k) if (h->d_team_desc[k]) (void)hipFree(h->d_team_desc[k]);
+  for (auto& g : h->step_graph) if (g.exec) (void)hipGraphExecDestroy(g.exec);
   for (auto& b : h->blocks) {
     void* bp[] = {b.d_nodes, b.d_ipar, b.d_par, b.d_sp_tptr, b.d_sp_info, b.d_sp_rec, b.d_cache, b.d_sp_rowoff,
                   b.sp_gen.tptr, b.sp_gen.info, b.sp_gen.rec, b.sp_gen.rowoff, b.sp_plain.tptr, b.sp_plain.info, b.sp_plain.rec, b.sp_plain.rowoff};
@@ -231,6 +232,7 @@ void cadnip_destroy(CadnipHandle* h) {
 }
 
 int cadnip_set_params(CadnipHandle* h, int32_t block, const double* par_host) {
+  if (h) ++h->graph_epoch;
   if (!h || block < 0 || block >= (int)h->blocks.size() || !par_host) return CADNIP_BADARG;
   auto& b = h->blocks[block];
   HIP_TRY(hipMemcpy(b.d_par, par_host, (size_t)h->B * b.n_par * b.count * sizeof(double), hipMemcpyHostToDevice));
@@ -259,10 +261,11 @@ int cadnip_set_params(CadnipHandle* h, int32_t block, const double* par_host) {
 int cadnip_set_spec(CadnipHandle* h, const CadnipSpec* spec) {
   if (!h || !spec || spec->mode < 0 || spec->mode > 2) return CADNIP_BADARG;
   h->spec = *spec;
+  ++h->graph_epoch;
   return upload_homotopy(h, nullptr, nullptr);
 }
 
-int cadnip_set_initjct(CadnipHandle* h, int32_t on) { if (!h) return CADNIP_BADARG; h->initjct = on ? 1 : 0; return CADNIP_OK; }
+int cadnip_set_initjct(CadnipHandle* h, int32_t on) { if (!h) return CADNIP_BADARG; h->initjct = on ? 1 : 0; ++h->graph_epoch; return CADNIP_OK; }
 
 // ---- host-pointer transfers of the callback entry points.  Small ones are staged through mapped pinned memory and moved by a copy KERNEL
 // on the stream (kernels of a stream stay ordered among themselves; asynchronous copies were not ordered with them under a counter pass -- see
@@ -507,6 +510,126 @@ int cadnip_host_f2_get(const CadnipHostF2* f, int32_t which, void* dst) {
 void cadnip_host_f2_free(CadnipHostF2* f) { delete f; }
 void cadnip_host_lu_free(CadnipHostLU* lu) { delete lu; }
 
+// One Newton iteration of the DAE form in ONE call: what a host integrator that keeps the Newton loop to itself (IDA through the Julia
+// shim: residual callback, Jacobian callback, KLU refactor / solve -- src/mna/precompile.jl:546-585, src/mna/solve.jl:2138-2160) otherwise
+// does with five entry points and five stream synchronisations.  The SAME kernels in the same order as cadnip_rebuild -> cadnip_residual ->
+// [cadnip_jacobian -> cadnip_factor] -> cadnip_solve, so the results are the same doubles; all transfers are staged (one upload kernel,
+// one download kernel), and the launch sequence is an instantiated HIP graph that is replayed while nothing it depends on changes.
+//   refresh != 0: J = G + gamma C is formed and refactored (factors stay in HBM); 0: the factors of the last refreshing call solve.
+//   delta [B][n] = J^-1 resid with resid = C du + G u - b;  resid_norm [B] (optional) = ||resid||_2;  resid [B][n] (optional).
+int cadnip_newton_step(CadnipHandle* h, const double* u_host, const double* du_host, const double* gamma_host, const double* t_host, int32_t refresh,
+                       double* delta_host, double* resid_norm_host, double* resid_host) {
+  if (!h || !u_host || !du_host || !delta_host || (refresh && !gamma_host)) return CADNIP_BADARG;
+  if (!h->analyzed) return CADNIP_NOTREADY;
+  const size_t B = h->B, n = h->n, vec = B * n * sizeof(double);
+  stage_begin(h);
+  char *s_u = stage_take(h, vec), *s_du = stage_take(h, vec), *s_g = stage_take(h, B * 8), *s_t = stage_take(h, B * 8), *s_d = stage_take(h, vec),
+       *s_r = stage_take(h, vec), *s_nrm = stage_take(h, B * 8), *s_nf = stage_take(h, B * 4), *s_fl = stage_take(h, B * 4);
+  if (!s_fl) {
+    // too large for the staging area: the five entry points (blocking copies), same results
+    TRY(cadnip_rebuild(h, u_host, t_host));
+    std::vector<double> r(B * n);
+    TRY(cadnip_residual(h, du_host, nullptr, r.data()));
+    if (refresh) { TRY(cadnip_jacobian(h, gamma_host, nullptr)); TRY(cadnip_factor(h)); }
+    TRY(cadnip_solve(h, r.data(), delta_host));
+    if (resid_host) memcpy(resid_host, r.data(), vec);
+    if (resid_norm_host) for (size_t i = 0; i < B; ++i) { double a = 0; for (size_t k = 0; k < n; ++k) a += r[i * n + k] * r[i * n + k]; resid_norm_host[i] = sqrt(a); }
+    return CADNIP_OK;
+  }
+  auto dv = [&](char* p) { return h->d_stage + (p - h->h_stage); };
+  memcpy(s_u, u_host, vec); memcpy(s_du, du_host, vec);
+  if (gamma_host) memcpy(s_g, gamma_host, B * 8);
+  if (t_host) memcpy(s_t, t_host, B * 8);
+  const bool have_g = gamma_host != nullptr, have_t = t_host != nullptr;
+  auto enqueue = [&]() -> int {
+    MultiCopy up;
+    up.add(h->d_u, dv(s_u), vec); up.add(h->d_du, dv(s_du), vec);
+    if (have_g) up.add(h->d_gamma, dv(s_g), B * 8);
+    if (have_t) up.add(h->d_t, dv(s_t), B * 8);
+    up.add(h->d_nonfinite, nullptr, B * 4); up.add(h->d_flags, nullptr, B * 4);
+    TRY_RC(dev_multi_async(h, up, false));
+    TRY_RC(launch_rebuild(h));
+    TRY_RC(launch_residual(h, h->d_du));
+    if (refresh) { TRY_RC(launch_jacobian(h)); TRY_RC(launch_factor(h, false)); }
+    TRY_RC(launch_solve(h, h->d_resid, h->d_delta));
+    TRY_RC(launch_norm2(h, h->d_resid, h->d_tmp));
+    MultiCopy down;
+    down.add(dv(s_d), h->d_delta, vec); down.add(dv(s_r), h->d_resid, vec); down.add(dv(s_nrm), h->d_tmp, B * 8);
+    down.add(dv(s_nf), h->d_nonfinite, B * 4); down.add(dv(s_fl), h->d_flags, B * 4);
+    TRY_RC(dev_multi_async(h, down, true));
+    return CADNIP_OK;
+  };
+  // graph variants: refresh x (gamma given) x (t given) change the launch sequence: keyed by the first only, the other two recorded in the epoch
+  CadnipHandle::StepGraph& g = h->step_graph[refresh ? 1 : 0];
+  const unsigned long long key = h->graph_epoch * 4 + (have_g ? 2 : 0) + (have_t ? 1 : 0);
+  if (h->prof_on || getenv("CADNIP_NO_GRAPH")) { TRY(enqueue()); }
+  else if (g.exec && g.epoch == key) { HIP_TRY(hipGraphLaunch(g.exec, h->stream)); }
+  else if (g.warmed != key) { TRY(enqueue()); g.warmed = key; }        // first call in this configuration: plain launches (lazy set-up inside the launchers runs here)
+  else {
+    if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue();
+    const hipError_t ec = hipStreamEndCapture(h->stream, &graph);
+    if (rc || ec != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); if (rc) return rc; set_last_error("hipStreamEndCapture", ec); return CADNIP_HIPERROR; }
+    const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) { g.exec = nullptr; set_last_error("hipGraphInstantiate", ei); return CADNIP_HIPERROR; }
+    g.epoch = key;
+    HIP_TRY(hipGraphLaunch(g.exec, h->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->stage_off = 0;
+  memcpy(delta_host, s_d, vec);
+  if (resid_host) memcpy(resid_host, s_r, vec);
+  if (resid_norm_host) memcpy(resid_norm_host, s_nrm, B * 8);
+  const int* nf = (const int*)s_nf; const int* fl = (const int*)s_fl;
+  for (size_t i = 0; i < B; ++i) if (nf[i]) return CADNIP_NONFINITE;
+  for (size_t i = 0; i < B; ++i) if (fl[i] & 1) return CADNIP_SINGULAR;
+  for (size_t k = 0; k < B * n; ++k) if (delta_host[k] - delta_host[k] != 0.0) return CADNIP_NONFINITE;
+  return CADNIP_OK;
+}
+
+// The same iteration in the fused team kernel (csrc/fused_team_kernel.hpp, STEP mode): stamping, residual, refactorisation (or the kept
+// factors) and the solve of every instance in ONE kernel between the staged upload and download.  Same mathematics, another summation order
+// (the devices add into the LDS-resident work array): the results agree with cadnip_newton_step to rounding, not bit for bit.  For circuits
+// the team kernel runs (linear elements, sources, plain sp_mos1; tables within LDS); CADNIP_BADARG otherwise -- call cadnip_newton_step then.
+int cadnip_newton_step_fused(CadnipHandle* h, const double* u_host, const double* du_host, const double* gamma_host, const double* t_host, int32_t refresh,
+                             double* delta_host, double* resid_norm_host, double* resid_host) {
+  if (!h || !u_host || !du_host || !delta_host || (refresh && !gamma_host)) return CADNIP_BADARG;
+  if (!h->analyzed) return CADNIP_NOTREADY;
+  if (h->homotopy || h->spec.gshunt != 0.0 || h->spec.srcFact < 1.0) return CADNIP_BADARG;
+  const size_t B = h->B, n = h->n, vec = B * n * sizeof(double);
+  stage_begin(h);
+  char *s_u = stage_take(h, vec), *s_du = stage_take(h, vec), *s_g = stage_take(h, B * 8), *s_t = stage_take(h, B * 8), *s_d = stage_take(h, vec),
+       *s_r = stage_take(h, vec), *s_nrm = stage_take(h, B * 8), *s_fl = stage_take(h, B * 4);
+  if (!s_fl) return CADNIP_BADARG;
+  auto dv = [&](char* p) { return h->d_stage + (p - h->h_stage); };
+  memcpy(s_u, u_host, vec); memcpy(s_du, du_host, vec);
+  MultiCopy up;
+  up.add(h->d_u, dv(s_u), vec); up.add(h->d_du, dv(s_du), vec);
+  if (gamma_host) { memcpy(s_g, gamma_host, B * 8); up.add(h->d_gamma, dv(s_g), B * 8); }
+  if (t_host) { memcpy(s_t, t_host, B * 8); up.add(h->d_t, dv(s_t), B * 8); }
+  up.add(h->d_flags, nullptr, B * 4);
+  const int saved_mode = h->spec.mode;
+  TRY_RC(dev_multi_async(h, up, false));
+  { const int rc = launch_fused_step(h, refresh ? 1 : 0, resid_host ? h->d_resid : nullptr, h->d_tmp); if (rc) { (void)hipStreamSynchronize(h->stream); h->stage_off = 0; return rc; } }
+  (void)saved_mode;
+  MultiCopy down;
+  down.add(dv(s_d), h->d_delta, vec); if (resid_host) down.add(dv(s_r), h->d_resid, vec);
+  down.add(dv(s_nrm), h->d_tmp, B * 8); down.add(dv(s_fl), h->d_flags, B * 4);
+  TRY_RC(dev_multi_async(h, down, true));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->stage_off = 0;
+  memcpy(delta_host, s_d, vec);
+  if (resid_host) memcpy(resid_host, s_r, vec);
+  if (resid_norm_host) memcpy(resid_norm_host, s_nrm, B * 8);
+  const int* fl = (const int*)s_fl;
+  for (size_t i = 0; i < B; ++i) if (fl[i] & 1) return CADNIP_SINGULAR;
+  for (size_t k = 0; k < B * n; ++k) if (delta_host[k] - delta_host[k] != 0.0) return CADNIP_NONFINITE;
+  return CADNIP_OK;
+}
+
 int cadnip_factor(CadnipHandle* h) {
   if (!h) return CADNIP_BADARG;
   TRY_RC(dev_zero_async(h, h->d_flags, (size_t)h->B * sizeof(int)));
@@ -605,6 +728,7 @@ int cadnip_profile_read(CadnipHandle* h, int32_t max_entries, const char** names
 
 namespace cadnip {
 int upload_homotopy(CadnipHandle* h, const double* gshunt, const double* srcfact) {
+  ++h->graph_epoch;
   const size_t B = (size_t)h->B;
   std::vector<double> g(B, h->spec.gshunt), sf(B, h->spec.srcFact);
   if (gshunt) g.assign(gshunt, gshunt + B);
@@ -618,6 +742,7 @@ int upload_homotopy(CadnipHandle* h, const double* gshunt, const double* srcfact
   return CADNIP_OK;
 }
 int upload_lu(CadnipHandle* h) {
+  ++h->graph_epoch;
   LUProgram& P = h->lu;
   int** olds[] = {&h->d_load_src, &h->d_load_dst, &h->d_ent_pos, &h->d_ent_diag, &h->d_ent_ptr, &h->d_term_a, &h->d_term_b, &h->d_lev_ptr,
                   &h->d_lu_rowptr, &h->d_lu_col, &h->d_lu_diag, &h->d_rperm, &h->d_cperm, &h->d_fwd_rows, &h->d_fwd_lev_ptr, &h->d_bwd_rows, &h->d_bwd_lev_ptr};

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include <vector>
 #include "fused_team_kernel.hpp"
@@ -144,6 +145,7 @@ static bool f2_prepare(CadnipHandle* h, F2Tables& T, const std::vector<int>& g_p
 }
 
 struct F2DcOpts { double abstol; int maxiters, use_pcnr, mode, initjct; int* dcstate; };
+struct F2StepOpts { int refresh; double *resid, *norm; };   // cadnip_newton_step_fused: one Newton iteration in the team kernel (STEP mode)
 
 // Build (or rebuild) the structure tables; CADNIP_BADARG if the circuit cannot be expressed in them (16-bit offsets)
 static int fused2_tables(CadnipHandle* h) {
@@ -239,11 +241,11 @@ static int fused2_blocks(CadnipHandle* h) {
 // the mode (driver.hip), instead of failing
 bool fused2_mode1_ok(CadnipHandle* h) { return fused2_blocks(h) == CADNIP_OK && h->f2_direct && h->f2_lean; }
 
-static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F2DcOpts* dc) {
+static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F2DcOpts* dc, const F2StepOpts* step = nullptr) {
   if (!h->analyzed) return CADNIP_NOTREADY;
   if (h->homotopy || h->spec.gshunt != 0.0 || h->spec.srcFact < 1.0) return CADNIP_BADARG;   // homotopies run on the per-op path
   { int rc = fused2_blocks(h); if (rc) return rc; }
-  ProfScope ps(h, dc ? "fused2_dc" : "fused2_newton");
+  ProfScope ps(h, dc ? "fused2_dc" : step ? "fused_step" : "fused2_newton");
   const LUProgram& P = h->lu;
   F2Args f;
   f.n_blk = h->f2_n_blk; f.rc_blk = h->f2_rc_blk; f.src_blk = h->f2_src_blk;
@@ -255,7 +257,8 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
   f.n = h->n; f.nnz = h->nnz; f.nnz_lu = h->f2_lu_words;
   f.n_pre = h->f2_n_pre; f.n_post = h->f2_n_post; f.nc = h->f2_nc; f.dn0 = h->f2_dn0; f.n_fwd = h->f2_n_fwd;
   f.lufac = nullptr; f.team_desc = nullptr; f.team_desc_len = 0; f.par_words = 0; f.ts_pre = f.ts_post = f.ts_fwd = 0;
-  if (!dc && t.newton_mode) {
+  f.step_refresh = step ? step->refresh : 0; f.step_resid = step ? step->resid : nullptr; f.step_norm = step ? step->norm : nullptr;
+  if (!dc && (t.newton_mode || step)) {
     // IDA-style Jacobian reuse exists in the lean direct-residual variant (fused2_kernel.hpp); the kept factors of instances that
     // are not resident live in HBM
     if (!(h->f2_direct && h->f2_lean)) return CADNIP_BADARG;
@@ -285,6 +288,7 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
   if (!dc && h->f2_direct && h->f2_lean) {
     int nw = h->B <= h->n_cu ? 4 : 0;
     if (const char* e = getenv("CADNIP_F2_TEAM")) nw = atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 0;
+    if (step) nw = 4;
     const size_t shmem_t = (tab_dbl + per + 2 + 4 * (size_t)nw + (size_t)h->f2_par_words + (nw ? (size_t)h->team_desc_len[nw / 4] : 0) +
                             (nw ? (size_t)(nw - 1) * ((size_t)h->f2_lu_words + h->n + F2_TRASH) : 0)) * 8;     // (+ the two constant words behind the trash words)
     if (nw && h->d_team_desc[nw / 4] && shmem_t <= lds_cap) {
@@ -295,11 +299,13 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
       const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(lds_cap / shmem_t, (size_t)(16 / nw)));
       const int grid = std::min(h->B, h->n_cu * wg_per_cu);
       if (getenv("CADNIP_F2_DEBUG")) fprintf(stderr, "[cadnip f2] team of %d waves: B %d n_cu %d grid %d shmem %zu rounds %d nc %d steps %d+%d / %d\n", nw, h->B, h->n_cu, grid, shmem_t, rounds, h->f2_nc, f.ts_pre, f.ts_post, f.ts_fwd);
-      TRY_RC(fteam_launch(nw, grid, shmem_t, h->stream, f));
+      if (step) TRY_RC(fteam_launch_step(std::min(h->B, h->n_cu), shmem_t, h->stream, f));
+      else TRY_RC(fteam_launch(nw, grid, shmem_t, h->stream, f));
       HIP_TRY(hipGetLastError());
       return CADNIP_OK;
     }
   }
+  if (step) return CADNIP_BADARG;                       // (no team kernel for this circuit: the caller takes the per-op kernels)
   // waves (= instances) per workgroup: 8 (two waves per SIMD) when they fit into LDS; fewer when the whole batch is then
   // still resident in one generation with a workgroup on every CU -- a wave runs about 20 % faster with half as many
   // neighbours on its CU (1024 instances: 4 per workgroup on 256 CUs, 57.7 M iterations/s, against 48.1 M as 8 x 128)
@@ -324,6 +330,18 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
 }
 
 int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds) { return launch_fused2(h, t, rounds, nullptr); }
+
+// one Newton iteration of every instance at (d_u, d_du, d_gamma, d_t) in the team kernel: residual -> d_resid_out / d_norm_out (optional),
+// Newton step -> d_delta, bit 0 of d_flags on a failed solve; CADNIP_BADARG when the circuit has no team kernel (not lean, too large for LDS)
+int launch_fused_step(CadnipHandle* h, int refresh, double* d_resid_out, double* d_norm_out) {
+  if (h->va_ext || !fused2_fits(h)) return CADNIP_BADARG;
+  TranArgs t;
+  memset(&t, 0, sizeof(t));
+  t.u = h->d_u; t.du = h->d_du; t.delta = h->d_delta; t.limit_w = h->d_limit_w; t.tcur = h->d_t; t.gamma = h->d_gamma; t.active = h->d_active; t.flags = h->d_flags;
+  t.B = h->B; t.n = h->n; t.n_limits = h->n_limits;
+  F2StepOpts so{refresh, d_resid_out, d_norm_out};
+  return launch_fused2(h, t, 1 << 30, nullptr, &so);
+}
 
 int launch_fused2_dc(CadnipHandle* h, const TranArgs& t, int rounds, double abstol, int maxiters, int use_pcnr, int mode, int initjct, int* d_dcstate) {
   F2DcOpts dc{abstol, maxiters, use_pcnr, mode, initjct, d_dcstate};

@@ -5,13 +5,19 @@ namespace cadnip {
 
 template <int NW>
 static int fteam_launch_one(int grid, size_t shmem, hipStream_t stream, const F2Args& f) {
-  if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_fteam<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL((k_fteam<NW>), dim3(grid), dim3(64 * NW), shmem, stream, f);
+  if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_fteam<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL((k_fteam<NW, false>), dim3(grid), dim3(64 * NW), shmem, stream, f);
   return CADNIP_OK;
 }
 
 int fteam_launch(int nw, int grid, size_t shmem, hipStream_t stream, const F2Args& f) {
   return nw == 4 ? fteam_launch_one<4>(grid, shmem, stream, f) : fteam_launch_one<2>(grid, shmem, stream, f);
+}
+
+int fteam_launch_step(int grid, size_t shmem, hipStream_t stream, const F2Args& f) {
+  if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_fteam<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL((k_fteam<4, true>), dim3(grid), dim3(256), shmem, stream, f);
+  return CADNIP_OK;
 }
 
 #ifdef CADNIP_TRACE

@@ -111,7 +111,10 @@ struct TeamVecs {
   __device__ __forceinline__ double emask_of(const TranArgs& a, int i, int k) const { return k >= 0 ? pf_em[k] : a.emask[i]; }
 };
 
-template <int NW>
+// STEP: ONE Newton iteration of the DAE form for cadnip_newton_step_fused (api.hip) instead of a transient: u, du, gamma, t come from the
+// caller (TranArgs: u, du, gamma, tcur), the residual C du + G u - b and its norm go to f.step_resid / f.step_norm, the Newton step J^-1 resid
+// to TranArgs::delta; f.step_refresh says whether J = G + gamma C is refactored (and kept in f.lufac) or the kept factors solve.
+template <int NW, bool STEP>
 __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
   static_assert(NW == 2 || NW == 4, "teams of two or four waves");
   constexpr int NT = 64 * NW;
@@ -236,7 +239,7 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
   for (int k = 0; k < M1_NPAR; ++k) rv.p[k] = 0.0;
   TeamVecs<NT, KPF> vec;
   vec.us = us; vec.betas = betas; vec.W = W; vec.qinv = qinv; vec.red = red; vec.z0 = f.nnz_lu; vec.z1 = nW;
-  vec.load_weights(a, tid);
+  if constexpr (!STEP) vec.load_weights(a, tid);
   // The team works through instances one after the other: its first one by position, further ones from the grid's queue.
   int inst = blockIdx.x;
   int budget = f.rounds;
@@ -244,6 +247,14 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
     StepState st;
     bool have = false;
     while (inst < f.B) {
+      if constexpr (STEP) {
+        // the caller's point and leading coefficient; the refactor decision of begin_round follows f.step_refresh
+        st.t = st.h = st.hprev = st.hpp = 0.0; st.tn = kargs()->t.tcur[inst]; st.a0 = kargs()->t.gamma[inst];
+        st.nhist = 1; st.ord = 1; st.k = 1; st.status = 0; st.bp = st.si = 0; st.c_newton = st.c_accept = st.c_reject = st.c_fail = 0;
+        st.t_break = st.t_save = 0.0; st.a0f = st.a0; st.ss = 20.0; st.dnp = 0.0; st.dsc = 1.0; st.mflags = f.step_refresh ? MN_NEED : MN_VALID;
+        make_uniform(st);
+        have = true; break;
+      }
       const TranStateView sv = state_view();
       st = load_state(sv, inst); make_uniform(st);
       if (st.status == 0) { have = true; break; }
@@ -256,8 +267,14 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
     const size_t vo = (size_t)inst * n;
     double* lw = a.use_pcnr ? kargs()->t.limit_w + vo : nullptr;
     vec.vo = vo; vec.lw = lw;
-    vec.load_history(n, tid);
-    {
+    if constexpr (STEP) {
+      // beta = du - a0 u, so that the devices' a0 u + beta is the caller's du
+      const F2ArgsK ka = kargs();
+      const double *ug = ka->t.u + vo, *dug = ka->t.du + vo;
+      const double a0 = st.a0;
+      for (int i = tid; i < n; i += NT) { const double x = ug[i]; us[i] = x; betas[i] = fma(-a0, x, dug[i]); }
+    } else {
+      vec.load_history(n, tid);
       const F2ArgsK ka = kargs();
       const double *ug = ka->t.u + vo, *betag = ka->t.beta + vo;
       for (int i = tid; i < n; i += NT) { us[i] = ug[i]; betas[i] = betag[i]; }
@@ -270,7 +287,7 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
       const double* src = B.par + (size_t)inst * words;
       for (int i = tid; i < words; i += NT) parc[B.lds_par + i] = src[i];
     }
-    const bool mn = a.newton_mode != 0;
+    const bool mn = STEP || a.newton_mode != 0;
     if (mn && (st.mflags & MN_VALID)) {
       const double* src = kargs()->lufac + (size_t)inst * f.nnz_lu;
       for (int i = tid; i < f.nnz_lu; i += NT) W[i] = src[i];
@@ -421,6 +438,15 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
         W[i] = acc;
       }
       __syncthreads();
+      if constexpr (STEP) {
+        // the residual as the caller sees it (unknown order) and its 2-norm, before the linear solve overwrites the right-hand side
+        double* ro = kargs()->step_resid ? kargs()->step_resid + vo : nullptr;
+        double s2 = 0.0;
+        for (int i = tid; i < n; i += NT) { const double r = W[rowof[i]]; s2 += r * r; if (ro) ro[i] = r; }
+        double dummy = 0.0; int nob = 0;
+        vec.reduce3(s2, dummy, nob);
+        if (tid == 0 && kargs()->step_norm) kargs()->step_norm[inst] = sqrt(s2);
+      }
       CADNIP_TRACE_POINT(1);
       // ---- refactor + forward + backward substitution: straight-line steps (f2_program.cpp: f2_build_team).  A step gives every thread of
       // the team one entry share W[pos] = (W[pos] - W[a] W[b] summed over the entry's lane group) / W[piv]; the next step's descriptor is
@@ -473,6 +499,14 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
       CADNIP_TRACE_POINT(5);
       run_steps(f.ts_pre, f.ts_post);
       CADNIP_TRACE_POINT(3);
+      if constexpr (STEP) {
+        double* dout = kargs()->t.delta + vo;
+        for (int i = tid; i < n; i += NT) { const double dd = W[qinv[i]]; if (!isfinite(dd)) bad = 1; dout[i] = dd; }
+        if (__syncthreads_or(bad) && tid == 0) atomicOr(&kargs()->t.flags[inst], 1);
+        st.status = 1;                                        // one iteration: done
+        --budget;
+        break;
+      }
       // ---- Newton update + step controller: thread t owns unknown t; every wave decides for itself from the same sums
       tran_update_body(a, vec, st, inst, tid, bad);
       make_uniform(st);
@@ -485,6 +519,12 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
     __syncthreads();
     {
       const F2ArgsK ka = kargs();
+      if constexpr (STEP) {
+        if (f.step_refresh) {                                 // the factors stay for the caller's next iterations on this Jacobian
+          double* dst = ka->lufac + (size_t)inst * f.nnz_lu;
+          for (int i = tid; i < f.nnz_lu; i += NT) dst[i] = W[i];
+        }
+      } else {
       double *ug = ka->t.u + vo, *betag = ka->t.beta + vo, *dug = ka->t.du + vo;
       const double a0 = st.a0;
       for (int i = tid; i < n; i += NT) { double x = us[i], b = betas[i]; ug[i] = x; betag[i] = b; dug[i] = a0 * x + b; }
@@ -494,6 +534,7 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
       }
       vec.store_history(n, tid);
       store_state(state_view(), inst, tid, st);
+      }
     }
     __syncthreads();
     if (st.status == 0) break;                // out of budget in the middle of this instance: the next launch resumes it
@@ -504,5 +545,6 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
 }
 
 int fteam_launch(int nw, int grid, size_t shmem, hipStream_t stream, const F2Args& f);   // fused_team.hip
+int fteam_launch_step(int grid, size_t shmem, hipStream_t stream, const F2Args& f);      // ... k_fteam<4, true>
 
 }  // namespace cadnip

@@ -182,6 +182,11 @@ struct CadnipHandle {
   // by a copy KERNEL on the stream that reads / writes the staging area across the bus; large ones are blocking copies
   char* h_stage = nullptr; char* d_stage = nullptr; size_t stage_bytes = 0, stage_off = 0;   // (d_stage: the same memory as the device sees it)
   struct PendingDown { void* dst; const void* src; size_t bytes; };
+  // cadnip_newton_step: the launch sequence of one call as an instantiated HIP graph per variant (refresh or not); `graph_epoch` moves whenever
+  // something a captured kernel argument depends on changes (spec, parameters' structure, LU program): a stale graph is captured again
+  struct StepGraph { hipGraphExec_t exec = nullptr; unsigned long long epoch = 0, warmed = 0; };
+  StepGraph step_graph[2];
+  unsigned long long graph_epoch = 1;
   std::vector<PendingDown> stage_pending;   // the same words as the device sees them: small results are PUBLISHED there by a kernel (driver.hip: k_publish_int), not copied
 };
 
@@ -202,11 +207,16 @@ int upload_lu(CadnipHandle* h);
 int upload_homotopy(CadnipHandle* h, const double* gshunt /* [B] or null = spec */, const double* srcfact /* [B] or null = spec */);
 int launch_calib_copy(CadnipHandle* h, long n, int reps);
 #define TRY_RC(x) do { int _rc_ = (x); if (_rc_) return _rc_; } while (0)
+struct MultiCopy { struct Seg { unsigned* dst; const unsigned* src; size_t words; }; Seg seg[8]; int n = 0;
+  void add(void* dst, const void* src, size_t bytes) { seg[n].dst = (unsigned*)dst; seg[n].src = (const unsigned*)src; seg[n].words = bytes / 4; ++n; } };
+int dev_multi_async(CadnipHandle* h, const MultiCopy& m, bool to_host);   // kernels.hip: up to 8 word copies / clears (src = null) in one launch
+int launch_norm2(CadnipHandle* h, const double* d_x, double* d_out);      // kernels.hip: per-instance 2-norm
 int dev_zero_async(CadnipHandle* h, void* p, size_t bytes);
 int dev_copy_async(CadnipHandle* h, void* dst, const void* src, size_t bytes, bool to_host);   // kernels.hip: word copy as a kernel on the handle's stream       // kernels.hip: zero-fill as a kernel on the handle's stream (ordered with the other kernels)
 int launch_negate(CadnipHandle* h, double* d_x, long n);
 struct TranArgs;                                                          // tran_ctrl.hpp
 int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds); // fused2.hip
+int launch_fused_step(CadnipHandle* h, int refresh, double* d_resid_out, double* d_norm_out);   // fused2.hip: one Newton iteration in the team kernel
 int launch_va_setup(CadnipHandle* h, DeviceBlock& b);                        // stamp_csr.hip: the setup pass of a generated external model's block
 bool fused2_tables_ready(CadnipHandle* h);                                 // the packed tables exist (built on demand)
 bool fused2_fits(CadnipHandle* h);                                        // false: circuit too large for the LDS-resident kernel

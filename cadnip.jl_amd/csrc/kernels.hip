@@ -11,6 +11,7 @@
 #include <string.h>
 #include "devices.hpp"
 #include "internal.hpp"
+#include "tran_ctrl.hpp"
 
 namespace cadnip {
 
@@ -274,6 +275,36 @@ int dev_copy_async(CadnipHandle* h, void* dst, const void* src, size_t bytes, bo
   const size_t n = bytes / 4;
   const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 1024);
   hipLaunchKernelGGL(k_copy_words, dim3(grid), dim3(256), 0, h->stream, (unsigned*)dst, (const unsigned*)src, n, to_host ? 1 : 0);
+  return CADNIP_OK;
+}
+
+// Several small transfers / clears in ONE launch (cadnip_newton_step: four uploads and two clears, four downloads): segment blockIdx.y
+// copies src -> dst word by word, or clears dst when src is null.
+__global__ void __launch_bounds__(256) k_multi_words(MultiCopy m, int to_host) {
+  const MultiCopy::Seg sg = m.seg[blockIdx.y];
+  if (sg.src) { for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < sg.words; i += (size_t)gridDim.x * 256) sg.dst[i] = sg.src[i]; }
+  else { for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < sg.words; i += (size_t)gridDim.x * 256) sg.dst[i] = 0u; }
+  if (to_host) __threadfence_system();
+}
+int dev_multi_async(CadnipHandle* h, const MultiCopy& m, bool to_host) {
+  if (m.n <= 0) return CADNIP_OK;
+  size_t most = 0;
+  for (int k = 0; k < m.n; ++k) most = std::max(most, m.seg[k].words);
+  const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>((most + 255) / 256, 1), 256);
+  hipLaunchKernelGGL(k_multi_words, dim3(grid, (unsigned)m.n), dim3(256), 0, h->stream, m, to_host ? 1 : 0);
+  return CADNIP_OK;
+}
+
+// ||x||_2 of every instance's vector (cadnip_newton_step's residual norm): one wave per instance
+__global__ void __launch_bounds__(64) k_norm2(const double* x, int n, double* out) {
+  const double* v = x + (size_t)blockIdx.x * n;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += v[i] * v[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[blockIdx.x] = sqrt(s);
+}
+int launch_norm2(CadnipHandle* h, const double* d_x, double* d_out) {
+  hipLaunchKernelGGL(k_norm2, dim3(h->B), dim3(64), 0, h->stream, d_x, h->n, d_out);
   return CADNIP_OK;
 }
 

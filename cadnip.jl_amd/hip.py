@@ -21,7 +21,7 @@ STATUS_NAMES = {0: "CADNIP_OK", 1: "CADNIP_BADARG", 2: "CADNIP_SINGULAR", 3: "CA
 EXPORTS = [
     "cadnip_create", "cadnip_destroy", "cadnip_set_params", "cadnip_set_spec", "cadnip_set_initjct",
     "cadnip_rebuild", "cadnip_residual", "cadnip_jacobian", "cadnip_ode_rhs", "cadnip_ode_jacobian", "cadnip_get_GCb", "cadnip_get_contributions", "cadnip_analyze",
-    "cadnip_analyze_values", "cadnip_factor", "cadnip_solve", "cadnip_lu_stats", "cadnip_dc_run",
+    "cadnip_analyze_values", "cadnip_factor", "cadnip_solve", "cadnip_newton_step", "cadnip_newton_step_fused", "cadnip_lu_stats", "cadnip_dc_run",
     "cadnip_dc_log_size", "cadnip_dc_log_get", "cadnip_tran_run", "cadnip_tran_state", "cadnip_dev_ptr", "cadnip_stream", "cadnip_set_u", "cadnip_get_u", "cadnip_get_flags",
     "cadnip_sync", "cadnip_debug_copy", "cadnip_debug_stamp_time", "cadnip_profile_enable", "cadnip_profile_read", "cadnip_version",
     "cadnip_host_lu_analyze", "cadnip_host_lu_analyze_leaves", "cadnip_host_lu_size", "cadnip_host_lu_get", "cadnip_host_lu_free",
@@ -305,6 +305,20 @@ class Handle:
         x = np.empty_like(r)
         _check(self.lib.cadnip_solve(self.h, _dp(r), _dp(x)), "cadnip_solve")
         return x
+
+    def newton_step(self, u, du, gamma=None, t=None, refresh=True, want_resid=False, fused=False):
+        """cadnip_newton_step: resid = C du + G u - b, [J = G + gamma C refactored,] delta = J^-1 resid -- one call, one synchronisation.
+        ``fused``: cadnip_newton_step_fused (one kernel; agrees to rounding).  Returns (delta [B, n], ||resid||_2 [B]) and resid [B, n]
+        with ``want_resid``."""
+        uu, dd = self._bn(u), self._bn(du)
+        delta, nrm = np.empty_like(uu), np.empty(self.B)
+        resid = np.empty_like(uu) if want_resid else None
+        g = None if gamma is None else np.ascontiguousarray(np.broadcast_to(np.asarray(gamma, dtype=np.float64), (self.B,)))
+        tt = None if t is None else np.ascontiguousarray(np.broadcast_to(np.asarray(t, dtype=np.float64), (self.B,)))
+        fn = self.lib.cadnip_newton_step_fused if fused else self.lib.cadnip_newton_step
+        _check(fn(self.h, _dp(uu), _dp(dd), None if g is None else _dp(g), None if tt is None else _dp(tt), C.c_int32(1 if refresh else 0),
+                  _dp(delta), _dp(nrm), None if resid is None else _dp(resid)), "cadnip_newton_step_fused" if fused else "cadnip_newton_step")
+        return (delta, nrm, resid) if want_resid else (delta, nrm)
 
     def lu_stats(self):
         v = [C.c_int32() for _ in range(5)]

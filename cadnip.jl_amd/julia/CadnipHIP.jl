@@ -140,6 +140,17 @@ function solve!(x::Vector{Float64}, ws::GPUEvalWorkspace, rhs::Vector{Float64})
     return x
 end
 
+# One Newton iteration in one ccall (cadnip_newton_step): resid = C du + G u - b, [J = G + gamma C refactored when `refresh`,] delta = J^-1 resid.
+# For a hand-written Newton loop around the library (the shape of _dc_pcnr_newton, src/mna/solve.jl:599-698, on the DAE residual) and for an
+# integrator whose nonlinear solver can be replaced: five entry points and five synchronisations become one.  Returns ||resid||_2.
+function newton_step!(delta::Vector{Float64}, du::Vector{Float64}, u::Vector{Float64}, ws::GPUEvalWorkspace, gamma::Real, t::Real; refresh::Bool=true)
+    ws.tbuf[1] = Float64(t); ws.gamma[1] = Float64(gamma)
+    nrm = Ref{Float64}(0.0)
+    check(ccall((:cadnip_newton_step, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                ws.handle, u, du, ws.gamma, ws.tbuf, refresh ? 1 : 0, delta, nrm, C_NULL), "cadnip_newton_step")
+    return nrm[]
+end
+
 # SciML closures identical in shape to make_workspace_dae_residual / _jacobian (src/mna/solve.jl:2497-2519)
 make_gpu_dae_residual() = (resid, du, u, ws::GPUEvalWorkspace, t) -> fast_residual!(resid, du, u, ws, t)
 make_gpu_dae_jacobian() = (J, du, u, ws::GPUEvalWorkspace, gamma, t) -> fast_jacobian!(J, du, u, ws, gamma, t)

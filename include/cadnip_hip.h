@@ -182,6 +182,26 @@ int cadnip_analyze(CadnipHandle* h, int32_t sample_instance);
 int cadnip_analyze_values(CadnipHandle* h, const double* J_csr_host);
 int cadnip_factor(CadnipHandle* h);
 int cadnip_solve(CadnipHandle* h, const double* rhs_host, double* x_host);
+
+/* One Newton iteration of the DAE form in one call -- what a host integrator that keeps the nonlinear loop to itself (IDA behind the Julia
+ * shim: residual!, then jacobian! + klu_refactor when it decides on a set-up, then klu_solve; src/mna/precompile.jl:546-585,
+ * src/mna/solve.jl:2138-2160, src/sweeps.jl:600) otherwise does with five entry points and five synchronisations:
+ *   resid = C du + G u - b at (u, t)          [cadnip_rebuild, cadnip_residual]
+ *   refresh != 0: J = G + gamma C, refactored  [cadnip_jacobian, cadnip_factor]; 0: the factors of the last refreshing call are used
+ *   delta = J^-1 resid                         [cadnip_solve]
+ * with the same kernels in the same order (the results are the same doubles as the five calls'), one staged upload, one staged download,
+ * one synchronisation; the launch sequence is an instantiated HIP graph, replayed while the handle's configuration stays as it is.
+ * u, du, delta, resid: [B][n]; gamma, t, resid_norm: [B].  t_host NULL = times unchanged; gamma_host may be NULL when refresh == 0;
+ * resid_norm_host (||resid||_2 per instance) and resid_host are optional.  CADNIP_NONFINITE / CADNIP_SINGULAR as the separate calls. */
+int cadnip_newton_step(CadnipHandle* h, const double* u_host, const double* du_host, const double* gamma_host, const double* t_host, int32_t refresh,
+                       double* delta_host, double* resid_norm_host, double* resid_host);
+/* The same iteration in ONE kernel (the fused team kernel, csrc/fused_team_kernel.hpp): stamping, residual, refactorisation or kept factors,
+ * solve.  Same arguments; the results agree with cadnip_newton_step to rounding (the devices add into an LDS-resident work array in
+ * another order), not bit for bit.  CADNIP_BADARG for circuits the team kernel does not run (device types outside linear elements /
+ * sources / plain sp_mos1, tables beyond LDS, external generated models, homotopy in force): use cadnip_newton_step there.  The stamps use
+ * the transient device mode (a DAE residual is a transient's). */
+int cadnip_newton_step_fused(CadnipHandle* h, const double* u_host, const double* du_host, const double* gamma_host, const double* t_host, int32_t refresh,
+                             double* delta_host, double* resid_norm_host, double* resid_host);
 int cadnip_lu_stats(CadnipHandle* h, int32_t* nnz_lu, int32_t* n_terms, int32_t* n_levels, int32_t* n_fwd_levels, int32_t* n_bwd_levels);
 
 /* ---- host drivers (Newton loop + step controller; stand-in for IDA / _dc_pcnr_newton) ----

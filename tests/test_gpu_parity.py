@@ -246,3 +246,89 @@ def test_transient_edge_cases():
         out2, per2, stats2 = sim.tran((0.0, 2e-3), np.full(st.n, 1e-9), 1e-6, np.array([]), obs=[st.index_of("out")], fused=1)
         assert stats2["n_failed"] == 0 and out2.shape[1] == 0 and np.array_equal(per2[:, :3], per[:, :3])
         sim.close()
+
+
+@pytest.mark.parametrize("name", ["dff", "linear_zoo", "diode"])
+def test_newton_step_in_one_call_equals_the_five_calls(name):
+    """cadnip_newton_step (rebuild -> residual -> [jacobian -> factor] -> solve in one call, its launch sequence replayed as a HIP graph) gives
+    the same doubles as the five entry points called one after the other: with and without a refactorisation, first call (plain
+    launches), second call (graph capture), later calls (graph replay), and again after the handle's configuration changed (a stale
+    graph must not be replayed)."""
+    import cadnip_jl_amd as cj
+    from cadnip_jl_amd import benchmarks as bm, hip
+    from tests import circuits as tc
+    if name == "dff":
+        circ, params = bm.dff_circuit(), {"vdd": 5.0}
+    else:
+        mk, params = tc.ALL_STAMP[name]
+        circ = mk()
+    B = 3
+    st = cj.discover(circ, params)
+    h = hip.Handle(st, B)
+    h.set_params(cj.pack_params(st, circ, {k: np.full(B, float(v)) for k, v in params.items()}, np.array([27.0, -20.0, 110.0]), B))
+    h.set_spec(mode="tran")
+    rng = np.random.default_rng(5)
+    vs = 5.0 if name == "dff" else 1.0
+    gam = np.array([1e9, 3e8, 2e9])
+
+    def five(u, du, t, refresh):
+        h.rebuild(u, t)
+        r = h.residual(du, u)
+        if refresh:
+            h.jacobian(gam, readback=False)
+            h.factor()
+        return h.solve(r), r
+
+    u0 = rng.random((B, st.n)) * vs
+    h.rebuild(u0, np.zeros(B)); h.jacobian(gam, readback=True); h.analyze(0)
+    for rep in range(5):
+        u, du, t = rng.random((B, st.n)) * vs, rng.random((B, st.n)) * 1e6, rng.random(B) * 1e-7
+        for refresh in (True, False):
+            if rep == 3 and refresh:
+                h.set_spec(mode="tran", gmin=1e-11)        # the configuration moves: graphs captured before are stale
+            x5, r5 = five(u, du, t, refresh)
+            x1, nrm, r1 = h.newton_step(u, du, gam if refresh else None, t, refresh=refresh, want_resid=True)
+            assert np.array_equal(r1, r5) and np.array_equal(x1, x5), (name, rep, refresh)
+            assert np.allclose(nrm, np.sqrt(np.sum(r5 * r5, axis=1)), rtol=1e-12)
+    h.close()
+
+
+def test_newton_step_in_the_fused_kernel_agrees_with_the_per_op_kernels():
+    """cadnip_newton_step_fused: the same iteration (residual, refactorisation or kept factors, solve) in the team kernel's STEP mode --
+    another summation order, so the agreement is to rounding: residual 1e-12 of its largest entry, Newton step 1e-8 of its largest entry
+    (conditioning of J = G + 1e9 C); a circuit outside the team kernel's device set is refused (the caller takes cadnip_newton_step)."""
+    import cadnip_jl_amd as cj
+    from cadnip_jl_amd import benchmarks as bm, hip
+    from tests import circuits as tc
+    from cadnip_jl_amd import api
+    circ = bm.dff_circuit()
+    B = 5
+    sim = api.BatchSimulator(api.MNACircuit(circ, {"vdd": 5.0}), [{"vdd": float(v), "temp": float(tc_)} for v, tc_ in zip(np.linspace(4.5, 5.5, B), np.linspace(-40.0, 125.0, B))])
+    st, h = sim.st, sim.h
+    sim.analyze()
+    udc, conv, _ = sim.dc(abstol=1e-9, mode="tranop")
+    assert np.all(conv)
+    h.set_spec(mode="tran")
+    rng = np.random.default_rng(11)
+    gam = np.full(B, 1e9)
+    for rep in range(3):
+        # states near the operating point (a random state sends the exponentials of the junctions to 1e58: nothing to compare there)
+        u, du, t = udc + 1e-3 * (rng.random((B, st.n)) - 0.5), (rng.random((B, st.n)) - 0.5) * 1e5, rng.random(B) * 1e-7
+        for refresh in (True, False):
+            x1, n1, r1 = h.newton_step(u, du, gam if refresh else None, t, refresh=refresh, want_resid=True)
+            x2, n2, r2 = h.newton_step(u, du, gam if refresh else None, t, refresh=refresh, want_resid=True, fused=True)
+            assert np.max(np.abs(r1 - r2)) <= 1e-12 * np.max(np.abs(r1)) and np.allclose(n1, n2, rtol=1e-12)
+            assert np.max(np.abs(x1 - x2)) <= 1e-8 * np.max(np.abs(x1)), (rep, refresh, np.max(np.abs(x1 - x2)), np.max(np.abs(x1)))
+    sim.close()
+    mk, params = tc.ALL_STAMP["diode"]
+    circ = mk()
+    st = cj.discover(circ, params)
+    h = hip.Handle(st, 1)
+    h.set_params(cj.pack_params(st, circ, {}, np.array([27.0]), 1))
+    h.set_spec(mode="tran")
+    u = np.zeros((1, st.n))
+    h.rebuild(u, 0.0); h.jacobian(np.array([1e6]), readback=True); h.analyze(0)
+    with pytest.raises(hip.CadnipError):
+        h.newton_step(u, u, 1e6, 0.0, fused=True)
+    h.newton_step(u, u, 1e6, 0.0)
+    h.close()
