@@ -1,5 +1,6 @@
 // api.hip -- the C ABI of include/cadnip_hip.h (everything except the two host drivers).
 #include <hip/hip_runtime.h>
+#include <functional>
 #include <algorithm>
 #include <stdio.h>
 #include <string.h>
@@ -510,6 +511,26 @@ int cadnip_host_f2_get(const CadnipHostF2* f, int32_t which, void* dst) {
 void cadnip_host_f2_free(CadnipHostF2* f) { delete f; }
 void cadnip_host_lu_free(CadnipHostLU* lu) { delete lu; }
 
+// Replay of a fixed launch sequence as an instantiated HIP graph: the first call in a configuration (`key`) enqueues plainly (lazy set-up
+// inside the launchers runs there), the second captures and instantiates, later ones replay; profiling and CADNIP_NO_GRAPH=1 enqueue plainly.
+static int run_graphed(CadnipHandle* h, CadnipHandle::StepGraph& g, unsigned long long key, const std::function<int()>& enqueue) {
+  if (h->prof_on || getenv("CADNIP_NO_GRAPH")) return enqueue();
+  if (g.exec && g.epoch == key) { HIP_TRY(hipGraphLaunch(g.exec, h->stream)); return CADNIP_OK; }
+  if (g.warmed != key) { TRY_RC(enqueue()); g.warmed = key; return CADNIP_OK; }
+  if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+  hipGraph_t graph = nullptr;
+  HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  const int rc = enqueue();
+  const hipError_t ec = hipStreamEndCapture(h->stream, &graph);
+  if (rc || ec != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); if (rc) return rc; cadnip::set_last_error("hipStreamEndCapture", ec); return CADNIP_HIPERROR; }
+  const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ei != hipSuccess) { g.exec = nullptr; cadnip::set_last_error("hipGraphInstantiate", ei); return CADNIP_HIPERROR; }
+  g.epoch = key;
+  HIP_TRY(hipGraphLaunch(g.exec, h->stream));
+  return CADNIP_OK;
+}
+
 // One Newton iteration of the DAE form in ONE call: what a host integrator that keeps the Newton loop to itself (IDA through the Julia
 // shim: residual callback, Jacobian callback, KLU refactor / solve -- src/mna/precompile.jl:546-585, src/mna/solve.jl:2138-2160) otherwise
 // does with five entry points and five stream synchronisations.  The SAME kernels in the same order as cadnip_rebuild -> cadnip_residual ->
@@ -560,24 +581,7 @@ int cadnip_newton_step(CadnipHandle* h, const double* u_host, const double* du_h
     return CADNIP_OK;
   };
   // graph variants: refresh x (gamma given) x (t given) change the launch sequence: keyed by the first only, the other two recorded in the epoch
-  CadnipHandle::StepGraph& g = h->step_graph[refresh ? 1 : 0];
-  const unsigned long long key = h->graph_epoch * 4 + (have_g ? 2 : 0) + (have_t ? 1 : 0);
-  if (h->prof_on || getenv("CADNIP_NO_GRAPH")) { TRY(enqueue()); }
-  else if (g.exec && g.epoch == key) { HIP_TRY(hipGraphLaunch(g.exec, h->stream)); }
-  else if (g.warmed != key) { TRY(enqueue()); g.warmed = key; }        // first call in this configuration: plain launches (lazy set-up inside the launchers runs here)
-  else {
-    if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
-    hipGraph_t graph = nullptr;
-    HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    const int rc = enqueue();
-    const hipError_t ec = hipStreamEndCapture(h->stream, &graph);
-    if (rc || ec != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); if (rc) return rc; set_last_error("hipStreamEndCapture", ec); return CADNIP_HIPERROR; }
-    const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ei != hipSuccess) { g.exec = nullptr; set_last_error("hipGraphInstantiate", ei); return CADNIP_HIPERROR; }
-    g.epoch = key;
-    HIP_TRY(hipGraphLaunch(g.exec, h->stream));
-  }
+  TRY(run_graphed(h, h->step_graph[refresh ? 1 : 0], h->graph_epoch * 4 + (have_g ? 2 : 0) + (have_t ? 1 : 0), enqueue));
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->stage_off = 0;
   memcpy(delta_host, s_d, vec);
@@ -605,20 +609,18 @@ int cadnip_newton_step_fused(CadnipHandle* h, const double* u_host, const double
        *s_r = stage_take(h, vec), *s_nrm = stage_take(h, B * 8), *s_fl = stage_take(h, B * 4);
   if (!s_fl) return CADNIP_BADARG;
   auto dv = [&](char* p) { return h->d_stage + (p - h->h_stage); };
+  // ONE launch: the kernel reads u, du, gamma, t from the mapped pinned staging area (a few KB across the bus, once) and writes the Newton
+  // step, the residual, its norm and the failure flags back there; gamma / t stay what they were on the device when not given
   memcpy(s_u, u_host, vec); memcpy(s_du, du_host, vec);
-  MultiCopy up;
-  up.add(h->d_u, dv(s_u), vec); up.add(h->d_du, dv(s_du), vec);
-  if (gamma_host) { memcpy(s_g, gamma_host, B * 8); up.add(h->d_gamma, dv(s_g), B * 8); }
-  if (t_host) { memcpy(s_t, t_host, B * 8); up.add(h->d_t, dv(s_t), B * 8); }
-  up.add(h->d_flags, nullptr, B * 4);
-  const int saved_mode = h->spec.mode;
-  TRY_RC(dev_multi_async(h, up, false));
-  { const int rc = launch_fused_step(h, refresh ? 1 : 0, resid_host ? h->d_resid : nullptr, h->d_tmp); if (rc) { (void)hipStreamSynchronize(h->stream); h->stage_off = 0; return rc; } }
-  (void)saved_mode;
-  MultiCopy down;
-  down.add(dv(s_d), h->d_delta, vec); if (resid_host) down.add(dv(s_r), h->d_resid, vec);
-  down.add(dv(s_nrm), h->d_tmp, B * 8); down.add(dv(s_fl), h->d_flags, B * 4);
-  TRY_RC(dev_multi_async(h, down, true));
+  if (gamma_host) memcpy(s_g, gamma_host, B * 8);
+  if (t_host) memcpy(s_t, t_host, B * 8);
+  memset(s_fl, 0, B * 4);
+  FusedStepIO io;
+  io.u = (const double*)dv(s_u); io.du = (const double*)dv(s_du);
+  io.gamma = gamma_host ? (const double*)dv(s_g) : h->d_gamma; io.t = t_host ? (const double*)dv(s_t) : h->d_t;
+  io.gamma_keep = gamma_host ? h->d_gamma : nullptr; io.t_keep = t_host ? h->d_t : nullptr;
+  io.delta = (double*)dv(s_d); io.resid = resid_host ? (double*)dv(s_r) : nullptr; io.norm = (double*)dv(s_nrm); io.flags = (int*)dv(s_fl);
+  { const int rc = launch_fused_step(h, refresh ? 1 : 0, io); if (rc) { (void)hipStreamSynchronize(h->stream); h->stage_off = 0; return rc; } }
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->stage_off = 0;
   memcpy(delta_host, s_d, vec);

@@ -331,15 +331,16 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
 
 int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds) { return launch_fused2(h, t, rounds, nullptr); }
 
-// one Newton iteration of every instance at (d_u, d_du, d_gamma, d_t) in the team kernel: residual -> d_resid_out / d_norm_out (optional),
-// Newton step -> d_delta, bit 0 of d_flags on a failed solve; CADNIP_BADARG when the circuit has no team kernel (not lean, too large for LDS)
-int launch_fused_step(CadnipHandle* h, int refresh, double* d_resid_out, double* d_norm_out) {
+// one Newton iteration of every instance in the team kernel (STEP mode): residual -> io.resid / io.norm (optional), Newton step -> io.delta,
+// io.flags[inst] = 1 on a failed solve (the caller clears them); CADNIP_BADARG when the circuit has no team kernel (not lean, too large for LDS)
+int launch_fused_step(CadnipHandle* h, int refresh, const FusedStepIO& io) {
   if (h->va_ext || !fused2_fits(h)) return CADNIP_BADARG;
   TranArgs t;
   memset(&t, 0, sizeof(t));
-  t.u = h->d_u; t.du = h->d_du; t.delta = h->d_delta; t.limit_w = h->d_limit_w; t.tcur = h->d_t; t.gamma = h->d_gamma; t.active = h->d_active; t.flags = h->d_flags;
+  t.u = (double*)io.u; t.du = (double*)io.du; t.delta = io.delta; t.limit_w = h->d_limit_w; t.tcur = (double*)io.t; t.gamma = (double*)io.gamma; t.active = h->d_active; t.flags = io.flags;
+  t.t = io.t_keep; t.h = io.gamma_keep;                   // (STEP mode: where the caller's times / leading coefficients are also kept)
   t.B = h->B; t.n = h->n; t.n_limits = h->n_limits;
-  F2StepOpts so{refresh, d_resid_out, d_norm_out};
+  F2StepOpts so{refresh, io.resid, io.norm};
   return launch_fused2(h, t, 1 << 30, nullptr, &so);
 }
 

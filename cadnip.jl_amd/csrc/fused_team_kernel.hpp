@@ -250,6 +250,7 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
       if constexpr (STEP) {
         // the caller's point and leading coefficient; the refactor decision of begin_round follows f.step_refresh
         st.t = st.h = st.hprev = st.hpp = 0.0; st.tn = kargs()->t.tcur[inst]; st.a0 = kargs()->t.gamma[inst];
+        if (tid == 0) { if (kargs()->t.t) kargs()->t.t[inst] = st.tn; if (kargs()->t.h) kargs()->t.h[inst] = st.a0; }    // the handle's copies (api.hip)
         st.nhist = 1; st.ord = 1; st.k = 1; st.status = 0; st.bp = st.si = 0; st.c_newton = st.c_accept = st.c_reject = st.c_fail = 0;
         st.t_break = st.t_save = 0.0; st.a0f = st.a0; st.ss = 20.0; st.dnp = 0.0; st.dsc = 1.0; st.mflags = f.step_refresh ? MN_NEED : MN_VALID;
         make_uniform(st);
@@ -500,9 +501,10 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
       run_steps(f.ts_pre, f.ts_post);
       CADNIP_TRACE_POINT(3);
       if constexpr (STEP) {
-        double* dout = kargs()->t.delta + vo;
+        double* dout = kargs()->t.delta + vo;                 // (possibly mapped host memory: plain stores, a system-scope fence behind them)
         for (int i = tid; i < n; i += NT) { const double dd = W[qinv[i]]; if (!isfinite(dd)) bad = 1; dout[i] = dd; }
-        if (__syncthreads_or(bad) && tid == 0) atomicOr(&kargs()->t.flags[inst], 1);
+        if (__syncthreads_or(bad) && tid == 0) kargs()->t.flags[inst] = 1;
+        __threadfence_system();
         st.status = 1;                                        // one iteration: done
         --budget;
         break;

@@ -185,7 +185,7 @@ struct CadnipHandle {
   // cadnip_newton_step: the launch sequence of one call as an instantiated HIP graph per variant (refresh or not); `graph_epoch` moves whenever
   // something a captured kernel argument depends on changes (spec, parameters' structure, LU program): a stale graph is captured again
   struct StepGraph { hipGraphExec_t exec = nullptr; unsigned long long epoch = 0, warmed = 0; };
-  StepGraph step_graph[2];
+  StepGraph step_graph[4];      // per-op: no refresh / refresh; fused: no refresh / refresh
   unsigned long long graph_epoch = 1;
   std::vector<PendingDown> stage_pending;   // the same words as the device sees them: small results are PUBLISHED there by a kernel (driver.hip: k_publish_int), not copied
 };
@@ -216,7 +216,10 @@ int dev_copy_async(CadnipHandle* h, void* dst, const void* src, size_t bytes, bo
 int launch_negate(CadnipHandle* h, double* d_x, long n);
 struct TranArgs;                                                          // tran_ctrl.hpp
 int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds); // fused2.hip
-int launch_fused_step(CadnipHandle* h, int refresh, double* d_resid_out, double* d_norm_out);   // fused2.hip: one Newton iteration in the team kernel
+// one Newton iteration in the team kernel (fused2.hip): device-visible pointers (device memory or mapped pinned host memory) of its inputs and outputs;
+// gamma_keep / t_keep: device arrays that also receive the caller's gamma / t (the handle's state stays what the per-op entry points would leave)
+struct FusedStepIO { const double *u, *du, *gamma, *t; double *gamma_keep, *t_keep, *delta, *resid, *norm; int* flags; };
+int launch_fused_step(CadnipHandle* h, int refresh, const FusedStepIO& io);
 int launch_va_setup(CadnipHandle* h, DeviceBlock& b);                        // stamp_csr.hip: the setup pass of a generated external model's block
 bool fused2_tables_ready(CadnipHandle* h);                                 // the packed tables exist (built on demand)
 bool fused2_fits(CadnipHandle* h);                                        // false: circuit too large for the LDS-resident kernel
