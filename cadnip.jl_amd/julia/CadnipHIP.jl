@@ -179,6 +179,10 @@ end
 """
     export_structure(cs::MNA.CompiledStructure, ctx::MNA.MNAContext, table::Vector{DeviceRow}; n_instances=1, device=0)
 
+(The algorithm below has a Python twin, `cadnip.jl_amd/export_twin.py`, statement for statement: Julia is not installed where this
+library is built, so the twin is what the test-suite executes -- on a restatement of `compile_structure` -- and what must stay in
+step with this function.)
+
 `cs`, `ctx` as `compile_structure` leaves them (precompile.jl:312-443); `table` in builder order.  Returns the
 `GPUEvalWorkspace` whose CSR pattern, `to_ref_nz` permutation and per-nz gather lists reproduce `cs.G` / `cs.C` / `b`
 addition for addition (COO order), so `nonzeros(J)` comes back in `cs.G`'s own nzval order.
@@ -223,11 +227,12 @@ function export_structure(cs, ctx, table::Vector{DeviceRow}; n_instances=1, devi
             elseif stream === :C
                 kc += 1; push!(c_lists[csr_of[cs.C_coo_to_idx[kc]] + 1], c0 + slot * cnt + dev)
             else
-                kb += 1; push!(b_lists[d.nodes[lrow + 1] + 1], b0 + slot * cnt + dev)     # resolved row of the stamp (deferred ones: cs.b_deferred_resolved)
+                kb += 1; push!(b_lists[cs.b_deferred_resolved[kb]], b0 + slot * cnt + dev)     # the row the reference resolved for the kb-th stamp_b! (value_only.jl:440-478: every b stamp is positional; ground rows never reach the counter)
             end
         end
     end
-    (kg == cs.G_n_coo && kc == cs.C_n_coo) || error("device table does not account for every stamp of the builder pass ($kg/$(cs.G_n_coo) G, $kc/$(cs.C_n_coo) C)")
+    (kg == cs.G_n_coo && kc == cs.C_n_coo && kb == length(cs.b_deferred_resolved)) ||
+        error("device table does not account for every stamp of the builder pass ($kg/$(cs.G_n_coo) G, $kc/$(cs.C_n_coo) C, $kb/$(length(cs.b_deferred_resolved)) b)")
     flat(ls) = (Int32[0; cumsum(length.(ls))], reduce(vcat, ls; init=Int32[]))
     (g_ptr, g_slots), (c_ptr, c_slots), (b_ptr, b_slots) = flat(g_lists), flat(c_lists), flat(b_lists)
     diag = Int32[(e = findfirst(==(i - 1), view(colidx, rowptr[i] + 1:rowptr[i + 1])); e === nothing ? -1 : rowptr[i] + e - 1) for i in 1:n]
@@ -238,25 +243,8 @@ function export_structure(cs, ctx, table::Vector{DeviceRow}; n_instances=1, devi
     return ws
 end
 
-# ---- the GPU LU behind LinearSolve.jl: what `KLUFactorization()` is to src/mna/solve.jl:612-613 and to DFBDF / FBDF's `linsolve` ----
-# (Sundials' IDA takes its linear solver by name, src/sweeps.jl:600; a Julia host that wants the GPU factorisation inside IDA
-# wraps the same three calls in a SUNLinearSolver through Sundials.jl's `LinSolHandle` -- setup = factor!, solve = solve!.)
-#
-#   using LinearSolve
-#   struct CadnipLU <: LinearSolve.SciMLLinearSolveAlgorithm; ws::GPUEvalWorkspace; end
-#   LinearSolve.init_cacheval(alg::CadnipLU, A, b, u, Pl, Pr, maxiters, abstol, reltol, verbose, assumptions) = (analyze!(alg.ws); alg.ws)
-#   function SciMLBase.solve!(cache::LinearSolve.LinearCache, alg::CadnipLU; kwargs...)
-#       ws = cache.cacheval
-#       if cache.isfresh                      # a new Jacobian was written into cache.A by fast_jacobian!: it is already on the device
-#           factor!(ws); cache.isfresh = false
-#       end
-#       solve!(cache.u, ws, cache.b)
-#       return SciMLBase.build_linear_solution(alg, cache.u, nothing, cache)
-#   end
-#
-# The Jacobian never travels: fast_jacobian! leaves J = G + gamma C on the device (the nzval copy it returns is for the host's
-# own use), factor! refactors it with the stored pivot sequence (klu_refactor semantics; CADNIP_SINGULAR -> SingularException,
-# which the reference's callers catch: src/mna/solve.jl:887-897), solve! runs the two triangular sweeps.
+# The GPU LU behind LinearSolve.jl -- what `KLUFactorization()` is to src/mna/solve.jl:612-613 and to DFBDF / FBDF's `linsolve` -- lives in
+# CadnipHIPLinearSolve.jl beside this file (it needs LinearSolve.jl and SciMLBase.jl, which this module does not).
 
 Base.close(ws::GPUEvalWorkspace) = (ccall((:cadnip_destroy, LIB), Cvoid, (Ptr{Cvoid},), ws.handle); ws.handle = C_NULL; nothing)
 

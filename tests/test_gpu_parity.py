@@ -332,3 +332,42 @@ def test_newton_step_in_the_fused_kernel_agrees_with_the_per_op_kernels():
         h.newton_step(u, u, 1e6, 0.0, fused=True)
     h.newton_step(u, u, 1e6, 0.0)
     h.close()
+
+
+@pytest.mark.parametrize("name", ["dff", "linear_zoo"])
+def test_handle_built_from_the_exported_structure_matches_the_oracle(name):
+    """the structure a Julia host would export from the reference's CompiledStructure (cadnip.jl_amd/export_twin.py, the twin of
+    julia/CadnipHIP.jl: export_structure, run on the oracle's CompiledStructure) builds a handle whose rebuild / residual / Jacobian equal the
+    oracle's fast_rebuild! / fast_residual! / fast_jacobian! at 1e-12."""
+    import cadnip_jl_amd as cj
+    from cadnip_jl_amd import export_twin as X, hip
+    from oracle import mna_ref as M
+    from oracle.netlist_ref import make_builder
+    from tests import circuits as tc
+    mk, params = tc.ALL_STAMP[name]
+    circ = mk()
+    st0 = cj.discover(circ, params)
+    bld = make_builder(circ.to_dicts(params))
+    spec = M.MNASpec(mode="tran", temp=27.0)
+    ctx = M.build_with_detection(bld, {}, spec)
+    cs = M.compile_structure(bld, {}, spec, ctx=ctx)
+    st = X.to_structure(X.export_structure(cs, X.device_table(st0)), st0)
+    h = hip.Handle(st, 1)
+    h.set_params(cj.pack_params(st, circ, {k: np.array([float(v)]) for k, v in params.items()}, np.array([27.0]), 1))
+    h.set_spec(mode="tran")
+    rng = np.random.default_rng(3)
+    ws = M.create_workspace(cs, ctx=ctx)
+    for rep in range(3):
+        u, du, t, gamma = rng.random(st.n) * (5.0 if name == "dff" else 1.0), rng.random(st.n) * 1e3, 1e-8 * (rep + 1), 1e7
+        h.rebuild(u[None, :], t)
+        G, C, b, _ = h.get_GCb()
+        M.fast_rebuild(ws, u, t)
+        for got, ref in ((G[0], cs.G.data), (C[0], cs.C.data), (b[0], ws.dctx.b)):
+            assert np.max(np.abs(got - ref)) <= 1e-12 * max(np.max(np.abs(ref)), 1e-300), (name, rep)
+        r = h.residual(du[None, :], u[None, :])[0]
+        ref_r = np.zeros(st.n)
+        M.fast_residual(ref_r, du, u, ws, t)
+        assert np.max(np.abs(r - ref_r)) <= 1e-12 * np.max(np.abs(ref_r))
+        J = h.jacobian(np.array([gamma]))[0]
+        assert np.max(np.abs(J - (cs.G.data + gamma * cs.C.data))) <= 1e-12 * np.max(np.abs(cs.G.data + gamma * cs.C.data))
+    h.close()

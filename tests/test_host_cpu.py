@@ -724,3 +724,34 @@ def test_staged_continuation_order_and_structure_classes():
     assert sorted(i0 + i1) == list(range(12)) and all(pts[i]["rd"] == 0.0 for i in i0) and all(pts[i]["rd"] != 0.0 for i in i1)
     assert st1.n == st0.n + 1 and "m1_sp_mos1_d_int" in st1.node_names and "m1_sp_mos1_d_int" not in st0.node_names
     assert st0.signature() != st1.signature() and st0.signature() == cj.discover(c, {"rd": 0.0, "vg": 7.0}).signature()
+
+
+@pytest.mark.parametrize("name", ["dff", "linear_zoo", "diode", "nonlinear_zoo", "behavioral", "inverter", "mos1_rd", "va_zoo"])
+def test_exporter_twin_from_the_reference_compiled_structure(name):
+    """SURVEY.md 8f-1 without Julia: cadnip.jl_amd/export_twin.py is julia/CadnipHIP.jl's export_structure statement for statement.  Fed with
+    what the reference's CompiledStructure holds -- here the oracle's (oracle/mna_ref.py: compile_structure, precompile.jl:312-443):
+    colptr / rowval, the positional maps G_coo_to_idx / C_coo_to_idx, b_deferred_resolved -- and the device table in builder order, it
+    must produce the arrays the product's own structure discovery produces: CSR pattern, permutation to the reference's nzval order,
+    gather lists in COO order, b lists.  A table that does not account for every stamp of the builder pass is refused."""
+    from cadnip_jl_amd import export_twin as X
+    from oracle import mna_ref as M
+    from oracle.netlist_ref import make_builder
+    from tests import circuits as tc
+    mk, params = tc.ALL_STAMP[name]
+    circ = mk()
+    st = cj.discover(circ, params)
+    bld = make_builder(circ.to_dicts(params))
+    spec = M.MNASpec(mode="tran")
+    ctx = M.build_with_detection(bld, {}, spec)
+    cs = M.compile_structure(bld, {}, spec, ctx=ctx)
+    table = X.device_table(st)
+    ex = X.export_structure(cs, table)
+    for key in ("rowptr", "colidx", "to_ref_nz", "g_ptr", "g_slots", "c_ptr", "c_slots", "b_ptr", "b_slots", "diag_nz"):
+        assert np.array_equal(ex[key], getattr(st, key)), (name, key)
+    assert ex["ns"] == (st.ns_g, st.ns_c, st.ns_b) and len(ex["blocks"]) == len(st.blocks)
+    for a, b in zip(ex["blocks"], st.blocks):
+        assert a["type"] == b.type and a["count"] == b.count and np.array_equal(a["nodes"], b.nodes) and (a["g_base"], a["c_base"], a["b_base"]) == (b.g_base, b.c_base, b.b_base)
+    short = list(table)
+    short[-1] = X.DeviceRow(short[-1].type, short[-1].nodes, short[-1].ipar, short[-1].program[:-1], short[-1].shape)
+    with pytest.raises(ValueError):
+        X.export_structure(cs, short)
