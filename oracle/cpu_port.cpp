@@ -63,6 +63,10 @@ struct Port {
   std::vector<double> S, G, C, b, limit_w;
   LU lu;
   bool has_lu = false;
+  // External stamping: when set, fast_rebuild! is this callback (u, t -> G, C in the structure's CSR order, b, limit_w) instead of the
+  // port's own device code -- how a circuit of generated Verilog-A models (which the port does not know) gets a transient oracle: the
+  // literal Python interpreter (oracle/va_ref.py through oracle/mna_ref.py's fast_rebuild!) stamps, the port's controller and LU run.
+  void (*ext_stamp)(const double* u, double t, double* G, double* C, double* b, double* limit_w) = nullptr;
 };
 
 // ---- waves (devices.jl:30-103,155-203) ---------------------------------------------------------
@@ -308,6 +312,7 @@ void stamp_mos1(Port& P, const Block& B, int d, const double* u, const Slots& s)
 }
 
 void rebuild(Port& P, const double* u, double t) {
+  if (P.ext_stamp) { P.ext_stamp(u, t, P.G.data(), P.C.data(), P.b.data(), P.limit_w.data()); return; }
   for (auto& B : P.blocks) {
     for (int d = 0; d < B.count; ++d) {
       Slots s{P.S.data() + B.g_base, P.S.data() + P.ns_g + B.c_base, P.S.data() + P.ns_g + P.ns_c + B.b_base, B.count, d};
@@ -450,6 +455,7 @@ void port_add_block(void* p, int type, int count, int n_nodes, const int* nodes,
   B.par.assign(par, par + (size_t)n_par * count);
   P->blocks.push_back(B);
 }
+void port_set_stamp_callback(void* p, void (*cb)(const double*, double, double*, double*, double*, double*)) { ((Port*)p)->ext_stamp = cb; }
 void port_set_spec(void* p, int mode, double gmin, double gshunt, double srcFact, int initjct) {
   Port* P = (Port*)p; P->mode = mode; P->gmin = gmin; P->gshunt = gshunt; P->srcFact = srcFact; P->initjct = initjct;
 }

@@ -116,6 +116,23 @@ class Port:
         lib().port_set_spec(self.p, MODE[s["mode"]], C.c_double(s["gmin"]), C.c_double(s["gshunt"]), C.c_double(s["srcFact"]),
                             int(s["initjct"]))
 
+    def set_stamper(self, fn):
+        """External stamping: ``fn(u [n], t) -> (G_csr [nnz], C_csr [nnz], b [n], limit_w [n] or None)`` replaces the port's own device code in
+        fast_rebuild! (circuits of generated Verilog-A models: the literal interpreter stamps, the port's controller and LU run)."""
+        n, nnz = self.n, self.st.nnz
+        proto = C.CFUNCTYPE(None, _D, C.c_double, _D, _D, _D, _D)
+
+        def cb(u, t, G, Cm, b, lw):
+            g, c, bb, l = fn(np.ctypeslib.as_array(u, (n,)).copy(), float(t))
+            np.ctypeslib.as_array(G, (nnz,))[:] = g
+            np.ctypeslib.as_array(Cm, (nnz,))[:] = c
+            np.ctypeslib.as_array(b, (n,))[:] = bb
+            if l is not None:
+                np.ctypeslib.as_array(lw, (n,))[:] = l
+        self._stamper = proto(cb)            # keep the trampoline alive
+        lib().port_set_stamp_callback.restype = None
+        lib().port_set_stamp_callback(self.p, self._stamper)
+
     def set_lu(self, prog):
         """``prog``: dict of int32 arrays (rperm cperm rowptr col diag load_src load_dst ent_pos ent_diag ent_ptr term_a term_b)."""
         k = {nm: _ia(prog[nm]) for nm in ("rperm", "cperm", "rowptr", "col", "diag", "load_src", "load_dst", "ent_pos", "ent_diag",

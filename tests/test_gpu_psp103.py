@@ -134,3 +134,42 @@ def test_dff_with_the_reference_bsim4v8_text_latches():
     assert abs(q[0]) < 0.02 and abs(q[1]) < 0.02 and abs(q[2] - 1.8) < 0.02, q
     assert abs(qn[2]) < 0.02 and abs(qn[0] - 1.8) < 0.02, qn
     print("bsim4v8 DFF: %d Newton iterations, %d accepted / %d rejected steps, %.2f s" % (stats["newton_iters"], stats["steps_accepted"], stats["steps_rejected"], stats["wall_seconds"]))
+
+
+@pytest.mark.parametrize("name,case", [("psp103_ring", "ring"), ("bsim4_dff", "bsim4_dff")])
+def test_generated_model_transient_follows_the_oracle_trajectory(name, case):
+    """Config 5's trajectory pin (and the bsim4v8 flip-flop's): tests/golden/<name>_tran.npz holds slices of the transient as the C++ port's
+    controller and LU produce them on stamps of the literal Python interpreter (tools/make_tran_fixtures.py: oracle/va_ref.py behind
+    cpu_port.Port.set_stamper; newton_mode 2 = the per-op GPU path's mode 1).  Same start state, same pivot order (chosen on the fixture's
+    sample matrix), same options: the GPU's per-op path must take the same path -- identical Newton, accepted and rejected step counts -- and
+    land on the same waveforms.  The bar is 1e-9 relative wherever the circuit does not amplify differences itself: all of the flip-flop's
+    slice; the ring up to the kick, and the ring's second slice (a restart on the limit cycle).  Between the kick and saturation the ring
+    leaves a metastable point and multiplies whatever the two sides differ by -- the stamps' last bits, 3e-14 -- by its start-up gain
+    (measured: 2e-13 at 0.7 ns, 2e-10 at 1.3 ns, 3e-7 from 2 ns on, then flat): there the bar is 2e-6.  (Between this repository's
+    restatements: the reference holds no waveform for these decks.)"""
+    path = os.path.join(GOLD, "%s_tran.npz" % name)
+    if not os.path.exists(path):
+        pytest.skip("fixture %s not generated" % path)
+    f = np.load(path)
+    st, x, sim = _sim(case, mode="tran")
+    ref_order = np.empty(st.nnz)
+    ref_order[np.asarray(st.to_ref_nz)] = f["sample"]
+    sim.h.analyze_values(ref_order)
+    sim.h.set_spec(mode="tran")
+    slices = [(f["u0"], 0.0, float(f["t1"][0]), f["breaks"], f["save_t"], f["out"], f["counts"])]
+    if "u1" in f.files:
+        slices.append((f["u1"], float(f["t1"][0]), float(f["t2"][0]), f["breaks2"], f["save_t2"], f["out2"], f["counts2"]))
+    for k, (u0, t0, t1, breaks, save_t, ref, counts) in enumerate(slices):
+        sim.h.set_u(u0[None, :])
+        out, per, stats = sim.h.tran_run(t0, t1, f["atol"], float(f["reltol"][0]), breaks=breaks, save_t=save_t, obs=[int(j) for j in f["obs"]],
+                                         hmax=float(f["hmax"][0]), fused=0, newton_mode=1)
+        assert stats["n_failed"] == 0, stats
+        dev = np.max(np.abs(out[0] - ref) / np.maximum(np.abs(ref), 1.0), axis=1)
+        print("%s slice %d: GPU %d Newton iterations, %d accepted / %d rejected; oracle %s; worst relative deviation %.2e" % (
+            name, k, per[0, 0], per[0, 1], per[0, 2], counts[:3].tolist(), dev.max()))
+        assert (int(per[0, 0]), int(per[0, 1]), int(per[0, 2])) == tuple(int(c) for c in counts[:3])
+        if name == "psp103_ring" and k == 0:
+            assert np.all(dev[save_t <= 1.0e-9] <= 1e-9) and dev.max() <= 2e-6, dev
+        else:
+            assert dev.max() <= 1e-9, dev
+    sim.close()

@@ -755,3 +755,35 @@ def test_exporter_twin_from_the_reference_compiled_structure(name):
     short[-1] = X.DeviceRow(short[-1].type, short[-1].nodes, short[-1].ipar, short[-1].program[:-1], short[-1].shape)
     with pytest.raises(ValueError):
         X.export_structure(cs, short)
+
+
+def test_port_external_stamper_reproduces_its_own_transient():
+    """oracle/cpu_port.py: Port.set_stamper (the hook through which the literal Verilog-A interpreter drives the port's transient controller for
+    circuits of generated models, tools/make_tran_fixtures.py): with the stamps of a second, ordinary port behind the callback the
+    transient is the same doubles as the ordinary port's own."""
+    from cadnip_jl_amd import benchmarks as bm
+    from cadnip_jl_amd.structure import expand_breakpoints
+    from tests.port_util import make_port, analyze_port
+    circ = bm.inverter_circuit()
+    st, a = make_port(circ, {"vdd": 5.0}, 27.0, "tran")
+    _, b = make_port(circ, {"vdd": 5.0}, 27.0, "tran")
+    _, helper = make_port(circ, {"vdd": 5.0}, 27.0, "tran")
+
+    def stamper(u, t):
+        G, C, bb, lw = helper.rebuild(u, t)
+        full = np.zeros(st.n)
+        full[st.n - st.n_limits:] = lw
+        return G, C, bb, full
+    prog = analyze_port(st, a, 5.0)
+    b.set_lu(prog)
+    b.set_stamper(stamper)
+    a.set_spec(mode="tranop"); u0, ok, _ = a.dc(abstol=1e-9); a.set_spec(mode="tran")
+    assert ok
+    ts = np.linspace(0.0, 1.5e-7, 16)
+    kw = dict(breaks=expand_breakpoints(st.breakpoints, (0.0, 1.5e-7)), save_t=ts, err_mask=st.differential_mask(), use_pcnr=False, newton_mode=2)
+    atol = st.state_abstol(vntol=1e-6, iabstol=1e-9, chgtol=1e-6)
+    oa, _, sa, _ = a.tran(u0, 0.0, 1.5e-7, atol, 1e-4, **kw)
+    ob, _, sb, _ = b.tran(u0, 0.0, 1.5e-7, atol, 1e-4, **kw)
+    assert sa["status"] == 1 and np.array_equal(oa, ob) and (sa["newton_iters"], sa["accepted"], sa["rejected"]) == (sb["newton_iters"], sb["accepted"], sb["rejected"])
+    for p in (a, b, helper):
+        p.close()
