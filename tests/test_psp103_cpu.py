@@ -94,3 +94,35 @@ def test_bsim4_dff_fixture_layout():
         from cadnip_jl_amd.va import hipgen
         m = va.get("sp_bsim4v8")[1]
         assert (m.n_nodes, m.n_sites, hipgen.tl_lanes(m)) == (13, 18, 32) and hipgen.tl_lanes(va.get("PSP103VA")[1]) == 16
+
+
+@needs_source
+def test_psp103_passes_the_gummel_symmetry_test():
+    """A pin on the interpreted model that does not come from this repository's parser: PSP is a surface-potential model with a symmetric
+    linearisation and passes the Gummel symmetry test by construction (the property the model's authors publish it for) -- with
+    V(d) = +Vx, V(s) = -Vx at fixed gate and bulk the drain current is an ODD function of Vx, through the origin with a continuous slope.
+    Nothing in the parser, the preprocessor (the model is five include files of macros), the branch analysis or the dual arithmetic
+    knows that; a mis-read expression breaks it.  Checked on the oracle's DC solutions of the reference's NMOS test device
+    (test/mna/psp103_integration.jl:40-62: W = 10 u, L = 1 u, default card): Id(+Vx) = -Id(-Vx) to 1e-9 relative for Vx from 1 mV to
+    0.3 V, Id(0) = 0, and Id / Vx is the same to 0.5 % at 1 mV and 2 mV (no kink at the origin)."""
+    from cadnip_jl_amd import netlist
+    from oracle import mna_ref as M
+    from oracle.netlist_ref import make_builder
+
+    def drain_current(vx, vg=0.8):
+        deck = ("* PSP103VA Gummel symmetry\n.model nch psp103va type=1\nM1 d g s 0 nch W=10u L=1u\nVd d 0 DC %r\nVs s 0 DC %r\nVg g 0 DC %r\n" % (vx, -vx, vg))
+        circ = netlist.read_spice(deck)[0]
+        sol = M.solve_dc(make_builder(circ.to_dicts({})), {}, M.MNASpec(mode="dcop", temp=27.0))
+        assert sol.converged
+        return -float(sol["I_Vd"]), -float(sol["I_Vs"])
+
+    i0d, i0s = drain_current(0.0)
+    assert abs(i0d) < 1e-15 and abs(i0s) < 1e-15
+    slopes = []
+    for vx in (1e-3, 2e-3, 2e-2, 0.1, 0.3):
+        idp, isp = drain_current(vx)
+        idm, ism = drain_current(-vx)
+        assert idp > 0 and abs(idp + idm) <= 1e-9 * abs(idp), (vx, idp, idm)
+        assert abs(idp + isp) <= 1e-9 * abs(idp) + 1e-15 and abs(isp - idm) <= 1e-9 * abs(idp)       # what enters the drain leaves the source; swapping the terminals swaps the currents
+        slopes.append(idp / vx)
+    assert abs(slopes[0] - slopes[1]) <= 5e-3 * slopes[0], slopes
