@@ -360,19 +360,23 @@ class BatchSimulator:
         packed = pack_params(self.st, self.mc.circuit, self.params, self.temps, self.B, gmin=self.mc.spec.gmin, tnom_c=self.mc.spec.tnom)
         return [opinfo.operating_point(self.st, np.asarray(u)[i], Sg[i], Sb[i], packed, i) for i in range(self.B)]
 
-    def dc_continuation(self, abstol=1e-10, maxiters=100, mode="dcop", fused=False):
+    def dc_continuation(self, abstol=1e-10, maxiters=100, mode="dcop", fused=False, serial=False):
         """dc!(cs; continuation=true) (sweeps.jl:489-532) for a resident batch.  The reference walks the sweep serially and
         starts every point from the last CONVERGED solution.  Here the sweep is solved in 1 + ceil(log2 B) batch stages
         (``continuation_stages``): point 0 cold, then the midpoints, quarter points, ... each started from the nearest
         converged point of the earlier stages at a lower index (the reference's direction), else the nearest converged
-        one at all, else cold.  Continuation changes the path Newton takes, not where it lands (test/sweep.jl:332-345);
-        a point that failed is never a starting guess (sweeps.jl:522-524).  Returns (u, converged, stats)."""
+        one at all, else cold; a point that failed is never a starting guess (sweeps.jl:522-524).  For a circuit with ONE
+        operating point continuation changes the path Newton takes, not where it lands (test/sweep.jl:332-345).  A circuit with
+        several (a latch, a Schmitt trigger, the flip-flop itself) is different: the reference's strictly serial chain i - 1 -> i
+        follows one branch of the hysteresis, while a seed from B / 2 points away can land on another.  ``serial=True`` is that
+        chain: B stages of one point each, every point started from its converged predecessor (B launches instead of log2 B --
+        the price of following a branch).  Returns (u, converged, stats)."""
         st = self.st
         u = np.zeros((self.B, st.n))
         conv = np.zeros(self.B, dtype=bool)
         solved = np.zeros(self.B, dtype=bool)
         total = {"newton_iters": 0, "stages": 0, "cold_points": 0}
-        for stage in continuation_stages(self.B):
+        for stage in ([[i] for i in range(self.B)] if serial else continuation_stages(self.B)):
             start = np.zeros((self.B, st.n))
             mask = np.zeros(self.B, dtype=bool)
             mask[stage] = True
@@ -490,8 +494,10 @@ def _resolve_abstol(abstol, st):
 def dc(target, u0=None, device=0, continuation=True):
     """dc!(circuit) / dc!(cs::CircuitSweep; continuation=true) -- sweeps.jl:450-455, 489-532.  Goes through
     with_mode(:dcop), which keeps only temp+mode of the spec (solve.jl:1976-1989).  A sweep is partitioned by structure
-    (``structure_classes``); each class is one resident batch, solved with the staged continuation or as independent cold
-    solves (``continuation=False``: e.g. circuits with several DC solutions)."""
+    (``structure_classes``); each class is one resident batch, solved with the staged continuation (``continuation=True``), with the
+    reference's strictly serial chain point i - 1 -> point i (``continuation="serial"``: the choice for circuits with several DC
+    solutions, whose branch a sweep is meant to follow -- see ``BatchSimulator.dc_continuation``), or as independent cold solves
+    (``continuation=False``)."""
     if isinstance(target, CircuitSweep):
         mc = target.circuit
         mc = MNACircuit(mc.circuit, mc.params, MNASpec(temp=mc.spec.temp, mode="dcop"))
@@ -500,7 +506,7 @@ def dc(target, u0=None, device=0, continuation=True):
         for idx, st in structure_classes(mc, pts):
             sim = BatchSimulator(mc, [pts[i] for i in idx], device, st=st)
             try:
-                u, conv, _ = sim.dc_continuation() if continuation else sim.dc()
+                u, conv, _ = sim.dc_continuation(serial=continuation == "serial") if continuation else sim.dc()
                 ops = sim.operating_points(u)
                 for k, i in enumerate(idx):
                     sols[i] = DCSolution(sim.st, u[k], conv[k], ops[k])

@@ -367,6 +367,7 @@ int cadnip_jacobian(CadnipHandle* h, const double* gamma_host, double* J_ref_nz_
 // ODE form (src/mna/solve.jl:2241-2276): du = b - G u,  J = -G
 int cadnip_ode_rhs(CadnipHandle* h, const double* u_host, const double* t_host, double* du_host) {
   if (!h || !du_host) return CADNIP_BADARG;
+  stage_begin(h);          // (an earlier entry point that failed between stage_down and stage_finish must not leave its downloads pending)
   size_t B = h->B, n = h->n;
   if (u_host) { TRY(upload_state(h, u_host, t_host)); TRY(launch_rebuild(h)); }
   TRY_RC(dev_zero_async(h, h->d_du, B * n * sizeof(double)));
@@ -380,6 +381,7 @@ int cadnip_ode_rhs(CadnipHandle* h, const double* u_host, const double* t_host, 
 
 int cadnip_ode_jacobian(CadnipHandle* h, const double* u_host, const double* t_host, double* J_ref_nz_host) {
   if (!h || !J_ref_nz_host) return CADNIP_BADARG;
+  stage_begin(h);          // (an earlier entry point that failed between stage_down and stage_finish must not leave its downloads pending)
   TRY_RC(dev_zero_async(h, h->d_nonfinite, (size_t)h->B * sizeof(int)));
   if (u_host) { TRY(upload_state(h, u_host, t_host)); TRY(launch_rebuild(h)); }
   TRY_RC(dev_zero_async(h, h->d_gamma, (size_t)h->B * sizeof(double)));
@@ -391,6 +393,7 @@ int cadnip_ode_jacobian(CadnipHandle* h, const double* u_host, const double* t_h
 
 int cadnip_get_GCb(CadnipHandle* h, double* G_ref_nz, double* C_ref_nz, double* b, double* limit_w) {
   if (!h) return CADNIP_BADARG;
+  stage_begin(h);          // (an earlier entry point that failed between stage_down and stage_finish must not leave its downloads pending)
   size_t B = h->B, n = h->n;
   if (G_ref_nz) TRY(readback_ref_order(h, h->d_G, G_ref_nz));
   if (C_ref_nz) TRY(readback_ref_order(h, h->d_C, C_ref_nz));
@@ -709,6 +712,9 @@ int cadnip_debug_stamp_time(CadnipHandle* h, int32_t block, int32_t reps, double
   float ms = 0;
   HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   *ms_total = ms;
+  // a single block launched on its own adds to the words an earlier kernel of a restamp wrote (read-modify-write / atomic targets):
+  // leave G, C, b as one full restamp leaves them
+  if (block >= 0) { TRY(launch_rebuild(h)); HIP_TRY(hipStreamSynchronize(h->stream)); }
   return CADNIP_OK;
 }
 int cadnip_sync(CadnipHandle* h) { if (!h) return CADNIP_BADARG; HIP_TRY(hipStreamSynchronize(h->stream)); return CADNIP_OK; }

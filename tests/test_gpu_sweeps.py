@@ -71,3 +71,42 @@ def test_sweep_across_a_structural_boundary_is_split_by_structure():
         assert sol["d"] == pytest.approx(ref["d"], abs=1e-8) and sol["I_vd"] == pytest.approx(ref["I_vd"], rel=1e-7)
         if has_int:
             assert sol["m1_sp_mos1_d_int"] == pytest.approx(ref["m1_sp_mos1_d_int"], abs=1e-8)
+
+
+def test_serial_continuation_follows_a_branch_of_a_bistable_circuit():
+    """A latch (two cross-coupled sp_mos1 inverters, the first one's input driven through 4 kOhm) has two stable operating points over a
+    window of the drive voltage: which one a sweep reports depends on where it comes from.  The reference chains strictly point i - 1 ->
+    point i (sweeps.jl:511-532), so an upward sweep stays on the branch it started on until that branch ends, and a downward sweep on the
+    other: hysteresis.  continuation="serial" is that chain -- it lands, point for point, where the oracle's serial dc! lands, in both
+    directions, and the two directions differ inside the window; the staged continuation (seeds from far away) is not required to."""
+    from cadnip_jl_amd import benchmarks as bm
+
+    def latch():
+        c = cj.Circuit("latch")
+        c.V("vdd", "VDD", "0", dc=5.0)
+        c.V("vin", "in", "0", dc=cj.Param("vin"))
+        c.R("rin", "in", "a", 4e3)
+        c.MOS1("mn1", "b", "a", "0", "0", bm.NFET_06V0, w=0.36e-6, l=0.6e-6)
+        c.MOS1("mp1", "b", "a", "VDD", "VDD", bm.PFET_06V0, w=0.495e-6, l=0.5e-6)
+        c.MOS1("mn2", "a", "b", "0", "0", bm.NFET_06V0, w=0.36e-6, l=0.6e-6)
+        c.MOS1("mp2", "a", "b", "VDD", "VDD", bm.PFET_06V0, w=0.495e-6, l=0.5e-6)
+        return c
+
+    vals = np.linspace(0.0, 5.0, 21)
+    res = {}
+    for direction, vv in (("up", vals), ("down", vals[::-1])):
+        mc = api.MNACircuit(latch(), {"vin": float(vv[0])})
+        sweep = api.dc(api.CircuitSweep(mc, api.Sweep(vin=vv)), continuation="serial")
+        assert all(s.converged for _, s in sweep)
+        got = np.array([s["b"] for _, s in sweep])
+        # the oracle's serial chain: every point from its predecessor's solution
+        ref, u_prev = [], None
+        for v in vv:
+            sol = M.solve_dc(make_builder(latch().to_dicts({"vin": float(v)})), {}, M.MNASpec(mode="dcop"), u0=u_prev)
+            assert sol.converged
+            u_prev = np.asarray(sol.x, dtype=float)
+            ref.append(float(sol["b"]))
+        assert np.max(np.abs(got - np.array(ref))) < 1e-6, (direction, got, ref)
+        res[direction] = got if direction == "up" else got[::-1]
+    assert np.max(np.abs(res["up"] - res["down"])) > 4.0          # a window where the two branches differ by (almost) the supply
+    assert abs(res["up"][0] - res["down"][0]) < 1e-6 and abs(res["up"][-1] - res["down"][-1]) < 1e-6
