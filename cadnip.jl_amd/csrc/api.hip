@@ -511,6 +511,15 @@ int cadnip_host_f2_get(const CadnipHostF2* f, int32_t which, void* dst) {
   }
   return CADNIP_BADARG;
 }
+// steps of the team layout of the same program (f2_program.cpp: f2_build_team): out[0..2] = steps of the pre-core, post-core and forward-only lists,
+// out[3] = descriptor words (64-bit)
+int cadnip_host_f2_team_steps(const CadnipHostLU* lu, int32_t nc, int32_t nw, int32_t* out) {
+  if (!lu || !out || nc < 0 || nc > lu->p.n || (nw != 1 && nw != 2 && nw != 4)) return CADNIP_BADARG;
+  cadnip::F2Team T;
+  if (!cadnip::f2_build_team(lu->p, lu->p.n, nc, nw, T)) return CADNIP_BADARG;
+  out[0] = T.n_steps[0]; out[1] = T.n_steps[1]; out[2] = T.n_steps[2]; out[3] = (int32_t)T.desc.size();
+  return CADNIP_OK;
+}
 void cadnip_host_f2_free(CadnipHostF2* f) { delete f; }
 void cadnip_host_lu_free(CadnipHostLU* lu) { delete lu; }
 
@@ -715,6 +724,24 @@ int cadnip_debug_stamp_time(CadnipHandle* h, int32_t block, int32_t reps, double
   // a single block launched on its own adds to the words an earlier kernel of a restamp wrote (read-modify-write / atomic targets):
   // leave G, C, b as one full restamp leaves them
   if (block >= 0) { TRY(launch_rebuild(h)); HIP_TRY(hipStreamSynchronize(h->stream)); }
+  return CADNIP_OK;
+}
+// Measurement: the cost of ONE Newton iteration inside the team kernel, phase by phase.  The STEP-mode kernel repeats the iteration at the handle's
+// resident state (d_u, d_du, d_gamma, d_t) `reps` times in one launch; `skip` leaves phases out (1 stamping, 2 adding the waves' private
+// sums, 4 the linear solve's steps, 8 the dense core), so that differences of two calls are a phase's cost.  ms_total: the launch (HIP events).
+int cadnip_debug_step_time(CadnipHandle* h, int32_t refresh, int32_t reps, int32_t skip, double* ms_total) {
+  if (!h || reps <= 0 || !ms_total) return CADNIP_BADARG;
+  FusedStepIO io;
+  io.u = h->d_u; io.du = h->d_du; io.gamma = h->d_gamma; io.t = h->d_t; io.gamma_keep = nullptr; io.t_keep = nullptr;
+  io.delta = h->d_delta; io.resid = nullptr; io.norm = h->d_tmp; io.flags = h->d_flags; io.reps = reps; io.skip = skip;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  TRY(launch_fused_step(h, refresh ? 1 : 0, io));
+  HIP_TRY(hipEventRecord(h->ev1, h->stream));
+  HIP_TRY(hipEventSynchronize(h->ev1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *ms_total = ms;
   return CADNIP_OK;
 }
 int cadnip_sync(CadnipHandle* h) { if (!h) return CADNIP_BADARG; HIP_TRY(hipStreamSynchronize(h->stream)); return CADNIP_OK; }

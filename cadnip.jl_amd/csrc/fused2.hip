@@ -145,7 +145,7 @@ static bool f2_prepare(CadnipHandle* h, F2Tables& T, const std::vector<int>& g_p
 }
 
 struct F2DcOpts { double abstol; int maxiters, use_pcnr, mode, initjct; int* dcstate; };
-struct F2StepOpts { int refresh; double *resid, *norm; };   // cadnip_newton_step_fused: one Newton iteration in the team kernel (STEP mode)
+struct F2StepOpts { int refresh; double *resid, *norm; int reps, skip; };   // cadnip_newton_step_fused: one Newton iteration in the team kernel (STEP mode)
 
 // Build (or rebuild) the structure tables; CADNIP_BADARG if the circuit cannot be expressed in them (16-bit offsets)
 static int fused2_tables(CadnipHandle* h) {
@@ -258,6 +258,7 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
   f.n_pre = h->f2_n_pre; f.n_post = h->f2_n_post; f.nc = h->f2_nc; f.dn0 = h->f2_dn0; f.n_fwd = h->f2_n_fwd;
   f.lufac = nullptr; f.team_desc = nullptr; f.team_desc_len = 0; f.par_words = 0; f.ts_pre = f.ts_post = f.ts_fwd = 0;
   f.step_refresh = step ? step->refresh : 0; f.step_resid = step ? step->resid : nullptr; f.step_norm = step ? step->norm : nullptr;
+  f.step_reps = step ? step->reps : 1; f.step_skip = step ? step->skip : 0;
   if (!dc && (t.newton_mode || step)) {
     // IDA-style Jacobian reuse exists in the lean direct-residual variant (fused2_kernel.hpp); the kept factors of instances that
     // are not resident live in HBM
@@ -340,7 +341,7 @@ int launch_fused_step(CadnipHandle* h, int refresh, const FusedStepIO& io) {
   t.u = (double*)io.u; t.du = (double*)io.du; t.delta = io.delta; t.limit_w = h->d_limit_w; t.tcur = (double*)io.t; t.gamma = (double*)io.gamma; t.active = h->d_active; t.flags = io.flags;
   t.t = io.t_keep; t.h = io.gamma_keep;                   // (STEP mode: where the caller's times / leading coefficients are also kept)
   t.B = h->B; t.n = h->n; t.n_limits = h->n_limits;
-  F2StepOpts so{refresh, io.resid, io.norm};
+  F2StepOpts so{refresh, io.resid, io.norm, io.reps > 0 ? io.reps : 1, io.skip};
   return launch_fused2(h, t, 1 << 30, nullptr, &so);
 }
 

@@ -54,6 +54,7 @@ struct F2Args {
   int ts_pre, ts_post, ts_fwd;      // ... steps of the pre-core, post-core and forward-only lists
   int par_words;                    // team kernel: doubles of the LDS-staged sp_mos1 parameter rows (F2Block::lds_par)
   int step_refresh; double *step_resid, *step_norm;   // team kernel, STEP mode (cadnip_newton_step_fused): refactor or use f.lufac; optional outputs
+  int step_reps, step_skip;         // STEP mode, measurement only (cadnip_debug_step_time): repeat the same iteration, leave phases out (1 stamping, 2 combine, 4 linear-solve steps, 8 dense core)
   // DC mode (k_fused2<WPB, true>): PCNR / plain Newton on G u = b (driver.hip: k_dc_check, k_dc_update)
   double dc_abstol; int dc_maxiters, dc_pcnr, dc_mode, dc_initjct; int* dcstate;
   const int* cold;           // [B] DC mode: 1 = the instance starts cold (initjct applies to it), driver.hip: k_dc_init

@@ -309,6 +309,7 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
     // the right-hand side and the trash words.  Runs at the END of a round (and once at pick-up), so that one barrier closes the
     // update and the clearing together.
     bool refresh = true;
+    int step_rep = 0;
     auto begin_round = [&]() {
       refresh = true;
       if (mn) {
@@ -330,7 +331,8 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
       const double tcur = st.tn, a0 = st.a0;
       const unsigned trash_w = (unsigned)(f.nnz_lu + n + lane);
       // ---- stamp: every wave its share
-      if (others) {
+      const int skip = STEP ? f.step_skip : 0;                // (measurement: cadnip_debug_step_time)
+      if (others && !(skip & 1)) {
         auto at = [&](unsigned nd16) -> double { const double x = us[nd16 == 0xFFFFu ? 0u : nd16]; return nd16 == 0xFFFFu ? 0.0 : x; };
         auto dat = [&](unsigned nd16) -> double {
           const unsigned i = nd16 == 0xFFFFu ? 0u : nd16;
@@ -379,7 +381,7 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
         }
         CADNIP_TRACE_POINT(13);
       }
-      if (roles && m1_blk0 >= 0) {
+      if (roles && m1_blk0 >= 0 && !(skip & 1)) {
         const int side = lane & 1;
         rv.initjct = 0;
         if (!refresh) {       // round on kept factors: residuals only
@@ -390,7 +392,7 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
           stamp_mos1_team(rv, us, s, lw, side, m1_valid0, roles, vdep0);
         }
       }
-      if (more)
+      if (more && !(skip & 1))
       for (int bi = 0; bi < f.n_blk; ++bi) {
         const F2Block B = load_block(f.blk, bi);
         if (B.type == CADNIP_DEV_MOS1 && B.mos1_plain) {
@@ -432,6 +434,7 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
       CADNIP_TRACE_POINT(8);
       __syncthreads();
       // the other waves' contributions, in wave order (a round on kept factors has stamped the right-hand side only)
+      if (!(skip & 2))
       for (int i = (refresh ? 0 : f.nnz_lu) + tid; i < f.nnz_lu + n; i += NT) {
         double acc = W[i];
 #pragma unroll
@@ -479,10 +482,11 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
           D = Dn;
         }
       };
-      if (refresh) run_steps(0, f.ts_pre);
+      if (skip & 4) {}
+      else if (refresh) run_steps(0, f.ts_pre);
       else run_steps(f.ts_pre + f.ts_post, f.ts_fwd);
       CADNIP_TRACE_POINT(4);
-      if (f.nc > 0) {
+      if (f.nc > 0 && !(skip & 8)) {
         if (w == 0) {
           const int yc0 = f.nnz_lu + n - f.nc;
           if (refresh) {
@@ -498,13 +502,21 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
         __syncthreads();
       }
       CADNIP_TRACE_POINT(5);
-      run_steps(f.ts_pre, f.ts_post);
+      if (!(skip & 4)) run_steps(f.ts_pre, f.ts_post);
       CADNIP_TRACE_POINT(3);
       if constexpr (STEP) {
         double* dout = kargs()->t.delta + vo;                 // (possibly mapped host memory: plain stores, a system-scope fence behind them)
         for (int i = tid; i < n; i += NT) { const double dd = W[qinv[i]]; if (!isfinite(dd)) bad = 1; dout[i] = dd; }
         if (__syncthreads_or(bad) && tid == 0) kargs()->t.flags[inst] = 1;
         __threadfence_system();
+        if (++step_rep < f.step_reps) {                       // measurement: the same iteration again
+          __syncthreads();
+          vec.step_consumed(tid);
+          st.mflags = f.step_refresh ? MN_NEED : MN_VALID; st.k = 1;
+          begin_round();
+          __syncthreads();
+          continue;
+        }
         st.status = 1;                                        // one iteration: done
         --budget;
         break;

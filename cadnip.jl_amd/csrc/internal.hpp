@@ -218,7 +218,7 @@ struct TranArgs;                                                          // tra
 int launch_fused2_rounds(CadnipHandle* h, const TranArgs& t, int rounds); // fused2.hip
 // one Newton iteration in the team kernel (fused2.hip): device-visible pointers (device memory or mapped pinned host memory) of its inputs and outputs;
 // gamma_keep / t_keep: device arrays that also receive the caller's gamma / t (the handle's state stays what the per-op entry points would leave)
-struct FusedStepIO { const double *u, *du, *gamma, *t; double *gamma_keep, *t_keep, *delta, *resid, *norm; int* flags; };
+struct FusedStepIO { const double *u, *du, *gamma, *t; double *gamma_keep, *t_keep, *delta, *resid, *norm; int* flags; int reps = 1, skip = 0; };   // reps / skip: measurement (cadnip_debug_step_time)
 int launch_fused_step(CadnipHandle* h, int refresh, const FusedStepIO& io);
 int launch_va_setup(CadnipHandle* h, DeviceBlock& b);                        // stamp_csr.hip: the setup pass of a generated external model's block
 bool fused2_tables_ready(CadnipHandle* h);                                 // the packed tables exist (built on demand)

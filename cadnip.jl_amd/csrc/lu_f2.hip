@@ -198,6 +198,100 @@ __global__ void __launch_bounds__(64 * WPI) k_lu_f2_mw(LuF2Args f) {
   if (wave_any(bad) && lane == 0) atomicOr(&f.flags[inst], 1);
 }
 
+// The same refactor + solve as straight-line STEPS for a team of four waves per instance (f2_program.cpp: f2_build_team, as the fused team
+// kernel runs them): every thread owns one 8-byte descriptor per step -- word offsets of the entry, its pivot and the two factors of its
+// one multiply-add term -- so a step is ~60 instructions without branches, a barrier closes it.  The descriptors are per thread: they are
+// fetched from global memory a CHUNK of steps ahead into registers (the loads of chunk c + 1 are in flight while chunk c runs), nothing
+// of the program lives in LDS -- only the work array does, so a circuit whose tables do not fit beside it (the PSP103 ring: 86 steps x
+// 256 threads) runs here all the same.  For few instances -- where k_lu_f2's one wave per instance walks 100+ passes alone.
+struct LuStepArgs {
+  const u64* desc; int n_pre, n_post;
+  const u16 *loadpos, *rowof, *qinv;              // global copies of the table sections (csr entry -> W word, unknown -> rhs word, unknown -> solution word)
+  const double *G, *C, *gamma, *rhs; double* x;
+  const int* active; int* flags;
+  int B, n, nnz, lu_words, nc, dn0;
+};
+#define LU_CHUNK 8
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_lu_steps(LuStepArgs f) {
+  constexpr int NT = 64 * NW;
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), n = f.n;
+  const int inst = blockIdx.x;
+  if (inst >= f.B || !f.active[inst]) return;                 // (uniform over the workgroup)
+  const int nW = f.lu_words + n + F2_TRASH;
+  double* W = sm;
+  for (int i = tid; i < (nW >> 1); i += NT) ((double2*)W)[i] = make_double2(0.0, 0.0);
+  if (tid == 0) { W[nW] = 0.0; W[nW + 1] = 1.0; }            // the steps' constant words (f2_build_team)
+  // this thread's descriptors of the first chunk: requested before the matrix is loaded
+  const u64* dp = f.desc + tid;
+  u64 cur[LU_CHUNK], nxt[LU_CHUNK];
+  const int n_steps = f.n_pre + f.n_post;
+#pragma unroll
+  for (int k = 0; k < LU_CHUNK; ++k) cur[k] = dp[(size_t)(k < n_steps ? k : 0) * NT];
+  __syncthreads();
+  {
+    const double* G = f.G + (size_t)inst * f.nnz;
+    const double* C = f.C + (size_t)inst * f.nnz;
+    const double gam = f.gamma[inst];
+    for (int e = tid; e < f.nnz; e += NT) W[f.loadpos[e]] = G[e] + gam * C[e];
+    const double* rhs = f.rhs + (size_t)inst * n;
+    for (int i = tid; i < n; i += NT) W[f.rowof[i]] = rhs[i];
+  }
+  __syncthreads();
+  int bad = 0;
+  const unsigned trash_w = (unsigned)(f.lu_words + n + lane);
+  auto step = [&](const u64 D) {
+    const unsigned lo = (unsigned)D, hi = (unsigned)(D >> 32);
+    double* const pp = W + (lo & 0x7FFFu);
+    const double piv = W[(lo >> 16) & 0x7FFFu], av = W[hi & 0x7FFFu], bv = W[(hi >> 16) & 0x7FFFu];
+    const double acc0 = *pp;
+    const unsigned lg = (lo >> 31) | ((hi >> 14) & 2u) | ((hi >> 29) & 4u);
+    double part = av * bv;
+    { const double o = dpp_f64<0xB1>(part); part += lg >= 1 ? o : 0.0; }
+    { const double o = dpp_f64<0x4E>(part); part += lg >= 2 ? o : 0.0; }
+    { const double o = dpp_f64<0x141>(part); part += lg >= 3 ? o : 0.0; }
+    { const double o = dpp_f64<0x140>(part); part += lg >= 4 ? o : 0.0; }
+    if (piv == 0.0 || !isfinite(piv)) bad = 1;
+    const double acc = fast_div(acc0 - part, piv);
+    *((lo & 0x8000u) ? pp : W + trash_w) = acc;
+    __syncthreads();
+  };
+  // chunks of LU_CHUNK steps; the dense core sits between step n_pre - 1 and step n_pre
+  for (int c0 = 0; c0 < n_steps; c0 += LU_CHUNK) {
+#pragma unroll
+    for (int k = 0; k < LU_CHUNK; ++k) { const int sidx = c0 + LU_CHUNK + k; nxt[k] = dp[(size_t)(sidx < n_steps ? sidx : 0) * NT]; }
+#pragma unroll
+    for (int k = 0; k < LU_CHUNK; ++k) {
+      const int sidx = c0 + k;
+      if (sidx == f.n_pre && f.nc > 0) {                     // (uniform)
+        if (w == 0) {
+          const int yc0 = f.lu_words + n - f.nc;
+          if (f.nc == 8) dense_core_solve<8, 0>(W, f.dn0, yc0, lane, bad, false);
+          else if (f.nc == 12) dense_core_solve<12, 0>(W, f.dn0, yc0, lane, bad, false);
+          else dense_core_solve<F2_NCMAX, 0>(W, f.dn0, yc0, lane, bad, false);
+        }
+        __syncthreads();
+      }
+      if (sidx < n_steps) step(cur[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < LU_CHUNK; ++k) cur[k] = nxt[k];
+  }
+  if (f.n_post == 0 && f.nc > 0) {                            // (no step behind the core: it has not run yet)
+    if (w == 0) {
+      const int yc0 = f.lu_words + n - f.nc;
+      if (f.nc == 8) dense_core_solve<8, 0>(W, f.dn0, yc0, lane, bad, false);
+      else if (f.nc == 12) dense_core_solve<12, 0>(W, f.dn0, yc0, lane, bad, false);
+      else dense_core_solve<F2_NCMAX, 0>(W, f.dn0, yc0, lane, bad, false);
+    }
+    __syncthreads();
+  }
+  double* x = f.x + (size_t)inst * n;
+  for (int i = tid; i < n; i += NT) { const double v = W[f.qinv[i]]; if (!isfinite(v)) bad = 1; x[i] = v; }
+  if (wave_any(bad) && lane == 0) atomicOr(&f.flags[inst], 1);
+}
+
 // 0 = done with the program kernel; 1 = not applicable (the caller falls back to k_lu); < 0 never
 int launch_factor_solve_f2(CadnipHandle* h, const double* d_rhs, double* d_x) {
   if (!h->analyzed || !fused2_tables_ready(h)) return 1;   // (only the linear-solve prefix of the tables has to fit: checked below)
@@ -207,6 +301,23 @@ int launch_factor_solve_f2(CadnipHandle* h, const double* d_rhs, double* d_x) {
   f.G = h->d_G; f.C = h->d_C; f.gamma = h->d_gamma; f.rhs = d_rhs; f.x = d_x; f.active = h->d_active; f.flags = h->d_flags;
   f.B = h->B; f.n = h->n; f.nnz = h->nnz; f.lu_words = h->f2_lu_words; f.n_pre = h->f2_n_pre; f.n_post = h->f2_n_post; f.nc = h->f2_nc; f.dn0 = h->f2_dn0;
   const size_t tab_dbl = (size_t)h->f2_lu_len / 2, per = (size_t)h->f2_lu_words + h->n + F2_TRASH;
+  // at most two instances per CU: the straight-line steps of a team of four waves per instance (k_lu_steps).  CADNIP_LU_STEPS = 0 | 1 forces the choice
+  {
+    const char* e = getenv("CADNIP_LU_STEPS");
+    const bool steps = e ? atoi(e) != 0 : h->B <= 2 * h->n_cu_hint();
+    const size_t shmem_s = (per + 2) * 8;
+    if (steps && h->d_team_desc[1] && shmem_s <= 160 * 1024) {
+      LuStepArgs g;
+      g.desc = h->d_team_desc[1]; g.n_pre = h->team_steps[1][0]; g.n_post = h->team_steps[1][1];
+      g.loadpos = (const u16*)(h->d_f2tab + h->f2off[S_LOADPOS]); g.rowof = (const u16*)(h->d_f2tab + h->f2off[S_ROWOF]); g.qinv = (const u16*)(h->d_f2tab + h->f2off[S_QINV]);
+      g.G = h->d_G; g.C = h->d_C; g.gamma = h->d_gamma; g.rhs = d_rhs; g.x = d_x; g.active = h->d_active; g.flags = h->d_flags;
+      g.B = h->B; g.n = h->n; g.nnz = h->nnz; g.lu_words = h->f2_lu_words; g.nc = h->f2_nc; g.dn0 = h->f2_dn0;
+      if (shmem_s > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_lu_steps<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_s));
+      hipLaunchKernelGGL(k_lu_steps<4>, dim3(h->B), dim3(256), shmem_s, h->stream, g);
+      HIP_TRY(hipGetLastError());
+      return CADNIP_OK;
+    }
+  }
   // a few instances of a circuit with many passes: several waves per instance (k_lu_f2_mw).  CADNIP_LU_WPI forces 1 / 4 (diagnostic)
   {
     const char* e = getenv("CADNIP_LU_WPI");

@@ -21,11 +21,11 @@ STATUS_NAMES = {0: "CADNIP_OK", 1: "CADNIP_BADARG", 2: "CADNIP_SINGULAR", 3: "CA
 EXPORTS = [
     "cadnip_create", "cadnip_destroy", "cadnip_set_params", "cadnip_set_spec", "cadnip_set_initjct",
     "cadnip_rebuild", "cadnip_residual", "cadnip_jacobian", "cadnip_ode_rhs", "cadnip_ode_jacobian", "cadnip_get_GCb", "cadnip_get_contributions", "cadnip_analyze",
-    "cadnip_analyze_values", "cadnip_factor", "cadnip_solve", "cadnip_newton_step", "cadnip_newton_step_fused", "cadnip_lu_stats", "cadnip_dc_run",
+    "cadnip_analyze_values", "cadnip_factor", "cadnip_solve", "cadnip_newton_step", "cadnip_newton_step_fused", "cadnip_debug_step_time", "cadnip_lu_stats", "cadnip_dc_run",
     "cadnip_dc_log_size", "cadnip_dc_log_get", "cadnip_tran_run", "cadnip_tran_state", "cadnip_dev_ptr", "cadnip_stream", "cadnip_set_u", "cadnip_get_u", "cadnip_get_flags",
     "cadnip_sync", "cadnip_debug_copy", "cadnip_debug_stamp_time", "cadnip_profile_enable", "cadnip_profile_read", "cadnip_version",
     "cadnip_host_lu_analyze", "cadnip_host_lu_analyze_leaves", "cadnip_host_lu_size", "cadnip_host_lu_get", "cadnip_host_lu_free",
-    "cadnip_host_f2_build", "cadnip_host_f2_size", "cadnip_host_f2_get", "cadnip_host_f2_free",
+    "cadnip_host_f2_build", "cadnip_host_f2_size", "cadnip_host_f2_get", "cadnip_host_f2_free", "cadnip_host_f2_team_steps",
 ]
 
 
@@ -450,6 +450,11 @@ def host_lu_analyze(n, rowptr, colidx, vals, pivot_tol=1e-3, sample=False, f2_nc
             _check(lib.cadnip_host_lu_get(p, C.c_int32(k), _ip(a)), "cadnip_host_lu_get")
             out[nm] = a[:sz]
         if f2_nc is not None:
+            ts = (C.c_int32 * 4)()
+            out["team_steps"] = {}
+            for nw in (1, 2, 4):
+                if lib.cadnip_host_f2_team_steps(p, C.c_int32(int(f2_nc)), C.c_int32(nw), ts) == 0:
+                    out["team_steps"][nw] = tuple(int(v) for v in ts)
             # the fused kernel's entry program for this LU and core size (csrc/f2_program.cpp)
             lib.cadnip_host_f2_free.restype = None
             q = C.c_void_p()

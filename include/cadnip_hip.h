@@ -294,6 +294,9 @@ const char* cadnip_version(void);
 /* measurement aid: `reps` back-to-back launches of the stamping kernel of device block `block` (< 0: all blocks = one restamp)
  * at the handle's current u / t, timed with HIP events on the handle's stream */
 int cadnip_debug_stamp_time(CadnipHandle* h, int32_t block, int32_t reps, double* ms_total);
+/* diagnostic: one Newton iteration of the team kernel (STEP mode) repeated `reps` times at the resident state, phases left out by `skip`
+ * (1 stamping, 2 adding the waves' private sums, 4 linear-solve steps, 8 dense core); tools/team_phases.py */
+int cadnip_debug_step_time(CadnipHandle* h, int32_t refresh, int32_t reps, int32_t skip, double* ms_total);
 int cadnip_debug_copy(CadnipHandle* h, int64_t n_doubles, int32_t reps);
 
 /* ---- host-only helpers (no GPU needed): run the symbolic phase on any CSR matrix and read the
@@ -323,6 +326,7 @@ typedef enum { CADNIP_F2_POSW = 0, CADNIP_F2_LANES, CADNIP_F2_PASSES, CADNIP_F2_
 int cadnip_host_f2_build(const CadnipHostLU* lu, int32_t nc, CadnipHostF2** out);
 int32_t cadnip_host_f2_size(const CadnipHostF2* prog, int32_t which);
 int cadnip_host_f2_get(const CadnipHostF2* prog, int32_t which, void* dst);
+int cadnip_host_f2_team_steps(const CadnipHostLU* lu, int32_t nc, int32_t nw, int32_t* out4);   /* steps of the team layout (pre, post, forward-only) and its descriptor words */
 void cadnip_host_f2_free(CadnipHostF2* prog);
 
 #ifdef __cplusplus
