@@ -562,7 +562,7 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
              h->B, h->n, h->n_limits, o->n_break, o->n_save, n_obs, n_err,
              o->t0, o->t1, o->reltol, h0, hmin, hmax, o->newton_tol > 0 ? o->newton_tol : 1e-3,
              o->max_newton > 0 ? o->max_newton : 10, o->max_order > 0 ? o->max_order : 2, o->use_pcnr,
-             o->newton_mode ? 1 : 0, d->mn_a0f, d->mn_ss, d->mn_dnp, d->mn_flags};
+             o->newton_mode ? 1 : 0, d->mn_a0f, d->mn_ss, d->mn_dnp, d->mn_flags, o->step_rule ? 1 : 0};
   if (!h->analyzed) return CADNIP_NOTREADY;              // the symbolic LU phase (cadnip_analyze*) comes first
   // the per-op kernels take over where the fused kernel cannot run: external generated models (they exist in the per-op stamping kernel only), a
   // circuit too large for the LDS-resident kernel, Newton mode 1 on a circuit outside the lean device set

@@ -103,6 +103,7 @@ struct TranArgs {
   // IDANewtonIter; the rate is taken between successive updates).  Fused kernel and CPU port only.  Per-instance state:
   int newton_mode;
   double *mn_a0f, *mn_ss, *mn_dnp; int* mn_flags;
+  int step_rule;   // 0 = classical step controller, 1 = IDA's eta rule (CadnipTranOpts::step_rule)
 };
 #define MN_NEED 1     // the next round must refactor
 #define MN_JCUR 2     // a refactorisation happened in this step attempt
@@ -385,8 +386,15 @@ __device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, i
       int nh_new = s.nhist + 1 > 3 ? 3 : s.nhist + 1;
       double hnext;
       if (tested) {
-        double fac = errn > 0.0 ? 0.9 * step_root(errn, s.ord) : 2.0;
-        fac = fmin(2.0, fmax(0.2, fac));
+        double fac;
+        if (a.step_rule == 0) {
+          fac = errn > 0.0 ? 0.9 * step_root(errn, s.ord) : 2.0;
+          fac = fmin(2.0, fmax(0.2, fac));
+        } else {
+          // IDA (ida.c: IDACompleteStep / IDASetEta): double the step when the estimate allows it, shrink it by 0.5 .. 0.9 when it must, keep it otherwise
+          const double eta = errn > 0.0 ? fast_div(1.0, fast_div(1.0, step_root(2.0 * errn, s.ord)) + 1e-4) : 2.0;
+          fac = eta >= 2.0 ? 2.0 : (eta <= 1.0 ? fmax(0.5, fmin(0.9, eta)) : 1.0);
+        }
         hnext = h * fac;
       } else hnext = 2.0 * h;
       if (landed) {
@@ -408,8 +416,9 @@ __device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, i
       prepare_step(a, v, s, tid, tn, hnext, nh_new, s.hprev, s.hpp);
       CADNIP_TRACE_POINT(32);
     } else {
-      double fac = 0.9 * step_root(errn, s.ord);
-      fac = fmin(0.9, fmax(0.1, fac));
+      double fac;
+      if (a.step_rule == 0) { fac = 0.9 * step_root(errn, s.ord); fac = fmin(0.9, fmax(0.1, fac)); }
+      else { fac = fast_div(0.9, fast_div(1.0, step_root(2.0 * errn, s.ord)) + 1e-4); fac = fmin(0.9, fmax(0.25, fac)); }   // IDA after a failed error test
       double hn = h * fac;
       s.c_reject += 1;
       if (hn < a.hmin) { s.status = -1; return; }

@@ -76,7 +76,7 @@ class TranOptsC(C.Structure):
                 ("hmin", C.c_double), ("hmax", C.c_double), ("max_newton", C.c_int32), ("max_order", C.c_int32),
                 ("use_pcnr", C.c_int32), ("newton_tol", C.c_double), ("n_break", C.c_int32), ("breaks", _D),
                 ("n_save", C.c_int32), ("save_t", _D), ("n_obs", C.c_int32), ("obs", _I),
-                ("max_iterations", C.c_int64), ("fused", C.c_int32), ("newton_mode", C.c_int32)]
+                ("max_iterations", C.c_int64), ("fused", C.c_int32), ("newton_mode", C.c_int32), ("step_rule", C.c_int32)]
 
 
 class RunStatsC(C.Structure):
@@ -349,7 +349,7 @@ class Handle:
 
     def tran_run(self, t0, t1, abstol, reltol=1e-4, breaks=(), save_t=(), obs=None, h0=0.0, hmin=0.0, hmax=0.0,
                  max_newton=10, max_order=2, use_pcnr=False, newton_tol=1e-3, max_iterations=0, fused=False,
-                 err_mask="differential", newton_mode=0):
+                 err_mask="differential", newton_mode=0, step_rule=0):
         at = np.ascontiguousarray(np.broadcast_to(np.asarray(abstol, dtype=np.float64), (self.st.n,)))
         if isinstance(err_mask, str):
             em = self.st.differential_mask() if err_mask == "differential" else np.ones(self.st.n)
@@ -365,7 +365,7 @@ class Handle:
         st = RunStatsC()
         o = TranOptsC(t0, t1, reltol, _dp(at), _dp(em), h0, hmin, hmax, max_newton, max_order, int(use_pcnr), newton_tol,
                       br.size, _dp(br) if br.size else None, sv.size, _dp(sv) if sv.size else None,
-                      ob.size, _ip(ob) if ob.size else None, max_iterations, int(fused), int(newton_mode))  # fused: 0 = one kernel per op, non-zero = fused Newton kernel
+                      ob.size, _ip(ob) if ob.size else None, max_iterations, int(fused), int(newton_mode), int(step_rule))  # fused: 0 = one kernel per op, non-zero = fused Newton kernel
         rc = self.lib.cadnip_tran_run(self.h, C.byref(o), _dp(out), per.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(st))
         if rc not in (OK, NOCONV):
             _check(rc, "cadnip_tran_run")

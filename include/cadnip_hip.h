@@ -249,6 +249,11 @@ typedef struct {
                                only (first round, a0 outside [0.6, 1/0.6] of its last setup value, 20 steps, failure on a stale Jacobian), kept factors in between, rate-based
                                convergence test ss ||delta|| <= 0.33.  The fused kernel keeps the factors; the per-op kernels refactor every round (their
                                factors live in LDS for one launch) and take the convergence test only */
+  int32_t step_rule;        /* step size after the error test.  0 = the classical controller: factor 0.9 err^(-1/(k+1)) in [0.2, 2] after an accepted step, in
+                               [0.1, 0.9] after a rejected one.  1 = IDA's rule (ida.c: IDACompleteStep / IDASetEta, the reference's integrator, src/sweeps.jl:600):
+                               eta = 1 / ((2 err)^(1/(k+1)) + 1e-4); the step DOUBLES when eta >= 2, shrinks by max(0.5, min(0.9, eta)) when eta <= 1 and
+                               otherwise STAYS (fewer rejected steps, and a constant step keeps the kept factors of newton_mode 1 valid); after a failed
+                               error test the factor is 0.9 eta in [0.25, 0.9] */
 } CadnipTranOpts;
 
 typedef struct {

@@ -512,6 +512,7 @@ struct TranOpts {
   int n_break; const double* breaks; int n_save; const double* save_t; int n_obs; const int* obs;
   int newton_mode;   // 1 = IDA's nonlinear iteration: Jacobian reuse + rate test (cadnip.jl_amd/csrc/tran_ctrl.hpp, the same policy statement for statement);
                      // 2 = the same test with a refactorisation every round (what the per-op GPU path does with newton_mode 1)
+  int step_rule;     // 0 = classical step controller, 1 = IDA's eta rule (tran_ctrl.hpp, CadnipTranOpts::step_rule)
 };
 struct TranStats { int64_t newton_iters, accepted, rejected, newton_failures; int status; double wall_seconds; int64_t refactorisations; };
 
@@ -613,7 +614,12 @@ int port_tran(void* p, double* u_io, const TranOpts* o, double* out, TranStats* 
         u2 = u1; u1 = u0; u0 = u;
         bool landed = bp < o->n_break && tn == o->breaks[bp];
         int nh_new = std::min(nhist + 1, 3); double hnext;
-        if (nhist >= 2 && n_err > 0) { double fac = errn > 0.0 ? 0.9 * step_root(errn, ord) : 2.0; fac = std::min(2.0, std::max(0.2, fac)); hnext = h * fac; }
+        if (nhist >= 2 && n_err > 0) {
+          double fac;
+          if (o->step_rule == 0) { fac = errn > 0.0 ? 0.9 * step_root(errn, ord) : 2.0; fac = std::min(2.0, std::max(0.2, fac)); }
+          else { const double eta = errn > 0.0 ? 1.0 / (1.0 / step_root(2.0 * errn, ord) + 1e-4) : 2.0; fac = eta >= 2.0 ? 2.0 : (eta <= 1.0 ? std::max(0.5, std::min(0.9, eta)) : 1.0); }
+          hnext = h * fac;
+        }
         else hnext = 2.0 * h;
         double new_hprev = h, new_hpp = hprev;
         if (landed) { ++bp; nh_new = 1; double tstop = o->t1; if (bp < o->n_break && o->breaks[bp] < tstop) tstop = o->breaks[bp]; hnext = 0.1 * std::min(h, tstop - tn); }
@@ -624,7 +630,9 @@ int port_tran(void* p, double* u_io, const TranOpts* o, double* out, TranStats* 
         if (hnext < hmin) hnext = hmin;
         prepare_attempt(t, hnext, nhist, hprev, hpp);
       } else {
-        double fac = 0.9 * step_root(errn, ord); fac = std::min(0.9, std::max(0.1, fac));
+        double fac;
+        if (o->step_rule == 0) { fac = 0.9 * step_root(errn, ord); fac = std::min(0.9, std::max(0.1, fac)); }
+        else { fac = 0.9 / (1.0 / step_root(2.0 * errn, ord) + 1e-4); fac = std::min(0.9, std::max(0.25, fac)); }
         double hn = h * fac; S.rejected += 1;
         if (hn < hmin) { status = -1; break; }
         prepare_attempt(t, hn, nhist, hprev, hpp);

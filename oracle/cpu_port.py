@@ -31,7 +31,7 @@ class TranOptsC(C.Structure):
                 ("h0", C.c_double), ("hmin", C.c_double), ("hmax", C.c_double), ("max_newton", C.c_int32),
                 ("max_order", C.c_int32), ("use_pcnr", C.c_int32), ("newton_tol", C.c_double),
                 ("n_break", C.c_int32), ("breaks", _D), ("n_save", C.c_int32), ("save_t", _D),
-                ("n_obs", C.c_int32), ("obs", _I), ("newton_mode", C.c_int32)]
+                ("n_obs", C.c_int32), ("obs", _I), ("newton_mode", C.c_int32), ("step_rule", C.c_int32)]
 
 
 class TranStatsC(C.Structure):
@@ -163,7 +163,7 @@ class Port:
         return u, bool(ok), it.value
 
     def tran(self, u0, t0, t1, abstol, reltol, breaks=(), save_t=(), obs=None, err_mask=None, h0=0.0, hmin=0.0, hmax=0.0,
-             max_newton=10, max_order=2, use_pcnr=True, newton_tol=1e-3, trace_cap=0, newton_mode=0):
+             max_newton=10, max_order=2, use_pcnr=True, newton_tol=1e-3, trace_cap=0, newton_mode=0, step_rule=0):
         n = self.n
         u = np.array(u0, dtype=np.float64)
         at = _da(np.broadcast_to(np.asarray(abstol, dtype=np.float64), (n,)))
@@ -174,7 +174,7 @@ class Port:
         n_save = int(np.asarray(save_t).size)
         out = np.zeros((max(n_save, 1), n_obs))
         o = TranOptsC(t0, t1, reltol, _dp(at), _dp(em), h0, hmin, hmax, max_newton, max_order, int(use_pcnr), newton_tol,
-                      int(np.asarray(breaks).size), _dp(br), n_save, _dp(sv), len(obs) if obs is not None else 0, _ip(ob), int(newton_mode))
+                      int(np.asarray(breaks).size), _dp(br), n_save, _dp(sv), len(obs) if obs is not None else 0, _ip(ob), int(newton_mode), int(step_rule))
         st = TranStatsC()
         trace = np.zeros(max(trace_cap, 1))
         ntr = C.c_int32()

@@ -377,6 +377,41 @@ def test_dff_transient_newton_mode_1_matches_port(team, monkeypatch):
     sim.close()
 
 
+@pytest.mark.parametrize("fused,team", [(0, 0), (1, 0), (1, 4)])
+def test_ida_step_rule_matches_port(fused, team, monkeypatch):
+    """CadnipTranOpts.step_rule = 1: IDA's step-size rule (ida.c IDACompleteStep / IDASetEta: double, shrink by 0.5 .. 0.9, or keep the step)
+    in every GPU path against the port's statement-for-statement copy.  It rejects far fewer steps (DFF: 10 % -> 2 %) but, with orders
+    up to 2 only, takes 28 % more Newton iterations -- which is why it is an option and not the default."""
+    monkeypatch.setenv("CADNIP_F2_TEAM", str(team))
+    circ = bm.dff_circuit()
+    points = [{}, {"vdd": 4.5, "temp": 125.0}]
+    sim = api.BatchSimulator(api.MNACircuit(circ, {"vdd": 5.0}), points)
+    st = sim.st
+    sim.analyze()
+    u0, conv, _ = sim.dc(abstol=1e-9, mode="tranop")
+    assert np.all(conv)
+    ts = np.linspace(0.0, 7e-7, 71)
+    obs = list(range(st.n_nodes))
+    sim.h.set_spec(mode="tran")
+    breaks = expand_breakpoints(st.breakpoints, bm.DFF_TSPAN)
+    atol = st.state_abstol(**ABSTOL)
+    out, per, stats = sim.h.tran_run(0.0, 7e-7, atol, 1e-4, breaks=breaks, save_t=ts, obs=obs, fused=fused, newton_mode=1, step_rule=1)
+    assert stats["n_failed"] == 0
+    for i, pt in enumerate(points):
+        pst, port = make_port(circ, {"vdd": pt.get("vdd", 5.0)}, pt.get("temp", 27.0), "tran")
+        analyze_port(pst, port, sim.vscale())
+        ref, uf, rst, _ = port.tran(u0[i], 0.0, 7e-7, atol, 1e-4, breaks=breaks, save_t=ts, obs=obs, err_mask=pst.differential_mask(),
+                                    use_pcnr=False, newton_mode=1 if fused else 2, step_rule=1)
+        port.close()
+        assert rst["status"] == 1 and rst["rejected"] < 0.04 * rst["accepted"]
+        if fused == 0:
+            assert (per[i, 0], per[i, 1], per[i, 2]) == (rst["newton_iters"], rst["accepted"], rst["rejected"]), (pt, per[i], rst)
+        else:
+            assert abs(per[i, 0] - rst["newton_iters"]) <= 0.01 * rst["newton_iters"], (pt, per[i], rst)
+        assert np.max(np.abs(out[i] - ref) / np.maximum(np.abs(ref), 1.0)) <= REL_TOL
+    sim.close()
+
+
 def test_newton_mode_1_on_the_per_op_path_matches_port_mode_2():
     """The per-op kernels refactor every round; with newton_mode 1 they take IDA's convergence test only.  The port's newton_mode 2 is
     that policy: identical Newton / step / reject counts (the per-op path sums in the reference's order, like the port) and 1e-9."""
