@@ -34,7 +34,26 @@ if [ -f cadnip.jl_amd/libcadnip_hip_trace.so ]; then
   timeout -k 10 200 python3 tools/trace_fused2.py $B > $P/${TAG}_fused_B${B}_wave_trace.txt 2>&1 || true
   timeout -k 10 200 python3 tools/trace_stamp.py 8192 > $P/${TAG}_stamp_B8192_phase_trace.txt 2>&1 || true
 fi
+# ---- round 3: the team kernel (few instances), the callback ABI in one call, config 5 with the step LU
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_team -o run --output-format csv -- python3 tools/single_instance.py 1 f > $P/${TAG}_single_instance.txt 2>&1 || true
+cp $(find $OUT/${TAG}_team -name "*kernel_stats.csv" | head -1) $P/${TAG}_team_B1_kernel_stats.csv || true
+timeout -k 10 200 python3 tools/single_instance.py 1 f > $P/${TAG}_single_instance.txt 2>&1 || true
+CADNIP_F2_TEAM=0 timeout -k 10 200 python3 tools/single_instance.py 1 f >> $P/${TAG}_single_instance.txt 2>&1 || true
+timeout -k 10 200 python3 tools/team_phases.py > $P/${TAG}_team_phases.txt 2>&1 || true
+timeout -k 10 400 python3 tools/team_scan.py > $P/${TAG}_team_scan.txt 2>&1 || true
+timeout -k 10 200 python3 tools/callback_time.py > $P/${TAG}_callback_time.txt 2>&1 || true
+if [ -x tools/ubench/lat ]; then timeout -k 5 60 tools/ubench/lat > $P/${TAG}_ubench_lat.txt 2>&1 || true; timeout -k 5 60 tools/ubench/divcheck > $P/${TAG}_ubench_divcheck.txt 2>&1 || true; fi
+if [ -f cadnip.jl_amd/libcadnip_hip_trace.so ]; then
+  for wv in 0 1 2 3; do timeout -k 10 120 python3 tools/trace_fused2.py 1 1 $wv; done > $P/${TAG}_team_B1_wave_trace.txt 2>&1 || true
+fi
+for NB in 1 512; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_ring_${NB} -o run --output-format csv -- python3 tools/psp103_ring.py --tspan 2e-8 --batch $NB > $OUT/${TAG}_ring_${NB}.log 2>&1 || true
+  cp $(find $OUT/${TAG}_ring_${NB} -name "*kernel_stats.csv" | head -1) $P/${TAG}_psp103_ring_B${NB}_kernel_stats.csv || true
+done
+timeout -k 10 400 python3 tools/psp103_ring.py --tspan 1e-6 --batch 1 > $P/${TAG}_psp103_ring.txt 2>&1 || true
+timeout -k 10 300 python3 tools/psp103_ring.py --tspan 2e-8 --batch 1,64,512 >> $P/${TAG}_psp103_ring.txt 2>&1 || true
+echo "round-3 legs done"
 cp $OUT/${TAG}_bench.json $P/${TAG}_fused_B${B}_bench.json
 tail -c 600 $P/${TAG}_fused_B${B}_bench.json; echo
-rm -rf $OUT/${TAG}_stats $OUT/${TAG}_lds $OUT/${TAG}_perop_1024 $OUT/${TAG}_perop_8192   # raw traces: large, already condensed
+rm -rf $OUT/${TAG}_stats $OUT/${TAG}_lds $OUT/${TAG}_perop_1024 $OUT/${TAG}_perop_8192 $OUT/${TAG}_team $OUT/${TAG}_ring_1 $OUT/${TAG}_ring_512   # raw traces: large, already condensed
 echo "session $TAG done"
