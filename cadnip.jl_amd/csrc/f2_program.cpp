@@ -1,6 +1,8 @@
 // f2_program.cpp -- host side of the fused kernel's linear solve: the entry program (csrc/fused2.hip executes it).
 // Pure C++ (no HIP): also reachable through the host-only C ABI (cadnip_host_f2_*) so that the CPU test-suite can
 // emulate the program pass by pass.
+#include <stdio.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <vector>
 #include "internal.hpp"
@@ -264,6 +266,89 @@ bool f2_build_team(const LUProgram& P, int n, int nc, int nw, F2Team& T) {
   }
   T.desc.resize(T.desc.size() + lanes_per_step, idle);   // the kernel reads one step beyond a list's end
   if (T.desc.size() & 1) T.desc.push_back(idle);         // (what follows the descriptors in LDS stays 16-byte aligned)
+  return true;
+}
+
+// ---- ... and for ONE wave per instance (k_fused2's lean variant, fused2_kernel.hpp; k_lu_f2) ----------------------------------------
+// The pass program above costs a wave ~75 vector instructions per pass plus two LDS round trips per extra term of a lane (term list ->
+// operands), and the kernel is bound by instruction issue.  Here a step is straight-line code as for the teams, but a lane carries up to
+// THREE multiply-add terms in a 16-byte descriptor -- eight 15-bit word offsets: entry, pivot, (a0, b0), (a1, b1), (a2, b2) -- so that the
+// typical entry of a circuit matrix (one to three terms) needs one lane and no lane-group sum at all, and a wave without barriers need
+// not align steps with dependency levels: entries are list-scheduled into the earliest step behind their operands' last writers that
+// has an aligned lane group free.  The top bits of the eight fields: leader flag, log2 of the group width (3 bits), and -- the same in
+// all lanes of a step, read through v_readfirstlane -- the step's widest group (3 bits) and whether any of its entries divides.
+// DFF (core of 8): 12 + 10 steps (refactor + solve / forward + backward on kept factors: 10) instead of 17 / 13 passes.
+bool f2_build_steps(const LUProgram& P, int n, int nc, F2Team& T) {
+  F2Program G;
+  std::vector<F2Ent> lists[3];
+  constexpr int TPL = 3;                     // terms per lane
+  f2_build_entries(P, n, nc, 16 * TPL, G, lists[0], lists[1], lists[2]);
+  T = F2Team();
+  T.nw = 1; T.nc = G.nc; T.lu_words = G.lu_words; T.dn0 = G.dn0; T.posW = G.posW;
+  const unsigned zero_w = (unsigned)(G.lu_words + n + 64 /* F2_TRASH */), one_w = zero_w + 1u;
+  if (one_w >= (1u << 15)) return false;
+  auto p2c = [](size_t x) { size_t r = 1; while (r < x) r *= 2; return r; };
+  struct Lane { unsigned pos, leader, piv, lg, a[TPL], b[TPL]; };
+  const Lane idle{zero_w, 0, one_w, 0, {zero_w, zero_w, zero_w}, {zero_w, zero_w, zero_w}};
+  std::vector<int> fs(one_w + 1);            // step (within the current list) of a word's last writer so far, -1 = none
+  for (int li = 0; li < 3; ++li) {
+    auto& ents = lists[li];
+    std::stable_sort(ents.begin(), ents.end(), [](const F2Ent& p, const F2Ent& q) { return p.lvl < q.lvl; });
+    std::fill(fs.begin(), fs.end(), -1);
+    std::vector<std::vector<Lane>> steps;
+    std::vector<unsigned long long> occ;
+    std::vector<int> hasdiv, maxlg;
+    for (size_t i = 0; i < ents.size();) {
+      size_t j = i;
+      while (j < ents.size() && ents[j].lvl == ents[i].lvl) ++j;
+      std::vector<size_t> ord;
+      for (size_t e = i; e < j; ++e) ord.push_back(e);
+      auto width = [&](size_t e) { return std::min<size_t>(16, p2c(std::max<size_t>((ents[e].a.size() + TPL - 1) / TPL, 1))); };
+      std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return width(x) > width(y); });   // the wide groups of a level share steps
+      for (size_t e : ord) {
+        const F2Ent& x = ents[e];
+        const size_t L = width(e);
+        int ready = fs[x.pos];
+        if (x.dg >= 0) ready = std::max(ready, fs[x.dg]);
+        for (size_t t = 0; t < x.a.size(); ++t) ready = std::max(ready, std::max(fs[x.a[t]], fs[x.b[t]]));
+        const unsigned long long m = L == 64 ? ~0ull : ((1ull << L) - 1);
+        int s = ready + 1, at = -1;
+        for (;; ++s) {
+          if ((size_t)s >= steps.size()) { steps.emplace_back(64, idle); occ.push_back(0); hasdiv.push_back(0); maxlg.push_back(0); }
+          for (size_t o = 0; o < 64 && at < 0; o += L) if (!(occ[s] & (m << o))) at = (int)o;
+          if (at >= 0) break;
+        }
+        occ[s] |= m << at;
+        unsigned lg = 0;
+        while (((size_t)1 << lg) < L) ++lg;
+        maxlg[s] = std::max(maxlg[s], (int)lg);
+        if (x.dg >= 0) hasdiv[s] = 1;
+        for (size_t sub = 0; sub < L; ++sub) {
+          Lane& ln = steps[s][at + sub];
+          ln.pos = (unsigned)x.pos; ln.leader = sub == 0; ln.piv = x.dg < 0 ? one_w : (unsigned)x.dg; ln.lg = lg;
+          for (int k = 0; k < TPL; ++k) {
+            const size_t t = sub + (size_t)k * L;
+            ln.a[k] = t < x.a.size() ? (unsigned)x.a[t] : zero_w; ln.b[k] = t < x.a.size() ? (unsigned)x.b[t] : zero_w;
+          }
+        }
+        fs[x.pos] = s;
+      }
+      i = j;
+    }
+    T.n_steps[li] = (int)steps.size();
+    for (size_t s = 0; s < steps.size(); ++s)
+      for (const Lane& ln : steps[s]) {
+        const unsigned f0 = maxlg[s] & 1, f1 = (maxlg[s] >> 1) & 1, f2 = (maxlg[s] >> 2) & 1, f3 = hasdiv[s];
+        T.desc.push_back((unsigned long long)(ln.pos | ln.leader << 15) | (unsigned long long)(ln.piv | (ln.lg & 1u) << 15) << 16 |
+                         (unsigned long long)(ln.a[0] | ((ln.lg >> 1) & 1u) << 15) << 32 | (unsigned long long)(ln.b[0] | ((ln.lg >> 2) & 1u) << 15) << 48);
+        T.desc.push_back((unsigned long long)(ln.a[1] | f0 << 15) | (unsigned long long)(ln.b[1] | f1 << 15) << 16 |
+                         (unsigned long long)(ln.a[2] | f2 << 15) << 32 | (unsigned long long)(ln.b[2] | f3 << 15) << 48);
+      }
+  }
+  for (int l = 0; l < 64; ++l) {             // the kernel reads one step beyond a list's end
+    T.desc.push_back((unsigned long long)zero_w | (unsigned long long)one_w << 16 | (unsigned long long)zero_w << 32 | (unsigned long long)zero_w << 48);
+    T.desc.push_back((unsigned long long)zero_w | (unsigned long long)zero_w << 16 | (unsigned long long)zero_w << 32 | (unsigned long long)zero_w << 48);
+  }
   return true;
 }
 

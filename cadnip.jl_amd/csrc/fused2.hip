@@ -86,11 +86,17 @@ static bool f2_prepare(CadnipHandle* h, F2Tables& T, const std::vector<int>& g_p
   }
   for (int s = 0; s < h->ns_g; ++s) if (gs[s] < 0) gs[s] = trash0 + lane_g[s];
   for (int s = 0; s < h->ns_b; ++s) if (br[s] < 0) br[s] = trash0 + lane_b[s];
-  // ---- the linear-solve sections first: the per-op program LU (lu_f2.hip) stages only this prefix of the table in LDS
+  // ---- section order: [pass program, load map | permutations] = the prefix the per-op program LU (lu_f2.hip) stages; [permutations | stamp
+  // tables, node tables] = the range the lean kernels stage (their linear solve runs from step descriptors, fused2_kernel.hpp: run_steps);
+  // the J*u list of the assembled-residual variant last.  Range boundaries are multiples of 4 words (16-byte copies, aligned work arrays).
+  auto pad4 = [&]() { while (T.data.size() & 3) T.data.push_back(0); };
   T.begin(S_ENT); for (u64 wv : G.lanes) T.add64(wv);
   T.begin(S_TERM); for (unsigned t : G.terms) T.add32(t);
   T.begin(S_LEV); for (u64 wv : G.passes) T.add64(wv);
   T.add64(0); T.add64(0);   // two empty passes: the kernel reads pass descriptors two ahead
+  T.begin(S_LOADPOS); T.add16(dst);                 // csr entry -> W word: the per-op program LU loads J = G + gamma C through it
+  pad4();
+  h->f2_lean_lo = (int)T.data.size();
   std::vector<int> qoff(n);
   for (int j = 0; j < n; ++j) qoff[j] = y0 + qinv[j];
   T.begin(S_QINV); T.add16(qoff);
@@ -99,8 +105,7 @@ static bool f2_prepare(CadnipHandle* h, F2Tables& T, const std::vector<int>& g_p
     for (int i = 0; i < n; ++i) rowoff[i] = y0 + pinv[i];
     T.begin(S_ROWOF); T.add16(rowoff);
   }
-  T.begin(S_LOADPOS); T.add16(dst);                 // csr entry -> W word: the per-op program LU loads J = G + gamma C through it
-  while (T.data.size() & 3) T.data.push_back(0);   // the work arrays behind the staged prefix stay 16-byte aligned
+  pad4();
   h->f2_lu_len = (int)T.data.size();
   T.begin(S_GPOS); T.add16(gs);
   T.begin(S_CDESC);
@@ -109,6 +114,15 @@ static bool f2_prepare(CadnipHandle* h, F2Tables& T, const std::vector<int>& g_p
     else T.add64(pack4(cpos[s], crow[s], ccol[s], 0));
   }
   T.begin(S_BROW); T.add16(br);
+  T.begin(S_NODES);
+  h->f2_nodes_off.clear();
+  {
+    std::vector<int> all;
+    for (auto& b : h->blocks) { h->f2_nodes_off.push_back((int)all.size()); all.insert(all.end(), b.h_nodes.begin(), b.h_nodes.end()); }
+    T.add16(all);
+  }
+  pad4();
+  h->f2_lean_end = (int)T.data.size();
   T.begin(S_NZ);
   {
     // J*u adds every entry's product into its row with an LDS atomic, 64 entries per instruction.  In CSR order a long
@@ -121,15 +135,21 @@ static bool f2_prepare(CadnipHandle* h, F2Tables& T, const std::vector<int>& g_p
     for (int i = 0; i < n; ++i) for (int e = h->h_rowptr[i]; e < h->h_rowptr[i + 1]; ++e) row_of[e] = i;
     for (auto& oe : order) { const int e = oe.second; T.add64(pack4(dst[e], y0 + pinv[row_of[e]], h->h_colidx[e], 0)); }
   }
-  T.begin(S_NODES);
-  h->f2_nodes_off.clear();
+  pad4();                                          // the work arrays behind the tables stay 16-byte aligned
+  h->f2_lds_len = (int)T.data.size();              // what the full-table kernels copy to LDS ends here
+  // ---- one wave per instance, lean variant: list-scheduled steps with three terms per lane (f2_build_steps); the kernel stages them in LDS
   {
-    std::vector<int> all;
-    for (auto& b : h->blocks) { h->f2_nodes_off.push_back((int)all.size()); all.insert(all.end(), b.h_nodes.begin(), b.h_nodes.end()); }
-    T.add16(all);
+    F2Team TM;
+    if (h->d_steps1) { (void)hipFree(h->d_steps1); h->d_steps1 = nullptr; }
+    h->steps1_len = 0;
+    if (f2_build_steps(P, n, G.nc, TM) && TM.lu_words == G.lu_words &&
+        hipMalloc((void**)&h->d_steps1, TM.desc.size() * sizeof(unsigned long long)) == hipSuccess) {
+      if (hipMemcpy(h->d_steps1, TM.desc.data(), TM.desc.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) == hipSuccess) {
+        for (int li = 0; li < 3; ++li) h->steps1[li] = TM.n_steps[li];
+        h->steps1_len = (int)TM.desc.size();
+      } else { (void)hipFree(h->d_steps1); h->d_steps1 = nullptr; }
+    }
   }
-  while (T.data.size() & 3) T.data.push_back(0);   // the work arrays behind the tables stay 16-byte aligned
-  h->f2_lds_len = (int)T.data.size();              // what the kernels copy to LDS ends here
   // ---- team kernel (fused_team_kernel.hpp): the same program as straight-line steps for teams of 2 and 4 waves (f2_build_team); the
   // kernel stages the descriptors in LDS
   for (int k = 0; k < 2; ++k) {
@@ -182,7 +202,7 @@ bool fused2_fits(CadnipHandle* h) {
   int nb = 0;
   for (auto& b : h->blocks) nb += b.count > 0;
   if (nb > F2_MAX_BLOCKS) return false;
-  const size_t per = (size_t)h->f2_lu_words + 3 * (size_t)h->n + F2_TRASH;
+  const size_t per = (size_t)h->f2_lu_words + 3 * (size_t)h->n + F2_TRASH + 2;
   return ((size_t)h->f2len / 2 + per) * 8 <= 160 * 1024;
 }
 
@@ -215,6 +235,10 @@ static int fused2_blocks(CadnipHandle* h) {
                          ty == CADNIP_DEV_BISOURCE || ty == CADNIP_DEV_VA || (ty == CADNIP_DEV_MOS1 && !hb[i].mos1_plain);
       if (heavy) h->f2_lean = false;
     }
+    // ... and its linear solve runs from step descriptors staged in LDS: a circuit whose steps do not fit beside the tables and eight
+    // instances (long dependency chains: an RC ladder has one step per section) takes the full variant, whose pass program is compact
+    if (!h->d_steps1 || ((size_t)(h->f2_lean_end - h->f2_lean_lo) / 2 + (size_t)h->steps1_len + 8 * ((size_t)h->f2_lu_words + 3 * (size_t)h->n + F2_TRASH + 2)) * 8 > 160 * 1024)
+      h->f2_lean = false;
     h->f2_n_blk = nb;
     // team kernel (fused_team_kernel.hpp): the parameter rows of the lane-paired sp_mos1 blocks are staged in LDS
     // ... of what the register-resident first pass over the first block does not cover (more than 32 MOSFETs, several blocks)
@@ -253,7 +277,7 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
   f.wave = h->d_wave;
   f.tab = h->d_f2tab;
   for (int i = 0; i < S_NSEC; ++i) f.off[i] = h->f2off[i];
-  f.tab_len = h->f2len;
+  f.tab_len = h->f2len; f.tab_lo = 0;
   f.n = h->n; f.nnz = h->nnz; f.nnz_lu = h->f2_lu_words;
   f.n_pre = h->f2_n_pre; f.n_post = h->f2_n_post; f.nc = h->f2_nc; f.dn0 = h->f2_dn0; f.n_fwd = h->f2_n_fwd;
   f.lufac = nullptr; f.team_desc = nullptr; f.team_desc_len = 0; f.par_words = 0; f.ts_pre = f.ts_post = f.ts_fwd = 0;
@@ -275,8 +299,10 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
   f.rounds = rounds; f.B = h->B; f.t = t; f.cold = h->d_cold;
   f.dc_abstol = 0; f.dc_maxiters = 0; f.dc_pcnr = 0; f.dc_mode = 1; f.dc_initjct = 0; f.dcstate = nullptr;
   if (dc) { f.dc_abstol = dc->abstol; f.dc_maxiters = dc->maxiters; f.dc_pcnr = dc->use_pcnr; f.dc_mode = dc->mode; f.dc_initjct = dc->initjct; f.dcstate = dc->dcstate; }
-  const size_t tab_dbl = (size_t)h->f2len / 2;
-  const size_t per = (size_t)h->f2_lu_words + 3 * (size_t)h->n + F2_TRASH;
+  const bool lean = h->f2_direct && h->f2_lean;
+  if (lean) { f.tab_lo = h->f2_lean_lo; f.tab_len = h->f2_lean_end - h->f2_lean_lo; }   // the lean kernels stage [permutations | stamp and node tables] only
+  const size_t tab_dbl = (size_t)f.tab_len / 2;
+  const size_t per = (size_t)h->f2_lu_words + 3 * (size_t)h->n + F2_TRASH + 2;           // (+ the steps' constant words 0.0, 1.0 behind the trash words)
   const size_t lds_cap = 160 * 1024;
   if (h->n_cu <= 0) {
     int cu = 0;
@@ -290,7 +316,7 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
     int nw = h->B <= h->n_cu ? 4 : 0;
     if (const char* e = getenv("CADNIP_F2_TEAM")) nw = atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 0;
     if (step) nw = 4;
-    const size_t shmem_t = (tab_dbl + per + 2 + 4 * (size_t)nw + (size_t)h->f2_par_words + (nw ? (size_t)h->team_desc_len[nw / 4] : 0) +
+    const size_t shmem_t = (tab_dbl + per + 4 * (size_t)nw + (size_t)h->f2_par_words + (nw ? (size_t)h->team_desc_len[nw / 4] : 0) +
                             (nw ? (size_t)(nw - 1) * ((size_t)h->f2_lu_words + h->n + F2_TRASH) : 0)) * 8;     // (+ the two constant words behind the trash words)
     if (nw && h->d_team_desc[nw / 4] && shmem_t <= lds_cap) {
       f.team_desc = h->d_team_desc[nw / 4]; f.team_desc_len = h->team_desc_len[nw / 4]; f.par_words = h->f2_par_words;
@@ -310,17 +336,23 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
   // waves (= instances) per workgroup: 8 (two waves per SIMD) when they fit into LDS; fewer when the whole batch is then
   // still resident in one generation with a workgroup on every CU -- a wave runs about 20 % faster with half as many
   // neighbours on its CU (1024 instances: 4 per workgroup on 256 CUs, 57.7 M iterations/s, against 48.1 M as 8 x 128)
+  size_t desc_dbl = 0;
+  if (lean) {       // the lean variant's linear solve runs from step descriptors (f2_build_steps) staged behind the tables
+    if (!h->d_steps1) return CADNIP_BADARG;
+    f.team_desc = h->d_steps1; f.team_desc_len = h->steps1_len; f.ts_pre = h->steps1[0]; f.ts_post = h->steps1[1]; f.ts_fwd = h->steps1[2];
+    desc_dbl = (size_t)h->steps1_len;
+  }
   int wpb = 8;
   if (const char* e = getenv("CADNIP_F2_WPB")) wpb = atoi(e) >= 8 ? 8 : atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 1;   // diagnostic: cap the waves per workgroup
-  while (wpb > 1 && ((tab_dbl + wpb * per) * 8 > lds_cap || h->n_cu * (wpb / 2) >= h->B)) wpb >>= 1;
-  size_t shmem = (tab_dbl + wpb * per) * 8;
+  while (wpb > 1 && ((tab_dbl + desc_dbl + wpb * per) * 8 > lds_cap || h->n_cu * (wpb / 2) >= h->B)) wpb >>= 1;
+  size_t shmem = (tab_dbl + desc_dbl + wpb * per) * 8;
   if (shmem > lds_cap) return CADNIP_BADARG;
   // resident workgroups only: the instances beyond them are handed out by the in-kernel queue as waves become free
   TRY_RC(dev_zero_async(h, h->d_f2queue, sizeof(int)));
   f.queue = h->d_f2queue;
   const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(lds_cap / shmem, (size_t)(32 / wpb)));
   int grid = std::min((h->B + wpb - 1) / wpb, h->n_cu * wg_per_cu);
-  if (getenv("CADNIP_F2_DEBUG")) fprintf(stderr, "[cadnip f2] B %d n_cu %d wpb %d grid %d shmem %zu rounds %d nc %d passes %d+%d variant %d\n", h->B, h->n_cu, wpb, grid, shmem, rounds, h->f2_nc, h->f2_n_pre, h->f2_n_post, !h->f2_direct ? 2 : h->f2_lean ? 0 : 1);
+  if (getenv("CADNIP_F2_DEBUG")) fprintf(stderr, "[cadnip f2] B %d n_cu %d wpb %d grid %d shmem %zu (tables %zu, steps %zu, per instance %zu) rounds %d nc %d passes %d+%d steps %d+%d / %d variant %d\n", h->B, h->n_cu, wpb, grid, shmem, tab_dbl * 8, desc_dbl * 8, per * 8, rounds, h->f2_nc, h->f2_n_pre, h->f2_n_post, f.ts_pre, f.ts_post, f.ts_fwd, !h->f2_direct ? 2 : h->f2_lean ? 0 : 1);
   const int var = !h->f2_direct ? 2 : h->f2_lean ? 0 : 1;
   { int rc = var == 0 ? f2_launch_variant<0>(wpb, dc != nullptr, grid, shmem, h->stream, f)
            : var == 1 ? f2_launch_variant<1>(wpb, dc != nullptr, grid, shmem, h->stream, f)

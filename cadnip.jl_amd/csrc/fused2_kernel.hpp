@@ -45,7 +45,8 @@ struct F2Args {
   const double* wave;
   const unsigned* tab;       // packed tables in global memory
   int off[S_NSEC];
-  int tab_len;               // 32-bit words (even)
+  int tab_len;               // 32-bit words the kernel stages in LDS (a multiple of 4) ...
+  int tab_lo;                // ... starting at this word of `tab` (a multiple of 4): the lean kernels leave the pass program and the J*u list out
   int n, nnz, nnz_lu, rounds, B;   // nnz_lu: words of W before the rhs (sparse L\U entries + dense core block)
   int n_pre, n_post, nc, dn0;       // passes before / after the dense core solve, core size, first word of the core block
   int n_fwd;                        // Newton mode 1: passes of the forward substitution alone (kept factors), behind the pre / post passes
@@ -332,32 +333,42 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
   const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), n = f.n;
   // ---- shared tables: one cooperative copy per launch
   {
-    const uint2* src = (const uint2*)f.tab;
+    const uint2* src = (const uint2*)(f.tab + f.tab_lo);
     uint2* dst = (uint2*)sm;
     for (int i = tid; i < f.tab_len / 2; i += 64 * WPB) dst[i] = src[i];
   }
-  __syncthreads();
   const TranArgs& a = f.t;
   const unsigned* tab = (const unsigned*)sm;
   const int tab_dbl = f.tab_len / 2;
+  // lean variant: the linear solve as straight-line steps (f2_program.cpp: f2_build_steps), their 16-byte lane descriptors staged behind the tables
+  const uint4* tdesc = (const uint4*)(sm + tab_dbl);
+  const int desc_dbl = LEAN ? f.team_desc_len : 0;
+  if constexpr (LEAN) {
+    const uint2* src = (const uint2*)f.team_desc;
+    uint2* dst = (uint2*)(sm + tab_dbl);
+    for (int i = tid; i < f.team_desc_len; i += 64 * WPB) dst[i] = src[i];
+  }
+  __syncthreads();
   const int nW = f.nnz_lu + n + F2_TRASH;                 // LU | rhs | trash : zeroed every round
-  const int per = nW + 2 * n;                             // ... | u | beta
-  double* W = sm + tab_dbl + (size_t)w * per;
-  double* us = W + nW;
+  const int per = nW + 2 + 2 * n;                         // ... | the steps' constant words 0.0, 1.0 | u | beta
+  double* W = sm + tab_dbl + desc_dbl + (size_t)w * per;
+  double* us = W + nW + 2;
   double* betas = us + n;
-  const u16* gpos = (const u16*)(tab + f.off[S_GPOS]);
-  const u64* cdesc = (const u64*)(tab + f.off[S_CDESC]);
-  const u16* brow = (const u16*)(tab + f.off[S_BROW]);
-  const u64* nzd = (const u64*)(tab + f.off[S_NZ]);
-  const u64* laned = (const u64*)(tab + f.off[S_ENT]);
-  const unsigned* term = tab + f.off[S_TERM];
+  if (lane0 == 0) { W[nW] = 0.0; W[nW + 1] = 1.0; }
+  const int tlo = f.tab_lo;                               // (a section's offset minus tab_lo first: every pointer formed here lies inside the staged range)
+  const u16* gpos = (const u16*)(tab + (f.off[S_GPOS] - tlo));
+  const u64* cdesc = (const u64*)(tab + (f.off[S_CDESC] - tlo));
+  const u16* brow = (const u16*)(tab + (f.off[S_BROW] - tlo));
+  const u64* nzd = (const u64*)(tab + (LEAN ? 0 : f.off[S_NZ]));
+  const u64* laned = (const u64*)(tab + (LEAN ? 0 : f.off[S_ENT]));
+  const unsigned* term = tab + (LEAN ? 0 : f.off[S_TERM]);
   // pass descriptors are wave-uniform: read them with scalar loads from the table's copy in global memory (constant
   // cache) instead of an LDS read plus two v_readfirstlane per pass
   typedef const __attribute__((address_space(4))) u64* PassPtr;
   const PassPtr passd = (PassPtr)(const u64*)(f.tab + f.off[S_LEV]);
-  const u16* qinv = (const u16*)(tab + f.off[S_QINV]);
-  const short* nodes = (const short*)(tab + f.off[S_NODES]);
-  const u16* rowof = (const u16*)(tab + f.off[S_ROWOF]);
+  const u16* qinv = (const u16*)(tab + (f.off[S_QINV] - tlo));
+  const short* nodes = (const short*)(tab + (f.off[S_NODES] - tlo));
+  const u16* rowof = (const u16*)(tab + (f.off[S_ROWOF] - tlo));
   // Pinned stamp targets (DIRECT variants): the first capacitor / resistor block (two devices per lane) and the first
   // independent-source block (one per lane) are stamped from registers -- four matrix words, the residual words of
   // their rows and their unknowns, as 16-bit offsets.  They depend on the circuit only, so they are read once per
@@ -701,8 +712,48 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
         D = Dn; T0 = T0n; pd = pd1; pd1 = pd2;
       }
     };
-    if (refresh) run_passes(0, f.n_pre);
-    else run_passes(f.n_pre + f.n_post, f.n_fwd);          // kept factors: the forward substitution alone
+    // lean variant: the same program as straight-line steps -- one 16-byte descriptor per lane and step (entry, pivot, three multiply-add
+    // terms; f2_program.cpp: f2_build_steps), the next step's descriptor read with this step's operands; no term lists, no inner loops; the
+    // step's widest lane group and whether anything divides are the same bits in every lane's descriptor (scalar branches).  A wave's LDS
+    // operations execute in order, so steps need no fence between them.
+    auto run_steps = [&](const int s_first, const int s_count) {
+      if (s_count <= 0) return;
+      const uint4* dp = tdesc + (size_t)s_first * 64 + lane;
+      uint4 D = dp[0];
+      for (int si = 0; si < s_count; ++si) {
+        double* const pp = W + (D.x & 0x7FFFu);
+        const double piv = W[(D.x >> 16) & 0x7FFFu];
+        const double a0v = W[D.y & 0x7FFFu], b0v = W[(D.y >> 16) & 0x7FFFu];
+        const double a1v = W[D.z & 0x7FFFu], b1v = W[(D.z >> 16) & 0x7FFFu];
+        const double a2v = W[D.w & 0x7FFFu], b2v = W[(D.w >> 16) & 0x7FFFu];
+        const double acc0 = *pp;
+        const uint4 Dn = dp[(size_t)(si + 1) * 64];
+        const unsigned fz = __builtin_amdgcn_readfirstlane(D.z), fw = __builtin_amdgcn_readfirstlane(D.w);
+        const unsigned maxlg = ((fz >> 15) & 1u) | ((fz >> 30) & 2u) | ((fw >> 13) & 4u);
+        const unsigned lg = (D.x >> 31) | ((D.y >> 14) & 2u) | ((D.y >> 29) & 4u);
+        double part = fma(a2v, b2v, fma(a1v, b1v, a0v * b0v));
+        if (maxlg >= 1) { const double o = dpp_f64<0xB1>(part); part += lg >= 1 ? o : 0.0; }
+        if (maxlg >= 2) { const double o = dpp_f64<0x4E>(part); part += lg >= 2 ? o : 0.0; }
+        if (maxlg >= 3) { const double o = dpp_f64<0x141>(part); part += lg >= 3 ? o : 0.0; }
+        if (maxlg >= 4) { const double o = dpp_f64<0x140>(part); part += lg >= 4 ? o : 0.0; }
+        double acc = acc0 - part;
+        if (fw >> 31) {
+          if (piv == 0.0 || !isfinite(piv)) bad = 1;        // (lanes and entries without a division read the constant 1.0)
+          acc = fast_div(acc, piv);
+        }
+        // every lane stores -- the lanes that are not their group's leader into their trash word: no branch
+        *((D.x & 0x8000u) ? pp : W + trash_w) = acc;
+        D = Dn;
+      }
+      CADNIP_WAVE_SYNC();
+    };
+    if constexpr (LEAN) {
+      if (refresh) run_steps(0, f.ts_pre);
+      else run_steps(f.ts_pre + f.ts_post, f.ts_fwd);       // kept factors: the forward substitution alone
+    } else {
+      if (refresh) run_passes(0, f.n_pre);
+      else run_passes(f.n_pre + f.n_post, f.n_fwd);
+    }
     CADNIP_TRACE_POINT(4);
     if (f.nc > 0) {
       const int yc0 = f.nnz_lu + n - f.nc;
@@ -718,7 +769,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
       CADNIP_WAVE_SYNC();
     }
     CADNIP_TRACE_POINT(5);
-    run_passes(f.n_pre, f.n_post);
+    if constexpr (LEAN) run_steps(f.ts_pre, f.ts_post); else run_passes(f.n_pre, f.n_post);
     CADNIP_TRACE_POINT(3);
     // ---- Newton update + step controller (registers / LDS; HBM only for history and outputs)
     if (DC) {

@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
   __shared__ int s_next;
   const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), n = f.n;
   {
-    const uint2* src = (const uint2*)f.tab;
+    const uint2* src = (const uint2*)(f.tab + f.tab_lo);      // the lean range of the tables: permutations, stamp tables, node tables
     uint2* dst = (uint2*)sm;
     for (int i = tid; i < f.tab_len / 2; i += NT) dst[i] = src[i];
   }
@@ -150,12 +150,13 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
   for (int i = tid; i < (NW - 1) * nW; i += NT) WP[i] = 0.0;
   double* const Wacc = w == 0 ? W : WP + (size_t)(w - 1) * nW;
 
-  const u16* gpos = (const u16*)(tab + f.off[S_GPOS]);
-  const u64* cdesc = (const u64*)(tab + f.off[S_CDESC]);
-  const u16* brow = (const u16*)(tab + f.off[S_BROW]);
-  const u16* qinv = (const u16*)(tab + f.off[S_QINV]);
-  const short* nodes = (const short*)(tab + f.off[S_NODES]);
-  const u16* rowof = (const u16*)(tab + f.off[S_ROWOF]);
+  const int tlo = f.tab_lo;
+  const u16* gpos = (const u16*)(tab + (f.off[S_GPOS] - tlo));
+  const u64* cdesc = (const u64*)(tab + (f.off[S_CDESC] - tlo));
+  const u16* brow = (const u16*)(tab + (f.off[S_BROW] - tlo));
+  const u16* qinv = (const u16*)(tab + (f.off[S_QINV] - tlo));
+  const short* nodes = (const short*)(tab + (f.off[S_NODES] - tlo));
+  const u16* rowof = (const u16*)(tab + (f.off[S_ROWOF] - tlo));
   // what this wave stamps: a part of every sp_mos1 device, or all the other device blocks
   const int roles = NW == 4 ? (w == 0 ? M1_ROLE_J : w == 1 ? M1_ROLE_Q : w == 2 ? M1_ROLE_CH : 0) : (w == 0 ? (M1_ROLE_J | M1_ROLE_CH) : M1_ROLE_Q);
   const bool others = w == NW - 1;

@@ -70,6 +70,8 @@ struct F2Team {
   std::vector<unsigned long long> desc;    // [step][nw * 64 lanes] packed word offsets into W (f2_program.cpp: f2_build_team)
 };
 bool f2_build_team(const LUProgram& P, int n, int nc, int nw, F2Team& T);
+// ... for one wave per instance: list-scheduled steps of 64 lanes with up to three terms per lane, 16-byte descriptors (two words per lane in `desc`)
+bool f2_build_steps(const LUProgram& P, int n, int nc, F2Team& T);
 
 struct DeviceBlock {
   int type, count, n_nodes, n_ipar, n_par;
@@ -158,6 +160,9 @@ struct CadnipHandle {
   unsigned long long* d_team_desc[2] = {nullptr, nullptr};   // team kernel: step descriptors for teams of 2 / 4 waves (f2_build_team), built with the tables
   int team_steps[2][3] = {{0, 0, 0}, {0, 0, 0}};
   int team_desc_len[2] = {0, 0};   // 64-bit words each
+  unsigned long long* d_steps1 = nullptr;   // one wave per instance, lean variant: step descriptors (f2_build_steps), two words per lane
+  int steps1[3] = {0, 0, 0}, steps1_len = 0;
+  int f2_lean_lo = 0, f2_lean_end = 0;      // the table words [lo, end) the lean kernels stage in LDS (permutations, stamp tables, node tables)
   int f2_lds_len = 0;         // 32-bit words of the table that the fused kernels copy to LDS (f2len; the team kernel's step lists lie behind)
   int f2_par_words = 0;       // team kernel: doubles of the LDS-staged sp_mos1 parameter rows of one instance
   bool f2_direct = false;     // devices emit their residuals directly: no J*u pass (off: CADNIP_F2_NODIRECT=1)

@@ -25,7 +25,7 @@ EXPORTS = [
     "cadnip_dc_log_size", "cadnip_dc_log_get", "cadnip_tran_run", "cadnip_tran_state", "cadnip_dev_ptr", "cadnip_stream", "cadnip_set_u", "cadnip_get_u", "cadnip_get_flags",
     "cadnip_sync", "cadnip_debug_copy", "cadnip_debug_stamp_time", "cadnip_profile_enable", "cadnip_profile_read", "cadnip_version",
     "cadnip_host_lu_analyze", "cadnip_host_lu_analyze_leaves", "cadnip_host_lu_size", "cadnip_host_lu_get", "cadnip_host_lu_free",
-    "cadnip_host_f2_build", "cadnip_host_f2_size", "cadnip_host_f2_get", "cadnip_host_f2_free", "cadnip_host_f2_team_steps",
+    "cadnip_host_f2_build", "cadnip_host_f2_size", "cadnip_host_f2_get", "cadnip_host_f2_free", "cadnip_host_f2_team_steps", "cadnip_host_f2_steps",
 ]
 
 
@@ -455,6 +455,13 @@ def host_lu_analyze(n, rowptr, colidx, vals, pivot_tol=1e-3, sample=False, f2_nc
             for nw in (1, 2, 4):
                 if lib.cadnip_host_f2_team_steps(p, C.c_int32(int(f2_nc)), C.c_int32(nw), ts) == 0:
                     out["team_steps"][nw] = tuple(int(v) for v in ts)
+            # ... as straight-line steps: "steps" = {nw: (counts, uint64 descriptor words)}; nw = 1 is the sweep kernel's three-term layout
+            out["steps"] = {}
+            for nw in (1, 2, 4):
+                if lib.cadnip_host_f2_steps(p, C.c_int32(int(f2_nc)), C.c_int32(nw), ts, None) == 0:
+                    words = np.zeros(max(int(ts[3]), 1), dtype=np.uint64)
+                    _check(lib.cadnip_host_f2_steps(p, C.c_int32(int(f2_nc)), C.c_int32(nw), ts, words.ctypes.data_as(C.c_void_p)), "cadnip_host_f2_steps")
+                    out["steps"][nw] = (tuple(int(v) for v in ts[:3]), words[:int(ts[3])])
             # the fused kernel's entry program for this LU and core size (csrc/f2_program.cpp)
             lib.cadnip_host_f2_free.restype = None
             q = C.c_void_p()
