@@ -216,6 +216,7 @@ void cadnip_destroy(CadnipHandle* h) {
   if (h->d_f2tab) (void)hipFree(h->d_f2tab);
   for (int k = 0; k < 2; ++k) if (h->d_team_desc[k]) (void)hipFree(h->d_team_desc[k]);
   if (h->d_steps1) (void)hipFree(h->d_steps1);
+  if (h->d_steps4) (void)hipFree(h->d_steps4);
   for (auto& g : h->step_graph) if (g.exec) (void)hipGraphExecDestroy(g.exec);
   for (auto& b : h->blocks) {
     void* bp[] = {b.d_nodes, b.d_ipar, b.d_par, b.d_sp_tptr, b.d_sp_info, b.d_sp_rec, b.d_cache, b.d_sp_rowoff,
@@ -522,9 +523,11 @@ int cadnip_host_f2_team_steps(const CadnipHostLU* lu, int32_t nc, int32_t nw, in
   return CADNIP_OK;
 }
 int cadnip_host_f2_steps(const CadnipHostLU* lu, int32_t nc, int32_t nw, int32_t* out, uint64_t* dst) {
-  if (!lu || !out || nc < 0 || nc > lu->p.n || (nw != 1 && nw != 2 && nw != 4)) return CADNIP_BADARG;
+  // nw = 1, 2, 4: the 8-byte one-term team layouts for 2 / 4 waves, the 16-byte three-term layout for one wave; nw = 12, 14: the three-term layout for 2 / 4 waves
+  const bool three = nw == 1 || nw == 12 || nw == 14;
+  if (!lu || !out || nc < 0 || nc > lu->p.n || (!three && nw != 2 && nw != 4)) return CADNIP_BADARG;
   cadnip::F2Team T;
-  if (!(nw == 1 ? cadnip::f2_build_steps(lu->p, lu->p.n, nc, T) : cadnip::f2_build_team(lu->p, lu->p.n, nc, nw, T))) return CADNIP_BADARG;
+  if (!(three ? cadnip::f2_build_steps(lu->p, lu->p.n, nc, nw == 1 ? 1 : nw - 10, T) : cadnip::f2_build_team(lu->p, lu->p.n, nc, nw, T))) return CADNIP_BADARG;
   out[0] = T.n_steps[0]; out[1] = T.n_steps[1]; out[2] = T.n_steps[2]; out[3] = (int32_t)T.desc.size();
   if (dst) memcpy(dst, T.desc.data(), T.desc.size() * sizeof(unsigned long long));
   return CADNIP_OK;

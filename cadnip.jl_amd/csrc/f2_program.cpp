@@ -278,15 +278,16 @@ bool f2_build_team(const LUProgram& P, int n, int nc, int nw, F2Team& T) {
 // has an aligned lane group free.  The top bits of the eight fields: leader flag, log2 of the group width (3 bits), and -- the same in
 // all lanes of a step, read through v_readfirstlane -- the step's widest group (3 bits) and whether any of its entries divides.
 // DFF (core of 8): 12 + 10 steps (refactor + solve / forward + backward on kept factors: 10) instead of 17 / 13 passes.
-bool f2_build_steps(const LUProgram& P, int n, int nc, F2Team& T) {
+bool f2_build_steps(const LUProgram& P, int n, int nc, int nw, F2Team& T) {
   F2Program G;
   std::vector<F2Ent> lists[3];
   constexpr int TPL = 3;                     // terms per lane
   f2_build_entries(P, n, nc, 16 * TPL, G, lists[0], lists[1], lists[2]);
   T = F2Team();
-  T.nw = 1; T.nc = G.nc; T.lu_words = G.lu_words; T.dn0 = G.dn0; T.posW = G.posW;
+  T.nw = nw; T.nc = G.nc; T.lu_words = G.lu_words; T.dn0 = G.dn0; T.posW = G.posW;
   const unsigned zero_w = (unsigned)(G.lu_words + n + 64 /* F2_TRASH */), one_w = zero_w + 1u;
   if (one_w >= (1u << 15)) return false;
+  const size_t NL = 64 * (size_t)nw;         // lanes of a step (a team's step ends with a workgroup barrier: list scheduling holds for it as well)
   auto p2c = [](size_t x) { size_t r = 1; while (r < x) r *= 2; return r; };
   struct Lane { unsigned pos, leader, piv, lg, a[TPL], b[TPL]; };
   const Lane idle{zero_w, 0, one_w, 0, {zero_w, zero_w, zero_w}, {zero_w, zero_w, zero_w}};
@@ -296,7 +297,7 @@ bool f2_build_steps(const LUProgram& P, int n, int nc, F2Team& T) {
     std::stable_sort(ents.begin(), ents.end(), [](const F2Ent& p, const F2Ent& q) { return p.lvl < q.lvl; });
     std::fill(fs.begin(), fs.end(), -1);
     std::vector<std::vector<Lane>> steps;
-    std::vector<unsigned long long> occ;
+    std::vector<std::vector<unsigned short>> occ;   // per step: occupancy of its 16-lane rows
     std::vector<int> hasdiv, maxlg;
     for (size_t i = 0; i < ents.size();) {
       size_t j = i;
@@ -311,14 +312,14 @@ bool f2_build_steps(const LUProgram& P, int n, int nc, F2Team& T) {
         int ready = fs[x.pos];
         if (x.dg >= 0) ready = std::max(ready, fs[x.dg]);
         for (size_t t = 0; t < x.a.size(); ++t) ready = std::max(ready, std::max(fs[x.a[t]], fs[x.b[t]]));
-        const unsigned long long m = L == 64 ? ~0ull : ((1ull << L) - 1);
+        const unsigned m = (1u << L) - 1u;                  // (L <= 16: a group lies inside one row)
         int s = ready + 1, at = -1;
         for (;; ++s) {
-          if ((size_t)s >= steps.size()) { steps.emplace_back(64, idle); occ.push_back(0); hasdiv.push_back(0); maxlg.push_back(0); }
-          for (size_t o = 0; o < 64 && at < 0; o += L) if (!(occ[s] & (m << o))) at = (int)o;
+          if ((size_t)s >= steps.size()) { steps.emplace_back(NL, idle); occ.emplace_back(NL / 16, (unsigned short)0); hasdiv.push_back(0); maxlg.push_back(0); }
+          for (size_t o = 0; o < NL && at < 0; o += L) if (!(occ[s][o >> 4] & (m << (o & 15)))) at = (int)o;
           if (at >= 0) break;
         }
-        occ[s] |= m << at;
+        occ[s][at >> 4] |= (unsigned short)(m << (at & 15));
         unsigned lg = 0;
         while (((size_t)1 << lg) < L) ++lg;
         maxlg[s] = std::max(maxlg[s], (int)lg);
@@ -345,7 +346,7 @@ bool f2_build_steps(const LUProgram& P, int n, int nc, F2Team& T) {
                          (unsigned long long)(ln.a[2] | f2 << 15) << 32 | (unsigned long long)(ln.b[2] | f3 << 15) << 48);
       }
   }
-  for (int l = 0; l < 64; ++l) {             // the kernel reads one step beyond a list's end
+  for (size_t l = 0; l < NL; ++l) {          // the kernel reads one step beyond a list's end
     T.desc.push_back((unsigned long long)zero_w | (unsigned long long)one_w << 16 | (unsigned long long)zero_w << 32 | (unsigned long long)zero_w << 48);
     T.desc.push_back((unsigned long long)zero_w | (unsigned long long)zero_w << 16 | (unsigned long long)zero_w << 32 | (unsigned long long)zero_w << 48);
   }

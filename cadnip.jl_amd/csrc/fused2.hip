@@ -142,12 +142,23 @@ static bool f2_prepare(CadnipHandle* h, F2Tables& T, const std::vector<int>& g_p
     F2Team TM;
     if (h->d_steps1) { (void)hipFree(h->d_steps1); h->d_steps1 = nullptr; }
     h->steps1_len = 0;
-    if (f2_build_steps(P, n, G.nc, TM) && TM.lu_words == G.lu_words &&
+    if (f2_build_steps(P, n, G.nc, 1, TM) && TM.lu_words == G.lu_words &&
         hipMalloc((void**)&h->d_steps1, TM.desc.size() * sizeof(unsigned long long)) == hipSuccess) {
       if (hipMemcpy(h->d_steps1, TM.desc.data(), TM.desc.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) == hipSuccess) {
         for (int li = 0; li < 3; ++li) h->steps1[li] = TM.n_steps[li];
         h->steps1_len = (int)TM.desc.size();
       } else { (void)hipFree(h->d_steps1); h->d_steps1 = nullptr; }
+    }
+  }
+  // ... and for a team of four waves per instance: the per-op step LU (lu_f2.hip: k_lu_steps), descriptors read from global memory
+  {
+    F2Team TM;
+    if (h->d_steps4) { (void)hipFree(h->d_steps4); h->d_steps4 = nullptr; }
+    if (f2_build_steps(P, n, G.nc, 4, TM) && TM.lu_words == G.lu_words &&
+        hipMalloc((void**)&h->d_steps4, TM.desc.size() * sizeof(unsigned long long)) == hipSuccess) {
+      if (hipMemcpy(h->d_steps4, TM.desc.data(), TM.desc.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) == hipSuccess) {
+        for (int li = 0; li < 3; ++li) h->steps4[li] = TM.n_steps[li];
+      } else { (void)hipFree(h->d_steps4); h->d_steps4 = nullptr; }
     }
   }
   // ---- team kernel (fused_team_kernel.hpp): the same program as straight-line steps for teams of 2 and 4 waves (f2_build_team); the

@@ -71,7 +71,7 @@ struct F2Team {
 };
 bool f2_build_team(const LUProgram& P, int n, int nc, int nw, F2Team& T);
 // ... for one wave per instance: list-scheduled steps of 64 lanes with up to three terms per lane, 16-byte descriptors (two words per lane in `desc`)
-bool f2_build_steps(const LUProgram& P, int n, int nc, F2Team& T);
+bool f2_build_steps(const LUProgram& P, int n, int nc, int nw, F2Team& T);
 
 struct DeviceBlock {
   int type, count, n_nodes, n_ipar, n_par;
@@ -86,13 +86,13 @@ struct DeviceBlock {
   double* d_par = nullptr;   // [B][n_par][count]
   // reduction plan of the stamping kernel (stamp_csr.hip): devices per tile, tiles per instance, and per tile the targets
   // (CSR entries of G / C, rows of b) it contributes to with the LDS offsets of their contributions in COO order
-  int sp_cs = 0, sp_chunks = 0, sp_n_targets = 0, sp_levels = 1, sp_scratch = 0;
+  int sp_cs = 0, sp_chunks = 0, sp_n_targets = 0, sp_levels = 1, sp_scratch = 0, sp_max_steps = 0;   // (sp_max_steps: the longest chunk's reduction steps)
   struct Target { int chunk; unsigned word; std::vector<unsigned short> offs; };
   std::vector<Target> sp_targets;            // build-time only
   int *d_sp_tptr = nullptr, *d_sp_info = nullptr; uint4* d_sp_rec = nullptr;
   // sp_mos1 blocks carry two plans -- the lane-pair path (mos1_plain: the rows of the external d / g / s terminals and the d / s columns
   // are structural zeros there) stages fewer rows -- and the launch picks the one that matches the parameters in force
-  struct PlanSet { int n_targets = 0, levels = 1, scratch = 0, rows = 0; int *tptr = nullptr, *info = nullptr; uint4* rec = nullptr; unsigned short* rowoff = nullptr; };
+  struct PlanSet { int n_targets = 0, levels = 1, scratch = 0, rows = 0, max_steps = 0; int *tptr = nullptr, *info = nullptr; uint4* rec = nullptr; unsigned short* rowoff = nullptr; };
   PlanSet sp_gen, sp_plain;
   int sp_rows = 0;                           // staged rows of a tile: the slots some target reads (+ one trash row for the rest); see build_stamp_plan
   unsigned short* d_sp_rowoff = nullptr;     // [n_g + n_c + n_b] word offset of every slot's row inside a tile
@@ -162,6 +162,8 @@ struct CadnipHandle {
   int team_desc_len[2] = {0, 0};   // 64-bit words each
   unsigned long long* d_steps1 = nullptr;   // one wave per instance, lean variant: step descriptors (f2_build_steps), two words per lane
   int steps1[3] = {0, 0, 0}, steps1_len = 0;
+  unsigned long long* d_steps4 = nullptr;   // ... for a team of four waves (the per-op step LU, lu_f2.hip: k_lu_steps)
+  int steps4[3] = {0, 0, 0};
   int f2_lean_lo = 0, f2_lean_end = 0;      // the table words [lo, end) the lean kernels stage in LDS (permutations, stamp tables, node tables)
   int f2_lds_len = 0;         // 32-bit words of the table that the fused kernels copy to LDS (f2len; the team kernel's step lists lie behind)
   int f2_par_words = 0;       // team kernel: doubles of the LDS-staged sp_mos1 parameter rows of one instance

@@ -198,14 +198,15 @@ __global__ void __launch_bounds__(64 * WPI) k_lu_f2_mw(LuF2Args f) {
   if (wave_any(bad) && lane == 0) atomicOr(&f.flags[inst], 1);
 }
 
-// The same refactor + solve as straight-line STEPS for a team of four waves per instance (f2_program.cpp: f2_build_team, as the fused team
-// kernel runs them): every thread owns one 8-byte descriptor per step -- word offsets of the entry, its pivot and the two factors of its
-// one multiply-add term -- so a step is ~60 instructions without branches, a barrier closes it.  The descriptors are per thread: they are
-// fetched from global memory a CHUNK of steps ahead into registers (the loads of chunk c + 1 are in flight while chunk c runs), nothing
-// of the program lives in LDS -- only the work array does, so a circuit whose tables do not fit beside it (the PSP103 ring: 86 steps x
-// 256 threads) runs here all the same.  For few instances -- where k_lu_f2's one wave per instance walks 100+ passes alone.
+// The same refactor + solve as straight-line STEPS for a team of four waves per instance (f2_program.cpp: f2_build_steps with nw = 4):
+// every thread owns one 16-byte descriptor per step -- word offsets of the entry, its pivot and the factors of up to three multiply-add
+// terms; steps are list-scheduled (an entry runs in the first step behind its operands' last writers that has a lane group free), a
+// barrier closes each.  The descriptors are per thread: they are fetched from global memory a CHUNK of steps ahead into registers (the
+// loads of chunk c + 1 are in flight while chunk c runs), nothing of the program lives in LDS -- only the work array does, so a circuit
+// whose tables do not fit beside it (the PSP103 ring: 87 steps x 256 threads; 116 with one term per lane and level-aligned steps) runs
+// here all the same.  For few instances -- where k_lu_f2's one wave per instance walks 100+ passes alone.
 struct LuStepArgs {
-  const u64* desc; int n_pre, n_post;
+  const uint4* desc; int n_pre, n_post;
   const u16 *loadpos, *rowof, *qinv;              // global copies of the table sections (csr entry -> W word, unknown -> rhs word, unknown -> solution word)
   const double *G, *C, *gamma, *rhs; double* x;
   const int* active; int* flags;
@@ -222,10 +223,10 @@ __global__ void __launch_bounds__(64 * NW) k_lu_steps(LuStepArgs f) {
   const int nW = f.lu_words + n + F2_TRASH;
   double* W = sm;
   for (int i = tid; i < (nW >> 1); i += NT) ((double2*)W)[i] = make_double2(0.0, 0.0);
-  if (tid == 0) { W[nW] = 0.0; W[nW + 1] = 1.0; }            // the steps' constant words (f2_build_team)
+  if (tid == 0) { W[nW] = 0.0; W[nW + 1] = 1.0; }            // the steps' constant words (f2_build_steps)
   // this thread's descriptors of the first chunk: requested before the matrix is loaded
-  const u64* dp = f.desc + tid;
-  u64 cur[LU_CHUNK], nxt[LU_CHUNK];
+  const uint4* dp = f.desc + tid;
+  uint4 cur[LU_CHUNK], nxt[LU_CHUNK];
   const int n_steps = f.n_pre + f.n_post;
 #pragma unroll
   for (int k = 0; k < LU_CHUNK; ++k) cur[k] = dp[(size_t)(k < n_steps ? k : 0) * NT];
@@ -241,20 +242,22 @@ __global__ void __launch_bounds__(64 * NW) k_lu_steps(LuStepArgs f) {
   __syncthreads();
   int bad = 0;
   const unsigned trash_w = (unsigned)(f.lu_words + n + lane);
-  auto step = [&](const u64 D) {
-    const unsigned lo = (unsigned)D, hi = (unsigned)(D >> 32);
-    double* const pp = W + (lo & 0x7FFFu);
-    const double piv = W[(lo >> 16) & 0x7FFFu], av = W[hi & 0x7FFFu], bv = W[(hi >> 16) & 0x7FFFu];
+  auto step = [&](const uint4 D) {
+    double* const pp = W + (D.x & 0x7FFFu);
+    const double piv = W[(D.x >> 16) & 0x7FFFu];
+    const double a0v = W[D.y & 0x7FFFu], b0v = W[(D.y >> 16) & 0x7FFFu];
+    const double a1v = W[D.z & 0x7FFFu], b1v = W[(D.z >> 16) & 0x7FFFu];
+    const double a2v = W[D.w & 0x7FFFu], b2v = W[(D.w >> 16) & 0x7FFFu];
     const double acc0 = *pp;
-    const unsigned lg = (lo >> 31) | ((hi >> 14) & 2u) | ((hi >> 29) & 4u);
-    double part = av * bv;
+    const unsigned lg = (D.x >> 31) | ((D.y >> 14) & 2u) | ((D.y >> 29) & 4u);
+    double part = fma(a2v, b2v, fma(a1v, b1v, a0v * b0v));
     { const double o = dpp_f64<0xB1>(part); part += lg >= 1 ? o : 0.0; }
     { const double o = dpp_f64<0x4E>(part); part += lg >= 2 ? o : 0.0; }
     { const double o = dpp_f64<0x141>(part); part += lg >= 3 ? o : 0.0; }
     { const double o = dpp_f64<0x140>(part); part += lg >= 4 ? o : 0.0; }
     if (piv == 0.0 || !isfinite(piv)) bad = 1;
     const double acc = fast_div(acc0 - part, piv);
-    *((lo & 0x8000u) ? pp : W + trash_w) = acc;
+    *((D.x & 0x8000u) ? pp : W + trash_w) = acc;
     __syncthreads();
   };
   // chunks of LU_CHUNK steps; the dense core sits between step n_pre - 1 and step n_pre
@@ -306,9 +309,9 @@ int launch_factor_solve_f2(CadnipHandle* h, const double* d_rhs, double* d_x) {
     const char* e = getenv("CADNIP_LU_STEPS");
     const bool steps = e ? atoi(e) != 0 : h->B <= 2 * h->n_cu_hint();
     const size_t shmem_s = (per + 2) * 8;
-    if (steps && h->d_team_desc[1] && shmem_s <= 160 * 1024) {
+    if (steps && h->d_steps4 && shmem_s <= 160 * 1024) {
       LuStepArgs g;
-      g.desc = h->d_team_desc[1]; g.n_pre = h->team_steps[1][0]; g.n_post = h->team_steps[1][1];
+      g.desc = (const uint4*)h->d_steps4; g.n_pre = h->steps4[0]; g.n_post = h->steps4[1];
       g.loadpos = (const u16*)(h->d_f2tab + h->f2off[S_LOADPOS]); g.rowof = (const u16*)(h->d_f2tab + h->f2off[S_ROWOF]); g.qinv = (const u16*)(h->d_f2tab + h->f2off[S_QINV]);
       g.G = h->d_G; g.C = h->d_C; g.gamma = h->d_gamma; g.rhs = d_rhs; g.x = d_x; g.active = h->d_active; g.flags = h->d_flags;
       g.B = h->B; g.n = h->n; g.nnz = h->nnz; g.lu_words = h->f2_lu_words; g.nc = h->f2_nc; g.dn0 = h->f2_dn0;

@@ -119,36 +119,56 @@ static int lu_analyze_mode(int n, const std::vector<int>& rowptr, const std::vec
       // the shortest rows; keep going while nothing acceptable was found (threshold test) -- done below by widening
       for (auto it = by_len.begin(); it != by_len.end() && (int)cand.size() < LU_SEARCH_ROWS; ++it) cand.push_back(it->second);
     }
-    const int n_scan = bi >= 0 ? 0 : restricted ? (int)cand.size() : n;
-    for (int ci = 0; ci < n_scan || (n_scan > 0 && restricted && bi < 0 && ci < (int)by_len.size()); ++ci) {
-      if (restricted && ci >= (int)cand.size()) {      // widen: nothing passed the threshold among the shortest rows
+    // one candidate entry (i, j) against the best so far: Markowitz cost, threshold test, diagonal preferred on ties, then the larger
+    // relative magnitude
+    auto consider = [&](int i, int j, double val, long cost) {
+      const double av = std::fabs(val);
+      if (!(av > 0.0) || !std::isfinite(av)) return;
+      if (best_cost >= 0 && cost > best_cost) return;
+      if (colmax_stamp[j] < 0) {          // (valid until an elimination step touches the column: a rail's column is long and asked for often)
+        double m = 0;
+        for (int ii : cols[j]) m = std::max(m, std::fabs(rows[ii][j]));
+        colmax[j] = m;
+        colmax_stamp[j] = 0;
+      }
+      if (av < pivot_tol * colmax[j]) return;
+      const double rel = av / colmax[j];
+      const bool diag = (i == j);
+      bool better = false;
+      if (best_cost < 0 || cost < best_cost) better = true;
+      else if (diag != bdiag) better = diag;
+      else if (rel > brel * (1 + 1e-12)) better = true;
+      if (better) { best_cost = cost; bi = i; bj = j; bdiag = diag; brel = rel; }
+    };
+    if (bi < 0 && !restricted) {
+      for (int i = 0; i < n; ++i) {
+        if (rdone[i]) continue;
+        const long r = (long)rows[i].size();
+        for (auto& kv : rows[i]) consider(i, kv.first, kv.second, (r - 1) * ((long)cols[kv.first].size() - 1));
+      }
+    } else if (bi < 0) {
+      // The entries of the searched rows in ascending cost (stable: equal costs keep the row-by-row order, so the choice is the one a plain
+      // scan makes): the column maximum of the threshold test is then taken for cheap candidates only -- a scan in row order asked for it
+      // whenever no acceptable candidate had been seen yet, and for an entry in a supply rail's column (10 k rows in the c6288 multiplier)
+      // that is 10 k look-ups, at nearly every pivot step: 9.5 of the 10 s the search took there.
+      struct Cnd { long cost; int i, j; double v; };
+      std::vector<Cnd> cs;
+      auto gather = [&]() {
+        cs.clear();
+        for (int i : cand) {
+          if (rdone[i]) continue;
+          const long r = (long)rows[i].size();
+          for (auto& kv : rows[i]) cs.push_back(Cnd{(r - 1) * ((long)cols[kv.first].size() - 1), i, kv.first, kv.second});
+        }
+        std::stable_sort(cs.begin(), cs.end(), [](const Cnd& x, const Cnd& y) { return x.cost < y.cost; });
+      };
+      gather();
+      for (const Cnd& c : cs) { if (best_cost >= 0 && c.cost > best_cost) break; consider(c.i, c.j, c.v, c.cost); }
+      if (bi < 0 && cand.size() < by_len.size()) {      // widen: nothing passed the threshold among the shortest rows
         cand.clear();
         for (auto& pr : by_len) cand.push_back(pr.second);
-      }
-      const int i = restricted ? cand[ci] : ci;
-      if (rdone[i]) continue;
-      long r = (long)rows[i].size();
-      for (auto& kv : rows[i]) {
-        int j = kv.first;
-        double av = std::fabs(kv.second);
-        if (!(av > 0.0) || !std::isfinite(av)) continue;
-        long c = (long)cols[j].size();
-        long cost = (r - 1) * (c - 1);
-        if (best_cost >= 0 && cost > best_cost) continue;
-        if (colmax_stamp[j] != k) {
-          double m = 0;
-          for (int ii : cols[j]) m = std::max(m, std::fabs(rows[ii][j]));
-          colmax[j] = m;
-          colmax_stamp[j] = k;
-        }
-        if (av < pivot_tol * colmax[j]) continue;
-        double rel = av / colmax[j];
-        bool diag = (i == j);
-        bool better = false;
-        if (best_cost < 0 || cost < best_cost) better = true;
-        else if (diag != bdiag) better = diag;
-        else if (rel > brel * (1 + 1e-12)) better = true;
-        if (better) { best_cost = cost; bi = i; bj = j; bdiag = diag; brel = rel; }
+        gather();
+        for (const Cnd& c : cs) { if (best_cost >= 0 && c.cost > best_cost) break; consider(c.i, c.j, c.v, c.cost); }
       }
     }
     if (bi < 0) { err = "matrix is singular at pivot step " + std::to_string(k); return CADNIP_SINGULAR; }
@@ -173,11 +193,12 @@ static int lu_analyze_mode(int n, const std::vector<int>& rowptr, const std::vec
         if (it == rows[i].end()) { rows[i][j] = magnitudes ? std::fabs(f * kv.second) : -f * kv.second; cols[j].insert(i); }
         else if (magnitudes) it->second = std::fabs(it->second) + std::fabs(f * kv.second);
         else it->second -= f * kv.second;
+        colmax_stamp[j] = -1;
       }
       rows[i].erase(bj);
       if (restricted) by_len.insert({(int)rows[i].size(), i});
     }
-    for (auto& kv : rows[bi]) cols[kv.first].erase(bi);
+    for (auto& kv : rows[bi]) { cols[kv.first].erase(bi); colmax_stamp[kv.first] = -1; }
     cols[bj].clear();
     rdone[bi] = 1;
   }
@@ -223,28 +244,39 @@ static int lu_analyze_mode(int n, const std::vector<int>& rowptr, const std::vec
   std::vector<Ent> ents;
   // a candidate pivot IS the constant 1 if, besides, no elimination step updates its diagonal entry (no term in its recurrence):
   // decided here, row by row -- row j's diagonal is complete before any later row divides by it
-  for (int i = 0; i < n; ++i) {
-    int r0 = out.lu_rowptr[i], r1 = out.lu_rowptr[i + 1], dp = out.lu_diag[i];
-    for (int p = r0; p < r1; ++p) {
-      int j = out.lu_col[p];
-      Ent e;
-      e.pos = p;
-      e.diag = (j < i && !out.unit[j]) ? out.lu_diag[j] : -1;     // L entry: divided by its pivot, unless that is the constant 1
-      int lvl = 0;
-      for (int pl = r0; pl < dp; ++pl) {       // L(i,k), k ascending
-        int kk = out.lu_col[pl];
-        if (kk >= j) break;
-        auto it = posmap.find((long long)kk * n + j);
-        if (it == posmap.end()) continue;
-        e.a.push_back(pl);
-        e.b.push_back(it->second);
-        lvl = std::max(lvl, std::max(level[pl], level[it->second]) + 1);
+  // Terms of row i: for every L(i,k), k ascending, the entries (k,j), j > k, of row k that row i also holds -- found through a scatter of
+  // row i's positions (O(multiply-adds); looking every (k,j) pair of a row up in a hash map was quadratic in the row length: 167 M
+  // look-ups, half of the 13 s this phase took for the c6288 multiplier, whose supply rails have rows of thousands of entries).  An
+  // entry's terms arrive in ascending k, the order the look-up produced.
+  {
+    std::vector<int> wpos(n, -1);
+    std::vector<std::vector<int>> ta, tb;
+    for (int i = 0; i < n; ++i) {
+      const int r0 = out.lu_rowptr[i], r1 = out.lu_rowptr[i + 1], dp = out.lu_diag[i];
+      for (int p = r0; p < r1; ++p) wpos[out.lu_col[p]] = p;
+      ta.assign((size_t)(r1 - r0), std::vector<int>()); tb.assign((size_t)(r1 - r0), std::vector<int>());
+      for (int pl = r0; pl < dp; ++pl) {
+        const int kk = out.lu_col[pl];
+        for (int pu = out.lu_diag[kk] + 1; pu < out.lu_rowptr[kk + 1]; ++pu) {
+          const int q = wpos[out.lu_col[pu]];
+          if (q >= 0) { ta[(size_t)(q - r0)].push_back(pl); tb[(size_t)(q - r0)].push_back(pu); }
+        }
       }
-      if (j == i) out.unit[i] = (unit_cand[i] && e.a.empty()) ? 1 : 0;
-      if (e.diag >= 0) lvl = std::max(lvl, level[e.diag] + 1);
-      level[p] = lvl;
-      e.lvl = lvl;
-      if (!e.a.empty() || e.diag >= 0) ents.push_back(std::move(e));
+      for (int p = r0; p < r1; ++p) {
+        const int j = out.lu_col[p];
+        Ent e;
+        e.pos = p;
+        e.diag = (j < i && !out.unit[j]) ? out.lu_diag[j] : -1;     // L entry: divided by its pivot, unless that is the constant 1
+        e.a = std::move(ta[(size_t)(p - r0)]); e.b = std::move(tb[(size_t)(p - r0)]);
+        int lvl = 0;
+        for (size_t t = 0; t < e.a.size(); ++t) lvl = std::max(lvl, std::max(level[e.a[t]], level[e.b[t]]) + 1);
+        if (j == i) out.unit[i] = (unit_cand[i] && e.a.empty()) ? 1 : 0;
+        if (e.diag >= 0) lvl = std::max(lvl, level[e.diag] + 1);
+        level[p] = lvl;
+        e.lvl = lvl;
+        if (!e.a.empty() || e.diag >= 0) ents.push_back(std::move(e));
+      }
+      for (int p = r0; p < r1; ++p) wpos[out.lu_col[p]] = -1;
     }
   }
   std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.lvl < y.lvl; });

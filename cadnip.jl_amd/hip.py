@@ -457,7 +457,7 @@ def host_lu_analyze(n, rowptr, colidx, vals, pivot_tol=1e-3, sample=False, f2_nc
                     out["team_steps"][nw] = tuple(int(v) for v in ts)
             # ... as straight-line steps: "steps" = {nw: (counts, uint64 descriptor words)}; nw = 1 is the sweep kernel's three-term layout
             out["steps"] = {}
-            for nw in (1, 2, 4):
+            for nw in (1, 2, 4, 12, 14):
                 if lib.cadnip_host_f2_steps(p, C.c_int32(int(f2_nc)), C.c_int32(nw), ts, None) == 0:
                     words = np.zeros(max(int(ts[3]), 1), dtype=np.uint64)
                     _check(lib.cadnip_host_f2_steps(p, C.c_int32(int(f2_nc)), C.c_int32(nw), ts, words.ctypes.data_as(C.c_void_p)), "cadnip_host_f2_steps")

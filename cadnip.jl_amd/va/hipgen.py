@@ -372,6 +372,11 @@ def generate_function(m, tl=False, with_functions=True):
     L.append("template <class Ctx, class Out>")
     if tl:
         L.append("__device__ inline void stamp_va_%s_tl(const Ctx& d, const double* u, const Out& s, double* lw, const int dir) {" % m.name)
+        # the function is too large to be inlined: through `d` the compiler sees generic pointers and every parameter / cache reference
+        # would be a flat load (PSP103: 1 700 of them); typed pointers make them global loads
+        L.append("  typedef const __attribute__((address_space(1))) double* VaGlobalPtr;   // the parameter rows and the setup cache lie in global memory: say so")
+        L.append("  const VaGlobalPtr va_gpar = (VaGlobalPtr)d.par + d.dev, va_gcache = (VaGlobalPtr)d.cache + d.dev;")
+        L.append("  const int va_count = d.count;")
     else:
         L.append("__device__ inline void stamp_va_%s(const Ctx& d, const double* u, const Out& s, double* lw) {" % m.name)
     L.append("  constexpr int N = %d, B = %d, S = %d, NL = %d;   // nodes, branches, $limit sites, limit unknowns" % (N, B, S, NL))
@@ -399,19 +404,19 @@ def generate_function(m, tl=False, with_functions=True):
         if m.param_kind.get(p) == "string":
             continue
         if tl:
-            macros.append(("p_%s" % p, "par_of(d, %d)" % i))
+            macros.append(("p_%s" % p, "va_gpar[%d * va_count]" % i))
         else:
             L.append("  const double p_%s = par_of(d, %d);" % (p, i))
     L.append("  const VaSys sys{par_of(d, %d), par_of(d, %d), par_of(d, %d), d.initjct ? 1.0 : 0.0, d.mode, d.t};   // $temperature, $mfactor, gmin, initjct, analysis(), $abstime" % (NP, NP + 1, NP + 2))
     if m.uses_given:
         for i, p in enumerate(m.params):
             if tl:
-                macros.append(("g_%s" % p, "par_of(d, %d)" % (NP + 3 + i)))
+                macros.append(("g_%s" % p, "va_gpar[%d * va_count]" % (NP + 3 + i)))
             else:
                 L.append("  const double g_%s = par_of(d, %d);   // $param_given(%s)" % (p, NP + 3 + i, p))
     for i, (p, lit) in enumerate(m.string_tests):
         if tl:
-            macros.append(("st_%d" % i, "par_of(d, %d)" % (NP + 3 + (NP if m.uses_given else 0) + i)))
+            macros.append(("st_%d" % i, "va_gpar[%d * va_count]" % (NP + 3 + (NP if m.uses_given else 0) + i)))
         else:
             L.append("  const double st_%d = par_of(d, %d);   // %s == \"%s\"" % (i, NP + 3 + (NP if m.uses_given else 0) + i, p, lit))
     L.append("  double ld[S > 0 ? S : 1] = {0.0};    // per $limit site: V(probe) - w, the lim_rhs delta (vasim.jl:2957-2966)")
@@ -422,7 +427,7 @@ def generate_function(m, tl=False, with_functions=True):
     for v in m.locals_:
         if hoist and v in m.hoist_vars:
             if v in m.cache_vars:
-                macros.append(("v_%s" % v, "va_cache(d, %d)" % m.cache_vars.index(v)))
+                macros.append(("v_%s" % v, "va_gcache[%d * va_count]" % m.cache_vars.index(v)))
             continue                                    # computed by the setup pass; read from the per-device cache where used
         L.append("  %s v_%s = 0.0;" % ("T" if m.var_is_dual[v] else "double", v))
         if m.var_is_reactive[v]:

@@ -333,7 +333,8 @@ int32_t cadnip_host_f2_size(const CadnipHostF2* prog, int32_t which);
 int cadnip_host_f2_get(const CadnipHostF2* prog, int32_t which, void* dst);
 int cadnip_host_f2_team_steps(const CadnipHostLU* lu, int32_t nc, int32_t nw, int32_t* out4);   /* steps of the team layout (pre, post, forward-only) and its descriptor words */
 /* The same program as straight-line steps (csrc/f2_program.cpp): nw = 1 -- the one-wave layout of the fused sweep kernel (list-scheduled steps of 64
- * lanes, three terms per lane, 16-byte descriptors = two uint64 per lane), nw = 2 / 4 -- the team layouts (8-byte descriptors).  out4 = steps of the
+ * lanes, three terms per lane, 16-byte descriptors = two uint64 per lane), nw = 2 / 4 -- the team layouts (8-byte descriptors), nw = 12 / 14 -- the
+ * three-term layout for teams of 2 / 4 waves (the per-op step LU).  out4 = steps of the
  * pre-core, post-core and forward-only lists and the number of uint64 words; dst (may be NULL) receives the words. */
 int cadnip_host_f2_steps(const CadnipHostLU* lu, int32_t nc, int32_t nw, int32_t* out4, uint64_t* dst);
 void cadnip_host_f2_free(CadnipHostF2* prog);
