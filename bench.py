@@ -65,6 +65,13 @@ def algorithmic_bytes(st, B, nnz_lu):
              "F": "cccs", "D": "diode", "DCAP": "diodecap", "SMOS": "simplemos", "MOS1": "mos1"}
     touched = stamp_targets(st)
     for k, blk in enumerate(st.blocks):
+        if blk.type.startswith("VA:"):
+            # a generated Verilog-A model: parameter rows, node indices, staged contributions + their maps, the unknowns, the reduced words
+            n_slots = blk.n_g + blk.n_c + blk.n_b
+            per_dev = 8 * blk.n_par + 4 * blk.nodes.shape[0] + (8 + 4) * n_slots
+            key = "stamp_va_" + blk.type[3:]
+            out[key] = out.get(key, 0) + B * (blk.count * per_dev + 8 * st.n + 8 * touched[k])
+            continue
         if blk.type not in names:
             continue
         n_slots = blk.n_g + blk.n_c + blk.n_b
@@ -497,6 +504,7 @@ def psp103_ring_leg(device):
             sim = api.BatchSimulator.from_packed(st, packed, api.MNASpec(mode="tran", temp=27.0), device=device, vscale=1.2)
             try:
                 sim.analyze()
+                nnz_lu = sim.h.lu_stats()["nnz_lu"]
                 u, conv, _ = sim.dc(abstol=1e-9, mode="tranop")
                 sim.h.set_spec(mode="tran")
                 t1 = 20e-9
@@ -507,6 +515,13 @@ def psp103_ring_leg(device):
             out["B%d" % B] = {"newton_iters": int(stats["newton_iters"]), "wall_s": round(stats["wall_seconds"], 3), "failed": int(stats["n_failed"]) + int((~conv).sum()),
                               "us_per_instance_iter": round(1e6 * stats["wall_seconds"] / max(stats["newton_iters"], 1), 3),
                               "us_per_newton_round": round(1e6 * stats["wall_seconds"] / max(stats["launches"], 1), 1)}
+            # SURVEY 8d's bytes for this circuit (per instance and Newton iteration: every array of the per-op kernels counted once per required
+            # read or write) against the HBM peak: the per-op path's roofline line for config 5
+            b_iter = algorithmic_bytes(st, 1, nnz_lu)["B_iter_per_instance"]
+            gbps = b_iter * stats["newton_iters"] / max(stats["wall_seconds"], 1e-12) / 1e9
+            out["B_iter_per_instance"] = int(b_iter)
+            out["B%d" % B]["roofline"] = {"bound": "hbm", "achieved": round(gbps, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBS, 5),
+                                          "note": "algorithmic bytes (B_iter_per_instance x Newton iterations) / wall time of the slice; a single ring is a latency problem (one PSP103 evaluation is ~10 k dependent vector instructions), the batch is bound by that evaluation's instruction stream, not by HBM"}
     except Exception as e:       # the headline line must not depend on this leg
         out["error"] = "%s: %s" % (type(e).__name__, e)
     return out

@@ -324,7 +324,9 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
   // Few instances: a team of waves per instance (fused_team_kernel.hpp) -- the latency of ONE transient is what counts when the batch
   // cannot fill the chip.  Transient, direct residuals, lean device set.  CADNIP_F2_TEAM = 0 | 2 | 4 forces the choice (diagnostic, tests).
   if (!dc && h->f2_direct && h->f2_lean) {
-    int nw = h->B <= h->n_cu ? 4 : 0;
+    // at most one instance per CU: a team of four waves (one per SIMD); at most two: teams of two waves, two workgroups per CU (their LDS allows it);
+    // beyond that the sweep kernel's one wave per instance
+    int nw = h->B <= h->n_cu ? 4 : h->B <= 2 * h->n_cu ? 2 : 0;
     if (const char* e = getenv("CADNIP_F2_TEAM")) nw = atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 0;
     if (step) nw = 4;
     const size_t shmem_t = (tab_dbl + per + 4 * (size_t)nw + (size_t)h->f2_par_words + (nw ? (size_t)h->team_desc_len[nw / 4] : 0) +

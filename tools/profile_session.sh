@@ -52,6 +52,7 @@ for NB in 1 512; do
 done
 timeout -k 10 400 python3 tools/psp103_ring.py --tspan 1e-6 --batch 1 > $P/${TAG}_psp103_ring.txt 2>&1 || true
 timeout -k 10 300 python3 tools/psp103_ring.py --tspan 2e-8 --batch 1,64,512 >> $P/${TAG}_psp103_ring.txt 2>&1 || true
+timeout -k 10 300 bash tools/pmc_ring.sh > $P/${TAG}_psp103_stamp_pmc.txt 2>&1 || true
 echo "round-3 legs done"
 cp $OUT/${TAG}_bench.json $P/${TAG}_fused_B${B}_bench.json
 tail -c 600 $P/${TAG}_fused_B${B}_bench.json; echo
