@@ -7,12 +7,16 @@
 // k_lu remains for what this program cannot do: factor-only / solve-only (the callback ABI's cadnip_factor /
 // cadnip_solve keep the factors in HBM) and circuits whose program does not fit.
 #include <hip/hip_runtime.h>
+#include <string.h>
+#include <stdlib.h>
 #include "fused2_kernel.hpp"
 
 namespace cadnip {
 
 struct LuF2Args {
   const unsigned* tab; int off[S_NSEC]; int tab_len;
+  int tab_lo;                                   // k_lu_f2s: the staged table range starts at this word (load map, permutations)
+  const uint4* steps; int steps_len, ts_pre, ts_post;   // k_lu_f2s: the one-wave step program (f2_build_steps), 16-byte lane descriptors
   const double *G, *C, *gamma, *rhs; double* x;
   const int* active; int* flags;
   int B, n, nnz, lu_words, n_pre, n_post, nc, dn0;
@@ -107,6 +111,113 @@ __global__ void __launch_bounds__(64 * WPB) k_lu_f2(LuF2Args f) {
     CADNIP_WAVE_SYNC();
   }
   run_passes(f.n_pre, f.n_post);
+  double* x = f.x + (size_t)inst * n;
+  for (int i = lane; i < n; i += 64) { const double v = W[qinv[i]]; if (!isfinite(v)) bad = 1; x[i] = v; }
+  if (wave_any(bad) && lane == 0) atomicOr(&f.flags[inst], 1);
+}
+
+// The same kernel on the fused sweep kernel's STEP program (f2_program.cpp: f2_build_steps; fused2_kernel.hpp: run_steps): straight-line
+// steps with three terms per lane, list-scheduled -- 7 + 6 steps instead of 9 + 8 passes on the flip-flop, and no term lists.  Staged in LDS:
+// the load map and the permutations of the table, the step descriptors, the instances' work arrays.  Taken when the descriptors fit (a long
+// dependency chain has one step per link: the pass program is the compact form).
+// UPD: the transient's Newton update and step controller (tran_ctrl.hpp: tran_update_body, what k_tran_update of driver.hip does in a launch
+// of its own) run right behind the solve, the Newton step read out of the work array instead of through HBM -- one launch less per round and
+// no round trip of the step.
+struct LuUpdVecs : GlobalVecsT<64> {
+  const double* Wl; const u16* qv;
+  __device__ LuUpdVecs(const TranArgs& a, int inst, const double* W_, const u16* q_) : GlobalVecsT<64>(a, inst), Wl(W_), qv(q_) {}
+  __device__ __forceinline__ double get_delta(int i, int) const { return Wl[qv[i]]; }
+};
+template <int WPB, bool UPD>
+__global__ void __launch_bounds__(64 * WPB) k_lu_f2s(LuF2Args f, TranArgs ta) {
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), n = f.n;
+  {
+    const uint2* src = (const uint2*)(f.tab + f.tab_lo);
+    uint2* dst = (uint2*)sm;
+    for (int i = tid; i < f.tab_len / 2; i += 64 * WPB) dst[i] = src[i];
+    const uint2* s2 = (const uint2*)f.steps;
+    uint2* d2 = (uint2*)(sm + f.tab_len / 2);
+    for (int i = tid; i < f.steps_len; i += 64 * WPB) d2[i] = s2[i];
+  }
+  __syncthreads();
+  const int inst = blockIdx.x * WPB + w;
+  if (inst >= f.B || !f.active[inst]) return;
+  const unsigned* tab = (const unsigned*)sm;
+  const uint4* tdesc = (const uint4*)(sm + f.tab_len / 2);
+  const int nW = f.lu_words + n + F2_TRASH;
+  double* W = sm + f.tab_len / 2 + f.steps_len + (size_t)w * (nW + 2);
+  const u16* loadpos = (const u16*)(tab + (f.off[S_LOADPOS] - f.tab_lo));
+  const u16* qinv = (const u16*)(tab + (f.off[S_QINV] - f.tab_lo));
+  const u16* rowof = (const u16*)(tab + (f.off[S_ROWOF] - f.tab_lo));
+  for (int i = lane; i < (nW >> 1); i += 64) ((double2*)W)[i] = make_double2(0.0, 0.0);   // nW is even (f2_program.cpp)
+  if (lane == 0) { W[nW] = 0.0; W[nW + 1] = 1.0; }                                        // the steps' constant words
+  CADNIP_WAVE_SYNC();
+  {
+    const double* G = f.G + (size_t)inst * f.nnz;
+    const double* C = f.C + (size_t)inst * f.nnz;
+    const double gam = f.gamma[inst];
+    for (int e = lane; e < f.nnz; e += 64) W[loadpos[e]] = G[e] + gam * C[e];
+    const double* rhs = f.rhs + (size_t)inst * n;
+    for (int i = lane; i < n; i += 64) W[rowof[i]] = rhs[i];
+  }
+  CADNIP_WAVE_SYNC();
+  int bad = 0;
+  const unsigned trash_w = (unsigned)(f.lu_words + n + lane);
+  auto run_steps = [&](const int s_first, const int s_count) {
+    if (s_count <= 0) return;
+    const uint4* dp = tdesc + (size_t)s_first * 64 + lane;
+    uint4 D = dp[0];
+    for (int si = 0; si < s_count; ++si) {
+      double* const pp = W + (D.x & 0x7FFFu);
+      const double piv = W[(D.x >> 16) & 0x7FFFu];
+      const double a0v = W[D.y & 0x7FFFu], b0v = W[(D.y >> 16) & 0x7FFFu];
+      const double a1v = W[D.z & 0x7FFFu], b1v = W[(D.z >> 16) & 0x7FFFu];
+      const double a2v = W[D.w & 0x7FFFu], b2v = W[(D.w >> 16) & 0x7FFFu];
+      const double acc0 = *pp;
+      const uint4 Dn = dp[(size_t)(si + 1) * 64];
+      const unsigned fz = __builtin_amdgcn_readfirstlane(D.z), fw = __builtin_amdgcn_readfirstlane(D.w);
+      const unsigned maxlg = ((fz >> 15) & 1u) | ((fz >> 30) & 2u) | ((fw >> 13) & 4u);
+      const unsigned lg = (D.x >> 31) | ((D.y >> 14) & 2u) | ((D.y >> 29) & 4u);
+      double part = fma(a2v, b2v, fma(a1v, b1v, a0v * b0v));
+      if (maxlg >= 1) { const double o = dpp_f64<0xB1>(part); part += lg >= 1 ? o : 0.0; }
+      if (maxlg >= 2) { const double o = dpp_f64<0x4E>(part); part += lg >= 2 ? o : 0.0; }
+      if (maxlg >= 3) { const double o = dpp_f64<0x141>(part); part += lg >= 3 ? o : 0.0; }
+      if (maxlg >= 4) { const double o = dpp_f64<0x140>(part); part += lg >= 4 ? o : 0.0; }
+      double acc = acc0 - part;
+      if (fw >> 31) {
+        if (piv == 0.0 || !isfinite(piv)) bad = 1;
+        acc = fast_div(acc, piv);
+      }
+      *((D.x & 0x8000u) ? pp : W + trash_w) = acc;
+      D = Dn;
+    }
+    CADNIP_WAVE_SYNC();
+  };
+  run_steps(0, f.ts_pre);
+  if (f.nc > 0) {
+    const int yc0 = f.lu_words + n - f.nc;
+    if (f.nc == 8) dense_core_solve<8, 0>(W, f.dn0, yc0, lane, bad, false);
+    else if (f.nc == 12) dense_core_solve<12, 0>(W, f.dn0, yc0, lane, bad, false);
+    else dense_core_solve<F2_NCMAX, 0>(W, f.dn0, yc0, lane, bad, false);
+    CADNIP_WAVE_SYNC();
+  }
+  run_steps(f.ts_pre, f.ts_post);
+  if constexpr (UPD) {
+    StepState s = load_state(ta, inst);
+    if (s.status != 0) return;
+    bad = wave_any(bad);
+    LuUpdVecs v(ta, inst, W, qinv);
+    if (ta.newton_mode) {       // (as k_tran_update, driver.hip: the per-op path refactors every round; the rate constant follows the fused kernel's events)
+      const bool setup = !(s.mflags & MN_VALID) || (s.k == 0 && (s.a0 < 0.6 * s.a0f || s.a0 * 0.6 > s.a0f || (s.mflags >> MN_SINCE_SHIFT) >= 20));
+      if (setup) { s.a0f = s.a0; s.ss = 20.0; s.mflags = MN_VALID | MN_JCUR; }
+      else s.mflags |= MN_JCUR;
+      s.dsc = 1.0;
+    }
+    tran_update_body(ta, v, s, inst, lane, bad);
+    store_state(ta, inst, lane, s);
+    return;
+  }
   double* x = f.x + (size_t)inst * n;
   for (int i = lane; i < n; i += 64) { const double v = W[qinv[i]]; if (!isfinite(v)) bad = 1; x[i] = v; }
   if (wave_any(bad) && lane == 0) atomicOr(&f.flags[inst], 1);
@@ -296,11 +407,14 @@ __global__ void __launch_bounds__(64 * NW) k_lu_steps(LuStepArgs f) {
 }
 
 // 0 = done with the program kernel; 1 = not applicable (the caller falls back to k_lu); < 0 never
-int launch_factor_solve_f2(CadnipHandle* h, const double* d_rhs, double* d_x) {
+// upd (optional): the transient controller's arguments -- when the step-program kernel takes the launch, the Newton update runs inside it and the
+// return value is 2 (the caller skips its k_tran_update)
+int launch_factor_solve_f2(CadnipHandle* h, const double* d_rhs, double* d_x, const TranArgs* upd) {
   if (!h->analyzed || !fused2_tables_ready(h)) return 1;   // (only the linear-solve prefix of the tables has to fit: checked below)
   ProfScope ps(h, "lu_factor_solve");
   LuF2Args f;
   f.tab = h->d_f2tab; for (int i = 0; i < S_NSEC; ++i) f.off[i] = h->f2off[i]; f.tab_len = h->f2_lu_len;
+  f.tab_lo = 0; f.steps = nullptr; f.steps_len = 0; f.ts_pre = f.ts_post = 0;
   f.G = h->d_G; f.C = h->d_C; f.gamma = h->d_gamma; f.rhs = d_rhs; f.x = d_x; f.active = h->d_active; f.flags = h->d_flags;
   f.B = h->B; f.n = h->n; f.nnz = h->nnz; f.lu_words = h->f2_lu_words; f.n_pre = h->f2_n_pre; f.n_post = h->f2_n_post; f.nc = h->f2_nc; f.dn0 = h->f2_dn0;
   const size_t tab_dbl = (size_t)h->f2_lu_len / 2, per = (size_t)h->f2_lu_words + h->n + F2_TRASH;
@@ -331,6 +445,30 @@ int launch_factor_solve_f2(CadnipHandle* h, const double* d_rhs, double* d_x) {
       hipLaunchKernelGGL(k_lu_f2_mw<4>, dim3(h->B), dim3(256), shmem_mw, h->stream, f);
       HIP_TRY(hipGetLastError());
       return CADNIP_OK;
+    }
+  }
+  // many instances: one wave each.  On the step program when its descriptors fit beside eight work arrays (CADNIP_LU_F2S = 0 keeps the passes)
+  if (h->d_steps1 && !(getenv("CADNIP_LU_F2S") && atoi(getenv("CADNIP_LU_F2S")) == 0)) {
+    const int lo = h->f2off[S_LOADPOS] & ~3;
+    const size_t tabs = (size_t)(h->f2_lu_len - lo) / 2, desc = (size_t)h->steps1_len, pers = per + 2;
+    int wpb = 8;
+    while (wpb > 1 && h->B < 256 * wpb / 2) wpb >>= 1;
+    const size_t shmem = (tabs + desc + wpb * pers) * 8;
+    if ((tabs + desc + 8 * pers) * 8 <= 160 * 1024) {
+      f.tab_lo = lo; f.tab_len = h->f2_lu_len - lo;
+      f.steps = (const uint4*)h->d_steps1; f.steps_len = h->steps1_len; f.ts_pre = h->steps1[0]; f.ts_post = h->steps1[1];
+      const int grid = (h->B + wpb - 1) / wpb;
+      const bool fuse_upd = upd && h->n < 4096 && !(getenv("CADNIP_LU_UPD") && atoi(getenv("CADNIP_LU_UPD")) == 0);
+      TranArgs ta;
+      if (fuse_upd) ta = *upd; else memset(&ta, 0, sizeof(ta));
+#define LAUNCH(W) do { if (fuse_upd) { if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_lu_f2s<W, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+      hipLaunchKernelGGL((k_lu_f2s<W, true>), dim3(grid), dim3(64 * W), shmem, h->stream, f, ta); } \
+    else { if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_lu_f2s<W, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+      hipLaunchKernelGGL((k_lu_f2s<W, false>), dim3(grid), dim3(64 * W), shmem, h->stream, f, ta); } } while (0)
+      if (wpb == 8) LAUNCH(8); else if (wpb == 4) LAUNCH(4); else if (wpb == 2) LAUNCH(2); else LAUNCH(1);
+#undef LAUNCH
+      HIP_TRY(hipGetLastError());
+      return fuse_upd ? 2 : CADNIP_OK;
     }
   }
   int wpb = 8;

@@ -462,6 +462,83 @@ def test_fused_linear_solve_program_on_cpu(nc):
             assert n_pre + n_post <= (30 if nc == 0 else 19), (nc, n_pre, n_post)   # 29 passes without a core, 17-18 with
 
 
+def _run_steps(W, words, nw, three, s0, cnt):
+    """Execute steps [s0, s0 + cnt) of a straight-line step list on the work array W, lane by lane as the kernels do (fused2_kernel.hpp:
+    run_steps -- 16-byte descriptors, three terms per lane; fused_team_kernel.hpp / lu_f2.hip: k_lu_steps -- the same for teams, and the
+    8-byte one-term team layout): every lane reads its operands, the lane groups are summed, the leaders store."""
+    NT = 64 * nw
+    fld = lambda x, sh: ((x >> np.uint64(sh)) & np.uint64(0x7FFF)).astype(np.int64)
+    bit = lambda x, sh: ((x >> np.uint64(sh)) & np.uint64(1)).astype(np.int64)
+    d = words.reshape(-1, 2) if three else words.reshape(-1, 1)
+    for s in range(s0, s0 + cnt):
+        D = d[s * NT:(s + 1) * NT]
+        lo = D[:, 0]
+        pos, piv, a0, b0 = fld(lo, 0), fld(lo, 16), fld(lo, 32), fld(lo, 48)
+        leader = bit(lo, 15)
+        lg = bit(lo, 31) | bit(lo, 47) << 1 | bit(lo, 63) << 2
+        part = W[a0] * W[b0]
+        if three:
+            hi = D[:, 1]
+            part = part + W[fld(hi, 0)] * W[fld(hi, 16)] + W[fld(hi, 32)] * W[fld(hi, 48)]
+            maxlg = bit(hi, 15) | bit(hi, 31) << 1 | bit(hi, 47) << 2
+            hasdiv = bit(hi, 63)
+            assert len(set(maxlg.tolist())) == 1 and len(set(hasdiv.tolist())) == 1 and lg.max() <= maxlg[0]     # the step's flags: the same in every lane
+            if not hasdiv[0]:
+                assert np.all(W[piv] == 1.0)
+        grp = np.array([part[(l >> lg[l]) << lg[l]:((l >> lg[l]) << lg[l]) + (1 << lg[l])].sum() for l in range(NT)])
+        acc = (W[pos] - grp) / W[piv]
+        assert len(set(pos[leader == 1].tolist())) == int(leader.sum())       # one writer per word and step
+        W[pos[leader == 1]] = acc[leader == 1]
+
+
+@pytest.mark.parametrize("nc", [0, 8, 12])
+def test_step_programs_on_cpu(nc):
+    """The linear solve as straight-line steps (csrc/f2_program.cpp): f2_build_steps -- list-scheduled, three terms per lane: the fused sweep
+    kernel's lean variant (one wave) and the per-op step LU (four waves) -- and f2_build_team (level-aligned, one term per lane: the team
+    kernel), executed step by step on the DFF Jacobian and a random MNA-like matrix against SuperLU; the DFF's step counts are pinned (the
+    LDS budget of the sweep kernel depends on them)."""
+    import scipy.sparse.linalg as spla
+    st, port = make_port(bm.dff_circuit(), {"vdd": 5.0})
+    rng = np.random.default_rng(11)
+    u = rng.random(st.n) * 5.0
+    G, Cm, b, lw = port.rebuild(u, 2.005e-7)
+    J = G + 1e9 * Cm
+    port.close()
+    cases = [(st.n, np.asarray(st.rowptr), np.asarray(st.colidx), J, hip.leaves_of(st))]
+    n = 70
+    A = sp.random(n, n, density=4.0 / n, random_state=5, format="lil")
+    for i in range(n):
+        A[i, i] = 4.0 + rng.random(); A[i, (i + 1) % n] = rng.random() - 0.5; A[(i + 3) % n, i] = rng.random() - 0.5
+    A = A.tocsr(); A.sort_indices()
+    cases.append((n, A.indptr, A.indices, A.data, None))
+    for n, rp, ci, vals, leaves in cases:
+        if nc > n:
+            continue
+        P = hip.host_lu_analyze(n, rp, ci, vals, f2_nc=nc, leaves=leaves)
+        f2 = P["f2"]
+        ncc, lu_words, dn0 = [int(x) for x in f2["meta"][:3]]
+        y0 = lu_words
+        pinv = np.empty(n, int); pinv[P["rperm"]] = np.arange(n)
+        dst = np.zeros(len(vals), int); dst[P["load_src"]] = f2["posW"][P["load_dst"]]
+        Asp = sp.csr_matrix((vals, ci, rp), shape=(n, n))
+        rhs = rng.random(n) - 0.5
+        for key, nw, three in ((1, 1, True), (14, 4, True), (2, 2, False), (4, 4, False)):
+            (n_pre, n_post, n_fwd), words = P["steps"][key]
+            W = np.zeros(y0 + n + 64 + 2); W[y0 + n + 64 + 1] = 1.0
+            W[dst] = vals
+            W[y0 + pinv] = rhs
+            _run_steps(W, words, nw, three, 0, n_pre)
+            if ncc:
+                S = W[dn0:dn0 + ncc * ncc].reshape(ncc, ncc); yc = slice(y0 + n - ncc, y0 + n)
+                W[yc] = np.linalg.solve(S, W[yc])
+            _run_steps(W, words, nw, three, n_pre, n_post)
+            x = np.empty(n); x[P["cperm"]] = W[y0:y0 + n]
+            bw = np.max(np.abs(Asp @ x - rhs) / (abs(Asp) @ np.abs(x) + np.abs(rhs) + 1e-300))
+            assert bw < 1e-9, (n, nc, key, bw)
+            if n == st.n and nc == 8:
+                assert (n_pre, n_post, n_fwd) == {1: (7, 6, 5), 14: (7, 5, 5), 2: (8, 9, 5), 4: (7, 6, 5)}[key], (key, n_pre, n_post, n_fwd)
+
+
 def test_cpu_port_ring_oscillator_fixture():
     """test/mna/vadistiller_integration.jl:649-692: the 3-stage sp_mos1 ring oscillates -- swing > 2 V, max > 2.5 V,
     min < 0.8 V, more than 10 mid-level crossings between 100 and 200 ns (dtmax = 1 ns).  The reference starts from
