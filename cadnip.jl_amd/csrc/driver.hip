@@ -612,14 +612,10 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
     for (int c = 0; c < check_every; ++c) {
       rc = launch_rebuild(h); if (rc) break;
       rc = launch_residual(h, h->d_du); if (rc) break;
-      rc = launch_factor_solve(h, true, h->d_resid, h->d_delta, &a);
-      if (rc == 2) rc = CADNIP_OK;                   // the step-program LU ran the Newton update and the step controller behind its solve
-      else {
-        if (rc) break;
-        ProfScope ps(h, "tran_update");
+      rc = launch_factor_solve(h, true, h->d_resid, h->d_delta); if (rc) break;
+      { ProfScope ps(h, "tran_update");
         if (h->n >= 4096) hipLaunchKernelGGL(k_tran_update<256>, dim3(h->B), dim3(256), 0, h->stream, a);
-        else hipLaunchKernelGGL(k_tran_update<64>, dim3(h->B), dim3(64), 0, h->stream, a);
-      }
+        else hipLaunchKernelGGL(k_tran_update<64>, dim3(h->B), dim3(64), 0, h->stream, a); }
       ++launches;
     }
     if (rc) break;

@@ -209,8 +209,7 @@ int launch_residual(CadnipHandle* h, const double* d_du);  // d_resid = C du + G
 int launch_jacobian(CadnipHandle* h);                      // d_J = G + gamma C
 int launch_factor(CadnipHandle* h, bool fuse_jacobian);    // LU of J (or of G + gamma C)
 int launch_solve(CadnipHandle* h, const double* d_rhs, double* d_x);
-struct TranArgs;
-int launch_factor_solve(CadnipHandle* h, bool fuse_jacobian, const double* d_rhs, double* d_x, const TranArgs* upd = nullptr);
+int launch_factor_solve(CadnipHandle* h, bool fuse_jacobian, const double* d_rhs, double* d_x);
 int upload_lu(CadnipHandle* h);
 int upload_homotopy(CadnipHandle* h, const double* gshunt /* [B] or null = spec */, const double* srcfact /* [B] or null = spec */);
 int launch_calib_copy(CadnipHandle* h, long n, int reps);

@@ -373,13 +373,12 @@ static int launch_lu(CadnipHandle* h, const char* name, int do_factor, int do_so
 
 int launch_factor(CadnipHandle* h, bool fuse) { return launch_lu(h, "lu_factor", 1, 0, fuse, nullptr, nullptr); }
 int launch_solve(CadnipHandle* h, const double* d_rhs, double* d_x) { return launch_lu(h, "lu_solve", 0, 1, false, d_rhs, d_x); }
-int launch_factor_solve_f2(CadnipHandle* h, const double* d_rhs, double* d_x, const TranArgs* upd);   // lu_f2.hip
-// upd (optional, transient driver): returns 2 when the kernel that took the launch also ran the Newton update and step controller (lu_f2.hip: k_lu_f2s)
-int launch_factor_solve(CadnipHandle* h, bool fuse, const double* d_rhs, double* d_x, const TranArgs* upd) {
+int launch_factor_solve_f2(CadnipHandle* h, const double* d_rhs, double* d_x);   // lu_f2.hip
+int launch_factor_solve(CadnipHandle* h, bool fuse, const double* d_rhs, double* d_x) {
   // refactor of G + gamma C followed by the solve: the entry-program kernel (lu_f2.hip) when the circuit's tables fit into
   // LDS; CADNIP_LU_PLAIN=1 forces the level-by-level kernel below (diagnostic: the two must agree)
   if (fuse && !getenv("CADNIP_LU_PLAIN")) {
-    const int rc = launch_factor_solve_f2(h, d_rhs, d_x, upd);
+    const int rc = launch_factor_solve_f2(h, d_rhs, d_x);
     if (rc != 1) return rc;
   }
   return launch_lu(h, "lu_factor_solve", 1, 1, fuse, d_rhs, d_x);

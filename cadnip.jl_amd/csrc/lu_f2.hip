@@ -120,16 +120,8 @@ __global__ void __launch_bounds__(64 * WPB) k_lu_f2(LuF2Args f) {
 // steps with three terms per lane, list-scheduled -- 7 + 6 steps instead of 9 + 8 passes on the flip-flop, and no term lists.  Staged in LDS:
 // the load map and the permutations of the table, the step descriptors, the instances' work arrays.  Taken when the descriptors fit (a long
 // dependency chain has one step per link: the pass program is the compact form).
-// UPD: the transient's Newton update and step controller (tran_ctrl.hpp: tran_update_body, what k_tran_update of driver.hip does in a launch
-// of its own) run right behind the solve, the Newton step read out of the work array instead of through HBM -- one launch less per round and
-// no round trip of the step.
-struct LuUpdVecs : GlobalVecsT<64> {
-  const double* Wl; const u16* qv;
-  __device__ LuUpdVecs(const TranArgs& a, int inst, const double* W_, const u16* q_) : GlobalVecsT<64>(a, inst), Wl(W_), qv(q_) {}
-  __device__ __forceinline__ double get_delta(int i, int) const { return Wl[qv[i]]; }
-};
-template <int WPB, bool UPD>
-__global__ void __launch_bounds__(64 * WPB) k_lu_f2s(LuF2Args f, TranArgs ta) {
+template <int WPB>
+__global__ void __launch_bounds__(64 * WPB) k_lu_f2s(LuF2Args f) {
   extern __shared__ double sm[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), n = f.n;
   {
@@ -203,21 +195,6 @@ __global__ void __launch_bounds__(64 * WPB) k_lu_f2s(LuF2Args f, TranArgs ta) {
     CADNIP_WAVE_SYNC();
   }
   run_steps(f.ts_pre, f.ts_post);
-  if constexpr (UPD) {
-    StepState s = load_state(ta, inst);
-    if (s.status != 0) return;
-    bad = wave_any(bad);
-    LuUpdVecs v(ta, inst, W, qinv);
-    if (ta.newton_mode) {       // (as k_tran_update, driver.hip: the per-op path refactors every round; the rate constant follows the fused kernel's events)
-      const bool setup = !(s.mflags & MN_VALID) || (s.k == 0 && (s.a0 < 0.6 * s.a0f || s.a0 * 0.6 > s.a0f || (s.mflags >> MN_SINCE_SHIFT) >= 20));
-      if (setup) { s.a0f = s.a0; s.ss = 20.0; s.mflags = MN_VALID | MN_JCUR; }
-      else s.mflags |= MN_JCUR;
-      s.dsc = 1.0;
-    }
-    tran_update_body(ta, v, s, inst, lane, bad);
-    store_state(ta, inst, lane, s);
-    return;
-  }
   double* x = f.x + (size_t)inst * n;
   for (int i = lane; i < n; i += 64) { const double v = W[qinv[i]]; if (!isfinite(v)) bad = 1; x[i] = v; }
   if (wave_any(bad) && lane == 0) atomicOr(&f.flags[inst], 1);
@@ -407,9 +384,7 @@ __global__ void __launch_bounds__(64 * NW) k_lu_steps(LuStepArgs f) {
 }
 
 // 0 = done with the program kernel; 1 = not applicable (the caller falls back to k_lu); < 0 never
-// upd (optional): the transient controller's arguments -- when the step-program kernel takes the launch, the Newton update runs inside it and the
-// return value is 2 (the caller skips its k_tran_update)
-int launch_factor_solve_f2(CadnipHandle* h, const double* d_rhs, double* d_x, const TranArgs* upd) {
+int launch_factor_solve_f2(CadnipHandle* h, const double* d_rhs, double* d_x) {
   if (!h->analyzed || !fused2_tables_ready(h)) return 1;   // (only the linear-solve prefix of the tables has to fit: checked below)
   ProfScope ps(h, "lu_factor_solve");
   LuF2Args f;
@@ -458,17 +433,12 @@ int launch_factor_solve_f2(CadnipHandle* h, const double* d_rhs, double* d_x, co
       f.tab_lo = lo; f.tab_len = h->f2_lu_len - lo;
       f.steps = (const uint4*)h->d_steps1; f.steps_len = h->steps1_len; f.ts_pre = h->steps1[0]; f.ts_post = h->steps1[1];
       const int grid = (h->B + wpb - 1) / wpb;
-      const bool fuse_upd = upd && h->n < 4096 && !(getenv("CADNIP_LU_UPD") && atoi(getenv("CADNIP_LU_UPD")) == 0);
-      TranArgs ta;
-      if (fuse_upd) ta = *upd; else memset(&ta, 0, sizeof(ta));
-#define LAUNCH(W) do { if (fuse_upd) { if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_lu_f2s<W, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-      hipLaunchKernelGGL((k_lu_f2s<W, true>), dim3(grid), dim3(64 * W), shmem, h->stream, f, ta); } \
-    else { if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_lu_f2s<W, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-      hipLaunchKernelGGL((k_lu_f2s<W, false>), dim3(grid), dim3(64 * W), shmem, h->stream, f, ta); } } while (0)
+#define LAUNCH(W) do { if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_lu_f2s<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+    hipLaunchKernelGGL(k_lu_f2s<W>, dim3(grid), dim3(64 * W), shmem, h->stream, f); } while (0)
       if (wpb == 8) LAUNCH(8); else if (wpb == 4) LAUNCH(4); else if (wpb == 2) LAUNCH(2); else LAUNCH(1);
 #undef LAUNCH
       HIP_TRY(hipGetLastError());
-      return fuse_upd ? 2 : CADNIP_OK;
+      return CADNIP_OK;
     }
   }
   int wpb = 8;
