@@ -366,6 +366,35 @@ int cadnip_jacobian(CadnipHandle* h, const double* gamma_host, double* J_ref_nz_
   return CADNIP_OK;
 }
 
+// dense fast_jacobian! (precompile.jl:588-603): the CSR entries of J = G + gamma C scattered into a zeroed column-major n x n block per instance
+__global__ void __launch_bounds__(256) k_dense_scatter(const double* J, const int* rowptr, const int* colidx, double* D, int B, int n, int nnz) {
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (long)B * n) return;
+  const int inst = (int)(tid / n), i = (int)(tid - (long)inst * n);
+  double* Di = D + (size_t)inst * n * n;
+  const double* Ji = J + (size_t)inst * nnz;
+  for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) Di[(size_t)colidx[p] * n + i] = Ji[p];
+}
+int cadnip_jacobian_dense(CadnipHandle* h, const double* gamma_host, double* J_dense_host) {
+  if (!h || !gamma_host || !J_dense_host) return CADNIP_BADARG;
+  const size_t words = (size_t)h->B * h->n * h->n;
+  if (words > ((size_t)1 << 28)) return CADNIP_BADARG;            // (2 GiB of dense Jacobians: this entry point is for small systems)
+  stage_begin(h);
+  TRY(stage_up(h, h->d_gamma, gamma_host, (size_t)h->B * sizeof(double)));
+  TRY(launch_jacobian(h));
+  double* d_dense = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_dense, words * sizeof(double)));
+  int rc = dev_zero_async(h, d_dense, words * sizeof(double));
+  if (!rc) {
+    const long total = (long)h->B * h->n;
+    hipLaunchKernelGGL(k_dense_scatter, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->d_J, (const int*)h->d_rowptr, (const int*)h->d_colidx,
+                       d_dense, h->B, h->n, h->nnz);
+    if (hipStreamSynchronize(h->stream) != hipSuccess || hipMemcpy(J_dense_host, d_dense, words * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = CADNIP_HIPERROR;
+  }
+  (void)hipFree(d_dense);
+  return rc;
+}
+
 // ODE form (src/mna/solve.jl:2241-2276): du = b - G u,  J = -G
 int cadnip_ode_rhs(CadnipHandle* h, const double* u_host, const double* t_host, double* du_host) {
   if (!h || !du_host) return CADNIP_BADARG;

@@ -20,7 +20,7 @@ STATUS_NAMES = {0: "CADNIP_OK", 1: "CADNIP_BADARG", 2: "CADNIP_SINGULAR", 3: "CA
 # every symbol declared in include/cadnip_hip.h
 EXPORTS = [
     "cadnip_create", "cadnip_destroy", "cadnip_set_params", "cadnip_set_spec", "cadnip_set_initjct",
-    "cadnip_rebuild", "cadnip_residual", "cadnip_jacobian", "cadnip_ode_rhs", "cadnip_ode_jacobian", "cadnip_get_GCb", "cadnip_get_contributions", "cadnip_analyze",
+    "cadnip_rebuild", "cadnip_residual", "cadnip_jacobian", "cadnip_jacobian_dense", "cadnip_ode_rhs", "cadnip_ode_jacobian", "cadnip_get_GCb", "cadnip_get_contributions", "cadnip_analyze",
     "cadnip_analyze_values", "cadnip_factor", "cadnip_solve", "cadnip_newton_step", "cadnip_newton_step_fused", "cadnip_debug_step_time", "cadnip_lu_stats", "cadnip_dc_run",
     "cadnip_dc_log_size", "cadnip_dc_log_get", "cadnip_tran_run", "cadnip_tran_state", "cadnip_dev_ptr", "cadnip_stream", "cadnip_set_u", "cadnip_get_u", "cadnip_get_flags",
     "cadnip_sync", "cadnip_debug_copy", "cadnip_debug_stamp_time", "cadnip_profile_enable", "cadnip_profile_read", "cadnip_version",
@@ -258,6 +258,13 @@ class Handle:
         J = np.empty((self.B, self.st.nnz)) if readback else None
         _check(self.lib.cadnip_jacobian(self.h, _dp(g), _dp(J) if readback else None), "cadnip_jacobian")
         return J
+
+    def jacobian_dense(self, gamma):
+        """fast_jacobian!(J::Matrix, ...) of a dense structure (precompile.jl:588-603) minus the restamp: [B, n, n] with J[b, i, j]."""
+        g = self._b(gamma)
+        J = np.empty((self.B, self.st.n * self.st.n))
+        _check(self.lib.cadnip_jacobian_dense(self.h, _dp(g), _dp(J)), "cadnip_jacobian_dense")
+        return J.reshape(self.B, self.st.n, self.st.n).transpose(0, 2, 1)        # column-major blocks -> [i, j]
 
     def ode_rhs(self, u, t=0.0):
         """rhs!(du, u, p, t) of the ODE form (src/mna/solve.jl:2241-2248): restamp, du = b - G*u."""

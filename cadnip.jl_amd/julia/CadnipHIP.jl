@@ -122,6 +122,15 @@ function fast_jacobian!(J::SparseMatrixCSC, du::AbstractVector, u::AbstractVecto
     return nothing
 end
 
+"fast_jacobian!(J::Matrix, ...) -- the dense form, src/mna/precompile.jl:588-603 (test/mna/audio_integration.jl:505-520 solves `J \\ resid` with it)"
+function fast_jacobian!(J::Matrix{Float64}, du::AbstractVector, u::AbstractVector, ws::GPUEvalWorkspace, gamma::Real, t::Real)
+    _same_point(ws, u, t) || fast_rebuild!(ws, u, t)
+    ws.gamma[1] = Float64(gamma)
+    size(J) == (ws.n, ws.n) || throw(DimensionMismatch("J must be n x n"))
+    check(ccall((:cadnip_jacobian_dense, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ws.handle, ws.gamma, J), "cadnip_jacobian_dense")
+    return nothing
+end
+
 # ---- ODE form (src/mna/solve.jl:2241-2276): mass matrix cs.C, rhs! = b - G*u, jac! = -G ------------------------
 function ode_rhs!(du::AbstractVector, u::AbstractVector, ws::GPUEvalWorkspace, t::Real)
     ws.tbuf[1] = Float64(t)

@@ -155,6 +155,10 @@ int cadnip_set_initjct(CadnipHandle* h, int32_t on);            /* DirectStampCo
 int cadnip_rebuild(CadnipHandle* h, const double* u_host, const double* t_host);
 int cadnip_residual(CadnipHandle* h, const double* du_host, const double* u_host, double* resid_host);
 int cadnip_jacobian(CadnipHandle* h, const double* gamma_host, double* J_ref_nz_host /* may be NULL */);
+/* fast_jacobian!(J::Matrix, ...) of a structure compiled with dense = true (precompile.jl:588-603; the form the reference's canonical boundary
+ * test drives, test/mna/audio_integration.jl:505-520): J = G + gamma C as a dense matrix per instance, [B][n * n] in Julia's column-major
+ * layout (J[i, j] at j * n + i), structural zeros written as 0.  Meant for the small systems that test uses (n^2 words per instance). */
+int cadnip_jacobian_dense(CadnipHandle* h, const double* gamma_host, double* J_dense_host);
 /* ODE-form callbacks (mass matrix C constant; used by the reference with FBDF / QNDF / Rodas):
  *   cadnip_ode_rhs      == rhs!(du, u, p, t):  restamp at (u, t), du = b - G u      src/mna/solve.jl:2241-2248
  *   cadnip_ode_jacobian == jac!(J, u, p, t):   restamp at (u, t), J = -G            src/mna/solve.jl:2251-2276

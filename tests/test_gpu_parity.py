@@ -68,6 +68,10 @@ def test_rebuild_matches_oracle(name, mode, t):
         assert _close(r, rr, scale=max(np.max(np.abs(cs.G.data)) * max(1.0, np.max(np.abs(u))), np.max(np.abs(rr)), 1e-30))
         J = h.jacobian(1e7)[0]
         assert _close(J, cs.G.data + 1e7 * cs.C.data)
+        if st.n <= 300:     # the dense form (precompile.jl:588-603; test/mna/audio_integration.jl:505-520 drives the boundary through it)
+            Jd = h.jacobian_dense(1e7)[0]
+            ref = (cs.G + 1e7 * cs.C).toarray()
+            assert Jd.shape == ref.shape and _close(Jd, ref, scale=max(np.max(np.abs(ref)), 1e-30))
         # ODE form (solve.jl:2241-2276): du = b - G u, J = -G, each with its own restamp
         du_ref, J_ref = np.empty(st.n), np.empty(st.nnz)
         M.ode_rhs(du_ref, u, ws, t)
