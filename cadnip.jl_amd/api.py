@@ -309,10 +309,17 @@ class BatchSimulator:
                     v.append(max(abs(float(y)) for y in d.wave[2]))
         return max(v)
 
-    def analyze(self, gamma=1e9, n_samples=6, seed=1234):
+    def analyze(self, gamma=1e9, n_samples=6, seed=1234, sample=None):
         """Symbolic LU phase on the element-wise max |G + gamma*C| over several operating points
-        (cold start with initjct, zero, and random points), so the static pivot order suits all.
-        Each sample is clipped (``clip_sample``) before it enters the max."""
+        (cold start with initjct, zero, and random points) and over ALL instances of the handle, so the static pivot order suits all.
+        Each sample is clipped (``clip_sample``) before it enters the max.  The order therefore belongs to the batch: a subset of
+        its points analysed on its own may get another one and then agrees with the batch to rounding, not bit for bit;
+        ``sample`` (the ``pivot_sample`` of another simulator of the same structure) reuses that simulator's order."""
+        if sample is not None:
+            self.pivot_sample = np.array(sample, dtype=float)
+            self.h.analyze_values(self.pivot_sample)
+            self._analyzed = True
+            return
         rng = np.random.default_rng(seed)
         st, h = self.st, self.h
         vs = self.vscale()
@@ -332,6 +339,7 @@ class BatchSimulator:
             J = h.jacobian(gamma)
             acc = np.maximum(acc, np.max(clip_sample(J), axis=0))
         h.analyze_values(acc)
+        self.pivot_sample = acc
         self._analyzed = True
 
     def analyze_at(self, u, t=0.0, gamma=0.0, instance=0):

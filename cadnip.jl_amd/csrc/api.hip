@@ -474,6 +474,11 @@ int cadnip_analyze_values(CadnipHandle* h, const double* J_csr_host) {
   std::string err;
   int rc = lu_analyze(h->n, h->h_rowptr, h->h_colidx, vals, 1e-3, true, h->lu, err, h->leaves.q_begin >= 0 ? &h->leaves : nullptr);
   if (rc) { fprintf(stderr, "[cadnip_hip] analyze: %s\n", err.c_str()); return rc; }
+  if (getenv("CADNIP_LU_DEBUG")) {
+    unsigned long long hsh = 1469598103934665603ull;
+    for (int k = 0; k < h->n; ++k) { hsh = (hsh ^ (unsigned)h->lu.rperm[k]) * 1099511628211ull; hsh = (hsh ^ (unsigned)h->lu.cperm[k]) * 1099511628211ull; }
+    fprintf(stderr, "[cadnip lu] B %d pivot order hash %016llx nnz_lu %d\n", h->B, hsh, h->lu.nnz_lu);
+  }
   return upload_lu(h);
 }
 

@@ -299,9 +299,11 @@ bool f2_build_steps(const LUProgram& P, int n, int nc, int nw, F2Team& T) {
     std::vector<std::vector<Lane>> steps;
     std::vector<std::vector<unsigned short>> occ;   // per step: occupancy of its 16-lane rows
     std::vector<int> hasdiv, maxlg;
+    const bool aligned = getenv("CADNIP_F2_LEVEL_ALIGNED") != nullptr;     // (diagnostic: steps that do not mix dependency levels)
     for (size_t i = 0; i < ents.size();) {
       size_t j = i;
       while (j < ents.size() && ents[j].lvl == ents[i].lvl) ++j;
+      const int floor_step = aligned ? (int)steps.size() - 1 : -1;
       std::vector<size_t> ord;
       for (size_t e = i; e < j; ++e) ord.push_back(e);
       auto width = [&](size_t e) { return std::min<size_t>(16, p2c(std::max<size_t>((ents[e].a.size() + TPL - 1) / TPL, 1))); };
@@ -309,7 +311,7 @@ bool f2_build_steps(const LUProgram& P, int n, int nc, int nw, F2Team& T) {
       for (size_t e : ord) {
         const F2Ent& x = ents[e];
         const size_t L = width(e);
-        int ready = fs[x.pos];
+        int ready = std::max(fs[x.pos], floor_step);
         if (x.dg >= 0) ready = std::max(ready, fs[x.dg]);
         for (size_t t = 0; t < x.a.size(); ++t) ready = std::max(ready, std::max(fs[x.a[t]], fs[x.b[t]]));
         const unsigned m = (1u << L) - 1u;                  // (L <= 16: a group lies inside one row)

@@ -166,7 +166,8 @@ static bool f2_prepare(CadnipHandle* h, F2Tables& T, const std::vector<int>& g_p
   for (int k = 0; k < 2; ++k) {
     F2Team TM;
     if (h->d_team_desc[k]) { (void)hipFree(h->d_team_desc[k]); h->d_team_desc[k] = nullptr; }
-    if (!f2_build_team(P, n, G.nc, k == 0 ? 2 : 4, TM) || TM.lu_words != G.lu_words) continue;      // (no team kernel for this circuit then)
+    // teams of two: three-term list-scheduled steps; teams of four: one-term level-aligned steps (fused_team_kernel.hpp: run_steps)
+    if (!(k == 0 ? f2_build_steps(P, n, G.nc, 2, TM) : f2_build_team(P, n, G.nc, 4, TM)) || TM.lu_words != G.lu_words) continue;     // (no team kernel for this circuit then)
     if (hipMalloc((void**)&h->d_team_desc[k], TM.desc.size() * sizeof(unsigned long long)) != hipSuccess) { h->d_team_desc[k] = nullptr; continue; }
     if (hipMemcpy(h->d_team_desc[k], TM.desc.data(), TM.desc.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(h->d_team_desc[k]); h->d_team_desc[k] = nullptr; continue; }
     for (int li = 0; li < 3; ++li) h->team_steps[k][li] = TM.n_steps[li];
@@ -329,7 +330,7 @@ static int launch_fused2(CadnipHandle* h, const TranArgs& t, int rounds, const F
     int nw = h->B <= h->n_cu ? 4 : h->B <= 2 * h->n_cu ? 2 : 0;
     if (const char* e = getenv("CADNIP_F2_TEAM")) nw = atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 0;
     if (step) nw = 4;
-    const size_t shmem_t = (tab_dbl + per + 4 * (size_t)nw + (size_t)h->f2_par_words + (nw ? (size_t)h->team_desc_len[nw / 4] : 0) +
+    const size_t shmem_t = (tab_dbl + per + 4 * (size_t)nw + (((size_t)h->f2_par_words + 1) & ~(size_t)1) + (nw ? (size_t)h->team_desc_len[nw / 4] : 0) +
                             (nw ? (size_t)(nw - 1) * ((size_t)h->f2_lu_words + h->n + F2_TRASH) : 0)) * 8;     // (+ the two constant words behind the trash words)
     if (nw && h->d_team_desc[nw / 4] && shmem_t <= lds_cap) {
       f.team_desc = h->d_team_desc[nw / 4]; f.team_desc_len = h->team_desc_len[nw / 4]; f.par_words = h->f2_par_words;

@@ -139,14 +139,14 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
   double* betas = us + n;
   double* parc = betas + n;                               // sp_mos1 parameter rows of the resident instance (F2Block::lds_par)
   const int par_words = f.par_words;
-  u64* tdesc = (u64*)(parc + par_words);                  // step descriptors of the linear solve (f2_build_team)
-  for (int i = tid; i < f.team_desc_len; i += NT) tdesc[i] = f.team_desc[i];
+  uint4* tdesc = (uint4*)(parc + ((par_words + 1) & ~1));  // step descriptors of the linear solve (f2_program.cpp: f2_build_steps, 16 bytes per lane and step)
+  for (int i = tid; i < f.team_desc_len; i += NT) ((u64*)tdesc)[i] = f.team_desc[i];
   // Reproducible sums.  Four waves adding into one word with LDS atomics would do so in the order in which they happen to arrive, and a
   // floating-point sum depends on that order: the last bits of a transient would change from run to run.  So only wave 0 accumulates into
   // W itself; every other wave has a private copy of the work array (matrix words and right-hand side), and after the stamping barrier the
   // copies are added to W in wave order (and cleared for the next round by the thread that reads them).  Within a wave the atomics of one
   // instruction are applied in lane order and the instructions in program order (as in k_fused2), so every word's sum is a fixed sequence.
-  double* const WP = (double*)(tdesc + f.team_desc_len);  // [NW - 1][nW]
+  double* const WP = (double*)((u64*)tdesc + f.team_desc_len);  // [NW - 1][nW]
   for (int i = tid; i < (NW - 1) * nW; i += NT) WP[i] = 0.0;
   double* const Wacc = w == 0 ? W : WP + (size_t)(w - 1) * nW;
 
@@ -453,34 +453,62 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
         if (tid == 0 && kargs()->step_norm) kargs()->step_norm[inst] = sqrt(s2);
       }
       CADNIP_TRACE_POINT(1);
-      // ---- refactor + forward + backward substitution: straight-line steps (f2_program.cpp: f2_build_team).  A step gives every thread of
-      // the team one entry share W[pos] = (W[pos] - W[a] W[b] summed over the entry's lane group) / W[piv]; the next step's descriptor is
-      // read (LDS) together with this step's operands.  Lanes without work and entries without a division point at the constant words
+      // ---- refactor + forward + backward substitution: straight-line steps (f2_program.cpp: f2_build_steps, list-scheduled).  A step gives every
+      // thread of the team one entry share W[pos] = (W[pos] - sum of up to three W[a] W[b], summed over the entry's lane group) / W[piv]; the
+      // next step's descriptor is read (LDS) together with this step's operands.  Lanes without work and entries without a division point at the constant words
       // (0.0, 1.0) behind the work array.  Every step ends with a workgroup barrier.
       int bad = 0;
+      // Teams of four run the level-aligned ONE-term layout (f2_build_team, 8-byte descriptors): with 256 lanes a level fits a step anyway and
+      // the step is shorter (four operand reads); teams of two the list-scheduled THREE-term layout (f2_build_steps, 16 bytes): 17 instead of
+      // 22 steps on the flip-flop.  (Measured: three terms on four waves 14.3 -> 15.7 ms per transient, on two waves 17.2 -> 16.6 ms.)
       auto run_steps = [&](const int s_first, const int s_count) {
         if (s_count <= 0) return;
-        const u64* dp = tdesc + (size_t)s_first * NT + tid;
-        u64 D = dp[0];
-        for (int si = 0; si < s_count; ++si) {
-          const unsigned lo = (unsigned)D, hi = (unsigned)(D >> 32);
-          double* const pp = W + (lo & 0x7FFFu);
-          const double piv = W[(lo >> 16) & 0x7FFFu], av = W[hi & 0x7FFFu], bv = W[(hi >> 16) & 0x7FFFu];
-          const double acc0 = *pp;
-          const u64 Dn = dp[(size_t)(si + 1) * NT];
-          const unsigned lg = (lo >> 31) | ((hi >> 14) & 2u) | ((hi >> 29) & 4u);
-          double part = av * bv;
-          { const double o = dpp_f64<0xB1>(part); part += lg >= 1 ? o : 0.0; }
-          { const double o = dpp_f64<0x4E>(part); part += lg >= 2 ? o : 0.0; }
-          { const double o = dpp_f64<0x141>(part); part += lg >= 3 ? o : 0.0; }
-          { const double o = dpp_f64<0x140>(part); part += lg >= 4 ? o : 0.0; }
-          if (piv == 0.0 || !isfinite(piv)) bad = 1;
-          const double acc = fast_div(acc0 - part, piv);
-          // every lane divides and stores -- the lanes that are not their group's leader into their trash word: no branch, and the entry's
-          // old value is read with the other operands instead of behind the group sum
-          *((lo & 0x8000u) ? pp : W + trash_w) = acc;
-          __syncthreads();
-          D = Dn;
+        if constexpr (NW == 4) {
+          const u64* dp = (const u64*)tdesc + (size_t)s_first * NT + tid;
+          u64 D = dp[0];
+          for (int si = 0; si < s_count; ++si) {
+            const unsigned lo = (unsigned)D, hi = (unsigned)(D >> 32);
+            double* const pp = W + (lo & 0x7FFFu);
+            const double piv = W[(lo >> 16) & 0x7FFFu], av = W[hi & 0x7FFFu], bv = W[(hi >> 16) & 0x7FFFu];
+            const double acc0 = *pp;
+            const u64 Dn = dp[(size_t)(si + 1) * NT];
+            const unsigned lg = (lo >> 31) | ((hi >> 14) & 2u) | ((hi >> 29) & 4u);
+            double part = av * bv;
+            { const double o = dpp_f64<0xB1>(part); part += lg >= 1 ? o : 0.0; }
+            { const double o = dpp_f64<0x4E>(part); part += lg >= 2 ? o : 0.0; }
+            { const double o = dpp_f64<0x141>(part); part += lg >= 3 ? o : 0.0; }
+            { const double o = dpp_f64<0x140>(part); part += lg >= 4 ? o : 0.0; }
+            if (piv == 0.0 || !isfinite(piv)) bad = 1;
+            const double acc = fast_div(acc0 - part, piv);
+            // every lane divides and stores -- the lanes that are not their group's leader into their trash word: no branch, and the entry's
+            // old value is read with the other operands instead of behind the group sum
+            *((lo & 0x8000u) ? pp : W + trash_w) = acc;
+            __syncthreads();
+            D = Dn;
+          }
+        } else {
+          const uint4* dp = tdesc + (size_t)s_first * NT + tid;
+          uint4 D = dp[0];
+          for (int si = 0; si < s_count; ++si) {
+            double* const pp = W + (D.x & 0x7FFFu);
+            const double piv = W[(D.x >> 16) & 0x7FFFu];
+            const double a0v = W[D.y & 0x7FFFu], b0v = W[(D.y >> 16) & 0x7FFFu];
+            const double a1v = W[D.z & 0x7FFFu], b1v = W[(D.z >> 16) & 0x7FFFu];
+            const double a2v = W[D.w & 0x7FFFu], b2v = W[(D.w >> 16) & 0x7FFFu];
+            const double acc0 = *pp;
+            const uint4 Dn = dp[(size_t)(si + 1) * NT];
+            const unsigned lg = (D.x >> 31) | ((D.y >> 14) & 2u) | ((D.y >> 29) & 4u);
+            double part = fma(a2v, b2v, fma(a1v, b1v, a0v * b0v));
+            { const double o = dpp_f64<0xB1>(part); part += lg >= 1 ? o : 0.0; }
+            { const double o = dpp_f64<0x4E>(part); part += lg >= 2 ? o : 0.0; }
+            { const double o = dpp_f64<0x141>(part); part += lg >= 3 ? o : 0.0; }
+            { const double o = dpp_f64<0x140>(part); part += lg >= 4 ? o : 0.0; }
+            if (piv == 0.0 || !isfinite(piv)) bad = 1;
+            const double acc = fast_div(acc0 - part, piv);
+            *((D.x & 0x8000u) ? pp : W + trash_w) = acc;
+            __syncthreads();
+            D = Dn;
+          }
         }
       };
       if (skip & 4) {}
