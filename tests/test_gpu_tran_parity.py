@@ -62,6 +62,45 @@ def test_dff_transient_matches_port(points, fused, monkeypatch):
     sim.close()
 
 
+@pytest.mark.parametrize("newton_mode", [0, 1])
+@pytest.mark.parametrize("fused", [0, 1, 5])
+def test_inverter_transient_matches_port(fused, newton_mode, monkeypatch):
+    """BASELINE.json config 2 (benchmarks/inverter_performance_bench.jl: a single CMOS inverter transient) against the C++ port: the per-op
+    kernels take the port's step sequence exactly (in Newton mode 1 the port's mode 2: the per-op path refactors every round), the fused kernels
+    (one wave, team of four) stay within 1 % of its Newton count; every node and the load's charge state agree to 1e-9 -- two corners."""
+    if fused:
+        monkeypatch.setenv("CADNIP_F2_TEAM", str(fused - 1 if fused > 1 else 0))
+    circ = bm.inverter_circuit()
+    points = [{"vdd": 5.0, "temp": 27.0}, {"vdd": 4.5, "temp": 125.0}]
+    sim = api.BatchSimulator(api.MNACircuit(circ, {"vdd": 5.0}), points)
+    st = sim.st
+    sim.analyze()
+    u0, conv, _ = sim.dc(abstol=1e-9, mode="tranop")
+    assert np.all(conv)
+    tspan = (0.0, 4e-7)
+    ts = np.linspace(tspan[0], tspan[1], 81)
+    obs = list(range(st.n_nodes))
+    atol = st.state_abstol(**ABSTOL)
+    breaks = expand_breakpoints(st.breakpoints, tspan)
+    sim.h.set_spec(mode="tran")
+    out, per, stats = sim.h.tran_run(tspan[0], tspan[1], atol, 1e-4, breaks=breaks, save_t=ts, obs=obs, fused=fused, newton_mode=newton_mode)
+    assert stats["n_failed"] == 0
+    for i, pt in enumerate(points):
+        pst, port = make_port(circ, {"vdd": pt["vdd"]}, pt["temp"], "tran")
+        analyze_port(pst, port, sim.vscale())
+        ref, _, rst, _ = port.tran(u0[i], tspan[0], tspan[1], atol, 1e-4, breaks=breaks, save_t=ts, obs=obs, err_mask=pst.differential_mask(), use_pcnr=False,
+                                   newton_mode=(2 if fused == 0 else 1) if newton_mode else 0)
+        port.close()
+        assert rst["status"] == 1
+        if fused == 0:
+            assert (per[i, 0], per[i, 1], per[i, 2]) == (rst["newton_iters"], rst["accepted"], rst["rejected"]), (pt, per[i], rst)
+        else:
+            assert abs(per[i, 0] - rst["newton_iters"]) <= 0.01 * rst["newton_iters"] + 2, (pt, per[i], rst)
+        err = np.max(np.abs(out[i] - ref) / np.maximum(np.abs(ref), 1.0))
+        assert err <= REL_TOL, (pt, err)
+    sim.close()
+
+
 def _meyer_inverter():
     """Inverter with `tox` cards (Meyer gate charge) and series resistances: the sp_mos1 path that is NOT lane-paired."""
     c = cj.Circuit()
