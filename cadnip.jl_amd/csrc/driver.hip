@@ -36,6 +36,7 @@ struct Driver {
   long long* cnt = nullptr;   // [B][4]
   double *mn_a0f = nullptr, *mn_ss = nullptr, *mn_dnp = nullptr; int* mn_flags = nullptr;   // Newton mode 1 (tran_ctrl.hpp)
   double *u0 = nullptr, *u1 = nullptr, *u2 = nullptr, *up = nullptr, *beta = nullptr;
+  double *u3 = nullptr, *hp3 = nullptr;   // max_order = 3 (allocated when first asked for)
   double *atol = nullptr, *emask = nullptr, *breaks = nullptr, *save_t = nullptr, *out = nullptr;
   int* obs = nullptr;
   int* nactive = nullptr;
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(64) k_tran_init(TranArgs a) {
   }
   __syncthreads();
   StepState s;
-  s.t = a.t0; s.h = a.h0; s.hprev = a.h0; s.hpp = a.h0; s.tn = a.t0; s.a0 = 0.0;
+  s.t = a.t0; s.h = a.h0; s.hprev = a.h0; s.hpp = a.h0; s.hp3 = a.h0; s.tn = a.t0; s.a0 = 0.0;
   s.nhist = 1; s.ord = 1; s.k = 0; s.status = 0; s.bp = bp; s.si = si;
   s.c_newton = s.c_accept = s.c_reject = s.c_fail = 0;
   s.t_break = next_break(a, bp); s.t_save = next_save(a, si);
@@ -312,7 +313,7 @@ void cadnip_driver_free(CadnipHandle* h) {
   Driver* d = h->drv;
   void* ptrs[] = {d->t, d->h, d->hprev, d->hpp, d->nhist, d->order, d->k, d->status, d->bp_idx, d->save_idx, d->dcstate, d->action, d->cnt,
                   d->u0, d->u1, d->u2, d->up, d->beta, d->atol, d->emask, d->breaks, d->save_t, d->out, d->obs, d->nactive, d->part,
-                  d->mn_a0f, d->mn_ss, d->mn_dnp, d->mn_flags};
+                  d->mn_a0f, d->mn_ss, d->mn_dnp, d->mn_flags, d->u3, d->hp3};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete d;
   h->drv = nullptr;
@@ -562,7 +563,12 @@ int cadnip_tran_run(CadnipHandle* h, const CadnipTranOpts* o, double* out_host, 
              h->B, h->n, h->n_limits, o->n_break, o->n_save, n_obs, n_err,
              o->t0, o->t1, o->reltol, h0, hmin, hmax, o->newton_tol > 0 ? o->newton_tol : 1e-3,
              o->max_newton > 0 ? o->max_newton : 10, o->max_order > 0 ? o->max_order : 2, o->use_pcnr,
-             o->newton_mode ? 1 : 0, d->mn_a0f, d->mn_ss, d->mn_dnp, d->mn_flags, o->step_rule ? 1 : 0};
+             o->newton_mode ? 1 : 0, d->mn_a0f, d->mn_ss, d->mn_dnp, d->mn_flags, o->step_rule ? 1 : 0, nullptr, nullptr};
+  if (a.max_order > 3) a.max_order = 3;
+  if (a.max_order >= 3) {                                 // variable-step BDF3: a fourth history vector and a third step size per instance
+    TRY(dalloc(&d->u3, (size_t)h->B * h->n)); TRY(dalloc(&d->hp3, (size_t)h->B));
+    a.u3 = d->u3; a.hp3 = d->hp3;
+  }
   if (!h->analyzed) return CADNIP_NOTREADY;              // the symbolic LU phase (cadnip_analyze*) comes first
   // the per-op kernels take over where the fused kernel cannot run: external generated models (they exist in the per-op stamping kernel only), a
   // circuit too large for the LDS-resident kernel, Newton mode 1 on a circuit outside the lean device set

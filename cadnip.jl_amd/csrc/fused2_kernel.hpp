@@ -82,6 +82,7 @@ struct TranStateView {
   const double *breaks, *save_t;
   int n_break, n_save;
   int newton_mode; double *mn_a0f, *mn_ss, *mn_dnp; int* mn_flags;
+  int max_order; double* hp3;
 };
 __device__ __forceinline__ TranStateView state_view() {
   const F2ArgsK p = kargs();
@@ -90,6 +91,7 @@ __device__ __forceinline__ TranStateView state_view() {
   v.nhist = p->t.nhist; v.order = p->t.order; v.k = p->t.k; v.status = p->t.status; v.bp_idx = p->t.bp_idx; v.save_idx = p->t.save_idx;
   v.active = p->t.active; v.cnt = p->t.cnt; v.breaks = p->t.breaks; v.save_t = p->t.save_t; v.n_break = p->t.n_break; v.n_save = p->t.n_save;
   v.newton_mode = p->t.newton_mode; v.mn_a0f = p->t.mn_a0f; v.mn_ss = p->t.mn_ss; v.mn_dnp = p->t.mn_dnp; v.mn_flags = p->t.mn_flags;
+  v.max_order = p->t.max_order; v.hp3 = p->t.hp3;
   return v;
 }
 
@@ -276,6 +278,9 @@ struct FusedVecs {
   __device__ __forceinline__ double h1(int i, int k) const { return k >= 0 ? r_u1[k] : p_u1()[i]; }
   __device__ __forceinline__ double h2(int i, int k) const { return k >= 0 ? r_u2[k] : p_u2()[i]; }
   __device__ __forceinline__ double hp(int i, int k) const { return k >= 0 ? r_up[k] : p_up()[i]; }
+  // (max_order = 3: the fourth history point stays in memory -- the kernel has no registers to spare, and the default order never reads it)
+  __device__ __forceinline__ double h3(int i, int) const { return (kargs()->t.u3 + vo)[i]; }
+  __device__ __forceinline__ void set_h3(int i, int, double v) { (kargs()->t.u3 + vo)[i] = v; }
   __device__ __forceinline__ void set_h0(int i, int k, double v) { if (k >= 0) r_u0[k] = v; else p_u0()[i] = v; }
   __device__ __forceinline__ void set_h1(int i, int k, double v) { if (k >= 0) r_u1[k] = v; else p_u1()[i] = v; }
   __device__ __forceinline__ void set_h2(int i, int k, double v) { if (k >= 0) r_u2[k] = v; else p_u2()[i] = v; }

@@ -103,6 +103,8 @@ struct TeamVecs {
   __device__ __forceinline__ double h1(int i, int k) const { return k >= 0 ? r_u1[k] : p_u1()[i]; }
   __device__ __forceinline__ double h2(int i, int k) const { return k >= 0 ? r_u2[k] : p_u2()[i]; }
   __device__ __forceinline__ double hp(int i, int k) const { return k >= 0 ? r_up[k] : p_up()[i]; }
+  __device__ __forceinline__ double h3(int i, int) const { return (kargs()->t.u3 + vo)[i]; }          // (max_order = 3: the fourth history point stays in memory)
+  __device__ __forceinline__ void set_h3(int i, int, double v) { (kargs()->t.u3 + vo)[i] = v; }
   __device__ __forceinline__ void set_h0(int i, int k, double v) { if (k >= 0) r_u0[k] = v; else p_u0()[i] = v; }
   __device__ __forceinline__ void set_h1(int i, int k, double v) { if (k >= 0) r_u1[k] = v; else p_u1()[i] = v; }
   __device__ __forceinline__ void set_h2(int i, int k, double v) { if (k >= 0) r_u2[k] = v; else p_u2()[i] = v; }
@@ -253,7 +255,7 @@ __global__ void __launch_bounds__(64 * NW) k_fteam(F2Args f) {
         st.t = st.h = st.hprev = st.hpp = 0.0; st.tn = kargs()->t.tcur[inst]; st.a0 = kargs()->t.gamma[inst];
         if (tid == 0) { if (kargs()->t.t) kargs()->t.t[inst] = st.tn; if (kargs()->t.h) kargs()->t.h[inst] = st.a0; }    // the handle's copies (api.hip)
         st.nhist = 1; st.ord = 1; st.k = 1; st.status = 0; st.bp = st.si = 0; st.c_newton = st.c_accept = st.c_reject = st.c_fail = 0;
-        st.t_break = st.t_save = 0.0; st.a0f = st.a0; st.ss = 20.0; st.dnp = 0.0; st.dsc = 1.0; st.mflags = f.step_refresh ? MN_NEED : MN_VALID;
+        st.t_break = st.t_save = 0.0; st.a0f = st.a0; st.ss = 20.0; st.dnp = 0.0; st.dsc = 1.0; st.mflags = f.step_refresh ? MN_NEED : MN_VALID; st.hp3 = 0.0;
         make_uniform(st);
         have = true; break;
       }

@@ -67,6 +67,7 @@ __device__ __forceinline__ double fast_div(double a, double b) {
 // copy (step_root) returns the same double.
 __device__ __forceinline__ double step_root(double x, int ord) {
   if (ord == 1) return fast_div(1.0, sqrt(x));
+  if (ord == 3) return fast_div(1.0, sqrt(sqrt(x)));
   int e;
   double m = frexp(x, &e);                 // x = m 2^e, m in [0.5, 1)
   const int q = (e >= 0 ? e : e - 2) / 3;  // floor(e / 3)
@@ -104,6 +105,7 @@ struct TranArgs {
   int newton_mode;
   double *mn_a0f, *mn_ss, *mn_dnp; int* mn_flags;
   int step_rule;   // 0 = classical step controller, 1 = IDA's eta rule (CadnipTranOpts::step_rule)
+  double *u3, *hp3;   // max_order >= 3: u at the fourth-last accepted point [B][n], the third-last step size [B] (set by the driver behind the aggregate)
 };
 #define MN_NEED 1     // the next round must refactor
 #define MN_JCUR 2     // a refactorisation happened in this step attempt
@@ -117,6 +119,7 @@ struct StepState {
   double t_break, t_save;                     // breaks[bp] / save_t[si], +inf past the end: derived, refreshed when bp / si move
   double a0f, ss, dnp, dsc;                   // Newton mode 1: a0 of the kept factors, rate constant, previous update norm; scale of this round's update
   int mflags;
+  double hp3;                                 // max_order >= 3: the step before hpp
 };
 template <class A> __device__ __forceinline__ double next_break(const A& a, int bp) { return bp < a.n_break ? a.breaks[bp] : __builtin_inf(); }
 template <class A> __device__ __forceinline__ double next_save(const A& a, int si) { return si < a.n_save ? a.save_t[si] : __builtin_inf(); }
@@ -135,6 +138,7 @@ __device__ __forceinline__ void make_uniform(StepState& s) {
   s.c_reject = __builtin_amdgcn_readfirstlane(s.c_reject); s.c_fail = __builtin_amdgcn_readfirstlane(s.c_fail);
   s.a0f = uniform_f64(s.a0f); s.ss = uniform_f64(s.ss); s.dnp = uniform_f64(s.dnp); s.dsc = uniform_f64(s.dsc);
   s.mflags = __builtin_amdgcn_readfirstlane(s.mflags);
+  s.hp3 = uniform_f64(s.hp3);
 }
 
 // A: TranArgs, or a view with the same member names (the fused kernel fetches these rarely used pointers on demand)
@@ -146,6 +150,7 @@ template <class A> __device__ inline StepState load_state(const A& a, int inst) 
   s.t_break = next_break(a, s.bp); s.t_save = next_save(a, s.si);
   s.a0f = 0.0; s.ss = 20.0; s.dnp = 0.0; s.dsc = 1.0; s.mflags = MN_NEED;
   if (a.newton_mode) { s.a0f = a.mn_a0f[inst]; s.ss = a.mn_ss[inst]; s.dnp = a.mn_dnp[inst]; s.mflags = a.mn_flags[inst]; }
+  s.hp3 = a.max_order >= 3 ? a.hp3[inst] : 0.0;
   return s;
 }
 template <class A> __device__ inline void store_state(const A& a, int inst, int tid, const StepState& s) {
@@ -154,6 +159,7 @@ template <class A> __device__ inline void store_state(const A& a, int inst, int 
   a.nhist[inst] = s.nhist; a.order[inst] = s.ord; a.k[inst] = s.k; a.status[inst] = s.status; a.bp_idx[inst] = s.bp; a.save_idx[inst] = s.si;
   a.active[inst] = s.status == 0 ? 1 : 0;
   if (a.newton_mode) { a.mn_a0f[inst] = s.a0f; a.mn_ss[inst] = s.ss; a.mn_dnp[inst] = s.dnp; a.mn_flags[inst] = s.mflags; }
+  if (a.max_order >= 3) a.hp3[inst] = s.hp3;
   long long* c = a.cnt + (size_t)inst * 4;
   c[0] += s.c_newton; c[1] += s.c_accept; c[2] += s.c_reject; c[3] += s.c_fail;
 }
@@ -207,10 +213,11 @@ struct GlobalVecsT {
   static constexpr int NT = NT_;
   static constexpr bool OWN_REDUCE = false;
   double *__restrict__ u, *__restrict__ du, *__restrict__ up, *__restrict__ beta, *__restrict__ u0, *__restrict__ u1, *__restrict__ u2;
+  double* u3;
   const double *__restrict__ delta, *__restrict__ lw;
   __device__ GlobalVecsT(const TranArgs& a, int inst) {
     const size_t o = (size_t)inst * a.n;
-    u = a.u + o; du = a.du + o; up = a.up + o; beta = a.beta + o; u0 = a.u0 + o; u1 = a.u1 + o; u2 = a.u2 + o; delta = a.delta + o; lw = a.limit_w + o;
+    u = a.u + o; du = a.du + o; up = a.up + o; beta = a.beta + o; u0 = a.u0 + o; u1 = a.u1 + o; u2 = a.u2 + o; u3 = a.max_order >= 3 ? a.u3 + o : nullptr; delta = a.delta + o; lw = a.limit_w + o;
   }
   __device__ __forceinline__ double get_delta(int i, int) const { return delta[i]; }
   __device__ __forceinline__ void step_consumed(int) const {}
@@ -226,6 +233,8 @@ struct GlobalVecsT {
   __device__ __forceinline__ double h1(int i, int) const { return u1[i]; }
   __device__ __forceinline__ double h2(int i, int) const { return u2[i]; }
   __device__ __forceinline__ double hp(int i, int) const { return up[i]; }
+  __device__ __forceinline__ double h3(int i, int) const { return u3[i]; }
+  __device__ __forceinline__ void set_h3(int i, int, double v) { u3[i] = v; }
   __device__ __forceinline__ void set_h0(int i, int, double v) { u0[i] = v; }
   __device__ __forceinline__ void set_h1(int i, int, double v) { u1[i] = v; }
   __device__ __forceinline__ void set_h2(int i, int, double v) { u2[i] = v; }
@@ -280,6 +289,26 @@ __device__ inline void prepare_step(const TranArgs& a, V& v, StepState& s, int t
       double p = x0 + w * (x0 - v.h1(i, k));
       v.set_hp(i, k, p); v.set_u(i, p);
       double b = fast_div(-x0, h);
+      v.set_beta(i, b); v.set_du(i, a0 * p + b);
+    });
+  } else if (nhist >= 4 && a.max_order >= 3) {
+    // variable-step BDF3: the derivative at t_n of the cubic through (t_n, u) and the three last accepted points (d1 < d2 < d3: their distances
+    // from t_n); the predictor is the cubic through the FOUR last accepted points.  oracle/cpu_port.cpp carries the same operations in the same order.
+    ord = 3;
+    const double hr = s.hp3;
+    const double d1 = h, d2 = h + hprev, d3 = d2 + hpp, s12 = hprev + hpp;
+    a0 = (fast_div(1.0, d1) + fast_div(1.0, d2)) + fast_div(1.0, d3);
+    const double a1 = -fast_div(d2 * d3, d1 * (hprev * s12)), a2 = fast_div(d1 * d3, d2 * (hprev * hpp)), a3 = -fast_div(d1 * d2, d3 * (s12 * hpp));
+    const double x1 = -hprev, x2 = -s12, x3 = -(s12 + hr), x = h;
+    const double L0 = fast_div(((x - x1) * (x - x2)) * (x - x3), ((0.0 - x1) * (0.0 - x2)) * (0.0 - x3));
+    const double L1 = fast_div(((x - 0.0) * (x - x2)) * (x - x3), ((x1 - 0.0) * (x1 - x2)) * (x1 - x3));
+    const double L2 = fast_div(((x - 0.0) * (x - x1)) * (x - x3), ((x2 - 0.0) * (x2 - x1)) * (x2 - x3));
+    const double L3 = fast_div(((x - 0.0) * (x - x1)) * (x - x2), ((x3 - 0.0) * (x3 - x1)) * (x3 - x2));
+    each_elem<V>(n, tid, [&](int i, int k) {
+      const double x0 = v.h0(i, k), xm1 = v.h1(i, k), xm2 = v.h2(i, k);
+      const double p = ((L0 * x0 + L1 * xm1) + L2 * xm2) + L3 * v.h3(i, k);
+      v.set_hp(i, k, p); v.set_u(i, p);
+      const double b = (a1 * x0 + a2 * xm1) + a3 * xm2;
       v.set_beta(i, b); v.set_du(i, a0 * p + b);
     });
   } else {
@@ -373,6 +402,7 @@ __device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, i
     if (tested) {
       double errc;
       if (s.ord == 1) errc = fast_div(h, h + hprev);
+      else if (s.ord == 3) errc = fast_div(fast_div(1.0, s.a0), ((h + hprev) + hpp) + s.hp3);
       else { double w = fast_div(h, hprev); errc = fast_div(fast_div((1.0 + w) * h, 1.0 + 2.0 * w), h + hprev + hpp); }
       errn = errc * sqrt(fast_div(s2, (double)a.n_err));
       accept = errn <= 1.0;
@@ -380,10 +410,12 @@ __device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, i
     if (accept) {
       grp_sync<V>();
       save_outputs(a, v, s, inst, tid);
+      if (a.max_order >= 3) each_elem<V>(n, tid, [&](int i, int k) { v.set_h3(i, k, v.h2(i, k)); });
       each_elem<V>(n, tid, [&](int i, int k) { double v1 = v.h1(i, k), v0 = v.h0(i, k); v.set_h2(i, k, v1); v.set_h1(i, k, v0); v.set_h0(i, k, v.get_u(i)); });
       const double tn = s.tn;
       bool landed = tn == s.t_break;
-      int nh_new = s.nhist + 1 > 3 ? 3 : s.nhist + 1;
+      const int nh_cap = a.max_order >= 3 ? 4 : 3;
+      int nh_new = s.nhist + 1 > nh_cap ? nh_cap : s.nhist + 1;
       double hnext;
       if (tested) {
         double fac;
@@ -406,6 +438,7 @@ __device__ inline void tran_update_body(const TranArgs& a, V& v, StepState& s, i
         hnext = 0.1 * fmin(h, tstop - tn);
       }
       hnext = fmin(hnext, a.hmax);
+      s.hp3 = hpp;
       s.t = tn; s.hpp = hprev; s.hprev = h; s.nhist = nh_new;
       s.c_accept += 1;
       s.mflags += 1 << MN_SINCE_SHIFT;

@@ -236,7 +236,8 @@ typedef struct {
   double h0;                /* initial step (<=0: automatic) */
   double hmin, hmax;        /* hmax <= 0: (t1-t0)/50 */
   int32_t max_newton;       /* IDA max_nonlinear_iters = 10, sweeps.jl:600 */
-  int32_t max_order;        /* 1 = backward Euler only, 2 = variable-step BDF2 */
+  int32_t max_order;        /* 1 = backward Euler only, 2 = variable-step BDF2 (default), 3 = variable-step BDF3 where four accepted points exist
+                             * (the reference's IDA goes to 5, src/sweeps.jl:600; orders restart at 1 on every source breakpoint) */
   int32_t use_pcnr;         /* apply the PCNR corrector inside transient Newton */
   double newton_tol;        /* weighted-RMS norm of the Newton update that counts as converged */
   int32_t n_break; const double* breaks; /* sorted tstops from source breakpoints (solve.jl:1847-1960) */

@@ -27,6 +27,7 @@ namespace {
 // for order 1; for order 2 exact frexp / ldexp, products and fused multiply-adds only, so that both sides get the same double.
 static double step_root(double x, int ord) {
   if (ord == 1) return 1.0 / std::sqrt(x);
+  if (ord == 3) return 1.0 / std::sqrt(std::sqrt(x));
   int e;
   double m = std::frexp(x, &e);
   const int q = (e >= 0 ? e : e - 2) / 3;
@@ -525,19 +526,36 @@ int port_tran(void* p, double* u_io, const TranOpts* o, double* out, TranStats* 
   std::vector<double> emask(n, 1.0); int n_err = n;
   if (o->err_mask) { n_err = 0; for (int i = 0; i < n; ++i) { emask[i] = o->err_mask[i] != 0 ? 1.0 : 0.0; n_err += emask[i] != 0; } }
   const int n_obs = o->n_obs > 0 ? o->n_obs : n;
-  std::vector<double> u(u_io, u_io + n), u0 = u, u1 = u, u2 = u, up(n), beta(n), du(n), r(n), delta(n);
-  double t = o->t0, h = h0, hprev = h0, hpp = h0, tn = 0, a0 = 0; int nhist = 1, ord = 1, k = 0, bp = 0, si = 0, status = 0;
+  std::vector<double> u(u_io, u_io + n), u0 = u, u1 = u, u2 = u, u3 = u, up(n), beta(n), du(n), r(n), delta(n);
+  double t = o->t0, h = h0, hprev = h0, hpp = h0, hp3 = h0, tn = 0, a0 = 0; int nhist = 1, ord = 1, k = 0, bp = 0, si = 0, status = 0;
   int savedmode = P.mode; P.mode = 1;
   while (bp < o->n_break && o->breaks[bp] <= o->t0) ++bp;
   while (si < o->n_save && o->save_t[si] <= o->t0) { for (int j = 0; j < n_obs; ++j) out[(size_t)si * n_obs + j] = u[o->n_obs > 0 ? o->obs[j] : j]; ++si; }
   TranStats S{0, 0, 0, 0, 0, 0.0, 0}; int ntrace = 0;
   const char* dbg_env = getenv("PORT_DEBUG"); const double dbg_from = dbg_env ? atof(dbg_env) : 0.0; bool dbg = false;
-  auto prepare = [&](double tt, double hh, int nh, double hp, double hq) {
+  auto prepare = [&](double tt, double hh, int nh, double hp, double hq, double hr) {
     double tstop = o->t1; if (bp < o->n_break && o->breaks[bp] < tstop) tstop = o->breaks[bp];
     double rem = tstop - tt;
     if (hh >= rem * (1.0 - 1e-9)) { hh = rem; tn = tstop; } else if (2.0 * hh > rem) { hh = 0.5 * rem; tn = tt + hh; } else tn = tt + hh;
     if (nh <= 1) { ord = 1; a0 = 1.0 / hh; for (int i = 0; i < n; ++i) { double pv = u0[i]; up[i] = pv; u[i] = pv; double bb = -u0[i] / hh; beta[i] = bb; du[i] = a0 * pv + bb; } }
     else if (nh == 2 || maxo < 2) { ord = 1; a0 = 1.0 / hh; double w = hh / hp; for (int i = 0; i < n; ++i) { double pv = u0[i] + w * (u0[i] - u1[i]); up[i] = pv; u[i] = pv; double bb = -u0[i] / hh; beta[i] = bb; du[i] = a0 * pv + bb; } }
+    else if (nh >= 4 && maxo >= 3) {
+      // variable-step BDF3 (tran_ctrl.hpp: prepare_step, operation for operation): the derivative at t_n of the cubic through (t_n, u) and the three
+      // last accepted points, d1 < d2 < d3 their distances from t_n; the predictor is the cubic through the FOUR last accepted points
+      ord = 3;
+      const double d1 = hh, d2 = hh + hp, d3 = d2 + hq, s12 = hp + hq;
+      a0 = (1.0 / d1 + 1.0 / d2) + 1.0 / d3;
+      const double a1 = -((d2 * d3) / (d1 * (hp * s12))), a2 = (d1 * d3) / (d2 * (hp * hq)), a3 = -((d1 * d2) / (d3 * (s12 * hq)));
+      const double x1 = -hp, x2 = -s12, x3 = -(s12 + hr), x = hh;
+      const double L0 = ((x - x1) * (x - x2)) * (x - x3) / (((0.0 - x1) * (0.0 - x2)) * (0.0 - x3));
+      const double L1 = ((x - 0.0) * (x - x2)) * (x - x3) / (((x1 - 0.0) * (x1 - x2)) * (x1 - x3));
+      const double L2 = ((x - 0.0) * (x - x1)) * (x - x3) / (((x2 - 0.0) * (x2 - x1)) * (x2 - x3));
+      const double L3 = ((x - 0.0) * (x - x1)) * (x - x2) / (((x3 - 0.0) * (x3 - x1)) * (x3 - x2));
+      for (int i = 0; i < n; ++i) {
+        double pv = ((L0 * u0[i] + L1 * u1[i]) + L2 * u2[i]) + L3 * u3[i]; up[i] = pv; u[i] = pv;
+        double bb = (a1 * u0[i] + a2 * u1[i]) + a3 * u2[i]; beta[i] = bb; du[i] = a0 * pv + bb;
+      }
+    }
     else {
       ord = 2; double w = hh / hp; a0 = (1.0 + 2.0 * w) / ((1.0 + w) * hh); double a1 = -(1.0 + w) / hh, a2 = (w * w) / ((1.0 + w) * hh);
       double x1 = -hp, x2 = -(hp + hq), x = hh;
@@ -550,7 +568,7 @@ int port_tran(void* p, double* u_io, const TranOpts* o, double* out, TranStats* 
   const int mode = o->newton_mode;
   double a0f = 0.0, ss = 20.0, dnp = 0.0; bool need = true, jcur = false, valid = false; int since = 0;
   auto prepare0 = prepare;
-  auto prepare_attempt = [&](double tt, double hh, int nh, double hp, double hq) { prepare0(tt, hh, nh, hp, hq); jcur = false; };
+  auto prepare_attempt = [&](double tt, double hh, int nh, double hp, double hq) { prepare0(tt, hh, nh, hp, hq, hp3); jcur = false; };
   prepare_attempt(t, h, nhist, hprev, hpp);
   while (status == 0) {
     dbg = dbg_env && tn >= dbg_from;
@@ -598,7 +616,8 @@ int port_tran(void* p, double* u_io, const TranOpts* o, double* out, TranStats* 
     if (conv) {
       double errn = 0; bool accept = true;
       if (nhist >= 2 && n_err > 0) {
-        double errc; if (ord == 1) errc = h / (h + hprev); else { double w = h / hprev; errc = ((1.0 + w) * h / (1.0 + 2.0 * w)) / (h + hprev + hpp); }
+        double errc; if (ord == 1) errc = h / (h + hprev); else if (ord == 3) errc = (1.0 / a0) / (((h + hprev) + hpp) + hp3);
+        else { double w = h / hprev; errc = ((1.0 + w) * h / (1.0 + 2.0 * w)) / (h + hprev + hpp); }
         errn = errc * std::sqrt(s2 / n_err); accept = errn <= 1.0;
       }
       if (accept) {
@@ -611,9 +630,10 @@ int port_tran(void* p, double* u_io, const TranOpts* o, double* out, TranStats* 
           } else { double s = (ts - t) / hh; for (int j = 0; j < n_obs; ++j) { int i = o->n_obs > 0 ? o->obs[j] : j; oo[j] = u0[i] + s * (u[i] - u0[i]); } }
           ++si;
         }
+        if (maxo >= 3) u3 = u2;
         u2 = u1; u1 = u0; u0 = u;
         bool landed = bp < o->n_break && tn == o->breaks[bp];
-        int nh_new = std::min(nhist + 1, 3); double hnext;
+        int nh_new = std::min(nhist + 1, maxo >= 3 ? 4 : 3); double hnext;
         if (nhist >= 2 && n_err > 0) {
           double fac;
           if (o->step_rule == 0) { fac = errn > 0.0 ? 0.9 * step_root(errn, ord) : 2.0; fac = std::min(2.0, std::max(0.2, fac)); }
@@ -624,6 +644,7 @@ int port_tran(void* p, double* u_io, const TranOpts* o, double* out, TranStats* 
         double new_hprev = h, new_hpp = hprev;
         if (landed) { ++bp; nh_new = 1; double tstop = o->t1; if (bp < o->n_break && o->breaks[bp] < tstop) tstop = o->breaks[bp]; hnext = 0.1 * std::min(h, tstop - tn); }
         hnext = std::min(hnext, hmax);
+        hp3 = hpp;
         t = tn; hprev = new_hprev; hpp = new_hpp; nhist = nh_new; S.accepted += 1; since += 1;
         if (trace_t && ntrace < trace_cap) trace_t[ntrace++] = t;
         if (tn >= o->t1) { status = 1; break; }

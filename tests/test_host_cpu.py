@@ -150,6 +150,45 @@ def test_cpu_port_rc_charge_analytic():
     port.close()
 
 
+def test_cpu_port_bdf3_accuracy_and_stability():
+    """max_order = 3 in the port (the oracle side of CadnipTranOpts.max_order = 3, mirrored operation for operation in csrc/tran_ctrl.hpp): on the
+    RC step response it needs fewer steps than BDF2 for a smaller error against 5 (1 - exp(-t / tau)) (test/mna/core.jl:785-912's closed form),
+    and on a lightly damped series RLC (Q = 3.2) it stays stable and tracks the ringing -- BDF3 is not A-stable, the controller has to keep it honest."""
+    c = cj.Circuit()
+    c.V("v1", "vin", "0", dc=0.0, wave=("pwl", [0.0, 1e-9], [0.0, 5.0]))
+    c.R("r1", "vin", "out", 1e3)
+    c.C("c1", "out", "0", 1e-6)
+    st, port = make_port(c, {}, 27.0, "tranop")
+    analyze_port(st, port, 5.0)
+    u0, ok, _ = port.dc(abstol=1e-9)
+    port.set_spec(mode="tran")
+    tau = 1e-3
+    ts = np.array([0.5, 1.0, 2.0, 3.0, 5.0]) * tau
+    res = {}
+    for mo in (2, 3):
+        out, _, stats, _ = port.tran(u0, 0.0, 5e-3, 1e-9, 1e-6, breaks=[1e-9], save_t=ts, obs=[st.index_of("out")], err_mask=st.differential_mask(), max_order=mo)
+        assert stats["status"] == 1
+        res[mo] = (stats["accepted"], np.max(np.abs(out[:, 0] - 5.0 * (1 - np.exp(-ts / tau))) / 5.0))
+    port.close()
+    assert res[3][0] < 0.6 * res[2][0] and res[3][1] < res[2][1] < 1e-4, res
+    c = cj.Circuit()
+    c.V("v1", "in", "0", dc=0.0, wave=("pwl", [0.0, 1e-9], [0.0, 1.0]))
+    c.R("r1", "in", "a", 10.0)
+    c.L("l1", "a", "out", 1e-3)
+    c.C("c1", "out", "0", 1e-6)
+    st, port = make_port(c, {}, 27.0, "tranop")
+    analyze_port(st, port, 1.0)
+    u0, ok, _ = port.dc(abstol=1e-9)
+    port.set_spec(mode="tran")
+    al, w0 = 10.0 / (2 * 1e-3), 1.0 / np.sqrt(1e-3 * 1e-6)
+    wd = np.sqrt(w0 ** 2 - al ** 2)
+    ts = np.linspace(1e-5, 2e-3, 40)
+    exact = 1 - np.exp(-al * ts) * (np.cos(wd * ts) + al / wd * np.sin(wd * ts))
+    out, _, stats, _ = port.tran(u0, 0.0, 2e-3, 1e-9, 1e-6, breaks=[1e-9], save_t=ts, obs=[st.index_of("out")], err_mask=st.differential_mask(), max_order=3)
+    port.close()
+    assert stats["status"] == 1 and np.max(np.abs(out[:, 0] - exact)) < 2e-4
+
+
 def test_cpu_port_dff_transient_logic_pins():
     # test/gf180_dff.jl:29-33 logic-level pins (race-free ones; see tests/test_gpu_drivers.py)
     circ = bm.dff_circuit()
