@@ -567,6 +567,7 @@ int cadnip_host_f2_steps(const CadnipHostLU* lu, int32_t nc, int32_t nw, int32_t
   return CADNIP_OK;
 }
 void cadnip_host_f2_free(CadnipHostF2* f) { delete f; }
+int32_t cadnip_host_lu_blocks(const CadnipHostLU* lu) { return lu ? lu->p.n_blocks : -1; }
 void cadnip_host_lu_free(CadnipHostLU* lu) { delete lu; }
 
 // Replay of a fixed launch sequence as an instantiated HIP graph: the first call in a configuration (`key`) enqueues plainly (lazy set-up

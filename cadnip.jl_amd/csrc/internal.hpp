@@ -26,6 +26,7 @@ void set_last_error(const char* what, hipError_t e);
 // host-side result of the symbolic phase (symbolic.cpp)
 struct LUProgram {
   int n = 0;
+  int n_blocks = 0;                    // CADNIP_LU_ORDER=klu: diagonal blocks of the block triangular form (0: the Markowitz search was used)
   std::vector<int> rperm, cperm;       // pivot k uses original row rperm[k], column cperm[k]
   std::vector<char> unit;              // pivot k is the stamped constant 1 (a charge / limit row's own diagonal): no division by it
   int nnz_lu = 0;
@@ -199,6 +200,8 @@ struct CadnipHandle {
 
 namespace cadnip {
 // symbolic.cpp
+// KLU's ordering (klu_order.cpp): column sequence, the maximum transversal's row per column, block boundaries; false = structurally singular
+bool klu_style_order(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, std::vector<int>& colorder, std::vector<int>& match_row, std::vector<int>& block_ptr);
 int lu_analyze(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, const std::vector<double>& vals,
                double pivot_tol, bool sample, LUProgram& out, std::string& err, const LULeaves* leaves = nullptr);
 // kernels.hip launchers (all asynchronous on h->stream)

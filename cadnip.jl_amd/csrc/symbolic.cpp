@@ -21,6 +21,8 @@
 #include <map>
 #include <set>
 #include <unordered_map>
+#include <stdio.h>
+#include <stdlib.h>
 #include "internal.hpp"
 
 namespace cadnip {
@@ -93,6 +95,32 @@ static int lu_analyze_mode(int n, const std::vector<int>& rowptr, const std::vec
   // only (rows are kept ordered by their current length), the classic restricted Markowitz strategy; the pivot rule inside
   // the searched rows is the same.
   const bool restricted = n > LU_EXHAUSTIVE_MAX;
+  // CADNIP_LU_ORDER=klu: KLU's ordering instead of the Markowitz search (klu_order.cpp) -- block triangular form, minimum degree inside the
+  // blocks; the pivot row of every column by threshold partial pivoting on the sample, the matched entry preferred (KLU's diagonal preference)
+  std::vector<int> klu_cols, klu_match, klu_blocks;
+  bool klu = false;
+  // Default: the Markowitz search for the circuits of a sweep (n <= 4 096: on the flip-flop it gives 14 dependency levels and 194 multiply-adds
+  // where the KLU-style order gives 23 and 339 -- device-local unknowns first, constant-1 pivots), KLU's ordering for a single large circuit
+  // (c6288, n = 75 908: 241 levels and 272 k multiply-adds instead of 322 and 694 k, 4 % less fill).  CADNIP_LU_ORDER = klu | markowitz forces one.
+  bool want_klu = restricted;
+  if (const char* e = getenv("CADNIP_LU_ORDER")) want_klu = e[0] == 'k' || e[0] == 'K';
+  std::vector<double> klu_rscale;
+  if (want_klu) {
+    klu_rscale.assign(n, 1.0);
+    for (int i = 0; i < n; ++i) {
+      double mx = 0;
+      for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) mx = std::max(mx, std::fabs(vals[p]));
+      if (mx > 0.0 && std::isfinite(mx)) klu_rscale[i] = 1.0 / mx;
+    }
+    klu = klu_style_order(n, rowptr, colidx, klu_cols, klu_match, klu_blocks);
+    if (!klu) { err = "matrix is structurally singular (no perfect matching)"; return CADNIP_SINGULAR; }
+    out.n_blocks = (int)klu_blocks.size() - 1;
+    leaf_order.clear();
+    if (getenv("CADNIP_LU_DEBUG")) {
+      int big = 0; for (size_t b = 0; b + 1 < klu_blocks.size(); ++b) big = std::max(big, klu_blocks[b + 1] - klu_blocks[b]);
+      fprintf(stderr, "[cadnip lu] KLU-style order: %d diagonal blocks, the largest of %d unknowns\n", out.n_blocks, big);
+    }
+  }
   std::set<std::pair<int, int>> by_len;      // (current row length, row) of the rows not yet eliminated
   if (restricted) for (int i = 0; i < n; ++i) by_len.insert({(int)rows[i].size(), i});
   std::vector<int> cand;
@@ -140,7 +168,20 @@ static int lu_analyze_mode(int n, const std::vector<int>& rowptr, const std::vec
       else if (rel > brel * (1 + 1e-12)) better = true;
       if (better) { best_cost = cost; bi = i; bj = j; bdiag = diag; brel = rel; }
     };
-    if (bi < 0 && !restricted) {
+    if (klu) {
+      // partial pivoting in column j on ROW-SCALED magnitudes (KLU scales rows by their largest entry before it factors: MNA rows differ by
+      // twenty orders of magnitude -- a charge row carries 1 and 1e12 dQ/dV, a node row conductances down to gmin -- and unscaled column
+      // pivoting loses the flip-flop's Jacobian entirely); the matched entry is taken when it is within pivot_tol of the best
+      const int j = klu_cols[k];
+      double m = 0;
+      for (int ii : cols[j]) m = std::max(m, std::fabs(rows[ii][j]) * klu_rscale[ii]);
+      const int pref = klu_match[j];
+      if (m > 0.0 && std::isfinite(m)) {
+        auto it = rows[pref].find(j);
+        if (!rdone[pref] && it != rows[pref].end() && std::fabs(it->second) * klu_rscale[pref] >= pivot_tol * m && std::fabs(it->second) > 0.0) { bi = pref; bj = j; }
+        else for (int ii : cols[j]) if (std::fabs(rows[ii][j]) * klu_rscale[ii] == m) { bi = ii; bj = j; break; }
+      }
+    } else if (bi < 0 && !restricted) {
       for (int i = 0; i < n; ++i) {
         if (rdone[i]) continue;
         const long r = (long)rows[i].size();

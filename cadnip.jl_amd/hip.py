@@ -24,7 +24,7 @@ EXPORTS = [
     "cadnip_analyze_values", "cadnip_factor", "cadnip_solve", "cadnip_newton_step", "cadnip_newton_step_fused", "cadnip_debug_step_time", "cadnip_lu_stats", "cadnip_dc_run",
     "cadnip_dc_log_size", "cadnip_dc_log_get", "cadnip_tran_run", "cadnip_tran_state", "cadnip_dev_ptr", "cadnip_stream", "cadnip_set_u", "cadnip_get_u", "cadnip_get_flags",
     "cadnip_sync", "cadnip_debug_copy", "cadnip_debug_stamp_time", "cadnip_profile_enable", "cadnip_profile_read", "cadnip_version",
-    "cadnip_host_lu_analyze", "cadnip_host_lu_analyze_leaves", "cadnip_host_lu_size", "cadnip_host_lu_get", "cadnip_host_lu_free",
+    "cadnip_host_lu_analyze", "cadnip_host_lu_analyze_leaves", "cadnip_host_lu_size", "cadnip_host_lu_blocks", "cadnip_host_lu_get", "cadnip_host_lu_free",
     "cadnip_host_f2_build", "cadnip_host_f2_size", "cadnip_host_f2_get", "cadnip_host_f2_free", "cadnip_host_f2_team_steps", "cadnip_host_f2_steps",
 ]
 
@@ -433,9 +433,21 @@ def leaves_of(st):
     return q0, l0, ok
 
 
-def host_lu_analyze(n, rowptr, colidx, vals, pivot_tol=1e-3, sample=False, f2_nc=None, leaves=None):
+def host_lu_analyze(n, rowptr, colidx, vals, pivot_tol=1e-3, sample=False, f2_nc=None, leaves=None, order=None):
     """Host-only symbolic phase (no GPU needed): returns the LU program as a dict of int32 arrays.  ``leaves``: ``leaves_of(st)`` for
-    the pivot order of a handle (device-local unknowns first), None for the plain Markowitz search."""
+    the pivot order of a handle (device-local unknowns first), None for the plain Markowitz search.  ``order``: "klu" | "markowitz" forces
+    the ordering (csrc/symbolic.cpp: default Markowitz up to 4 096 unknowns, KLU's block triangular form + minimum degree beyond);
+    ``out["n_blocks"]`` = diagonal blocks found (0 with the Markowitz search)."""
+    if order is not None:
+        prev = os.environ.get("CADNIP_LU_ORDER")
+        os.environ["CADNIP_LU_ORDER"] = order
+        try:
+            return host_lu_analyze(n, rowptr, colidx, vals, pivot_tol, sample, f2_nc, leaves)
+        finally:
+            if prev is None:
+                os.environ.pop("CADNIP_LU_ORDER", None)
+            else:
+                os.environ["CADNIP_LU_ORDER"] = prev
     lib = load_library()
     rp = np.ascontiguousarray(rowptr, dtype=np.int32)
     ci = np.ascontiguousarray(colidx, dtype=np.int32)
@@ -456,6 +468,8 @@ def host_lu_analyze(n, rowptr, colidx, vals, pivot_tol=1e-3, sample=False, f2_nc
             a = np.zeros(max(sz, 1), dtype=np.int32)
             _check(lib.cadnip_host_lu_get(p, C.c_int32(k), _ip(a)), "cadnip_host_lu_get")
             out[nm] = a[:sz]
+        lib.cadnip_host_lu_blocks.restype = C.c_int32
+        out["n_blocks"] = int(lib.cadnip_host_lu_blocks(p))
         if f2_nc is not None:
             ts = (C.c_int32 * 4)()
             out["team_steps"] = {}

@@ -325,6 +325,7 @@ int cadnip_host_lu_analyze(int32_t n, const int32_t* rowptr, const int32_t* coli
 int cadnip_host_lu_analyze_leaves(int32_t n, const int32_t* rowptr, const int32_t* colidx, const double* vals, double pivot_tol, int32_t sample,
                                   int32_t q_begin, int32_t lim_begin, const uint8_t* unit_ok, CadnipHostLU** out);
 int32_t cadnip_host_lu_size(const CadnipHostLU* lu, int32_t which);
+int32_t cadnip_host_lu_blocks(const CadnipHostLU* lu);   /* diagonal blocks of the block triangular form when KLU's ordering was used (csrc/klu_order.cpp), 0 = Markowitz search */
 int cadnip_host_lu_get(const CadnipHostLU* lu, int32_t which, int32_t* dst);
 void cadnip_host_lu_free(CadnipHostLU* lu);
 

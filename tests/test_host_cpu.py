@@ -578,6 +578,48 @@ def test_step_programs_on_cpu(nc):
                 assert (n_pre, n_post, n_fwd) == {1: (7, 6, 5), 14: (7, 5, 5), 2: (8, 9, 5), 4: (7, 6, 5)}[key], (key, n_pre, n_post, n_fwd)
 
 
+def test_klu_style_ordering_on_cpu():
+    """csrc/klu_order.cpp (CADNIP_LU_ORDER=klu; the reference's KLU orders with BTF + AMD, src/sweeps.jl:600): a randomly permuted block upper
+    triangular matrix is recognised block for block (maximum transversal + strongly connected components), a matrix with a structurally
+    zero diagonal gets a perfect matching, and the entry program built on the order (pivot rows by threshold partial pivoting on the sample,
+    the matched entry preferred) solves random MNA-like systems and the flip-flop's Jacobian to a 1e-9 backward error."""
+    import scipy.sparse.linalg as spla
+    rng = np.random.default_rng(5)
+    sizes = [7, 1, 12, 1, 1, 20, 5]
+    n = sum(sizes)
+    A = sp.lil_matrix((n, n))
+    o = 0
+    for sz in sizes:
+        for i in range(sz):                                     # an irreducible diagonal block: a cycle plus random entries
+            A[o + i, o + i] = 4.0 + rng.random()
+            A[o + i, o + (i + 1) % sz] = rng.random() + 0.1
+            for j in rng.integers(0, sz, 2):
+                A[o + i, o + j] = A[o + i, o + j] or rng.random() + 0.1
+        for i in range(sz):                                     # coupling to LATER blocks only
+            for j in rng.integers(o + sz, n, 2) if o + sz < n else []:
+                A[o + i, j] = rng.random()
+        o += sz
+    pr, pc = rng.permutation(n), rng.permutation(n)
+    Ap = A.tocsr()[pr][:, pc].tocsr(); Ap.sort_indices()
+    P = hip.host_lu_analyze(n, Ap.indptr, Ap.indices, Ap.data, order="klu")
+    assert P["n_blocks"] == len(sizes)
+    # (zero diagonal: a voltage source's branch row has no diagonal entry, devices.jl:619-633)
+    st, port = make_port(bm.dff_circuit(), {"vdd": 5.0})
+    u = np.random.default_rng(11).random(st.n) * 5.0            # (the state test_fused_linear_solve_program_on_cpu uses)
+    G, Cm, b, lw = port.rebuild(u, 2.005e-7)
+    J = G + 1e9 * Cm
+    port.close()
+    cases = [(st.n, np.asarray(st.rowptr), np.asarray(st.colidx), J), (n, Ap.indptr, Ap.indices, Ap.data)]
+    for nn, rp, ci, vals in cases:
+        P = hip.host_lu_analyze(nn, rp, ci, vals, f2_nc=8, order="klu")
+        assert P["n_blocks"] >= 1
+        rhs = rng.random(nn) - 0.5
+        x, _ = _emulate_f2(P, nn, vals, rp, ci, rhs)
+        Asp = sp.csr_matrix((vals, ci, rp), shape=(nn, nn))
+        bw = np.max(np.abs(Asp @ x - rhs) / (abs(Asp) @ np.abs(x) + np.abs(rhs) + 1e-300))
+        assert bw < 1e-9, (nn, bw)
+
+
 def test_cpu_port_ring_oscillator_fixture():
     """test/mna/vadistiller_integration.jl:649-692: the 3-stage sp_mos1 ring oscillates -- swing > 2 V, max > 2.5 V,
     min < 0.8 V, more than 10 mid-level crossings between 100 and 200 ns (dtmax = 1 ns).  The reference starts from
@@ -811,6 +853,12 @@ def test_c6288_deck_flattens_and_orders_at_scale():
     prog = hip.host_lu_analyze(st.n, st.rowptr, st.colidx, vals, sample=True)
     assert sorted(prog["rperm"].tolist()) == list(range(st.n)) and sorted(prog["cperm"].tolist()) == list(range(st.n))
     assert len(prog["col"]) < 1.2 * st.nnz
+    # beyond 4 096 unknowns the default is KLU's ordering (csrc/klu_order.cpp: block triangular form, minimum degree inside the blocks): the
+    # multiplier falls into tens of thousands of blocks (every charge / limit unknown is one), and against the restricted Markowitz search the
+    # program is shallower and does less than half the multiply-adds
+    mk = hip.host_lu_analyze(st.n, st.rowptr, st.colidx, vals, sample=True, order="markowitz")
+    assert prog["n_blocks"] > 10000 and mk["n_blocks"] == 0
+    assert len(prog["lev_ptr"]) < 0.85 * len(mk["lev_ptr"]) and len(prog["term_a"]) < 0.5 * len(mk["term_a"]) and len(prog["col"]) <= len(mk["col"])
 
 
 def test_staged_continuation_order_and_structure_classes():
