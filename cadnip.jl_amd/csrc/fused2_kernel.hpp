@@ -520,6 +520,7 @@ __global__ void __launch_bounds__(64 * WPB) k_fused2(F2Args f) {
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
+          if (q == 1 && rc_count <= 64) break;             // (the second device of a lane exists only beyond 64: its stamps would all go to the trash word)
           if (refresh) {
             atomicAdd(&W[rc_gp[q][0] & 0xFFFFu], jv[q]); atomicAdd(&W[rc_gp[q][0] >> 16], -jv[q]);
             atomicAdd(&W[rc_gp[q][1] & 0xFFFFu], -jv[q]); atomicAdd(&W[rc_gp[q][1] >> 16], jv[q]);
