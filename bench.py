@@ -249,8 +249,8 @@ def cpu_model():
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--instances", type=int, default=4096, help="weak-scaling sweep instances per GPU (32 Vdd x instances/32 temps)")
     ap.add_argument("--total-instances", type=int, default=1024, help="strong-scaling sweep: this many points split over the GPUs (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=1536, help="corner points timed on the host for cpu_baseline")
