@@ -81,6 +81,40 @@ def test_rebuild_matches_oracle(name, mode, t):
     h.close()
 
 
+@pytest.mark.parametrize("B", [16, 37, 150])
+def test_rebuild_of_a_batch_matches_oracle(B):
+    """The stamping kernels' workgroup geometry depends on the batch (csrc/stamp_csr.hip: from 16 tiles per chunk on, up to eight waves per
+    workgroup share one LDS copy of the reduction records and loop over the chunk's tiles; below, one wave per workgroup): a batch of B
+    flip-flop corners with their own supplies, temperatures, states and times -- B not a multiple of the workgroup's waves, more tiles than
+    one pass of the resident workgroups -- restamped in one call; several instances against the oracle at 1e-12, and every instance against
+    its own single-instance restamp bit for bit."""
+    mk, params = ALL_STAMP["dff"]
+    circ = mk()
+    rng = np.random.default_rng(B)
+    vdds, temps = 4.5 + rng.random(B), -40.0 + 165.0 * rng.random(B)
+    st = cj.discover(circ, params)
+    h = hip.Handle(st, B)
+    h.set_params(cj.pack_params(st, circ, {"vdd": vdds}, temps, B))
+    h.set_spec(mode="tran")
+    u = rng.random((B, st.n)) * 5.0
+    t = rng.random(B) * 7e-7
+    h.rebuild(u, t)
+    G, C, b, lw = h.get_GCb()
+    r = h.residual(u * 0.5, u)
+    h.close()
+    for i in sorted({0, 7, B // 2, B - 1}):
+        cs, ws = _oracle(circ, {"vdd": float(vdds[i])}, "tran", temp=float(temps[i]))
+        M.fast_rebuild(ws, u[i], float(t[i]))
+        for got, ref in ((G[i], cs.G.data), (C[i], cs.C.data), (b[i], ws.dctx.b)):
+            assert _close(got, ref), (B, i, np.max(np.abs(got - ref)), np.max(np.abs(ref)))
+        st1, h1 = _handle(circ, {"vdd": float(vdds[i])}, temps=float(temps[i]))
+        h1.rebuild(u[i], float(t[i]))
+        G1, C1, b1, lw1 = h1.get_GCb()
+        r1 = h1.residual(u[i] * 0.5, u[i])
+        h1.close()
+        assert np.array_equal(G1[0], G[i]) and np.array_equal(C1[0], C[i]) and np.array_equal(b1[0], b[i]) and np.array_equal(lw1[0], lw[i]) and np.array_equal(r1[0], r[i]), (B, i)
+
+
 def test_initjct_stamp_matches_oracle():
     mk, params = ALL_STAMP["dff"]
     circ = mk()
