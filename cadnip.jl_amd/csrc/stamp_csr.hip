@@ -264,8 +264,6 @@ static int build_plan_variant(CadnipHandle* h, const CadnipStructure* s, bool pl
     }
     b.sp_n_targets = (int)rec.size();
     b.sp_levels = n_levels; b.sp_scratch = n_scratch;
-    b.sp_max_steps = 0;
-    for (int c = 0; c < b.sp_chunks; ++c) b.sp_max_steps = std::max(b.sp_max_steps, sptr[c + 1] - sptr[c]);
     int rc;
     if ((rc = upload_vec(&b.d_sp_tptr, sptr))) return rc;
     if ((rc = upload_vec(&b.d_sp_info, sinfo))) return rc;
@@ -282,7 +280,7 @@ static int build_plan_variant(CadnipHandle* h, const CadnipStructure* s, bool pl
 int build_stamp_plan(CadnipHandle* h, const CadnipStructure* s) {
   auto take = [](DeviceBlock& b) {
     DeviceBlock::PlanSet p;
-    p.n_targets = b.sp_n_targets; p.levels = b.sp_levels; p.scratch = b.sp_scratch; p.rows = b.sp_rows; p.max_steps = b.sp_max_steps;
+    p.n_targets = b.sp_n_targets; p.levels = b.sp_levels; p.scratch = b.sp_scratch; p.rows = b.sp_rows;
     p.tptr = b.d_sp_tptr; p.info = b.d_sp_info; p.rec = b.d_sp_rec; p.rowoff = b.d_sp_rowoff;
     b.d_sp_tptr = nullptr; b.d_sp_info = nullptr; b.d_sp_rec = nullptr; b.d_sp_rowoff = nullptr;
     return p;
@@ -330,53 +328,25 @@ static int launch_stamp_csr_pass(CadnipHandle* h, DeviceBlock& b, bool dump_only
   const int lpd = pair ? 2 : (TYPE == CADNIP_DEV_VA && b.va_tl) ? b.va_tl : 1;
   DeviceBlock::PlanSet P;                              // the plan in force
   if (TYPE == CADNIP_DEV_MOS1) P = b.mos1_plain ? b.sp_plain : b.sp_gen;
-  else { P.levels = b.sp_levels; P.scratch = b.sp_scratch; P.rows = b.sp_rows; P.max_steps = b.sp_max_steps; P.tptr = b.d_sp_tptr; P.info = b.d_sp_info; P.rec = b.d_sp_rec; P.rowoff = b.d_sp_rowoff; }
+  else { P.levels = b.sp_levels; P.scratch = b.sp_scratch; P.rows = b.sp_rows; P.tptr = b.d_sp_tptr; P.info = b.d_sp_info; P.rec = b.d_sp_rec; P.rowoff = b.d_sp_rowoff; }
   const int rows = dump_only ? nslots : P.rows;        // the read-out pass stages every slot in a row of its own
   int ipw = 1;
   if (b.sp_chunks == 1) ipw = std::min(8, std::max(1, 64 / (b.count * lpd)));   // (a wave reduces its instances one after the other: few per wave)
   const size_t tile_words = (size_t)rows * b.sp_cs + P.scratch;
   while (ipw > 1 && (size_t)ipw * tile_words * 8 > 64 * 1024) --ipw;
-  int u_lds = (size_t)ipw * h->n * 8 <= 16 * 1024 ? 1 : 0;
-  if (getenv("CADNIP_SC_NOULDS")) u_lds = 0;                                    // (diagnostic)
+  const int u_lds = (size_t)ipw * h->n * 8 <= 16 * 1024 ? 1 : 0;
   static const size_t lds_pad = getenv("CADNIP_SC_PAD") ? (size_t)atol(getenv("CADNIP_SC_PAD")) : 0;        // experiments: occupancy as a function of the LDS request
-  // LDS: shared by the workgroup -- the chunk's reduction records (16 B each, STEP_W per step), the steps' classes, the slots' row offsets --
-  // and per wave: tiles (staged rows + tree scratch), per-instance scalars, u
-  const int rec_cap = dump_only ? 0 : P.max_steps;
-  const size_t shared_bytes = (size_t)rec_cap * STEP_W * 16 + (((size_t)rec_cap + 1) & ~(size_t)1) * 4 + (((size_t)nslots * 2 + 15) & ~(size_t)15);
-  auto wave_bytes = [&](int ul) { return (((size_t)ipw * tile_words + 3 * (size_t)ipw + (ul ? (size_t)ipw * h->n : 0)) * 8 + 15) & ~(size_t)15; };
-  size_t per_wave_bytes = wave_bytes(u_lds);
-  // Waves per workgroup: as many as share the record copy usefully -- eight (the built-in types' kernels are compiled for two waves per SIMD) when
-  // a chunk has that many tiles and the LDS holds them; the external models' kernels (up to 512 registers) and circuits with few instances
-  // keep one wave per workgroup.  The grid is the resident workgroups; a wave works through the tiles wg * nwv + w, + n_wg * nwv, ...
-  const int n_grp = (h->B + ipw - 1) / ipw;
-  int nwv = 1;
-  if (!(TYPE == CADNIP_DEV_VA && b.va_tl) && n_grp >= 16) {
-    nwv = 8;
-    if (const char* e = getenv("CADNIP_SC_NWV")) nwv = std::max(1, std::min(8, atoi(e)));      // (diagnostic)
-    // every resident wave counts (the kernel is latency-bound): when staging u in LDS costs the eighth wave, the devices read u from memory instead
-    if (u_lds && shared_bytes + 8 * per_wave_bytes + lds_pad > 160 * 1024 && shared_bytes + 8 * wave_bytes(0) + lds_pad <= 160 * 1024) { u_lds = 0; per_wave_bytes = wave_bytes(0); }
-    while (nwv > 1 && shared_bytes + (size_t)nwv * per_wave_bytes + lds_pad > 160 * 1024) --nwv;
-  }
-  const size_t shmem = shared_bytes + (size_t)nwv * per_wave_bytes + lds_pad;
-  if (shmem > 160 * 1024) return CADNIP_BADARG;
-  if (h->n_cu <= 0) {
-    int cu = 0;
-    HIP_TRY(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, h->device));
-    h->n_cu = cu > 0 ? cu : 256;
-  }
-  const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)(160 * 1024) / shmem, (size_t)(nwv > 1 ? 1 : 8)));
-  const int wg_need = (n_grp + nwv - 1) / nwv;                       // workgroups per chunk that have a first tile
-  const int wg_chunk = std::max(1, std::min(wg_need, std::max(1, h->n_cu * wg_per_cu / b.sp_chunks)));
+  // tiles (staged rows + tree scratch), per-instance scalars, u, the slots' row offsets
+  const size_t shmem = ((size_t)ipw * tile_words + 3 * (size_t)ipw + (u_lds ? (size_t)ipw * h->n : 0)) * 8 + (((size_t)nslots * 2 + 7) & ~(size_t)7) + lds_pad;
   CsrStampArgs a{b.d_nodes, b.d_ipar, b.d_par, h->d_wave, h->d_u, h->d_t, h->d_active, h->d_cold, h->d_G, h->d_C, h->d_b, h->d_limit_w, h->d_nonfinite,
                  h->d_diag_flag, h->d_gshunt, h->d_srcfact, P.tptr, P.info, P.rec,
                  h->B, b.count, h->n, h->nnz, b.n_par, b.n_g, b.n_c, b.n_b, b.sp_cs, b.sp_chunks, ipw, lpd, h->spec.mode, h->initjct,
                  (TYPE == CADNIP_DEV_MOS1 || TYPE == CADNIP_DEV_VA) ? 1 : 0, P.levels, P.scratch, u_lds,
                  b.d_cache, b.n_cache, dump_only ? h->d_dump : nullptr, h->ns, b.g_base, h->ns_g + b.c_base, h->ns_g + h->ns_c + b.b_base,
-                 dump_only ? nullptr : P.rowoff, rows, dump_only ? 1 : 0,
-                 nwv, n_grp, rec_cap, (int)(shared_bytes / 8), (int)(per_wave_bytes / 8)};
-  const unsigned grid = (unsigned)b.sp_chunks * (unsigned)wg_chunk;
-  if (getenv("CADNIP_SC_DEBUG")) fprintf(stderr, "[cadnip stamp] type %d count %d cs %d chunks %d ipw %d lpd %d slots %d rows %d scratch %d tile_words %zu steps %d shared %zu per wave %zu nwv %d shmem %zu grid %u (tiles per chunk %d) levels %d%s\n",
-                                         TYPE, b.count, b.sp_cs, b.sp_chunks, ipw, lpd, nslots, rows, P.scratch, tile_words, rec_cap, shared_bytes, per_wave_bytes, nwv, shmem, grid, n_grp, P.levels, dump_only ? " (read-out pass)" : "");
+                 dump_only ? nullptr : P.rowoff, rows, dump_only ? 1 : 0};
+  const unsigned grid = (unsigned)b.sp_chunks * (unsigned)((h->B + ipw - 1) / ipw);
+  if (getenv("CADNIP_SC_DEBUG")) fprintf(stderr, "[cadnip stamp] type %d count %d cs %d chunks %d ipw %d lpd %d slots %d rows %d scratch %d tile_words %zu shmem %zu grid %u levels %d%s\n",
+                                         TYPE, b.count, b.sp_cs, b.sp_chunks, ipw, lpd, nslots, rows, P.scratch, tile_words, shmem, grid, P.levels, dump_only ? " (read-out pass)" : "");
   if (TYPE == CADNIP_DEV_VA && b.va_tl) {           // external model: its own kernel (va_ext/<module>.hip)
     const int ext = b.va_model - CADNIP_VA_NBUILTIN;
     if (ext < 0 || ext >= CADNIP_VA_NEXT) return CADNIP_BADARG;

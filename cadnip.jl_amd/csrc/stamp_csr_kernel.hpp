@@ -62,234 +62,226 @@ struct CsrStampArgs {
                                                     // contributions written out as [B][ns], slot (k, dev) of array A at A_base + k * count + dev
   const unsigned short* rowoff; int n_rows;        // row offsets of the slots (null: identity, n_rows = all slots), rows of a tile
   int dump_only;                                    // operating-point read-out pass: stage with the identity layout, write `dump`, skip the reduction
-  // workgroup geometry (launch_stamp_csr_pass): nwv waves per workgroup share ONE copy of their chunk's reduction records in LDS and each
-  // works through the tiles grp = wg * nwv + w, + n_wg * nwv, ... of the chunk
-  int nwv, n_grp, rec_cap;                          // waves per workgroup, tiles per chunk, steps the shared record area holds (>= every chunk's)
-  int shared_dbl, per_wave_dbl;                     // LDS doubles: shared area (records, step classes, row offsets) | one wave's tiles, scalars and u
+
 };
 
 #ifdef CADNIP_TRACE
-// diagnostic build: cycles between the phases of the sp_mos1 kernel, summed over all tiles and launches
+// diagnostic build: cycles between the phases of the sp_mos1 kernel, summed over all waves and launches
 static __device__ unsigned long long g_sc_sum[8], g_sc_cnt;
-#define SC_POINT(id) do { if (TYPE == CADNIP_DEV_MOS1) { unsigned long long _t = clock64(); if (lane == 0) atomicAdd(&g_sc_sum[id], _t - sc_last); sc_last = _t; } } while (0)
+#define SC_POINT(id) do { if (TYPE == CADNIP_DEV_MOS1) { unsigned long long _t = clock64(); if (threadIdx.x == 0) atomicAdd(&g_sc_sum[id], _t - sc_last); sc_last = _t; } } while (0)
 #else
 #define SC_POINT(id) do {} while (0)
 #endif
 
 #define STEP_W 128   // records per reduction step (two per lane)
+#define PIPE 8       // steps whose records are in flight / in registers
 
 // EXT: void for the built-in device types; for a generated external model (va_ext/<module>.hip) a struct with
 //   template <class Ctx, class Out> static __device__ void stamp(const Ctx&, const double* u, const Out&, double* lw, int dir);
 // the kernel is then that model's own (its register budget is not the worst model's).
-// MAXW: the largest workgroup the instantiation is compiled for, in waves (its register budget follows: 8 waves = two per SIMD).
 #ifndef CADNIP_STAMP_KERNEL_ATTR
 #define CADNIP_STAMP_KERNEL_ATTR          // a generated unit may ask for a register budget of its own (e.g. amdgpu_waves_per_eu)
 #endif
-template <int TYPE, class EXT = void, int MAXW = 1>
-__global__ void __launch_bounds__(64 * MAXW) CADNIP_STAMP_KERNEL_ATTR k_stamp_csr(CsrStampArgs a) {
-  extern __shared__ double lds_all[];
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int chunk = blockIdx.x % a.n_chunks, wg = blockIdx.x / a.n_chunks, n_wg = gridDim.x / a.n_chunks;
-  // ---- shared by the workgroup: the chunk's reduction records.  They form *steps* of STEP_W = 128 records (two per lane), every step
-  // homogeneous in class and level (build_stamp_plan pads).  Round 2's kernel fetched them per wave through a register pipeline from L2
-  // -- 20 KB per tile, the same 20 KB for every instance -- and its stores shared the vmcnt counter with those loads; one cooperative
-  // copy per workgroup serves every tile its waves work through, and the reduce loop reads records out of LDS while its stores stream.
+template <int TYPE, class EXT = void>
+__global__ void __launch_bounds__(64) CADNIP_STAMP_KERNEL_ATTR k_stamp_csr(CsrStampArgs a) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+#ifdef CADNIP_TRACE
+  unsigned long long sc_last = clock64();
+  if (TYPE == CADNIP_DEV_MOS1 && threadIdx.x == 0) atomicAdd(&g_sc_cnt, 1ull);
+#endif
+  const int chunk = blockIdx.x % a.n_chunks, grp = blockIdx.x / a.n_chunks;
+  // ---- the reduction's records.  The chunk's records form *steps* of STEP_W = 128 (two per lane), every step homogeneous
+  // in class and level (build_stamp_plan pads).  The reduce loop is ROLLED -- this kernel runs once per wave, so every
+  // instruction it executes is an instruction-cache miss waiting to happen, and a 32-fold unrolled loop ran at ~800 cycles
+  // per step for that reason alone -- and keeps a shift register of PIPE steps' records: the first PIPE are requested
+  // here, before the stamp phase, a new one enters with every step.  step_lane: lane s holds the descriptor of step s
+  // (class | first-step-of-a-level flag << 8), read with v_readlane.
   const int s0 = a.step_ptr[chunk], n_steps = a.dump_only ? 0 : a.step_ptr[chunk + 1] - s0;
-  uint4* const rec_l = (uint4*)lds_all;                                              // [rec_cap][STEP_W]
-  int* const info_l = (int*)(rec_l + (size_t)a.rec_cap * STEP_W);                   // [rec_cap] class | first-step-of-a-level flag << 8
-  constexpr bool REMAP = TYPE == CADNIP_DEV_MOS1 || TYPE == CADNIP_DEV_VA;
-  const int nslots = a.n_g + a.n_c + a.n_b;
-  unsigned short* const rowoff_s = (unsigned short*)(info_l + ((a.rec_cap + 1) & ~1));   // [nslots] (REMAP)
-  {
-    const uint4* src = a.tgt_rec + (size_t)s0 * STEP_W;
-    for (int i = threadIdx.x; i < n_steps * STEP_W; i += blockDim.x) rec_l[i] = src[i];
-    for (int i = threadIdx.x; i < n_steps; i += blockDim.x) info_l[i] = a.step_info[s0 + i];
-    if (REMAP) for (int i = threadIdx.x; i < nslots; i += blockDim.x) rowoff_s[i] = a.rowoff ? a.rowoff[i] : (unsigned short)(i * a.cs);
+  const int step_lane = a.step_info[s0 + (lane < n_steps ? lane : 0)];   // steps beyond 64 read their descriptor from memory
+  const uint4* recs = a.tgt_rec + (size_t)s0 * STEP_W + lane;
+  uint4 pipe[PIPE][2];                                                    // stage p holds the records of step q + p
+#pragma unroll
+  for (int p = 0; p < PIPE; ++p) {
+    const int st = p < n_steps ? p : 0;
+    pipe[p][0] = recs[(size_t)st * STEP_W]; pipe[p][1] = recs[(size_t)st * STEP_W + 64];
   }
-  __syncthreads();
-  double* const lds = lds_all + a.shared_dbl + (size_t)w * a.per_wave_dbl;          // this wave's tiles | instance scalars | u
-  const int tile_words = a.n_rows * a.cs + a.n_scratch;                              // staged rows | scratch of the reduction tree
+  const int nslots = a.n_g + a.n_c + a.n_b, tile_words = a.n_rows * a.cs + a.n_scratch;   // staged rows | scratch of the reduction tree
   // lane -> (instance of the tile, device of the chunk, side of a lane pair)
   const int dl = lane / a.lpd, side = lane - dl * a.lpd;
   const int ii = a.n_chunks == 1 ? dl / a.count : 0;
-  const int ldev0 = a.n_chunks == 1 ? dl - ii * a.count : dl;
-  const int dev0 = chunk * a.cs + ldev0;
-  double* const tile = lds + (size_t)(ii < a.ipw ? ii : 0) * tile_words;
-  double* const inst_par = lds + (size_t)a.ipw * tile_words;                         // [ipw][3]: active, gshunt, srcFact
-  double* const u_tile = inst_par + 3 * a.ipw;                                       // [ipw][n] when u_lds
+  const int ldev = a.n_chunks == 1 ? dl - ii * a.count : dl;
+  const int dev = chunk * a.cs + ldev;
+  const int inst = grp * a.ipw + ii;
+  const bool lane_on = ii < a.ipw && inst < a.B && dev < a.count && ldev < a.cs;
+  const bool valid = lane_on && a.active[inst] != 0;
+  const int inst_c = inst < a.B ? inst : a.B - 1;                 // clamped: every lane runs the device code (lane-pair DPP)
+  double* tile = lds + (size_t)(ii < a.ipw ? ii : 0) * tile_words;
+  if (a.zero_first) {
+    // (tile_words is even for every type that needs this: n_g + n_c + n_b of sp_mos1 = 114; an odd tail is covered below)
+    const int words = a.ipw * tile_words;
+    for (int i = lane; i < (words >> 1); i += 64) ((double2*)lds)[i] = make_double2(0.0, 0.0);
+    if ((words & 1) && lane == 0) lds[words - 1] = 0.0;
+    CADNIP_WAVE_SYNC();
+  }
+  if (lane < a.ipw) lds[(size_t)(lane + 1) * tile_words - 1] = 0.0;   // the tile's zero word: operand slots a record does not use
+  // per-instance scalars of the tile's instances, behind the tiles: the reduction reads them per instance
+  double* inst_par = lds + (size_t)a.ipw * tile_words;             // [ipw][3]: active, gshunt, srcFact
+  if (lane < a.ipw) {
+    const int i2 = grp * a.ipw + lane;
+    const bool in = i2 < a.B;
+    inst_par[3 * lane] = in && a.active[i2] ? 1.0 : 0.0;
+    inst_par[3 * lane + 1] = in ? a.gshunt[i2] : 0.0;
+    inst_par[3 * lane + 2] = in ? a.srcFact[i2] : 1.0;
+  }
+  double* u_tile = inst_par + 3 * a.ipw;                           // [ipw][n] when u_lds
+  constexpr bool REMAP = TYPE == CADNIP_DEV_MOS1 || TYPE == CADNIP_DEV_VA;
+  unsigned short* rowoff = (unsigned short*)(u_tile + (a.u_lds ? (size_t)a.ipw * a.n : 0));   // [nslots]
+  if (REMAP) {
+    for (int i = lane; i < nslots; i += 64) rowoff[i] = a.rowoff ? a.rowoff[i] : (unsigned short)(i * a.cs);
+    if (!a.u_lds) CADNIP_WAVE_SYNC();
+  }
+  if (a.u_lds) {
+    for (int r = 0; r < a.ipw; ++r) {
+      const int i2 = grp * a.ipw + r < a.B ? grp * a.ipw + r : a.B - 1;
+      const double* ug = a.u + (size_t)i2 * a.n;
+      for (int i = lane; i < a.n; i += 64) u_tile[(size_t)r * a.n + i] = ug[i];
+    }
+    CADNIP_WAVE_SYNC();
+  }
+  SC_POINT(0);
+  {
+    DevCtx d{a.nodes, a.ipar, a.par + (size_t)inst_c * a.n_par * a.count, a.wave, a.count, dev < a.count ? dev : a.count - 1, a.t[inst_c], a.mode, (a.initjct && a.cold[inst_c]) ? 1 : 0,
+             a.cache ? a.cache + (size_t)inst_c * a.n_cache * a.count : nullptr};
+    LdsOutT<REMAP> s{tile, rowoff, rowoff + a.n_g, rowoff + a.n_g + a.n_c, ldev, valid, a.cs, 0, a.n_g, a.n_g + a.n_c};
+    const double* u = a.u_lds ? u_tile + (size_t)(ii < a.ipw ? ii : 0) * a.n : a.u + (size_t)inst_c * a.n;
+    double* lw = valid ? a.limit_w + (size_t)inst_c * a.n : nullptr;
+    if (TYPE == CADNIP_DEV_RESISTOR) stamp_resistor(d, u, s, lw);
+    else if (TYPE == CADNIP_DEV_CAPACITOR) stamp_capacitor(d, u, s, lw);
+    else if (TYPE == CADNIP_DEV_INDUCTOR) stamp_inductor(d, u, s, lw);
+    else if (TYPE == CADNIP_DEV_VSOURCE) stamp_vsource(d, u, s, lw);
+    else if (TYPE == CADNIP_DEV_ISOURCE) stamp_isource(d, u, s, lw);
+    else if (TYPE == CADNIP_DEV_VCVS) stamp_vcvs(d, u, s, lw);
+    else if (TYPE == CADNIP_DEV_VCCS) stamp_vccs(d, u, s, lw);
+    else if (TYPE == CADNIP_DEV_CCVS) stamp_ccvs(d, u, s, lw);
+    else if (TYPE == CADNIP_DEV_CCCS) stamp_cccs(d, u, s, lw);
+    else if (TYPE == CADNIP_DEV_DIODE) stamp_diode(d, u, s, lw);
+    else if (TYPE == CADNIP_DEV_DIODECAP) stamp_diodecap(d, u, s, lw);
+    else if (TYPE == CADNIP_DEV_SIMPLEMOS) stamp_simplemos(d, u, s, lw);
+    else if (TYPE == CADNIP_DEV_MOS1) {
+      if (a.lpd == 2) stamp_mos1_pair(d, u, s, lw, side, valid);   // two lanes per MOSFET (devices.hpp)
+      else stamp_mos1(d, u, s, lw);
+    }
+    else if (TYPE == CADNIP_DEV_BVSOURCE) stamp_bvsource(d, u, s, lw);
+    else if (TYPE == CADNIP_DEV_BISOURCE) stamp_bisource(d, u, s, lw);
+    else if (TYPE == CADNIP_DEV_VA) {
+      if constexpr (std::is_void<EXT>::value) stamp_va(d, u, s, lw);
+      else EXT::stamp(d, u, s, lw, side);                         // external model: lane `side` of the device's group carries direction `side`
+    }
+  }
+  CADNIP_WAVE_SYNC();
+  if (a.dump_only && a.dump && valid && side == 0) {
+    double* D = a.dump + (size_t)inst * a.ns;
+    // (dump_only pass: identity layout, every slot has its own row)
+    for (int k = 0; k < a.n_g; ++k) D[a.dump_g + k * a.count + dev] = tile[k * a.cs + ldev];
+    for (int k = 0; k < a.n_c; ++k) D[a.dump_c + k * a.count + dev] = tile[(a.n_g + k) * a.cs + ldev];
+    for (int k = 0; k < a.n_b; ++k) D[a.dump_b + k * a.count + dev] = tile[(a.n_g + a.n_c + k) * a.cs + ldev];
+  }
+  SC_POINT(1);
+  // ---- segmented reduction: one target per lane and step, contributions summed in COO order out of LDS.  A target is
+  // one 16-byte record (destination, count, up to five staging offsets inline); RED_U records per lane are requested
+  // before the first is used, so the batch costs one memory latency, not one per target.
+  // Step by step: class 0 / 1 / 2 = sole writer of a word of G / C / b (plain store), 3 = partial sum into LDS scratch,
+  // 4 = the rest (read-modify-write behind an earlier kernel, atomics between tiles), 5 = padding.  Class, destination and
+  // the instance's scalars are wave-uniform, so a record costs five LDS reads issued together (operand slots it does not
+  // use point at the tile's zero word), four adds and one store.
+  // everything a record needs about its instance, gathered once (not per record: the compiler would re-read kernel
+  // arguments and LDS words in every step)
+  struct InstCtx { double *Gb, *Cb, *bb; int* nf; double sf, gsh; int tile_off; };   // (the tile is addressed by offset: an LDS pointer inside a struct decays to a generic one)
+  auto inst_ctx = [&](int ri) {
+    const int rinst = grp * a.ipw + ri;
+    InstCtx c;
+    c.tile_off = ri * tile_words;
+    c.Gb = a.G + (size_t)rinst * a.nnz; c.Cb = a.C + (size_t)rinst * a.nnz; c.bb = a.b + (size_t)rinst * a.n;
+    c.nf = a.nonfinite + rinst;
+    c.gsh = uniform_f64(inst_par[3 * ri + 1]); c.sf = uniform_f64(inst_par[3 * ri + 2]);
+    return c;
+  };
   const unsigned char* const diag_flag = a.diag_flag;
-  for (int grp = wg * a.nwv + w; grp < a.n_grp; grp += n_wg * a.nwv) {
-#ifdef CADNIP_TRACE
-    unsigned long long sc_last = clock64();
-    if (TYPE == CADNIP_DEV_MOS1 && lane == 0) atomicAdd(&g_sc_cnt, 1ull);
-#endif
-    // Whatever depends only on the lane -- the device's node indices, the slots' row offsets -- is the same for every tile of the loop; hoisted
-    // out of it, it would occupy (and spill from) ~100 vector registers for the kernel's life.  Opaque copies per tile keep it local.
-    int dev = dev0, ldev = ldev0;
-    const unsigned short* rowoff = rowoff_s;
-    asm volatile("" : "+v"(dev), "+v"(ldev), "+v"(rowoff));
-    const int inst = grp * a.ipw + ii;
-    const bool lane_on = ii < a.ipw && inst < a.B && dev < a.count && ldev < a.cs;
-    const bool valid = lane_on && a.active[inst] != 0;
-    const int inst_c = inst < a.B ? inst : a.B - 1;                 // clamped: every lane runs the device code (lane-pair DPP)
-    if (a.zero_first) {
-      // (tile_words is even for every type that needs this: n_g + n_c + n_b of sp_mos1 = 114; an odd tail is covered below)
-      const int words = a.ipw * tile_words;
-      for (int i = lane; i < (words >> 1); i += 64) ((double2*)lds)[i] = make_double2(0.0, 0.0);
-      if ((words & 1) && lane == 0) lds[words - 1] = 0.0;
-      CADNIP_WAVE_SYNC();
-    }
-    if (lane < a.ipw) lds[(size_t)(lane + 1) * tile_words - 1] = 0.0;   // the tile's zero word: operand slots a record does not use
-    // per-instance scalars of the tile's instances, behind the tiles: the reduction reads them per instance
-    if (lane < a.ipw) {
-      const int i2 = grp * a.ipw + lane;
-      const bool in = i2 < a.B;
-      inst_par[3 * lane] = in && a.active[i2] ? 1.0 : 0.0;
-      inst_par[3 * lane + 1] = in ? a.gshunt[i2] : 0.0;
-      inst_par[3 * lane + 2] = in ? a.srcFact[i2] : 1.0;
-    }
-    if (a.u_lds) {
-      for (int r = 0; r < a.ipw; ++r) {
-        const int i2 = grp * a.ipw + r < a.B ? grp * a.ipw + r : a.B - 1;
-        const double* ug = a.u + (size_t)i2 * a.n;
-        for (int i = lane; i < a.n; i += 64) u_tile[(size_t)r * a.n + i] = ug[i];
-      }
-    }
-    CADNIP_WAVE_SYNC();
-    SC_POINT(0);
-    {
-      DevCtx d{a.nodes, a.ipar, a.par + (size_t)inst_c * a.n_par * a.count, a.wave, a.count, dev < a.count ? dev : a.count - 1, a.t[inst_c], a.mode, (a.initjct && a.cold[inst_c]) ? 1 : 0,
-               a.cache ? a.cache + (size_t)inst_c * a.n_cache * a.count : nullptr};
-      LdsOutT<REMAP> s{tile, rowoff, rowoff + a.n_g, rowoff + a.n_g + a.n_c, ldev, valid, a.cs, 0, a.n_g, a.n_g + a.n_c};
-      const double* u = a.u_lds ? u_tile + (size_t)(ii < a.ipw ? ii : 0) * a.n : a.u + (size_t)inst_c * a.n;
-      double* lw = valid ? a.limit_w + (size_t)inst_c * a.n : nullptr;
-      if (TYPE == CADNIP_DEV_RESISTOR) stamp_resistor(d, u, s, lw);
-      else if (TYPE == CADNIP_DEV_CAPACITOR) stamp_capacitor(d, u, s, lw);
-      else if (TYPE == CADNIP_DEV_INDUCTOR) stamp_inductor(d, u, s, lw);
-      else if (TYPE == CADNIP_DEV_VSOURCE) stamp_vsource(d, u, s, lw);
-      else if (TYPE == CADNIP_DEV_ISOURCE) stamp_isource(d, u, s, lw);
-      else if (TYPE == CADNIP_DEV_VCVS) stamp_vcvs(d, u, s, lw);
-      else if (TYPE == CADNIP_DEV_VCCS) stamp_vccs(d, u, s, lw);
-      else if (TYPE == CADNIP_DEV_CCVS) stamp_ccvs(d, u, s, lw);
-      else if (TYPE == CADNIP_DEV_CCCS) stamp_cccs(d, u, s, lw);
-      else if (TYPE == CADNIP_DEV_DIODE) stamp_diode(d, u, s, lw);
-      else if (TYPE == CADNIP_DEV_DIODECAP) stamp_diodecap(d, u, s, lw);
-      else if (TYPE == CADNIP_DEV_SIMPLEMOS) stamp_simplemos(d, u, s, lw);
-      else if (TYPE == CADNIP_DEV_MOS1) {
-        if (a.lpd == 2) stamp_mos1_pair(d, u, s, lw, side, valid);   // two lanes per MOSFET (devices.hpp)
-        else stamp_mos1(d, u, s, lw);
-      }
-      else if (TYPE == CADNIP_DEV_BVSOURCE) stamp_bvsource(d, u, s, lw);
-      else if (TYPE == CADNIP_DEV_BISOURCE) stamp_bisource(d, u, s, lw);
-      else if (TYPE == CADNIP_DEV_VA) {
-        if constexpr (std::is_void<EXT>::value) stamp_va(d, u, s, lw);
-        else EXT::stamp(d, u, s, lw, side);                         // external model: lane `side` of the device's group carries direction `side`
-      }
-    }
-    CADNIP_WAVE_SYNC();
-    if (a.dump_only && a.dump && valid && side == 0) {
-      double* D = a.dump + (size_t)inst * a.ns;
-      // (dump_only pass: identity layout, every slot has its own row)
-      for (int k = 0; k < a.n_g; ++k) D[a.dump_g + k * a.count + dev] = tile[k * a.cs + ldev];
-      for (int k = 0; k < a.n_c; ++k) D[a.dump_c + k * a.count + dev] = tile[(a.n_g + k) * a.cs + ldev];
-      for (int k = 0; k < a.n_b; ++k) D[a.dump_b + k * a.count + dev] = tile[(a.n_g + a.n_c + k) * a.cs + ldev];
-    }
-    SC_POINT(1);
-    // ---- segmented reduction: one target per lane and step, contributions summed in COO order out of LDS.  A target is
-    // one 16-byte record (destination, count, up to five staging offsets inline).
-    // Step by step: class 0 / 1 / 2 = sole writer of a word of G / C / b (plain store), 3 = partial sum into LDS scratch,
-    // 4 = the rest (read-modify-write behind an earlier kernel, atomics between tiles), 5 = padding.  Class, destination and
-    // the instance's scalars are wave-uniform, so a record costs five LDS reads issued together (operand slots it does not
-    // use point at the tile's zero word), four adds and one store.
-    // everything a record needs about its instance, gathered once (not per record: the compiler would re-read kernel
-    // arguments and LDS words in every step)
-    struct InstCtx { double *Gb, *Cb, *bb; int* nf; double sf, gsh; int tile_off; };   // (the tile is addressed by offset: an LDS pointer inside a struct decays to a generic one)
-    auto inst_ctx = [&](int ri) {
-      const int rinst = grp * a.ipw + ri;
-      InstCtx c;
-      c.tile_off = ri * tile_words;
-      c.Gb = a.G + (size_t)rinst * a.nnz; c.Cb = a.C + (size_t)rinst * a.nnz; c.bb = a.b + (size_t)rinst * a.n;
-      c.nf = a.nonfinite + rinst;
-      c.gsh = uniform_f64(inst_par[3 * ri + 1]); c.sf = uniform_f64(inst_par[3 * ri + 2]);
-      return c;
-    };
-    auto reduce_instance = [&](const InstCtx& c, const uint4& ra, const uint4& rb, int cls) {
-      double* src = lds + c.tile_off;
-      const double a0 = src[ra.y >> 16], a1 = src[ra.z & 0xFFFFu], a2 = src[ra.z >> 16], a3 = src[ra.w & 0xFFFFu], a4 = src[ra.w >> 16];
-      const double b0 = src[rb.y >> 16], b1 = src[rb.z & 0xFFFFu], b2 = src[rb.z >> 16], b3 = src[rb.w & 0xFFFFu], b4 = src[rb.w >> 16];
-      double acc[2] = {(((a0 + a1) + a2) + a3) + a4, (((b0 + b1) + b2) + b3) + b4};
-      const unsigned e[2] = {ra.x & 0x0FFFFFFFu, rb.x & 0x0FFFFFFFu};
-      const bool on[2] = {(ra.y & 0xFFFFu) != 0u, (rb.y & 0xFFFFu) != 0u};   // padding records inside a step have count 0
-      const unsigned wx[2] = {ra.x, rb.x};
+  auto reduce_instance = [&](const InstCtx& c, const uint4& ra, const uint4& rb, int cls) {
+    double* src = lds + c.tile_off;
+    const double a0 = src[ra.y >> 16], a1 = src[ra.z & 0xFFFFu], a2 = src[ra.z >> 16], a3 = src[ra.w & 0xFFFFu], a4 = src[ra.w >> 16];
+    const double b0 = src[rb.y >> 16], b1 = src[rb.z & 0xFFFFu], b2 = src[rb.z >> 16], b3 = src[rb.w & 0xFFFFu], b4 = src[rb.w >> 16];
+    double acc[2] = {(((a0 + a1) + a2) + a3) + a4, (((b0 + b1) + b2) + b3) + b4};
+    const unsigned e[2] = {ra.x & 0x0FFFFFFFu, rb.x & 0x0FFFFFFFu};
+    const bool on[2] = {(ra.y & 0xFFFFu) != 0u, (rb.y & 0xFFFFu) != 0u};   // padding records inside a step have count 0
+    const unsigned wx[2] = {ra.x, rb.x};
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        if (!on[k]) continue;
-        double v = acc[k];
-        switch (cls) {                                 // wave-uniform
-          case 0:
-            if (c.gsh != 0.0 && diag_flag[e[k]]) v += c.gsh;                                     // precompile.jl:529-534
-            if (!isfinite(v)) *c.nf = 1;
-            c.Gb[e[k]] = v;
-            break;
-          case 1:
-            if (!isfinite(v)) *c.nf = 1;
-            c.Cb[e[k]] = v;
-            break;
-          case 2:
-            if (c.sf < 1.0) v *= c.sf;                                                           // precompile.jl:524-527
-            if (!isfinite(v)) *c.nf = 1;
-            c.bb[e[k]] = v;
-            break;
-          case 3: src[e[k]] = v; break;
-          default: {
-            const unsigned arr = (wx[k] >> 28) & 3u, md = wx[k] >> 30;
-            if (arr == 2u && c.sf < 1.0) v *= c.sf;
-            if (!isfinite(v)) *c.nf = 1;
-            double* dst = (arr == 0u ? c.Gb : arr == 1u ? c.Cb : c.bb) + e[k];
-            if (md == TGT_RMW) *dst += v;
-            else unsafeAtomicAdd(dst, v);
-          }
+    for (int k = 0; k < 2; ++k) {
+      if (!on[k]) continue;
+      double v = acc[k];
+      switch (cls) {                                 // wave-uniform
+        case 0:
+          if (c.gsh != 0.0 && diag_flag[e[k]]) v += c.gsh;                                     // precompile.jl:529-534
+          if (!isfinite(v)) *c.nf = 1;
+          c.Gb[e[k]] = v;
+          break;
+        case 1:
+          if (!isfinite(v)) *c.nf = 1;
+          c.Cb[e[k]] = v;
+          break;
+        case 2:
+          if (c.sf < 1.0) v *= c.sf;                                                           // precompile.jl:524-527
+          if (!isfinite(v)) *c.nf = 1;
+          c.bb[e[k]] = v;
+          break;
+        case 3: src[e[k]] = v; break;
+        default: {
+          const unsigned arr = (wx[k] >> 28) & 3u, md = wx[k] >> 30;
+          if (arr == 2u && c.sf < 1.0) v *= c.sf;
+          if (!isfinite(v)) *c.nf = 1;
+          double* dst = (arr == 0u ? c.Gb : arr == 1u ? c.Cb : c.bb) + e[k];
+          if (md == TGT_RMW) *dst += v;
+          else unsafeAtomicAdd(dst, v);
         }
       }
-    };
-    const bool single = a.ipw == 1;
-    const bool single_on = single && grp < a.B && inst_par[0] != 0.0;                 // (ipw == 1: the tile's instance is grp)
-    const InstCtx c0 = inst_ctx(0);
-    // the next step's records are read (LDS) while this step's sums and stores run
-    uint4 ra = rec_l[lane], rb = rec_l[64 + lane];
-    for (int q = 0; q < n_steps; ++q) {
-      const int info = __builtin_amdgcn_readfirstlane(info_l[q]);
-      const int qn = q + 1 < n_steps ? q + 1 : q;
-      const uint4 na = rec_l[(size_t)qn * STEP_W + lane], nb = rec_l[(size_t)qn * STEP_W + 64 + lane];
-      const int cls = info & 0xFF;
-      if (info & 0x100) CADNIP_WAVE_SYNC();          // first step of a level: the partial sums below it are complete
-      if (cls < 5) {
-        if (single) { if (single_on) reduce_instance(c0, ra, rb, cls); }
-        else
-          for (int ri = 0; ri < a.ipw; ++ri)
-            if (grp * a.ipw + ri < a.B && inst_par[3 * ri] != 0.0) reduce_instance(inst_ctx(ri), ra, rb, cls);   // wave-uniform
-      }
-      ra = na; rb = nb;
     }
-    CADNIP_WAVE_SYNC();                              // the tile's words are read out: the next tile may stage
-    SC_POINT(7);
+  };
+  const bool single = a.ipw == 1;
+  const bool single_on = single && grp < a.B && inst_par[0] != 0.0;                 // (ipw == 1: the tile's instance is grp)
+  const InstCtx c0 = inst_ctx(0);
+  // The loop body is PIPE steps (stage p of the register window serves steps p, p + PIPE, ...): a stage is refilled right
+  // after it has been consumed.  Result stores are acknowledged in order with the record reads (one vmcnt counter), so the
+  // window also decides how many steps of stores may be in flight: with 4 the loop ran at the store latency / 4 per step.
+  auto step = [&](int q, const uint4& ra, const uint4& rb) {
+    const int info = q < 64 ? __builtin_amdgcn_readlane(step_lane, q) : a.step_info[s0 + q];
+    const int cls = info & 0xFF;
+    if (info & 0x100) CADNIP_WAVE_SYNC();          // first step of a level: the partial sums below it are complete
+    if (cls >= 5) return;
+    if (single) { if (single_on) reduce_instance(c0, ra, rb, cls); return; }
+    for (int ri = 0; ri < a.ipw; ++ri)
+      if (grp * a.ipw + ri < a.B && inst_par[3 * ri] != 0.0) reduce_instance(inst_ctx(ri), ra, rb, cls);   // wave-uniform
+  };
+  for (int q0 = 0; q0 < n_steps; q0 += PIPE) {
+#pragma unroll
+    for (int p = 0; p < PIPE; ++p) {
+      const int q = q0 + p;
+      const uint4 ra = pipe[p][0], rb = pipe[p][1];
+      const int st = q + PIPE < n_steps ? q + PIPE : 0;                              // past the end: a harmless re-read of step 0
+      pipe[p][0] = recs[(size_t)st * STEP_W]; pipe[p][1] = recs[(size_t)st * STEP_W + 64];
+      if (q < n_steps) step(q, ra, rb);                                              // wave-uniform
+    }
   }
+  CADNIP_WAVE_SYNC();
+  SC_POINT(7);
 }
 
 
-// launch of one instantiation (dynamic LDS above 64 KB is enabled here): workgroups of several waves take the instantiation compiled for eight
+// launch of one instantiation (dynamic LDS above 64 KB is enabled here)
 template <int TYPE, class EXT = void>
 static inline int launch_stamp_kernel(const CsrStampArgs& a, unsigned grid, size_t shmem, hipStream_t stream) {
-  if constexpr (std::is_void<EXT>::value) {
-    if (a.nwv > 1) {
-      if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_stamp_csr<TYPE, EXT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-      hipLaunchKernelGGL((k_stamp_csr<TYPE, EXT, 8>), dim3(grid), dim3(64 * a.nwv), shmem, stream, a);
-      return CADNIP_OK;
-    }
-  }
-  if (a.nwv != 1) return CADNIP_BADARG;
-  if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_stamp_csr<TYPE, EXT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL((k_stamp_csr<TYPE, EXT, 1>), dim3(grid), dim3(64), shmem, stream, a);
+  if (shmem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_stamp_csr<TYPE, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL((k_stamp_csr<TYPE, EXT>), dim3(grid), dim3(64), shmem, stream, a);
   return CADNIP_OK;
 }
 
