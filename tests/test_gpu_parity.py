@@ -83,11 +83,10 @@ def test_rebuild_matches_oracle(name, mode, t):
 
 @pytest.mark.parametrize("B", [16, 37, 150])
 def test_rebuild_of_a_batch_matches_oracle(B):
-    """The stamping kernels' workgroup geometry depends on the batch (csrc/stamp_csr.hip: from 16 tiles per chunk on, up to eight waves per
-    workgroup share one LDS copy of the reduction records and loop over the chunk's tiles; below, one wave per workgroup): a batch of B
-    flip-flop corners with their own supplies, temperatures, states and times -- B not a multiple of the workgroup's waves, more tiles than
-    one pass of the resident workgroups -- restamped in one call; several instances against the oracle at 1e-12, and every instance against
-    its own single-instance restamp bit for bit."""
+    """The stamping kernels' launch geometry depends on the batch (csrc/stamp_csr.hip: instances per wave for small device types, tiles per
+    chunk, grid): a batch of B flip-flop corners with their own supplies, temperatures, states and times -- B not a multiple of anything --
+    restamped in one call; several instances against the oracle at 1e-12, and every instance against its own single-instance restamp bit
+    for bit (the per-op path has one writer per word and sums in the reference's COO order: no batch dependence at all)."""
     mk, params = ALL_STAMP["dff"]
     circ = mk()
     rng = np.random.default_rng(B)
