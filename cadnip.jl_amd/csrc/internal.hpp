@@ -87,13 +87,13 @@ struct DeviceBlock {
   double* d_par = nullptr;   // [B][n_par][count]
   // reduction plan of the stamping kernel (stamp_csr.hip): devices per tile, tiles per instance, and per tile the targets
   // (CSR entries of G / C, rows of b) it contributes to with the LDS offsets of their contributions in COO order
-  int sp_cs = 0, sp_chunks = 0, sp_n_targets = 0, sp_levels = 1, sp_scratch = 0, sp_max_steps = 0;   // (sp_max_steps: the longest chunk's reduction steps)
+  int sp_cs = 0, sp_chunks = 0, sp_n_targets = 0, sp_levels = 1, sp_scratch = 0;
   struct Target { int chunk; unsigned word; std::vector<unsigned short> offs; };
   std::vector<Target> sp_targets;            // build-time only
   int *d_sp_tptr = nullptr, *d_sp_info = nullptr; uint4* d_sp_rec = nullptr;
   // sp_mos1 blocks carry two plans -- the lane-pair path (mos1_plain: the rows of the external d / g / s terminals and the d / s columns
   // are structural zeros there) stages fewer rows -- and the launch picks the one that matches the parameters in force
-  struct PlanSet { int n_targets = 0, levels = 1, scratch = 0, rows = 0, max_steps = 0; int *tptr = nullptr, *info = nullptr; uint4* rec = nullptr; unsigned short* rowoff = nullptr; };
+  struct PlanSet { int n_targets = 0, levels = 1, scratch = 0, rows = 0; int *tptr = nullptr, *info = nullptr; uint4* rec = nullptr; unsigned short* rowoff = nullptr; };
   PlanSet sp_gen, sp_plain;
   int sp_rows = 0;                           // staged rows of a tile: the slots some target reads (+ one trash row for the rest); see build_stamp_plan
   unsigned short* d_sp_rowoff = nullptr;     // [n_g + n_c + n_b] word offset of every slot's row inside a tile
